@@ -1,0 +1,137 @@
+/* nerf_sos_hip.h -- C ABI of the MI355X (gfx950) NeRF-SOS volumetric-rendering path.
+ *
+ * The reference (VITA-Group/NeRF-SOS) is 100 % Python and has no FFI/plugin interface: its
+ * boundary for this path is the nn.Module duck-type NeRFNet.forward()/render_rays()
+ * (models/nerf_net.py:71-195).  `nerf-sos_amd/` mirrors that module in Python; THIS header is
+ * what it binds underneath (ctypes), one entry point per fusion group of SURVEY.md section 2.3.
+ * Each function cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions (all functions):
+ *   - every pointer is a DEVICE pointer to fp32 (or int64 where stated), row-major, dense;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
+ *     work: they never synchronise, never allocate, never free, never touch host copies of
+ *     the data; the caller owns all buffers and keeps them alive until the stream drains;
+ *   - return value: NSOS_OK (0), a negative NSOS_ERR_* validation code, or a positive
+ *     hipError_t from the launch;
+ *   - stateless and re-entrant; thread-safe as far as the HIP runtime is.
+ *   - there is NO CPU fallback: without a gfx950 device every launch returns a hipError_t.
+ */
+#ifndef NERF_SOS_HIP_H
+#define NERF_SOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSOS_ABI_VERSION 1
+
+enum {
+    NSOS_OK = 0,
+    NSOS_ERR_NULL_POINTER = -1,   /* a required pointer argument is NULL */
+    NSOS_ERR_BAD_SHAPE = -2,      /* negative / zero / inconsistent sizes */
+    NSOS_ERR_UNSUPPORTED = -3,    /* shape outside what the kernels are specialised for */
+    NSOS_ERR_BUFFER_TOO_SMALL = -4,
+    NSOS_ERR_MISALIGNED = -5      /* a pointer that must be 16-byte aligned is not */
+};
+
+/* Fixed architecture of every shipped config (configs/ (all 34): N_samples 64, N_importance 128,
+ * use_viewdirs; run_nerf.py:96-101 defaults netdepth 8 / netwidth 256; models/nerf_net.py:44 skips=[4];
+ * run_nerf.py:109-112 multires 10 / multires_views 4). */
+#define NSOS_NET_DEPTH 8
+#define NSOS_NET_WIDTH 256
+#define NSOS_XYZ_FREQS 10
+#define NSOS_DIR_FREQS 4
+#define NSOS_XYZ_DIM 63 /* 3 + 6*10 */
+#define NSOS_DIR_DIM 27 /* 3 + 6*4  */
+
+/* Semantic-head variants (models/nerf_mlp.py:53-64; run_nerf.py:180-190). */
+enum { NSOS_SEM_NONE = 0, NSOS_SEM_PLAIN = 1, NSOS_SEM_COORD = 2 };
+
+/* The tensors of ONE NeRFMLP.mlp in PyTorch nn.Linear layout ([out,in] row-major fp32, device
+ * memory): exactly the state-dict entries `<net>.mlp.*` (models/nerf_mlp.py:40-64). */
+typedef struct nsos_mlp_tensors {
+    const float* pts_w[NSOS_NET_DEPTH]; /* pts_linears.i.weight: [256,63] [256,256]x4 [256,319] [256,256]x2 */
+    const float* pts_b[NSOS_NET_DEPTH]; /* pts_linears.i.bias  : [256] */
+    const float* alpha_w;               /* alpha_linear.weight  [1,256]   */
+    const float* alpha_b;               /* alpha_linear.bias    [1]       */
+    const float* feature_w;             /* feature_linear.weight[256,256] */
+    const float* feature_b;             /* feature_linear.bias  [256]     */
+    const float* views_w;               /* views_linears.0.weight [128,283] */
+    const float* views_b;               /* views_linears.0.bias   [128]     */
+    const float* rgb_w;                 /* rgb_linear.weight    [3,128]   */
+    const float* rgb_b;                 /* rgb_linear.bias      [3]       */
+    const float* sem0_w;                /* semantic_linear.0.weight [128,319] (COORD) / [128,256] (PLAIN) / NULL */
+    const float* sem0_b;                /* semantic_linear.0.bias   [128] */
+    const float* sem2_w;                /* semantic_linear.2.weight [2,128]   */
+    const float* sem2_b;                /* semantic_linear.2.bias   [2]       */
+} nsos_mlp_tensors;
+
+int32_t nsos_abi_version(void);
+const char* nsos_error_string(int32_t code);
+
+/* ---- weight packing ---------------------------------------------------------------------
+ * The fused MLP kernel streams its weights through LDS as 32 KiB chunks of MFMA A-operands in
+ * issue order (DESIGN.md "HBM layout").  nsos_mlp_pack gathers one net's tensors into that
+ * stream (call again whenever a parameter changes).  `packed` must be 16-byte aligned and hold
+ * nsos_mlp_packed_bytes(sem_mode) bytes.  Replaces nothing in the reference: nn.Linear keeps
+ * [out,in] tensors (models/nerf_mlp.py:40-64) and ATen re-reads them per addmm. */
+size_t nsos_mlp_packed_bytes(int32_t sem_mode);
+int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
+                      void* stream);
+
+/* ---- K1: ray set-up -----------------------------------------------------------------------
+ * viewdirs = d/|d| (models/nerf_net.py:163-166) and the stratified depths z
+ * (StratifiedSampler.forward, models/sampler.py:46-68): z = near(1-t)+far*t, t=linspace(0,1,S);
+ * if t_rand != NULL (perturb > 0) jitter inside the mid-point intervals with t_rand [R,S].
+ *   rays_d [R,3]; near, far [R]; z_vals out [R,S]; viewdirs out [R,3] (may be NULL). */
+int32_t nsos_ray_setup(const float* rays_d, const float* near, const float* far, const float* t_rand,
+                       int64_t n_rays, int32_t n_samples, float* z_vals, float* viewdirs, void* stream);
+
+/* pts = o + d*z (models/sampler.py:70,166) -- only for callers that ask for `retpts`; the MLP
+ * kernel forms the points on the fly and never reads this tensor.  pts out [R,S,3]. */
+int32_t nsos_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays,
+                        int32_t n_samples, float* pts, void* stream);
+
+/* ---- K2: positional encoding + MLP, fused ---------------------------------------------------
+ * PositionEncoder.forward x2 (models/embedder.py:34-48), the encoder join (models/nerf_mlp.py:208),
+ * MLP.forward (models/nerf_mlp.py:67-100) and the point-chunk loop (models/nerf_mlp.py:190-210)
+ * for R*S points x = o + d*z of R rays, with the per-ray view direction broadcast
+ * (models/nerf_net.py:94,111).  raw out [R,S,C], C = 4 (NSOS_SEM_NONE) or 6: [r,g,b,sigma,(sem0,sem1)]. */
+int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                              const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                              float* raw, void* stream);
+
+/* Same network on explicit points, the NeRFMLP.__call__(pts, viewdirs) form used by density
+ * export (engines/eval.py:297; models/nerf_mlp.py:179-215).  pts, dirs [P,3]; raw out [P,C]. */
+int32_t nsos_mlp_forward_points(const void* packed, int32_t sem_mode, const float* pts, const float* dirs,
+                                int64_t n_pts, float* raw, void* stream);
+
+/* ---- K3: compositing ------------------------------------------------------------------------
+ * VolumetricRenderer.forward (models/renderer.py:35-85): sigma->alpha, exclusive transmittance
+ * product, weights, and the weighted sums.  noise (may be NULL) is the raw randn [R,S]; it is
+ * scaled by noise_std in-kernel (models/renderer.py:47).  n_ch = 4 or 6.
+ *   weights out [R,S]; rgb out [R,3]; sem out [R,n_ch-4] (NULL iff n_ch == 4); depth/acc/disp out [R]. */
+int32_t nsos_composite(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
+                       float noise_std, int64_t n_rays, int32_t n_samples, int32_t n_ch, int32_t white_bkgd,
+                       float* weights, float* rgb, float* sem, float* depth, float* acc, float* disp,
+                       void* stream);
+
+/* ---- K4: hierarchical sampling ----------------------------------------------------------------
+ * ImportanceSampler.forward / sample_pdf (models/sampler.py:91-167) + z_std (models/nerf_net.py:124):
+ * pdf over the inner 62 coarse weights, cdf (fp64-accumulated), right-bisect search of u,
+ * lerp inside the bin, merge-sort with the coarse depths, population std of the new samples.
+ *   z_vals, weights [R,S] (S = 64); u [R,N] or NULL (= det: linspace(0,1,N), perturb == 0);
+ *   cdf_in [R,S-1] or NULL: if given it REPLACES the computed cdf (stage-wise index pinning);
+ *   outputs: z_fine [R,S+N] ascending; z_samples [R,N]; z_std [R];
+ *   optional outputs (NULL to skip): cdf_out [R,S-1], inds_out int64 [R,N] (the searchsorted result). */
+int32_t nsos_importance_sample(const float* z_vals, const float* weights, const float* u, const float* cdf_in,
+                               int64_t n_rays, int32_t n_coarse, int32_t n_importance, float* z_fine,
+                               float* z_samples, float* z_std, float* cdf_out, int64_t* inds_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_SOS_HIP_H */

@@ -1,0 +1,11 @@
+"""MI355X-native volumetric rendering path of NeRF-SOS.
+
+Host-side mirror of the reference's interface for this path (models/nerf_net.py, models/nerf_mlp.py,
+models/sampler.py, models/renderer.py) over the C ABI in ``include/nerf_sos_hip.h``.  There is no CPU or
+eager-PyTorch fallback: every op raises if the HIP library is missing or the tensors are not on a GPU.
+"""
+from .nerf_net import MLP, NeRFMLP, NeRFNet  # noqa: F401
+from . import ops  # noqa: F401
+from . import sharding  # noqa: F401
+
+__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding"]

@@ -1,0 +1,64 @@
+"""ctypes binding of libnerf_sos_hip.so (the C ABI declared in include/nerf_sos_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_sos_hip.so")
+
+_fp = C.c_void_p
+_i32, _i64, _f32, _sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class MlpTensors(C.Structure):
+    """struct nsos_mlp_tensors"""
+    _fields_ = [("pts_w", _fp * 8), ("pts_b", _fp * 8), ("alpha_w", _fp), ("alpha_b", _fp),
+                ("feature_w", _fp), ("feature_b", _fp), ("views_w", _fp), ("views_b", _fp),
+                ("rgb_w", _fp), ("rgb_b", _fp), ("sem0_w", _fp), ("sem0_b", _fp), ("sem2_w", _fp), ("sem2_b", _fp)]
+
+
+# name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "nsos_abi_version": (_i32, []),
+    "nsos_error_string": (C.c_char_p, [_i32]),
+    "nsos_mlp_packed_bytes": (_sz, [_i32]),
+    "nsos_mlp_pack": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
+    "nsos_ray_setup": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
+    "nsos_ray_points": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "nsos_mlp_forward_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),
+    "nsos_composite": (_i32, [_fp, _fp, _fp, _fp, _f32, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library or fail loudly -- there is deliberately no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C nerf-sos_amd/csrc`).  nerf_sos_amd has no CPU / eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.nsos_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(f"ABI version mismatch: library {handle.nsos_abi_version()} vs binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().nsos_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: [{code}] {msg}")

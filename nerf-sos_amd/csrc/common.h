@@ -1,0 +1,32 @@
+// Shared device/host helpers for the gfx950 NeRF-SOS kernels.  gfx950 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nerf_sos_hip.h"
+
+#define NSOS_WAVE 64
+
+#define NSOS_REQUIRE(cond, code) \
+    do {                         \
+        if (!(cond)) return (code); \
+    } while (0)
+
+static inline int32_t nsos_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NSOS_OK : (int32_t)e;
+}
+
+// torch.linspace(0, 1, n) fp32 exactly as ATen's CPU kernel evaluates it (symmetric fma form):
+// step = 1/(n-1);  i < n/2 : fma(step, i, 0)  else  fma(-step, n-1-i, 1).
+__device__ __forceinline__ float nsos_linspace01(int i, int n) {
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? __fmaf_rn(step, (float)i, 0.0f) : __fmaf_rn(-step, (float)(n - 1 - i), 1.0f);
+}
+
+// wave-wide sum of a double (all lanes receive the result)
+__device__ __forceinline__ double nsos_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, NSOS_WAVE);
+    return v;
+}

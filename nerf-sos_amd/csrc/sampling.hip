@@ -1,0 +1,218 @@
+// K1 (ray set-up + stratified depths), ray points, and K4 (hierarchical sampling) for gfx950.
+//
+// HBM-bound, tiny next to the MLP (< 1 % of the path) -- the design goal here
+// is bit-level agreement with the reference's arithmetic, not throughput:
+//   * every fp32 expression is evaluated exactly as the reference writes it (this file is
+//     compiled with -ffp-contract=off; the only fused ops are the explicit fmaf of linspace),
+//   * sums / scans are accumulated in fp64 and rounded once, which is what ATen's CPU
+//     cumsum / std do and within 1 ulp of its sum / norm,
+//   * one 64-lane wave owns one ray: the 64 coarse samples map 1:1 onto lanes, so the cdf scan,
+//     the bisection and the merge never leave the wave (no block barriers).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ K1
+// models/nerf_net.py:163-166 + models/sampler.py:46-68.   grid: one thread per (ray, sample).
+__global__ __launch_bounds__(256) void ray_setup_kernel(const float* __restrict__ rays_d,
+                                                        const float* __restrict__ near,
+                                                        const float* __restrict__ far,
+                                                        const float* __restrict__ t_rand, int64_t n_rays, int S,
+                                                        float* __restrict__ z_vals, float* __restrict__ viewdirs) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_rays * S) return;
+    const int64_t r = gid / S;
+    const int s = (int)(gid - r * S);
+    const float n = near[r], f = far[r];
+    auto zlin = [&](int i) {  // models/sampler.py:48   near*(1-t) + far*t
+        const float t = nsos_linspace01(i, S);
+        return n * (1.0f - t) + f * t;
+    };
+    float z = zlin(s);
+    if (t_rand) {  // models/sampler.py:54-68
+        const float zl = zlin(0), zh = zlin(S - 1);
+        const float lower = (s == 0) ? zl : 0.5f * (z + zlin(s - 1));
+        const float upper = (s == S - 1) ? zh : 0.5f * (zlin(s + 1) + z);
+        z = lower + (upper - lower) * t_rand[gid];
+    }
+    z_vals[gid] = z;
+    if (viewdirs && s == 0) {
+        const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+        const float nrm = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+        viewdirs[3 * r] = dx / nrm;
+        viewdirs[3 * r + 1] = dy / nrm;
+        viewdirs[3 * r + 2] = dz / nrm;
+    }
+}
+
+// models/sampler.py:70,166.   grid: one thread per output float (coalesced stores).
+__global__ __launch_bounds__(256) void ray_points_kernel(const float* __restrict__ rays_o,
+                                                         const float* __restrict__ rays_d,
+                                                         const float* __restrict__ z_vals, int64_t n_rays, int S,
+                                                         float* __restrict__ pts) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_rays * S * 3) return;
+    const int64_t ps = gid / 3;
+    const int c = (int)(gid - ps * 3);
+    const int64_t r = ps / S;
+    const float m = rays_d[3 * r + c] * z_vals[ps];
+    pts[gid] = rays_o[3 * r + c] + m;
+}
+
+// ------------------------------------------------------------------------------------------ K4
+// models/sampler.py:91-167 + models/nerf_net.py:124.   One wave per ray, 4 rays per block.
+// n_coarse is fixed at 64 (= one sample per lane); n_importance <= NSOS_MAX_IMPORTANCE.
+#define NSOS_MAX_IMPORTANCE 448  // 64 + 448 = 512 merged samples per ray at most
+
+struct ImportanceLds {
+    float cdf[64];    // 63 used
+    float bins[64];   // 63 used
+    float vals[512];  // coarse z (64) followed by the new samples (N)
+};
+
+__global__ __launch_bounds__(256) void importance_kernel(const float* __restrict__ z_vals,
+                                                         const float* __restrict__ weights,
+                                                         const float* __restrict__ u_in,
+                                                         const float* __restrict__ cdf_in, int64_t n_rays, int N,
+                                                         float* __restrict__ z_fine, float* __restrict__ z_samples,
+                                                         float* __restrict__ z_std, float* __restrict__ cdf_out,
+                                                         int64_t* __restrict__ inds_out) {
+    __shared__ ImportanceLds lds_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rays) return;  // whole wave exits together; no block-level barrier below
+    ImportanceLds& L = lds_all[wave];
+    constexpr int S = 64, NB = 63;
+
+    const float z = z_vals[r * S + lane];
+    // bins = mid-points (models/sampler.py:155): lane j holds .5*(z[j+1]+z[j]), j < 63
+    const float z_next = __shfl_down(z, 1, NSOS_WAVE);
+    L.vals[lane] = z;
+    if (lane < NB) L.bins[lane] = 0.5f * (z_next + z);
+
+    // cdf (models/sampler.py:93-97): entry k lives in lane k; entry 0 = 0, entry k>=1 = inclusive
+    // fp64 prefix sum of pdf over the inner weights w[1..k]
+    float cdf;
+    if (cdf_in) {
+        cdf = (lane < NB) ? cdf_in[r * NB + lane] : 0.0f;
+    } else {
+        const bool inner = (lane >= 1 && lane <= NB - 1);
+        const float w = inner ? (weights[r * S + lane] + 1e-5f) : 0.0f;
+        const float fsum = (float)nsos_wave_sum((double)w);
+        const float pdf = inner ? (w / fsum) : 0.0f;
+        double run = (double)pdf;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(run, off, NSOS_WAVE);
+            if (lane >= off) run += o;
+        }
+        cdf = (float)run;  // lane 0: pdf 0 -> 0
+    }
+    if (lane < NB) {
+        L.cdf[lane] = cdf;
+        if (cdf_out) cdf_out[r * NB + lane] = cdf;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // invert the cdf (models/sampler.py:116-132): each lane owns samples i = lane, lane+64, ...
+    double s1 = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const float u = u_in ? u_in[r * N + i] : nsos_linspace01(i, N);
+        int lo = 0, hi = NB;  // searchsorted(right=True): count of entries <= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (L.cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        if (inds_out) inds_out[r * N + i] = lo;
+        const int below = lo - 1 > 0 ? lo - 1 : 0;
+        const int above = lo < NB - 1 ? lo : NB - 1;
+        const float c0 = L.cdf[below], c1 = L.cdf[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u - c0) / denom;
+        const float b0 = L.bins[below], b1 = L.bins[above];
+        const float span = b1 - b0;
+        const float smp = b0 + t * span;
+        L.vals[S + i] = smp;
+        z_samples[r * N + i] = smp;
+        s1 += (double)smp;
+    }
+    // z_std: population std of the N new samples, two-pass in fp64 (models/nerf_net.py:124)
+    const double mean = nsos_wave_sum(s1) / (double)N;
+    double s2 = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const double dlt = (double)L.vals[S + i] - mean;
+        s2 += dlt * dlt;
+    }
+    s2 = nsos_wave_sum(s2);
+    if (lane == 0) z_std[r] = (float)sqrt(s2 / (double)N);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // merge (models/sampler.py:161: sort(cat([z, samples])), values only): rank sort in-wave.
+    // rank(e) = #{j : v_j < v_e} + #{j < e : v_j == v_e}; LDS reads below are wave-uniform broadcasts.
+    const int M = S + N;
+    for (int e0 = 0; e0 < M; e0 += 64 * 4) {
+        float v[4];
+        int rank[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * 64 + lane;
+            v[q] = e < M ? L.vals[e] : 0.0f;
+            rank[q] = 0;
+        }
+        for (int j = 0; j < M; ++j) {
+            const float vj = L.vals[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * 64 + lane;
+                rank[q] += (vj < v[q]) || (vj == v[q] && j < e);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * 64 + lane;
+            if (e < M) z_fine[r * M + rank[q]] = v[q];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int32_t nsos_ray_setup(const float* rays_d, const float* near, const float* far, const float* t_rand,
+                                  int64_t n_rays, int32_t n_samples, float* z_vals, float* viewdirs,
+                                  void* stream) {
+    NSOS_REQUIRE(rays_d && near && far && z_vals, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 2, NSOS_ERR_BAD_SHAPE);
+    if (n_rays == 0) return NSOS_OK;
+    const int64_t total = n_rays * n_samples;
+    NSOS_REQUIRE((total + 255) / 256 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_d, near, far, t_rand, n_rays, n_samples, z_vals, viewdirs);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays,
+                                   int32_t n_samples, float* pts, void* stream) {
+    NSOS_REQUIRE(rays_o && rays_d && z_vals && pts, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    if (n_rays == 0) return NSOS_OK;
+    const int64_t total = n_rays * n_samples * 3;
+    NSOS_REQUIRE((total + 255) / 256 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(ray_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, z_vals, n_rays, n_samples, pts);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_importance_sample(const float* z_vals, const float* weights, const float* u,
+                                          const float* cdf_in, int64_t n_rays, int32_t n_coarse,
+                                          int32_t n_importance, float* z_fine, float* z_samples, float* z_std,
+                                          float* cdf_out, int64_t* inds_out, void* stream) {
+    NSOS_REQUIRE(z_vals && (weights || cdf_in) && z_fine && z_samples && z_std, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays >= 0 && n_importance >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_coarse == 64 && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE((n_rays + 3) / 4 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(importance_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       z_vals, weights, u, cdf_in, n_rays, n_importance, z_fine, z_samples, z_std, cdf_out,
+                       inds_out);
+    return nsos_launch_status();
+}

@@ -1,0 +1,212 @@
+"""Drop-in modules for the reference's render path, backed by the gfx950 HIP kernels.
+
+Interface mirrored (reference file:line):
+  * ``NeRFNet(**ctor kwargs)``, ``NeRFNet.forward(ray_batch, bound_batch, **kwargs)``,
+    ``NeRFNet.render_rays(...)``                                   -- models/nerf_net.py:22-195
+  * ``NeRFMLP(...)(pts, viewdirs=...)`` point query                -- models/nerf_mlp.py:132-215
+  * ``MLP`` parameter container, same names / shapes / init order  -- models/nerf_mlp.py:24-64
+so that ``state_dict()`` keys (``nerf.mlp.pts_linears.0.weight`` ...) and reference checkpoints are
+interchangeable (engines/trainer.py:216-222, run_nerf.py:350-360), and the callers
+``model(batch_rays, (near, far), radii=radii)`` (engines/trainer.py:68, engines/eval.py:40) and
+``model.nerf_fine(pts, viewdirs=viewdirs)`` (engines/eval.py:297) work unchanged.
+
+What is NOT here on purpose: any arithmetic.  Modules only hold parameters and sequence kernel
+launches (ops.py -> include/nerf_sos_hip.h).  Non-GPU tensors raise; unsupported architectures raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_SUPPORTED = ("the HIP kernels are specialised for the architecture every shipped NeRF-SOS config uses: "
+              "netdepth=8, netwidth=256, skips=[4], viewdirs=True, use_embed=True, multires=10, multires_views=4, "
+              "conv_embed=False, sem_layer<=2, sem_dim=2, sem_with_geo=False")
+
+
+class MLP(nn.Module):
+    """Parameter container of the 8x256 NeRF MLP with the semantic head.  Layers are created in the
+    reference's order (models/nerf_mlp.py:40-64) so a given torch seed yields identical initial weights."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=(4,), use_viewdirs=True,
+                 use_semantics=True, sem_layer=2, sem_dim=2, sem_with_coord=False, sem_with_geo=False):
+        super().__init__()
+        if not (D == 8 and W == 256 and tuple(skips) == (4,) and use_viewdirs and input_ch == 63
+                and input_ch_views == 27 and output_ch == 4 and sem_layer <= 2 and sem_dim == 2 and not sem_with_geo):
+            raise NotImplementedError("nerf_sos_amd.MLP: " + _SUPPORTED)
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.skips = list(skips)
+        self.use_viewdirs, self.use_semantics, self.sem_with_coord = use_viewdirs, use_semantics, sem_with_coord
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] +
+            [nn.Linear(W + input_ch, W) if i in self.skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.alpha_linear = nn.Linear(W, 1)
+        self.feature_linear = nn.Linear(W, W)
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        self.rgb_linear = nn.Linear(W // 2, output_ch - 1)
+        if use_semantics:
+            sem_in = W + input_ch if sem_with_coord else W
+            self.semantic_linear = nn.Sequential(nn.Linear(sem_in, W // 2), nn.ReLU(), nn.Linear(W // 2, sem_dim))
+            self.geo_map_sem = None
+
+    @property
+    def sem_mode(self) -> int:
+        return ops.sem_mode_of(self.use_semantics, self.sem_with_coord)
+
+    def forward(self, x):  # the reference's MLP.forward takes pre-encoded inputs; the fused kernel never builds them
+        raise NotImplementedError("nerf_sos_amd.MLP holds parameters only; query points through NeRFMLP "
+                                  "(positional encoding and all layers are fused in one HIP kernel)")
+
+
+class NeRFMLP(nn.Module):
+    """Point query with embedding (models/nerf_mlp.py:132-215): ``raw = nerf(pts[...,3], viewdirs[...,3])``."""
+
+    def __init__(self, input_dim=3, output_dim=4, net_depth=8, net_width=256, skips=(4,), viewdirs=True,
+                 use_embed=True, multires=10, multires_views=4, conv_embed=False, netchunk=1024 * 64,
+                 use_semantics=False, sem_layer=2, sem_dim=2, sem_with_coord=False, sem_with_geo=False):
+        super().__init__()
+        if not (input_dim == 3 and viewdirs and use_embed and multires == 10 and multires_views == 4
+                and not conv_embed):
+            raise NotImplementedError("nerf_sos_amd.NeRFMLP: " + _SUPPORTED)
+        self.chunk = netchunk  # kept for interface parity; the fused kernel needs no point chunking
+        self.mlp = MLP(net_depth, net_width, skips=skips, input_ch=3 + 6 * multires, output_ch=output_dim,
+                       input_ch_views=3 + 6 * multires_views, use_viewdirs=viewdirs, use_semantics=use_semantics,
+                       sem_layer=sem_layer, sem_dim=sem_dim, sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+
+    @property
+    def sem_mode(self) -> int:
+        return self.mlp.sem_mode
+
+    def packed_weights(self) -> torch.Tensor:
+        """The MFMA-order weight stream, re-packed on device whenever a parameter changed
+        (optimizer steps and load_state_dict bump ``Tensor._version``)."""
+        params = dict(self.mlp.named_parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params.values())
+        if self._packed is None or key != self._packed_key:
+            self._packed = ops.pack_mlp(params, self.sem_mode, self._packed)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, inputs, viewdirs=None):
+        if viewdirs is None:
+            raise NotImplementedError("nerf_sos_amd.NeRFMLP: view directions are required (use_viewdirs=True)")
+        _no_autograd(self, "NeRFMLP.forward")
+        lead = inputs.shape[:-1]
+        pts = inputs.reshape(-1, inputs.shape[-1]).float()
+        dirs = viewdirs.expand(inputs.shape).reshape(-1, viewdirs.shape[-1]).float()
+        raw = ops.mlp_forward_points(self.packed_weights(), self.sem_mode, pts, dirs)
+        return raw.reshape(list(lead) + [raw.shape[-1]])
+
+
+def _no_autograd(module: nn.Module, what: str):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            f"{what}: the backward kernels (SURVEY.md K5) are not built yet -- call under torch.no_grad() "
+            "or freeze the parameters.  (No autograd fallback on purpose.)")
+
+
+class NeRFNet(nn.Module):
+    """Coarse + fine volumetric renderer with the reference's constructor and call contract
+    (models/nerf_net.py:22-195).  Note the reference's spelling ``pts_chuck``."""
+
+    def __init__(self, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, N_samples=64, N_importance=64,
+                 viewdirs=True, use_embed=True, multires=10, multires_views=4, conv_embed=False,
+                 ray_chunk=1024 * 32, pts_chuck=1024 * 64, perturb=1., raw_noise_std=0., white_bkgd=False,
+                 use_semantics=False, sem_layer=2, sem_dim=2, sem_with_coord=False, sem_with_geo=False):
+        super().__init__()
+        self.use_semantics = use_semantics
+        self.N_samples, self.N_importance = N_samples, N_importance
+        self.perturb, self.raw_noise_std, self.white_bkgd = perturb, raw_noise_std, white_bkgd
+        self.chunk = ray_chunk
+        self.use_viewdirs = viewdirs
+        common = dict(input_dim=3, output_dim=4, skips=(4,), viewdirs=viewdirs, use_embed=use_embed,
+                      multires=multires, multires_views=multires_views, conv_embed=conv_embed, netchunk=pts_chuck,
+                      use_semantics=use_semantics, sem_layer=sem_layer, sem_dim=sem_dim,
+                      sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
+        self.nerf = NeRFMLP(net_depth=netdepth, net_width=netwidth, **common)
+        self.nerf_fine = self.nerf  # models/nerf_net.py:49
+        if N_importance > 0:
+            self.nerf_fine = NeRFMLP(net_depth=netdepth_fine, net_width=netwidth_fine, **common)
+        self.render_kwargs_train = {'N_importance': N_importance, 'N_samples': N_samples, 'perturb': perturb,
+                                    'raw_noise_std': raw_noise_std, 'retraw': True, 'retpts': False}
+        self.render_kwargs_test = dict(self.render_kwargs_train, perturb=0., raw_noise_std=0.)
+
+    # ---------------------------------------------------------------------------------------------
+    def render_rays(self, rays_o, rays_d, near, far, viewdirs=None, raw_noise_std=0., verbose=False,
+                    retraw=False, retpts=False, pytest=False, **kwargs) -> Dict[str, torch.Tensor]:
+        """One ray chunk: coarse sample -> MLP -> composite -> importance sample -> fine MLP -> composite
+        (models/nerf_net.py:71-130).  Random tensors are drawn on the rays' device in the reference's
+        order (rand[R,S], randn[R,S], rand[R,N], randn[R,S+N]) and handed to the kernels."""
+        _no_autograd(self, "NeRFNet.render_rays")
+        perturb = kwargs.get('perturb', self.perturb)
+        n_samples = kwargs.get('N_samples', self.N_samples)
+        R, dev = rays_d.shape[0], rays_d.device
+        t_rand = torch.rand((R, n_samples), device=dev) if perturb > 0. else None          # sampler.py:61
+        z_vals, unit_dirs = ops.ray_setup(rays_d, near, far, n_samples, t_rand)
+        if viewdirs is None:
+            viewdirs = unit_dirs
+        raw = ops.mlp_forward_rays(self.nerf.packed_weights(), self.nerf.sem_mode, rays_o, rays_d, viewdirs, z_vals)
+        noise = torch.randn((R, n_samples), device=dev) if raw_noise_std > 0. else None    # renderer.py:47
+        ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
+        if retraw:
+            ret['raw'] = raw
+        if retpts:
+            ret['pts'] = ops.ray_points(rays_o, rays_d, z_vals)
+
+        n_importance = kwargs.get('N_importance', self.N_importance)
+        if self.N_importance > 0 and n_importance > 0:
+            ret0 = ret
+            # the sample count is the constructor's, not the per-call kwarg (sampler.py:100,103)
+            N = self.N_importance
+            u = torch.rand((R, N), device=dev) if perturb != 0.0 else None                 # sampler.py:103,158
+            z_fine, z_samples, z_std = ops.importance_sample(z_vals, ret0['weights'], N, u)
+            raw = ops.mlp_forward_rays(self.nerf_fine.packed_weights(), self.nerf_fine.sem_mode, rays_o, rays_d,
+                                       viewdirs, z_fine)
+            noise = torch.randn((R, n_samples + N), device=dev) if raw_noise_std > 0. else None
+            ret = ops.composite(raw, z_fine, rays_d, noise, raw_noise_std, self.white_bkgd)
+            if retraw:
+                ret['raw'] = raw
+            if retpts:
+                ret['pts'] = ops.ray_points(rays_o, rays_d, z_fine)
+            ret['z_std'] = z_std
+            for k in ret0:
+                ret[k + '0'] = ret0[k]
+        return ret
+
+    def forward(self, ray_batch, bound_batch, **kwargs) -> Dict[str, torch.Tensor]:
+        """models/nerf_net.py:132-195: kwargs selection by mode, flatten, per-chunk render, un-flatten.
+        Unknown kwargs (``radii``) are accepted and ignored like the reference does."""
+        render_kwargs = dict(self.render_kwargs_train if self.training else self.render_kwargs_test)
+        render_kwargs.update(kwargs)
+
+        rays_o, rays_d = ray_batch
+        assert rays_o.shape == rays_d.shape
+        old_shape = rays_d.shape
+        rays_o = rays_o.reshape(-1, rays_o.shape[-1]).float().contiguous()
+        rays_d = rays_d.reshape(-1, rays_d.shape[-1]).float().contiguous()
+        R = rays_d.shape[0]
+
+        near, far = bound_batch
+        near = self._bound(near, rays_d)
+        far = self._bound(far, rays_d)
+
+        all_ret: Dict[str, list] = {}
+        for i in range(0, R, self.chunk):
+            e = min(i + self.chunk, R)
+            ret = self.render_rays(rays_o[i:e], rays_d[i:e], near[i:e], far[i:e], viewdirs=None, **render_kwargs)
+            for k, v in ret.items():
+                all_ret.setdefault(k, []).append(v)
+        out = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+        return {k: v.reshape(list(old_shape[:-1]) + list(v.shape[1:])) for k, v in out.items()}
+
+    @staticmethod
+    def _bound(b, rays_d) -> torch.Tensor:
+        if isinstance(b, (int, float)):
+            return torch.full((rays_d.shape[0],), float(b), device=rays_d.device, dtype=torch.float32)
+        return b.to(device=rays_d.device, dtype=torch.float32).reshape(-1).contiguous()

@@ -1,0 +1,200 @@
+"""Tensor-level wrappers over the C ABI (include/nerf_sos_hip.h): one function per HIP fusion group.
+
+PyTorch is used for device memory, streams and shapes only; all arithmetic happens in the HIP kernels.
+Every function requires contiguous fp32 CUDA(ROCm) tensors and launches on the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+SEM_NONE, SEM_PLAIN, SEM_COORD = 0, 1, 2
+
+# Optional live timing of the fused-MLP launches (bench.py): when set to a list, every launch appends
+# (n_points, start_event, end_event), recorded on the stream the kernel is launched on.
+KERNEL_EVENTS = None
+
+
+def sem_mode_of(use_semantics: bool, sem_with_coord: bool) -> int:
+    return SEM_NONE if not use_semantics else (SEM_COORD if sem_with_coord else SEM_PLAIN)
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"nerf_sos_amd: `{name}` must be a GPU tensor -- this package has no CPU path "
+                           f"(got {'device ' + str(t.device) if isinstance(t, torch.Tensor) else type(t)})")
+    if t.dtype != torch.float32:
+        raise TypeError(f"nerf_sos_amd: `{name}` must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------ K1
+def ray_setup(rays_d: torch.Tensor, near: torch.Tensor, far: torch.Tensor, n_samples: int,
+              t_rand: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """z_vals [R,S] and viewdirs [R,3]  (models/sampler.py:46-68, models/nerf_net.py:163-166)."""
+    rays_d = _dev(rays_d, "rays_d")
+    R = rays_d.shape[0]
+    near = _dev(near, "near").reshape(-1)
+    far = _dev(far, "far").reshape(-1)
+    if near.numel() != R or far.numel() != R:
+        raise ValueError(f"near/far must have one value per ray ({R}), got {near.numel()}/{far.numel()}")
+    if t_rand is not None:
+        t_rand = _dev(t_rand, "t_rand")
+        if tuple(t_rand.shape) != (R, n_samples):
+            raise ValueError(f"t_rand must be [{R},{n_samples}]")
+    z = torch.empty((R, n_samples), device=rays_d.device, dtype=torch.float32)
+    v = torch.empty((R, 3), device=rays_d.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_ray_setup(_p(rays_d), _p(near), _p(far), _p(t_rand), R, n_samples, _p(z), _p(v),
+                                         _stream()), "nsos_ray_setup")
+    return z, v
+
+
+def ray_points(rays_o: torch.Tensor, rays_d: torch.Tensor, z_vals: torch.Tensor) -> torch.Tensor:
+    """pts = o + d*z  [R,S,3]  (models/sampler.py:70,166)."""
+    rays_o, rays_d, z_vals = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d"), _dev(z_vals, "z_vals")
+    R, S = z_vals.shape
+    pts = torch.empty((R, S, 3), device=z_vals.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_ray_points(_p(rays_o), _p(rays_d), _p(z_vals), R, S, _p(pts), _stream()),
+               "nsos_ray_points")
+    return pts
+
+
+# ------------------------------------------------------------------------------------------ K2
+_MLP_FIELDS = (("alpha", "alpha_linear"), ("feature", "feature_linear"), ("views", "views_linears.0"),
+               ("rgb", "rgb_linear"))
+
+
+def packed_bytes(sem_mode: int) -> int:
+    return int(_lib.lib().nsos_mlp_packed_bytes(sem_mode))
+
+
+def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gather one net's state-dict tensors (keys relative to `<net>.mlp.`) into the MFMA-order stream."""
+    keep = []
+
+    def g(name):
+        t = _dev(params[name].detach(), name)
+        keep.append(t)
+        return t.data_ptr()
+
+    T = _lib.MlpTensors()
+    for i in range(8):
+        T.pts_w[i] = g(f"pts_linears.{i}.weight")
+        T.pts_b[i] = g(f"pts_linears.{i}.bias")
+    for field, name in _MLP_FIELDS:
+        setattr(T, field + "_w", g(name + ".weight"))
+        setattr(T, field + "_b", g(name + ".bias"))
+    if sem_mode != SEM_NONE:
+        T.sem0_w, T.sem0_b = g("semantic_linear.0.weight"), g("semantic_linear.0.bias")
+        T.sem2_w, T.sem2_b = g("semantic_linear.2.weight"), g("semantic_linear.2.bias")
+    shapes = {"pts_linears.0.weight": (256, 63), "pts_linears.5.weight": (256, 319),
+              "views_linears.0.weight": (128, 283), "rgb_linear.weight": (3, 128), "alpha_linear.weight": (1, 256)}
+    if sem_mode != SEM_NONE:
+        shapes["semantic_linear.0.weight"] = (128, 319 if sem_mode == SEM_COORD else 256)
+        shapes["semantic_linear.2.weight"] = (2, 128)
+    for k, shp in shapes.items():
+        if tuple(params[k].shape) != shp:
+            raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
+    nbytes = packed_bytes(sem_mode)
+    dev = keep[0].device
+    if out is None or out.numel() * 4 < nbytes or out.device != dev:
+        out = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_pack(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
+    return out
+
+
+def mlp_forward_rays(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
+                     viewdirs: torch.Tensor, z_vals: torch.Tensor) -> torch.Tensor:
+    """raw [R,S,C] for the points o + d*z of each ray  (models/nerf_mlp.py:67-100,179-215)."""
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
+    R, S = z_vals.shape
+    Cn = 4 if sem_mode == SEM_NONE else 6
+    raw = torch.empty((R, S, Cn), device=z_vals.device, dtype=torch.float32)
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(_lib.lib().nsos_mlp_forward_rays(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
+                                                _p(z_vals), R, S, _p(raw), _stream()), "nsos_mlp_forward_rays")
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append((R * S, ev[0], ev[1]))
+    return raw
+
+
+def mlp_forward_points(packed: torch.Tensor, sem_mode: int, pts: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """raw [P,C] for explicit points / per-point directions  (NeRFMLP.forward, models/nerf_mlp.py:179)."""
+    pts, dirs = _dev(pts, "pts"), _dev(dirs, "viewdirs")
+    P = pts.shape[0]
+    if tuple(pts.shape) != (P, 3) or tuple(dirs.shape) != (P, 3):
+        raise ValueError(f"pts / viewdirs must both be [P,3], got {tuple(pts.shape)} / {tuple(dirs.shape)}")
+    Cn = 4 if sem_mode == SEM_NONE else 6
+    raw = torch.empty((P, Cn), device=pts.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_forward_points(_p(packed), sem_mode, _p(pts), _p(dirs), P, _p(raw), _stream()),
+               "nsos_mlp_forward_points")
+    return raw
+
+
+# ------------------------------------------------------------------------------------------ K3
+def composite(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noise: Optional[torch.Tensor] = None,
+              noise_std: float = 0.0, white_bkgd: bool = False) -> Dict[str, torch.Tensor]:
+    """VolumetricRenderer.forward (models/renderer.py:35-85); returns the reference's dict."""
+    raw, z_vals, rays_d = _dev(raw, "raw"), _dev(z_vals, "z_vals"), _dev(rays_d, "rays_d")
+    R, S, Cn = raw.shape
+    if noise is not None:
+        noise = _dev(noise, "noise")
+        if tuple(noise.shape) != (R, S):
+            raise ValueError(f"noise must be [{R},{S}]")
+    dev = raw.device
+    f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
+    weights, rgb, depth, acc, disp = f(R, S), f(R, 3), f(R, 1), f(R, 1), f(R, 1)
+    sem = f(R, Cn - 4) if Cn > 4 else None
+    _lib.check(_lib.lib().nsos_composite(_p(raw), _p(z_vals), _p(rays_d), _p(noise), float(noise_std), R, S, Cn,
+                                         int(bool(white_bkgd)), _p(weights), _p(rgb), _p(sem), _p(depth), _p(acc),
+                                         _p(disp), _stream()), "nsos_composite")
+    ret = dict(rgb=rgb, disp=disp, acc=acc, weights=weights, depth=depth)
+    if sem is not None:
+        ret["semantics"] = sem
+    return ret
+
+
+# ------------------------------------------------------------------------------------------ K4
+def importance_sample(z_vals: torch.Tensor, weights: torch.Tensor, n_importance: int,
+                      u: Optional[torch.Tensor] = None, cdf_in: Optional[torch.Tensor] = None,
+                      debug: bool = False):
+    """ImportanceSampler.forward (models/sampler.py:91-167) + z_std (models/nerf_net.py:124).
+    Returns (z_fine [R,S+N], z_samples [R,N], z_std [R]) and, with debug=True, also (cdf [R,S-1], inds int64 [R,N])."""
+    z_vals, weights = _dev(z_vals, "z_vals"), _dev(weights, "weights")
+    R, S = z_vals.shape
+    N = int(n_importance)
+    if u is not None:
+        u = _dev(u, "u")
+        if tuple(u.shape) != (R, N):
+            raise ValueError(f"u must be [{R},{N}]")
+    if cdf_in is not None:
+        cdf_in = _dev(cdf_in, "cdf_in")
+    dev = z_vals.device
+    z_fine = torch.empty((R, S + N), device=dev, dtype=torch.float32)
+    z_samples = torch.empty((R, N), device=dev, dtype=torch.float32)
+    z_std = torch.empty((R,), device=dev, dtype=torch.float32)
+    cdf = torch.empty((R, S - 1), device=dev, dtype=torch.float32) if debug else None
+    inds = torch.empty((R, N), device=dev, dtype=torch.int64) if debug else None
+    _lib.check(_lib.lib().nsos_importance_sample(_p(z_vals), _p(weights), _p(u), _p(cdf_in), R, S, N, _p(z_fine),
+                                                 _p(z_samples), _p(z_std), _p(cdf), _p(inds), _stream()),
+               "nsos_importance_sample")
+    if debug:
+        return z_fine, z_samples, z_std, cdf, inds
+    return z_fine, z_samples, z_std

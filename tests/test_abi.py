@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/nerf_sos_hip.h declares;
+validation paths that return before any launch behave as documented."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import nerf_sos_amd
+from nerf_sos_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "nerf_sos_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nsos_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.nsos_abi_version() == 1
+
+
+def test_packed_sizes_and_error_strings():
+    lib = _lib.lib()
+    # aux (3584 floats) + 73 / 77 / 78 chunks of 32 KiB (DESIGN.md "HBM layout")
+    assert lib.nsos_mlp_packed_bytes(0) == 4 * 3584 + 73 * 32768
+    assert lib.nsos_mlp_packed_bytes(1) == 4 * 3584 + 77 * 32768
+    assert lib.nsos_mlp_packed_bytes(2) == 4 * 3584 + 78 * 32768
+    assert lib.nsos_mlp_packed_bytes(7) == 0
+    assert lib.nsos_error_string(0) == b"ok"
+    assert b"NULL" in lib.nsos_error_string(-1)
+
+
+def test_validation_returns_before_launch():
+    lib = _lib.lib()
+    null = None
+    assert lib.nsos_ray_setup(null, null, null, null, 4, 64, null, null, null) == -1
+    one = C.c_void_p(16)
+    assert lib.nsos_ray_setup(one, one, one, null, -1, 64, one, null, null) == -2
+    assert lib.nsos_ray_setup(one, one, one, null, 0, 64, one, null, null) == 0          # empty batch: no launch
+    assert lib.nsos_composite(one, one, one, null, 0.0, 4, 64, 7, 0, one, one, one, one, one, one, null) == -3
+    assert lib.nsos_importance_sample(one, one, null, null, 4, 32, 128, one, one, one, null, null, null) == -3
+    assert lib.nsos_mlp_forward_points(C.c_void_p(8), 0, one, one, 4, one, null) == -5    # misaligned packed
+    assert lib.nsos_mlp_forward_points(one, 0, one, one, 0, one, null) == 0
+
+
+def test_no_cpu_fallback():
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128)
+    rays = torch.zeros(2, 8, 3)
+    rays[1, :, 2] = -1
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        net(rays, (1.2, 14.72))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        net.nerf_fine(torch.zeros(4, 3), viewdirs=torch.zeros(4, 3))
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing in the product package may import, link or load it."""
+    pkg = os.path.join(ROOT, "nerf-sos_amd")
+    banned = re.compile(r"import\s+oracle|from\s+oracle|liboracle|c_oracle|torch_port|nerf_oracle\.h|oracle/")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert not banned.search(txt), f"{f} references oracle/"

@@ -1,0 +1,292 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the reference goldens.
+
+Bars: integer indices bit-exact; fp32 within 1e-4 of the reference goldens (BASELINE.json north_star);
+against the C oracle (same canonical arithmetic) much tighter, bitwise where libm differences cannot enter.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_sos_amd
+from nerf_sos_amd import _lib, ops
+from oracle import c_oracle as co
+from oracle import torch_port as tp
+from helpers import CFGS, close, ref_state, tag_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RS = (1, 7, 64, 257)
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def test_native_library_is_the_in_tree_one():
+    lib = _lib.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(root, "nerf-sos_amd", "libnerf_sos_hip.so"))
+    with open("/proc/self/maps") as f:
+        assert "libnerf_sos_hip.so" in f.read(), "HIP library not mapped into this process"
+    assert lib.nsos_abi_version() == 1
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("R", RS)
+def test_ray_setup(golden, R):
+    g = golden("stratified")
+    o, d, near, far, t = (g[f"R{R}_{k}"] for k in ("o", "d", "near", "far", "t_rand"))
+    z, v = ops.ray_setup(T(d), T(near), T(far), 64, T(t))
+    zo, vo = co.ray_setup(o, d, near, far, t, 64)
+    assert np.array_equal(N(z), zo), "jittered z must equal the oracle bit for bit"
+    assert np.array_equal(N(v), vo), "viewdirs must equal the oracle bit for bit"
+    close(N(z), g[f"R{R}_z"], atol=2e-6, rtol=1e-6, what="z vs reference")
+    zd, _ = ops.ray_setup(T(d), T(near), T(far), 64, None)
+    assert np.array_equal(N(zd), g[f"R{R}_z_det"]), "deterministic z must equal the REFERENCE bit for bit"
+    pts = ops.ray_points(T(o), T(d), T(g[f"R{R}_z"]))
+    assert np.array_equal(N(pts), g[f"R{R}_pts"]), "o + d*z must equal the REFERENCE bit for bit"
+
+
+# ------------------------------------------------------------------------------------------ K3
+@pytest.mark.parametrize("C", [4, 6])
+@pytest.mark.parametrize("S", [64, 192])
+@pytest.mark.parametrize("white", [False, True])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_composite(golden, C, S, white, noisy):
+    g = golden("composite")
+    base = f"C{C}_S{S}_{'white' if white else 'black'}"
+    tag = base + ("_noise" if noisy else "_clean")
+    raw, z, d, nz = g[base + "_raw"], g[base + "_z"], g[base + "_d"], g[base + "_noise"]
+    out = ops.composite(T(raw), T(z), T(d), T(nz) if noisy else None, 0.7 if noisy else 0.0, white)
+    ref = co.composite(raw, z, d, nz if noisy else None, 0.7 if noisy else 0.0, white)
+    for k in ref:
+        got = N(out[k])
+        # same arithmetic; expf/sqrt of the device libm vs glibc may differ in the last ulp
+        close(got, ref[k], atol=1e-6, rtol=2e-6, what=f"{tag} {k} vs oracle")
+        close(got, g[f"{tag}_{k}"], atol=2e-6, rtol=2e-5, what=f"{tag} {k} vs reference")
+    if not noisy:
+        for r in (0, 1):  # empty rays
+            assert N(out["acc"])[r, 0] == 0.0 and N(out["depth"])[r, 0] == np.float32(1e10) and N(out["disp"])[r, 0] == 0.0
+
+
+def test_composite_ragged_sample_counts():
+    rng = np.random.default_rng(5)
+    for S in (1, 2, 63, 65, 100, 191, 193, 256, 300, 512):
+        R = 9
+        raw = rng.standard_normal((R, S, 6), dtype=np.float32) * 2
+        z = np.sort(1.2 + 13 * rng.random((R, S), dtype=np.float32), -1)
+        d = rng.standard_normal((R, 3), dtype=np.float32)
+        out = ops.composite(T(raw), T(z), T(d))
+        ref = co.composite(raw, z, d)
+        for k in ref:
+            close(N(out[k]), ref[k], atol=1e-6, rtol=2e-6, what=f"S={S} {k}")
+
+
+# ------------------------------------------------------------------------------------------ K4
+@pytest.mark.parametrize("R", RS)
+@pytest.mark.parametrize("det", [False, True])
+def test_importance(golden, R, det):
+    g = golden("importance")
+    tag = f"R{R}_{'det' if det else 'rand'}"
+    z, w, u, cdf = g[f"R{R}_z"], g[f"R{R}_w"], g[f"R{R}_u"], g[f"R{R}_cdf"]
+    uu = None if det else T(u)
+    # stage-wise index pin: reference cdf + u in -> integer indices out, BIT-EXACT
+    zf, zs, zstd, cdf_o, inds = ops.importance_sample(T(z), T(w), 128, uu, cdf_in=T(cdf), debug=True)
+    assert np.array_equal(N(inds), g[f"{tag}_inds"]), "searchsorted indices must equal the reference bit for bit"
+    assert np.array_equal(N(cdf_o), cdf)
+    close(N(zs), g[f"{tag}_z_samples"], atol=2e-6, rtol=1e-6, what="z_samples")
+    close(N(zf), g[f"{tag}_z_fine"], atol=2e-6, rtol=1e-6, what="z_fine")
+    close(N(zstd), g[f"{tag}_z_std"], atol=2e-6, rtol=1e-6, what="z_std")
+    ref = co.importance(z, w, None if det else u, 128, cdf_in=cdf)
+    for k, got in (("z_samples", zs), ("z_fine", zf), ("z_std", zstd)):
+        assert np.array_equal(N(got), ref[k]), f"{k} must equal the oracle bit for bit (same cdf in)"
+    # own cdf: equals the oracle's (fp64 accumulation), indices consistent with that cdf
+    zf2, zs2, zstd2, cdf2, inds2 = ops.importance_sample(T(z), T(w), 128, uu, debug=True)
+    own = co.importance(z, w, None if det else u, 128)
+    assert np.array_equal(N(cdf2), own["cdf"]), "cdf must equal the oracle bit for bit"
+    assert np.array_equal(N(inds2), own["inds"])
+    assert np.array_equal(N(zf2), own["z_fine"])
+    close(N(cdf2), cdf, atol=3e-7, rtol=0, what="cdf vs reference")
+    assert (np.diff(N(zf2), axis=-1) >= 0).all()
+
+
+def test_importance_other_counts():
+    rng = np.random.default_rng(11)
+    R = 33
+    z = np.sort(1.2 + 13 * rng.random((R, 64), dtype=np.float32), -1)
+    w = rng.random((R, 64), dtype=np.float32) ** 6
+    for n_imp in (1, 64, 100, 128, 200, 448):
+        u = rng.random((R, n_imp), dtype=np.float32)
+        for uu in (None, u):
+            zf, zs, zstd, cdf, inds = ops.importance_sample(T(z), T(w), n_imp, None if uu is None else T(uu), debug=True)
+            ref = co.importance(z, w, uu, n_imp)
+            assert np.array_equal(N(inds), ref["inds"]) and np.array_equal(N(zf), ref["z_fine"])
+            assert np.array_equal(N(zs), ref["z_samples"])
+            close(N(zstd), ref["z_std"], atol=1e-6, rtol=1e-6, what="z_std")
+    with pytest.raises(RuntimeError, match="specialised"):
+        ops.importance_sample(T(z[:, :32]), T(w[:, :32]), 128)
+
+
+# ------------------------------------------------------------------------------------------ K2
+def _packed(sd, prefix, name):
+    params = {k[len(prefix) + 5:]: v.to(DEV) for k, v in sd.items() if k.startswith(prefix + ".mlp.")}
+    return ops.pack_mlp(params, ops.sem_mode_of(**CFGS[name]))
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("peaky", [False, True])
+def test_mlp_points_golden(golden, manifest, name, peaky):
+    g = golden("mlp")
+    sd = ref_state(name, manifest, peaky)
+    tag = tag_of(name, peaky)
+    mode = ops.sem_mode_of(**CFGS[name])
+    for prefix in ("nerf", "nerf_fine"):
+        raw = N(ops.mlp_forward_points(_packed(sd, prefix, name), mode, T(g["pts"]), T(g["dirs"])))
+        ref = co.mlp(co.Weights(sd, prefix, **CFGS[name]), g["pts"], g["dirs"])
+        close(raw, ref, atol=5e-6, rtol=5e-6, what=f"{tag} {prefix} vs oracle")
+        close(raw, g[f"{tag}_{prefix}_raw"], atol=2e-5, rtol=2e-5, what=f"{tag} {prefix} vs reference")
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_mlp_exact_fp32_chain(manifest, name):
+    """At x = 0, dir = 0 every sin/cos is exactly 0/1 on any libm, so the only arithmetic left is the
+    fmaf chains: the exact-fp32 MFMA path must then equal the oracle BIT FOR BIT (k order, bias, ReLU,
+    vector-ALU heads, packing)."""
+    sd = ref_state(name, manifest, peaky=True)
+    mode = ops.sem_mode_of(**CFGS[name])
+    pts = np.zeros((130, 3), np.float32)
+    raw = N(ops.mlp_forward_points(_packed(sd, "nerf_fine", name), mode, T(pts), T(pts)))
+    ref = co.mlp(co.Weights(sd, "nerf_fine", **CFGS[name]), pts, pts)
+    assert np.array_equal(raw, ref), f"max abs diff {np.abs(raw - ref).max():.3e}"
+
+
+@pytest.mark.parametrize("n_pts", [1, 31, 32, 127, 128, 129, 1000, 128 * 300 + 5])
+def test_mlp_ragged_point_counts(manifest, n_pts):
+    sd = ref_state("semcoord", manifest, peaky=True)
+    rng = np.random.default_rng(n_pts)
+    pts = (rng.random((n_pts, 3), dtype=np.float32) * 8 - 4)
+    dirs = rng.standard_normal((n_pts, 3), dtype=np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    guard = torch.full((n_pts + 64, 6), 777.0, device=DEV)
+    raw = ops.mlp_forward_points(_packed(sd, "nerf_fine", "semcoord"), 2, T(pts), T(dirs))
+    assert raw.shape == (n_pts, 6)
+    sel = np.unique(np.concatenate([np.arange(min(n_pts, 40)), np.arange(max(0, n_pts - 40), n_pts),
+                                    rng.integers(0, n_pts, 40)]))
+    ref = co.mlp(co.Weights(sd, "nerf_fine", True, True), pts[sel], dirs[sel])
+    close(N(raw)[sel], ref, atol=2e-5, rtol=2e-5, what=f"n_pts={n_pts}")
+    assert (guard == 777.0).all()
+
+
+def test_mlp_rays_equals_points(manifest):
+    sd = ref_state("semcoord", manifest)
+    rays = tp.synthetic_rays(77, seed=1)
+    o, d = T(rays[0]), T(rays[1])
+    near = torch.full((77,), tp.NEAR, device=DEV)
+    far = torch.full((77,), tp.FAR, device=DEV)
+    packed = _packed(sd, "nerf", "semcoord")
+    for S in (64, 192, 50):
+        z, v = ops.ray_setup(d, near, far, S, torch.rand(77, S, device=DEV))
+        raw_r = ops.mlp_forward_rays(packed, 2, o, d, v, z)
+        pts = ops.ray_points(o, d, z)
+        raw_p = ops.mlp_forward_points(packed, 2, pts.reshape(-1, 3), v[:, None, :].expand(77, S, 3).reshape(-1, 3))
+        assert torch.equal(raw_r.reshape(-1, 6), raw_p), "ray-mode and point-mode kernels must agree bit for bit"
+
+
+def test_repack_on_parameter_change(manifest):
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
+    net.load_state_dict(ref_state("semcoord", manifest))
+    pts = torch.rand(64, 3, device=DEV)
+    with torch.no_grad():
+        a = net.nerf_fine(pts, viewdirs=pts)
+        b = net.nerf_fine(pts, viewdirs=pts)
+        assert torch.equal(a, b)
+        net.nerf_fine.mlp.semantic_linear[2].bias.add_(1.0)  # what an optimizer step does
+        c = net.nerf_fine(pts, viewdirs=pts)
+    assert torch.allclose(c[:, 4:], a[:, 4:] + 1.0, atol=1e-6) and torch.equal(c[:, :4], a[:, :4])
+
+
+# ------------------------------------------------------------------------------------------ end to end
+CASES = [("nosem", False, False, 128), ("semcoord", False, False, 128), ("semcoord", True, False, 128),
+         ("sem", True, True, 128), ("nosem", True, False, 0)]
+
+
+class _Draws:
+    def __init__(self, tensors):
+        self.q = list(tensors)
+
+    def __call__(self, shape, device=None, **kw):
+        t = self.q.pop(0)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.to(device)
+
+
+@pytest.mark.parametrize("name,peaky,white,n_imp", CASES)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_end_to_end_vs_reference(golden, manifest, monkeypatch, name, peaky, white, n_imp, mode):
+    g = golden("end_to_end")
+    tag = tag_of(name, peaky, white, n_imp == 0) + "_" + mode
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=n_imp, perturb=1.0, raw_noise_std=1.0, white_bkgd=white,
+                               **CFGS[name]).to(DEV)
+    net.load_state_dict(ref_state(name, manifest, peaky, n_imp))
+    net.train(mode == "train")
+    if mode == "train":
+        dr = [torch.as_tensor(g[f"{tag}_draw{i}"]) for i in range(4 if n_imp else 2)]
+        rand = _Draws([dr[0]] + ([dr[2]] if n_imp else []))
+        randn = _Draws([dr[1]] + ([dr[3]] if n_imp else []))
+        monkeypatch.setattr(torch, "rand", rand)
+        monkeypatch.setattr(torch, "randn", randn)
+    with torch.no_grad():
+        out = net(T(g["rays"]), (tp.NEAR, tp.FAR), radii=None)
+    keys = sorted(k[len(tag) + 1:] for k in g if k.startswith(tag + "_") and "draw" not in k)
+    assert sorted(out.keys()) == keys, "output dict keys must match the reference's"
+    for k in keys:
+        want = g[f"{tag}_{k}"]
+        got = N(out[k])
+        assert got.shape == want.shape, f"{k}: {got.shape} vs {want.shape}"
+        if k in ("weights", "raw", "z_std") and n_imp:
+            err = np.abs(got.astype(np.float64) - want)
+            tol = 1e-4 + 1e-4 * np.abs(want)
+            assert (err > tol).mean() < 5e-3, f"{tag} {k}: {(err > tol).mean():.4f} outside tol"
+        else:
+            close(got, want, what=f"{tag} {k}")
+
+
+def test_flower_full_batch_properties(manifest):
+    """BASELINE config C2 size (4096 rays x (64+192), fp32): size-independent properties + a sampled
+    oracle check, since the C oracle needs minutes for the full batch."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    rays = tp.synthetic_rays(4096, seed=0).to(DEV)
+    with torch.no_grad():
+        a = net(rays, (tp.NEAR, tp.FAR))
+        b = net(rays, (tp.NEAR, tp.FAR))
+        net.chunk = 1000  # ragged ray chunks: 4 x 1000 + 96
+        c = net(rays, (tp.NEAR, tp.FAR))
+        net.chunk = 32768
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: not deterministic"
+        assert torch.equal(a[k], c[k]), f"{k}: result depends on the ray chunking"
+        assert torch.isfinite(a[k]).all() or k in ("depth", "depth0")
+    assert a["raw"].shape == (4096, 192, 6) and a["weights"].shape == (4096, 192) and a["z_std"].shape == (4096,)
+    assert (a["acc"] <= 1 + 1e-5).all() and (a["weights"] >= 0).all()
+    assert torch.allclose(a["weights"].sum(-1, keepdim=True), a["acc"], atol=1e-5)
+    sel = torch.arange(0, 4096, 171)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = co.render(sd, rays[0][sel].cpu(), rays[1][sel].cpu(), tp.NEAR, tp.FAR, use_semantics=True, sem_with_coord=True)
+    for k in ("rgb", "depth", "acc", "disp", "semantics", "rgb0", "depth0", "semantics0", "weights0", "raw0"):
+        close(N(a[k][sel]).reshape(ref[k].shape), ref[k], what=f"C2-size {k}")
+
+
+def test_empty_batch():
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128).to(DEV).eval()
+    with torch.no_grad():
+        out = net.render_rays(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV),
+                              torch.zeros(0, device=DEV), torch.zeros(0, device=DEV))
+    assert out["rgb"].shape == (0, 3) and out["weights"].shape == (0, 192)

@@ -1,0 +1,58 @@
+"""CPU: host-side mirror of the reference interface -- parameter names, shapes, init order, state-dict
+interchange, mode switch, unsupported-architecture errors."""
+import pytest
+import torch
+
+import nerf_sos_amd
+from helpers import CFGS, ref_state, state_sha
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_same_init_and_keys_as_reference(manifest, name):
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS[name])
+    sd = net.state_dict()
+    assert list(sd.keys()) == manifest["state_keys"][name]
+    assert state_sha(sd) == manifest["state_sha256"][name], "seed-0 init must equal the reference's bit for bit"
+    want = ref_state(name, manifest)
+    for k in sd:
+        assert sd[k].shape == want[k].shape
+
+
+def test_coarse_only_aliases_fine(manifest):
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=0)
+    assert net.nerf_fine is net.nerf
+    assert state_sha(net.state_dict()) == manifest["state_sha256"]["nosem_coarse_only"]
+
+
+def test_load_reference_state_dict_strict(manifest):
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True)
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True), strict=True)
+    # frozen-backbone recipe of run_nerf.py:307-318 works on the mirrored names
+    n_train = 0
+    for n, p in net.named_parameters():
+        p.requires_grad = 'semantic_linear' in n
+        n_train += p.numel() if p.requires_grad else 0
+    assert n_train == 82436
+    assert sum(p.numel() for p in net.parameters()) == 1274124
+
+
+def test_mode_kwargs():
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0)
+    assert net.render_kwargs_train["perturb"] == 1.0 and net.render_kwargs_train["retraw"] is True
+    assert net.render_kwargs_test["perturb"] == 0.0 and net.render_kwargs_test["raw_noise_std"] == 0.0
+    assert net.chunk == 32768 and net.nerf.chunk == 65536
+
+
+@pytest.mark.parametrize("kw", [dict(netwidth=128), dict(multires=6), dict(viewdirs=False), dict(conv_embed=True),
+                                dict(use_semantics=True, sem_layer=4), dict(use_semantics=True, sem_dim=5)])
+def test_unsupported_architectures_raise(kw):
+    with pytest.raises(NotImplementedError, match="specialised"):
+        nerf_sos_amd.NeRFNet(**kw)
+
+
+def test_shape_assert_matches_reference():
+    net = nerf_sos_amd.NeRFNet()
+    with torch.no_grad(), pytest.raises(AssertionError):
+        net((torch.zeros(4, 3), torch.zeros(5, 3)), (1.0, 2.0))

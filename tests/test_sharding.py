@@ -1,0 +1,70 @@
+"""CPU: the N>1 path -- ray sharding and the patch all-gather -- on world_size-2 gloo."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_sos_amd import sharding
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 762048, 95256 * 8 + 3):
+        for world in (1, 2, 4, 8):
+            spans = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_bounds(762048, 0, 8) == (0, 95256)
+    assert sharding.local_patches(16, 3, 8) == [3, 11]
+
+
+def _fake_render(ray_batch, bounds, **kw):
+    o, d = ray_batch
+    near, far = bounds
+    near = near if isinstance(near, torch.Tensor) else torch.full((d.shape[0],), float(near))
+    return {"rgb": d * 2.0 + o, "depth": (d.sum(-1, keepdim=True) + near[:, None]), "weights": d.repeat(1, 2)}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        R = 1001  # not divisible by the world size
+        o, d = torch.randn(R, 3), torch.randn(R, 3)
+        near = torch.rand(R)
+        full = _fake_render((o, d), (near, 6.0))
+        got = sharding.render_image_sharded(_fake_render, o, d, (near, 6.0), gather=True)
+        ok = all(torch.equal(got[k], full[k]) for k in full)
+        mine = sharding.render_image_sharded(_fake_render, o, d, (near, 6.0), gather=False, keys=("rgb",))
+        s, e = sharding.shard_bounds(R, rank, world)
+        ok = ok and torch.equal(mine["rgb"], full["rgb"][s:e]) and list(mine) == ["rgb"]
+        # patches: B=5 patches of 4x4, owner = b mod world
+        B, P = 5, 4
+        allp = {"semantics": torch.randn(B, P, P, 2), "depth": torch.randn(B, P, P, 1), "rgb": torch.randn(B, P, P, 3)}
+        own = sharding.local_patches(B, rank, world)
+        local = {k: v[own].clone().requires_grad_(k == "semantics") for k, v in allp.items()}
+        g = sharding.all_gather_patches(local, B, keys=("semantics", "depth", "semantics0"))
+        ok = ok and set(g) == {"semantics", "depth"} and all(torch.equal(g[k], allp[k]) for k in g)
+        ok = ok and not g["semantics"].requires_grad
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gloo_world2_shard_and_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, True), (1, True)]
