@@ -28,26 +28,36 @@ FLOP_PER_RAY = 2 * MAC_PER_POINT * EVALS_PER_RAY       # 303.82 MFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def cpu_baseline(n_rays_sample: int, budget_s: float = 20.0):
+def cpu_baseline(n_rays_sample: int, budget_s: float = 25.0):
     """The reference's CPU path = the pure-torch op-for-op port (bit-identical to the reference on CPU,
-    tests/golden/make_goldens.py), eval-mode forward, all host cores, on a bounded sample of the workload."""
+    tests/golden/make_goldens.py), eval-mode forward, on a bounded sample of the workload.  torch's CPU
+    kernels do not scale to every logical CPU of the GPU box (measured: 256 threads are 35x SLOWER than 32 on
+    the 2x64-core EPYC host), so a few thread counts are tried inside the budget and the best is reported,
+    with the thread count actually used."""
     from oracle import torch_port as tp
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     cfg = tp.PortConfig(n_samples=N_COARSE, n_importance=N_IMPORTANCE, use_semantics=False, pts_chunk=1024 * 256)
     sd = tp.init_state_dict(cfg, seed=0)
     rays = tp.synthetic_rays(n_rays_sample, seed=0)
-    best, reps, t_all = float("inf"), 0, time.perf_counter()
+    best, best_threads, reps, t_all = float("inf"), 0, 0, time.perf_counter()
     with torch.no_grad():
-        tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)  # warm-up
-        while reps < 5 and (time.perf_counter() - t_all) < budget_s:
-            t0 = time.perf_counter()
-            tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
-            best = min(best, time.perf_counter() - t0)
-            reps += 1
-    return {"value": round(n_rays_sample / best, 1), "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n_rays_sample} of the {N_RAYS} rays of the same batch, eval forward, best of {reps}, "
-                      f"torch {torch.__version__} CPU ops ({cores} threads)"}
+        for threads in sorted({min(ncpu, t) for t in (32, 16, 64)}, key=lambda t: abs(t - 32)):
+            if reps and (time.perf_counter() - t_all) > budget_s * 0.6:
+                break
+            torch.set_num_threads(threads)
+            tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)  # warm-up
+            for _ in range(3):
+                t0 = time.perf_counter()
+                tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
+                dt = time.perf_counter() - t0
+                reps += 1
+                if dt < best:
+                    best, best_threads = dt, threads
+                if (time.perf_counter() - t_all) > budget_s:
+                    break
+    return {"value": round(n_rays_sample / best, 1), "unit": "rays/s", "cores": best_threads, "kind": "port",
+            "sample": f"{n_rays_sample} of the {N_RAYS} rays of the same batch, eval-mode forward, best of {reps} runs over "
+                      f"thread counts <= 64 (host has {ncpu} logical CPUs), torch {torch.__version__} CPU ops"}
 
 
 def main():
@@ -128,7 +138,7 @@ def main():
                          "whole_path_frac": round(value / world * FLOP_PER_RAY / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(512)
+            line["cpu_baseline"] = cpu_baseline(1024)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

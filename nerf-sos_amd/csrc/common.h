@@ -20,6 +20,7 @@ static inline int32_t nsos_launch_status() {
 // torch.linspace(0, 1, n) fp32 exactly as ATen's CPU kernel evaluates it (symmetric fma form):
 // step = 1/(n-1);  i < n/2 : fma(step, i, 0)  else  fma(-step, n-1-i, 1).
 __device__ __forceinline__ float nsos_linspace01(int i, int n) {
+    if (n == 1) return 0.0f;  // torch.linspace(0, 1, 1) == [0]
     const float step = 1.0f / (float)(n - 1);
     return (i < n / 2) ? __fmaf_rn(step, (float)i, 0.0f) : __fmaf_rn(-step, (float)(n - 1 - i), 1.0f);
 }

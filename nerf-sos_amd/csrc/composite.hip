@@ -115,6 +115,7 @@ extern "C" int32_t nsos_composite(const float* raw, const float* z_vals, const f
                                   float noise_std, int64_t n_rays, int32_t n_samples, int32_t n_ch,
                                   int32_t white_bkgd, float* weights, float* rgb, float* sem, float* depth,
                                   float* acc, float* disp, void* stream) {
+    if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(raw && z_vals && rays_d && weights && rgb && depth && acc && disp, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_ch == 4 || n_ch == 5 || n_ch == 6, NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(n_ch == 4 || sem, NSOS_ERR_NULL_POINTER);

@@ -501,6 +501,7 @@ extern "C" int32_t nsos_mlp_pack(const nsos_mlp_tensors* T, int32_t sem_mode, vo
 extern "C" int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, const float* rays_o,
                                          const float* rays_d, const float* viewdirs, const float* z_vals,
                                          int64_t n_rays, int32_t n_samples, float* raw, void* stream) {
+    if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
@@ -518,6 +519,7 @@ extern "C" int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, c
 
 extern "C" int32_t nsos_mlp_forward_points(const void* packed, int32_t sem_mode, const float* pts,
                                            const float* dirs, int64_t n_pts, float* raw, void* stream) {
+    if (n_pts == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(packed && pts && dirs && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_pts >= 0, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void importance_kernel(const float* __restrict
 extern "C" int32_t nsos_ray_setup(const float* rays_d, const float* near, const float* far, const float* t_rand,
                                   int64_t n_rays, int32_t n_samples, float* z_vals, float* viewdirs,
                                   void* stream) {
+    if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(rays_d && near && far && z_vals, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 2, NSOS_ERR_BAD_SHAPE);
     if (n_rays == 0) return NSOS_OK;
@@ -192,6 +193,7 @@ extern "C" int32_t nsos_ray_setup(const float* rays_d, const float* near, const 
 
 extern "C" int32_t nsos_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays,
                                    int32_t n_samples, float* pts, void* stream) {
+    if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(rays_o && rays_d && z_vals && pts, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     if (n_rays == 0) return NSOS_OK;
@@ -206,6 +208,7 @@ extern "C" int32_t nsos_importance_sample(const float* z_vals, const float* weig
                                           const float* cdf_in, int64_t n_rays, int32_t n_coarse,
                                           int32_t n_importance, float* z_fine, float* z_samples, float* z_std,
                                           float* cdf_out, int64_t* inds_out, void* stream) {
+    if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(z_vals && (weights || cdf_in) && z_fine && z_samples && z_std, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_importance >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_coarse == 64 && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);

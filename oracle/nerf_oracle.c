@@ -44,6 +44,7 @@ int32_t oracle_num_threads(void) {
 /* torch.linspace(start, end, n) on CPU, fp32: step = (end-start)/(n-1);
  * i < n/2 : fma(step, i, start)   else   fma(-step, n-1-i, end).   (verified bitwise) */
 static inline float linspace01(int i, int n) {
+    if (n == 1) return 0.0f; /* torch.linspace(0, 1, 1) == [0] */
     const float step = 1.0f / (float)(n - 1);
     return (i < n / 2) ? fmaf(step, (float)i, 0.0f) : fmaf(-step, (float)(n - 1 - i), 1.0f);
 }
