@@ -25,6 +25,8 @@
 // Compiled with -ffp-contract=off (x = o + d*z must stay a separately rounded multiply and add).
 #include "common.h"
 
+#include <type_traits>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -75,29 +77,91 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// 16 k-steps x 8 output tiles = 128 MFMAs.  wl = chunk base in LDS + lane*4 floats.
-__device__ __forceinline__ void chunk8(f32x16 (&acc)[8], const float* wl, const f32x16& b) {
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (ks * 2 + q) * 256);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 * q + j] = mfma(a[j], b[ks], acc[4 * q + j]);
-        }
+// ---- A-operand pipeline -------------------------------------------------------------------------
+// One ds_read_b128 feeds a group of 4 MFMAs (256 cycles of matrix pipe).  hipcc, left alone, issues each
+// read right before its use and waits lgkmcnt(0) (measured: 131 TF of the 157 TF peak), and with
+// source-level prefetching it still waits for the YOUNGEST read.  So the reads are inline asm, invisible to
+// the compiler's wait-count pass, with hand-counted waits (cdna_hip_programming.md section 5.7, form iii):
+// a ring of kRing slots; slot g%kRing is re-loaded for group g+kRing right after group g's MFMAs were
+// issued, so while group g computes, the reads of groups g+1 .. g+kRing-1 are in flight (LDS returns in
+// order: "lgkmcnt(kRing-1)" == "group g has landed").  Every chunk starts right after a __syncthreads()
+// (lgkmcnt(0)), and no other LGKM-counted op (ds_*, s_load) is issued inside a chunk, so the counts hold.
+constexpr int kRing = 3;
+#define NSOS_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <int OFF_BYTES>
+__device__ __forceinline__ void lds_read_a(f32x4& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF_BYTES) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
-// NKS k-steps x 4 output tiles.  b0 covers k-steps 0..15, b1 16..31.
-template <int NKS>
-__device__ __forceinline__ void chunk4(f32x16 (&acc)[4], const float* wl, const f32x16& b0, const f32x16& b1) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(wl + ks * 256);
-        const float b = ks < 16 ? b0[ks & 15] : b1[ks & 15];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = mfma(a[j], b, acc[j]);
+// NG groups of 4 MFMAs; group g's A operands are the f32x4 at byte offset g*1024 from wl (which already
+// includes lane*16).  mfma4(g, a) issues the 4 MFMAs of group g.
+template <int NG, class M>
+__device__ __forceinline__ void a_pipeline(unsigned wl, M&& mfma4) {
+    f32x4 ring[kRing];
+    static_for<0, (kRing < NG ? kRing : NG)>([&](auto ic) {
+        constexpr int g = decltype(ic)::value;
+        lds_read_a<g * 1024>(ring[g], wl);
+    });
+    static_for<0, NG>([&](auto ic) {
+        constexpr int g = decltype(ic)::value;
+        constexpr int in_flight_after = (NG - 1 - g) < (kRing - 1) ? (NG - 1 - g) : (kRing - 1);
+        lgkm_wait<in_flight_after>();
+        NSOS_PIN();
+        mfma4(ic, ring[g % kRing]);
+        NSOS_PIN();
+        if constexpr (g + kRing < NG) lds_read_a<(g + kRing) * 1024>(ring[g % kRing], wl);
+    });
+}
+
+// The DMA of the NEXT chunk (8 x 1 KiB pieces per wave) is issued from inside the current chunk: piece i
+// right after the i-th MFMA of groups 1-2, so its address arithmetic and issue slots are covered by the
+// 64-cycle MFMAs instead of idling the matrix pipe after every barrier.  side(i) issues piece i.
+template <int G, int J, class S>
+__device__ __forceinline__ void dma_slot(S&& side) {
+    if constexpr (G == 1 || G == 2) {
+        NSOS_PIN();
+        side((G - 1) * 4 + J);
+        NSOS_PIN();
     }
+}
+
+// 16 k-steps x 8 output tiles = 128 MFMAs; group g = (k-step g>>1, tile quad g&1).
+template <class S>
+__device__ __forceinline__ void chunk8(f32x16 (&acc)[8], unsigned wl, const f32x16& b, S&& side) {
+    a_pipeline<32>(wl, [&](auto ic, const f32x4& a) {
+        constexpr int g = decltype(ic)::value, q = g & 1;
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            acc[4 * q + j] = mfma(a[j], b[g >> 1], acc[4 * q + j]);
+            dma_slot<g, j>(side);
+        });
+    });
+}
+
+// NKS k-steps x 4 output tiles; group g = k-step g.  b0 covers k-steps 0..15, b1 16..31.
+template <int NKS, class S>
+__device__ __forceinline__ void chunk4(f32x16 (&acc)[4], unsigned wl, const f32x16& b0, const f32x16& b1, S&& side) {
+    a_pipeline<NKS>(wl, [&](auto ic, const f32x4& a) {
+        constexpr int g = decltype(ic)::value;
+        const float b = g < 16 ? b0[g & 15] : b1[g & 15];
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            acc[j] = mfma(a[j], b, acc[j]);
+            dma_slot<g, j>(side);
+        });
+    });
 }
 
 template <int NT>
@@ -181,30 +245,29 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
     constexpr int NCH = chunks_per_net(SEM);
     constexpr int C = SEM ? 6 : 4;
 
-    // ---- weight stream: chunk `cur` is consumed from buffer `par`; chunk cur+1 is in flight into par^1
+    // ---- weight stream: chunk `cur` is consumed from buffer `par`; chunk cur+1 is DMA'd into par^1 meanwhile
     int cur = 0, par = 0;
-    auto issue = [&](int chunk, int buf) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int piece = i * 4 + wave;  // 32 pieces of 1 KiB; this wave copies 8 of them
-            const float* src = P.chunks + (size_t)chunk * kChunkFloats + piece * 256 + lane * 4;
-            float* dst = lds + buf * kChunkFloats + piece * 256;  // wave-uniform; HW adds lane*16 B
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+    const float* const src_lane = P.chunks + wave * 256 + lane * 4;  // + chunk*8192 + i*1024 floats
+    auto dma_piece = [&](int chunk, int buf, int i) {  // 32 pieces of 1 KiB per chunk; this wave copies 8
+        const float* src = src_lane + (size_t)chunk * kChunkFloats + i * 1024;
+        float* dst = lds + buf * kChunkFloats + (i * 4 + wave) * 256;  // wave-uniform; HW adds lane*16 B
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    // stage protocol: the barrier proves (a) chunk `cur` has landed (every wave drained its own DMA
-    // before arriving) and (b) every wave is done reading buffer par^1, which the next DMA overwrites.
-    auto stage_begin = [&]() -> const float* {
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    // stage protocol: the barrier proves (a) chunk `cur` has landed (every wave drained its own DMA before
+    // arriving) and (b) every wave is done reading buffer par^1, which this stage's DMA pieces overwrite.
+    auto stage_begin = [&]() -> unsigned {  // LDS byte address of this lane's first A operand
         __syncthreads();
-        issue(cur + 1 == NCH ? 0 : cur + 1, par ^ 1);
-        return lds + par * kChunkFloats + lane * 4;
+        return lds_base + (unsigned)(par * kChunkFloats + lane * 4) * 4u;
     };
+    auto side = [&](int i) { dma_piece(cur + 1 == NCH ? 0 : cur + 1, par ^ 1, i); };
     auto stage_end = [&]() {
         cur = (cur + 1 == NCH) ? 0 : cur + 1;
         par ^= 1;
     };
-    issue(0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(0, 0, i);
 
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         // ---- this lane's point (both half-waves of a column hold the same point)
@@ -244,16 +307,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
             if (l == 0 || l == 5) {  // encoded xyz enters (layer 0; skip connection, input-first cat)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float* wl = stage_begin();
-                    chunk8(acc, wl, ex[c]);
+                    const unsigned wl = stage_begin();
+                    chunk8(acc, wl, ex[c], side);
                     stage_end();
                 }
             }
             if (l != 0) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float* wl = stage_begin();
-                    chunk8(acc, wl, hin[c]);
+                    const unsigned wl = stage_begin();
+                    chunk8(acc, wl, hin[c], side);
                     stage_end();
                 }
             }
@@ -275,13 +338,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
                     load_bias<4>(sacc, P.aux + kAuxSem0B + hi * 64);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float* wl = stage_begin();
-                        chunk4<32>(sacc, wl, hin[2 * c], hin[2 * c + 1]);
+                        const unsigned wl = stage_begin();
+                        chunk4<32>(sacc, wl, hin[2 * c], hin[2 * c + 1], side);
                         stage_end();
                     }
                     if constexpr (SEM == 2) {
-                        const float* wl = stage_begin();
-                        chunk4<32>(sacc, wl, ex[0], ex[1]);
+                        const unsigned wl = stage_begin();
+                        chunk4<32>(sacc, wl, ex[0], ex[1], side);
                         stage_end();
                     }
 #pragma unroll
@@ -302,13 +365,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         load_bias<4>(vacc, P.aux + kAuxViewsB + hi * 64);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float* wl = stage_begin();
-            chunk4<32>(vacc, wl, hin[2 * c], hin[2 * c + 1]);
+            const unsigned wl = stage_begin();
+            chunk4<32>(vacc, wl, hin[2 * c], hin[2 * c + 1], side);
             stage_end();
         }
         {
-            const float* wl = stage_begin();
-            chunk4<16>(vacc, wl, ed, ed);
+            const unsigned wl = stage_begin();
+            chunk4<16>(vacc, wl, ed, ed, side);
             stage_end();
         }
 #pragma unroll
