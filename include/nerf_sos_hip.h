@@ -109,6 +109,13 @@ int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, const float*
 int32_t nsos_mlp_forward_points(const void* packed, int32_t sem_mode, const float* pts, const float* dirs,
                                 int64_t n_pts, float* raw, void* stream);
 
+/* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
+ * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).
+ * Not on the product path; used to attribute the kernel's non-MFMA cycles (profiles/). */
+int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                              const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                              float* raw, uint64_t* stamps, void* stream);
+
 /* ---- K3: compositing ------------------------------------------------------------------------
  * VolumetricRenderer.forward (models/renderer.py:35-85): sigma->alpha, exclusive transmittance
  * product, weights, and the weighted sums.  noise (may be NULL) is the raw randn [R,S]; it is

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_sos_hip.so")
+# NERF_SOS_HIP_LIB overrides the in-tree library (A/B experiments with alternative kernel builds only)
+LIB_PATH = os.environ.get("NERF_SOS_HIP_LIB") or os.path.join(_HERE, "libnerf_sos_hip.so")
 
 _fp = C.c_void_p
 _i32, _i64, _f32, _sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -27,6 +28,7 @@ SIGNATURES = {
     "nsos_ray_setup": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_ray_points": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "nsos_mlp_profile_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),
     "nsos_composite": (_i32, [_fp, _fp, _fp, _fp, _f32, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -6,22 +6,30 @@
 // Mapping (DESIGN.md "K2"):
 //   * MFMA-bound (593k-634k MAC per point against 16-28 B of HBM I/O): everything is organised to keep
 //     v_mfma_f32_32x32x2_f32 issuing back to back (64 cycles each, 64 FLOP/clk/SIMD = the fp32 peak).
-//   * A workgroup = 4 waves = one wave per SIMD; wave w owns 32 points; a workgroup tile = 128 points.
-//     The products are computed TRANSPOSED: D[out feature i][point j] = sum_k W[i][k] * h[k][j], i.e.
-//     the weights are the MFMA A operand and the activations the B operand.  With that orientation the
-//     accumulator layout of layer L (lane (j, hi) holds features 32t + (r&3) + 8(r>>2) + 4hi of point j)
-//     IS the B-operand layout of layer L+1 (lane (j, hi) supplies k = hi of a k-pair), so activations
-//     never leave the register file: no LDS round trip, no shuffles, 128 live registers per lane.
+//   * A workgroup = 4 waves = one wave per SIMD (all 512 registers per lane); wave w owns 32 points; a
+//     workgroup tile = 128 points.  Products are computed TRANSPOSED: D[out feature i][point j] =
+//     sum_k W[i][k] * h[k][j]: weights are the MFMA A operand, activations the B operand.  With that
+//     orientation the accumulator layout of layer L (lane (j, hi) holds features 32t + (r&3) + 8(r>>2) + 4hi
+//     of point j) IS the B-operand layout of layer L+1 (lane (j, hi) supplies k = hi of a k-pair), so
+//     activations never leave the register file: no LDS round trip, no shuffles.  Accumulators Z live in
+//     the AGPR half of the file; after each layer ONE batched pass H = max(Z, 0) (v_accvgpr_read + v_max_f32
+//     per element) moves them to 128 VGPRs that the next layer's MFMAs name directly as srcB.
+//     Why batched: measured on this chip (scripts/ubench/mfma_gap.hip), a wave's own VALU instructions do
+//     NOT hide under its MFMAs -- an isolated VALU op between two MFMAs costs +12 cycles, a run of n costs
+//     ~8+4n -- while SALU, ds_read and s_waitcnt are free.  So chunks contain no VALU work at all.
 //     The price is a fixed, non-monotone k order of every contraction (0,4,1,5,2,6,3,7 per 8 features);
 //     since the fp32 MFMA is bitwise an fmaf chain, the oracle simply follows the same order.
-//   * The weights (2.3-2.4 MiB per net, L2-resident) are pre-packed by nsos_mlp_pack into the exact
-//     order the MFMAs consume them and streamed through LDS in 32 KiB chunks (128 A-operands each) by
-//     direct global->LDS DMA, double buffered: one s_barrier per 128 MFMAs (8192 cycles).
-//     Each lane fetches the A operands of 4 MFMAs with one conflict-free ds_read_b128.
+//   * Bias enters as a leading k-step with A = bias (k=0) / 0 (k=1), B = 1.0 and C = 0: fma(bias,1,0) = bias
+//     exactly, so the chain is bitwise "acc = bias; acc = fma(w, x, acc) ...", without bias loads, without
+//     accumulator initialisation, for 8 extra MFMAs per layer.
+//   * The weights (2.6-2.8 MiB per net incl. padding, L2-resident) are pre-packed by nsos_mlp_pack into the
+//     exact order the MFMAs consume them and streamed through LDS in 36 KiB slots by direct global->LDS DMA,
+//     three slots deep, ONE s_barrier per chunk (~8200 cycles).  Each lane fetches the A operands of 4 MFMAs
+//     with one conflict-free ds_read_b128 through a hand-counted register ring that never drains.
 //   * Small heads (sigma 256->1, rgb 128->3, semantics 128->2) would waste 31/32 of an MFMA tile, so they
 //     run on the vector ALU from the same registers (two half-wave partial sums + one cross-lane add).
-//   * Persistent grid (one workgroup per CU); the chunk stream is cyclic so the prefetch of the next
-//     tile's first chunk overlaps the current tile's tail.
+//   * Persistent grid (one workgroup per CU); the chunk stream is cyclic so the DMA of the next tile's
+//     first chunks overlaps the current tile's tail.
 // Compiled with -ffp-contract=off (x = o + d*z must stay a separately rounded multiply and add).
 #include "common.h"
 
@@ -33,30 +41,33 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int kChunkFloats = 8192;  // 32 KiB = 128 MFMA A-operands (64 lanes x 4 B each)
+constexpr int kGroupFloats = 256;                 // one group = A operands of 4 MFMAs = 64 lanes x 16 B = 1 KiB
+constexpr int kSlotGroups = 36;                   // LDS slot / packed-stream stride per chunk (34 used at most)
+constexpr int kSlotFloats = kSlotGroups * kGroupFloats;  // 36 KiB
+constexpr int kDmaPieces = kSlotGroups / 4;       // 1 KiB pieces per wave per chunk
 constexpr int kTilePts = 128;
 
-// aux stream (biases + vector-ALU head weights), offsets in floats.  256-wide vectors are stored in the
-// accumulator layout [hi][tile 0..7][reg 0..15], 128-wide ones as [hi][tile 0..3][reg 0..15].
-constexpr int kAuxBias = 0;         // 9 x 256: pts_linears.0..7, feature_linear
-constexpr int kAuxViewsB = 2304;    // 128
-constexpr int kAuxSem0B = 2432;     // 128
-constexpr int kAuxAlphaW = 2560;    // 256
-constexpr int kAuxRgbW = 2816;      // 3 x 128
-constexpr int kAuxSem2W = 3200;     // 2 x 128
-constexpr int kAuxScalars = 3456;   // alpha_b, rgb_b[3], sem2_b[2], 0, 0
-constexpr int kAuxFloats = 3584;
+// aux stream (vector-ALU head weights), offsets in floats.  256-wide vectors are stored in the accumulator
+// layout [hi][tile 0..7][reg 0..15], 128-wide ones as [hi][tile 0..3][reg 0..15].
+constexpr int kAuxAlphaW = 0;      // 256
+constexpr int kAuxRgbW = 256;      // 3 x 128
+constexpr int kAuxSem2W = 640;     // 2 x 128
+constexpr int kAuxScalars = 896;   // alpha_b, rgb_b[3], sem2_b[2], 0, 0
+constexpr int kAuxFloats = 1024;
 
+// Segment kinds of the packed stream.  "8"/"4" = output tiles; Hid = 256 hidden features in accumulator
+// order; Enc = the 63 encoded-xyz features (+1 pad) in natural order; Dir = the 27 encoded-direction features.
 enum SegKind { kHid8 = 0, kEnc8 = 1, kHid4 = 2, kEnc4 = 3, kDir4 = 4 };
 
 __host__ __device__ constexpr int chunks_per_net(int sem) {
-    // L0 enc(2) + L1-4 (4x8) + L5 enc(2)+hid(8) + L6,L7 (2x8) + [sem0 hid(4) (+enc 1)] + feature(8) + views hid(4)+dir(1)
+    // L0 enc(2) + L1-4 (4x8) + L5 hid(8)+enc(2) + L6,L7 (2x8) + [sem0 hid(4) (+enc 1)] + feature(8) + views hid(4)+dir(1)
     return 2 + 32 + 10 + 16 + (sem ? 4 + (sem == 2 ? 1 : 0) : 0) + 8 + 5;
 }
 
 // feature index held by (tile t, reg r, half hi) in the 32x32 accumulator layout
 __host__ __device__ constexpr int acc_feature(int t, int r, int hi) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+constexpr int kProfSlots = 64;
 struct MlpParams {
     const float* aux;
     const float* chunks;
@@ -70,6 +81,7 @@ struct MlpParams {
     long long n_pts;
     int n_samples;
     int n_tiles;
+    unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays): per-wave shader-clock stamps, or NULL
 };
 
 // ------------------------------------------------------------------------------------------ device helpers
@@ -77,26 +89,8 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// ---- A-operand pipeline -------------------------------------------------------------------------
-// One ds_read_b128 feeds a group of 4 MFMAs (256 cycles of matrix pipe).  hipcc, left alone, issues each
-// read right before its use and waits lgkmcnt(0) (measured: 131 TF of the 157 TF peak), and with
-// source-level prefetching it still waits for the YOUNGEST read.  So the reads are inline asm, invisible to
-// the compiler's wait-count pass, with hand-counted waits (cdna_hip_programming.md section 5.7, form iii):
-// a ring of kRing slots; slot g%kRing is re-loaded for group g+kRing right after group g's MFMAs were
-// issued, so while group g computes, the reads of groups g+1 .. g+kRing-1 are in flight (LDS returns in
-// order: "lgkmcnt(kRing-1)" == "group g has landed").  Every chunk starts right after a __syncthreads()
-// (lgkmcnt(0)), and no other LGKM-counted op (ds_*, s_load) is issued inside a chunk, so the counts hold.
-constexpr int kRing = 3;
 #define NSOS_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int OFF_BYTES>
-__device__ __forceinline__ void lds_read_a(f32x4& dst, unsigned lds_addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF_BYTES) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
-}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -105,79 +99,174 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// NG groups of 4 MFMAs; group g's A operands are the f32x4 at byte offset g*1024 from wl (which already
-// includes lane*16).  mfma4(g, a) issues the 4 MFMAs of group g.
-template <int NG, class M>
-__device__ __forceinline__ void a_pipeline(unsigned wl, M&& mfma4) {
-    f32x4 ring[kRing];
-    static_for<0, (kRing < NG ? kRing : NG)>([&](auto ic) {
-        constexpr int g = decltype(ic)::value;
-        lds_read_a<g * 1024>(ring[g], wl);
-    });
+// ---- A-operand pipeline -------------------------------------------------------------------------
+// One ds_read_b128 feeds a group of 4 MFMAs (256 cycles of matrix pipe).  hipcc, left alone, issues each
+// read right before its use and waits lgkmcnt(0), and with source-level prefetching it still waits for the
+// YOUNGEST read.  So the reads are inline asm, invisible to the compiler's wait-count pass, with hand-counted
+// waits (cdna_hip_programming.md section 5.7, form iii):
+//   * a ring of kRing slots: slot g%kRing is re-loaded for group g+kRing right after group g's MFMAs were
+//     issued, so while group g computes, the reads of the next kRing-1 groups are in flight (LDS returns in
+//     order, so "lgkmcnt(n)" with n = number of younger reads == "group g has landed");
+//   * the ring never drains at a chunk boundary: during groups NG-6..NG-4 the first kRing groups of the
+//     NEXT chunk (already resident in the next LDS slot) are read into `nxt`, and become the ring at the
+//     chunk's end (lgkmcnt(0) there is free: those reads are >= 3 groups old);
+//   * extra outstanding LGKM/VM operations the compiler may issue can only make a counted wait stricter
+//     (in-order return within a class), never looser, so the counts are safe.
+// Three LDS slots: chunk c is consumed from slot c%3 while chunk c+1 is resident in the next one and chunk
+// c+2 is being DMA'd into the third.  ONE workgroup barrier per chunk, before group kMidGroup: every wave
+// drains its own DMA (vmcnt(0), issued a whole chunk earlier) and arrives; passing it proves (a) chunk c+1
+// has landed for every wave and (b) every wave has finished chunk c-1, whose slot the DMA pieces issued right
+// after the barrier (one per MFMA shadow) overwrite.  The ring reads simply continue across the barrier.
+#ifdef NSOS_EXP_RING
+constexpr int kRing = NSOS_EXP_RING;
+#else
+constexpr int kRing = 3;
+#endif
+constexpr int kMidGroup = 4;
+
+template <int OFF_BYTES>
+__device__ __forceinline__ void lds_read_a(f32x4& dst, unsigned lds_addr) {
+#ifdef NSOS_EXP_NOLDS  // timing experiment only (garbage results)
+    asm volatile("" : "+v"(dst));
+    return;
+#endif
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF_BYTES) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+#ifdef NSOS_EXP_NOWAIT  // timing experiment only (racy)
+    return;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// Issue schedule of one chunk's LDS reads, in program order: after the MFMAs of group g:
+//   R(g+kRing) if g+kRing < NG   (ring reload),   then   N(g-(NG-6)) if NG-6 <= g < NG-6+kRing  (next chunk).
+// younger_reads(NG, g) = number of reads issued after R(g) and before group g's MFMAs (0 for g < kRing,
+// whose data was waited for at the previous chunk's end).
+__host__ __device__ constexpr int reads_after_group(int NG, int g) {
+    return (g + kRing < NG ? 1 : 0) + ((g >= NG - 6 && g < NG - 6 + kRing) ? 1 : 0);
+}
+__host__ __device__ constexpr int younger_reads(int NG, int g) {
+    if (g < kRing) return 0;
+    int n = reads_after_group(NG, g - kRing) - 1;  // R(g) is the first read issued after group g-kRing
+    for (int h = g - kRing + 1; h < g; ++h) n += reads_after_group(NG, h);
+    return n;
+}
+
+struct ChunkCtx {     // what a chunk needs from the weight stream
+    unsigned wl_cur;  // LDS byte address of this lane's A operands in the current chunk's slot
+    unsigned wl_nxt;  // same for the next chunk's slot
+};
+
+// NG groups of 4 MFMAs; group g's A operands are the f32x4 at byte offset g*1024 from ctx.wl_cur (which
+// already includes lane*16).  mfma4(g, a) issues the 4 MFMAs of group g plus whatever rides in their shadows.
+// tail() advances the weight stream's bookkeeping (slot rotation, DMA source pointer): it runs in the MFMA
+// shadow after group NG-3, i.e. after the last use of the current values, so nothing is left to compute
+// between two chunks (measured: ~150 exposed cycles per chunk boundary otherwise).
+template <int NG, class M, class B, class T>
+__device__ __forceinline__ void a_pipeline(f32x4 (&ring)[kRing], const ChunkCtx ctx, M&& mfma4, B&& mid, T&& tail) {
+    static_assert(NG >= kMidGroup + 3 + 6 && NG <= kSlotGroups, "chunk length outside the barrier/DMA/preload schedule");
+    f32x4 nxt[kRing];
     static_for<0, NG>([&](auto ic) {
         constexpr int g = decltype(ic)::value;
-        constexpr int in_flight_after = (NG - 1 - g) < (kRing - 1) ? (NG - 1 - g) : (kRing - 1);
-        lgkm_wait<in_flight_after>();
+        if constexpr (g == kMidGroup) {
+            NSOS_PIN();
+            mid();
+            NSOS_PIN();
+        }
+        if constexpr (g >= kRing) lgkm_wait<younger_reads(NG, g)>();
         NSOS_PIN();
         mfma4(ic, ring[g % kRing]);
         NSOS_PIN();
-        if constexpr (g + kRing < NG) lds_read_a<(g + kRing) * 1024>(ring[g % kRing], wl);
+        if constexpr (g + kRing < NG) lds_read_a<(g + kRing) * 1024>(ring[g % kRing], ctx.wl_cur);
+        if constexpr (g >= NG - 6 && g < NG - 6 + kRing) lds_read_a<(g - (NG - 6)) * 1024>(nxt[g - (NG - 6)], ctx.wl_nxt);
+        if constexpr (g == NG - 3) {
+            NSOS_PIN();
+            tail();
+            NSOS_PIN();
+        }
     });
+    lgkm_wait<0>();
+    NSOS_PIN();
+    // The next chunk starts at group 0, which uses slot 0: re-assignment in order is right for every NG.
+#pragma unroll
+    for (int i = 0; i < kRing; ++i) ring[i] = nxt[i];
 }
 
-// The DMA of the NEXT chunk (8 x 1 KiB pieces per wave) is issued from inside the current chunk: piece i
-// right after the i-th MFMA of groups 1-2, so its address arithmetic and issue slots are covered by the
-// 64-cycle MFMAs instead of idling the matrix pipe after every barrier.  side(i) issues piece i.
+// The DMA of chunk c+2 (kDmaPieces x 1 KiB per wave) is issued from inside chunk c: one piece after each of
+// the first kDmaPieces MFMAs that follow the barrier, so its issue slots are covered by the 64-cycle MFMAs.
 template <int G, int J, class S>
 __device__ __forceinline__ void dma_slot(S&& side) {
-    if constexpr (G == 1 || G == 2) {
+    constexpr int i = (G - kMidGroup) * 4 + J;
+    if constexpr (G >= kMidGroup && i < kDmaPieces) {
         NSOS_PIN();
-        side((G - 1) * 4 + J);
+        side(i);
         NSOS_PIN();
     }
 }
 
-// 16 k-steps x 8 output tiles = 128 MFMAs; group g = (k-step g>>1, tile quad g&1).
-template <class S>
-__device__ __forceinline__ void chunk8(f32x16 (&acc)[8], unsigned wl, const f32x16& b, S&& side) {
-    a_pipeline<32>(wl, [&](auto ic, const f32x4& a) {
-        constexpr int g = decltype(ic)::value, q = g & 1;
-        static_for<0, 4>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            acc[4 * q + j] = mfma(a[j], b[g >> 1], acc[4 * q + j]);
-            dma_slot<g, j>(side);
-        });
-    });
-}
-
-// NKS k-steps x 4 output tiles; group g = k-step g.  b0 covers k-steps 0..15, b1 16..31.
-template <int NKS, class S>
-__device__ __forceinline__ void chunk4(f32x16 (&acc)[4], unsigned wl, const f32x16& b0, const f32x16& b1, S&& side) {
-    a_pipeline<NKS>(wl, [&](auto ic, const f32x4& a) {
+// One chunk of an 8-tile layer: 16 k-steps x 8 tiles (+ a leading bias k-step if BIAS).
+//   group g (after the bias groups) = (k-step g>>1, tile quad g&1);  b: this chunk's 16 B operands, VGPRs.
+template <bool BIAS, class S, class B, class T>
+__device__ __forceinline__ void chunk8(f32x16 (&acc)[8], f32x4 (&ring)[kRing], const ChunkCtx ctx, const f32x16& b,
+                                       S&& side, B&& mid, T&& tail) {
+    constexpr int NB = BIAS ? 2 : 0;
+    a_pipeline<32 + NB>(ring, ctx, [&](auto ic, const f32x4& a) {
         constexpr int g = decltype(ic)::value;
-        const float b = g < 16 ? b0[g & 15] : b1[g & 15];
         static_for<0, 4>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            acc[j] = mfma(a[j], b, acc[j]);
+            if constexpr (g < NB) {  // acc = bias * 1 + 0
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[4 * g + j] = mfma(a[j], 1.0f, zero);
+            } else {
+                constexpr int gr = g - NB, q = gr & 1;
+                acc[4 * q + j] = mfma(a[j], b[gr >> 1], acc[4 * q + j]);
+            }
             dma_slot<g, j>(side);
         });
-    });
+    }, mid, tail);
 }
 
-template <int NT>
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[NT], const float* aux_lane /* base + hi*NT*16 */) {
+// One chunk of a 4-tile layer: NKS k-steps x 4 tiles (+ a leading bias k-step if BIAS); group = k-step.
+// b0 covers k-steps 0..15, b1 16..31.
+template <int NKS, bool BIAS, class S, class B, class T>
+__device__ __forceinline__ void chunk4(f32x16 (&acc)[4], f32x4 (&ring)[kRing], const ChunkCtx ctx, const f32x16& b0,
+                                       const f32x16& b1, S&& side, B&& mid, T&& tail) {
+    constexpr int NB = BIAS ? 1 : 0;
+    a_pipeline<NKS + NB>(ring, ctx, [&](auto ic, const f32x4& a) {
+        constexpr int g = decltype(ic)::value;
+        static_for<0, 4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (g < NB) {
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[j] = mfma(a[j], 1.0f, zero);
+            } else {
+                constexpr int ks = g - NB;
+                acc[j] = mfma(a[j], ks < 16 ? b0[ks & 15] : b1[ks & 15], acc[j]);
+            }
+            dma_slot<g, j>(side);
+        });
+    }, mid, tail);
+}
+
+// H = max(Z, floor) for one layer, as ONE batch of v_max_f32 (gfx950 has no packed f32 max).  floor = 0 is
+// the ReLU; -inf copies (feature_linear has no activation).  The asm keeps hipcc from CSE-ing / re-spreading
+// the pass (and from adding a NaN-canonicalising second v_max per element), and "=v" pins H into arch VGPRs,
+// where MFMAs can name it as srcB.  (v_max(0, NaN) = 0 where torch.relu propagates NaN: out of scope.)
+__device__ __forceinline__ void activate(f32x16 (&H)[8], const f32x16 (&Z)[8], float floor) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(aux_lane + t * 16 + q * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][q * 4 + j] = v[j];
+        for (int r = 0; r < 16; ++r) {
+            float out;
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(out) : "v"(Z[t][r]), "v"(floor));
+            H[t][r] = out;
         }
 }
 
 // vector-ALU head: this half-wave's partial fmaf chain over its NT*16 features (oracle: dot_halves)
-template <int NT>
+template <int NT, bool RELU>
 __device__ __forceinline__ float head_partial(const f32x16 (&h)[NT], const float* w_lane, float init) {
     float part = init;
 #pragma unroll
@@ -186,7 +275,10 @@ __device__ __forceinline__ float head_partial(const f32x16 (&h)[NT], const float
         for (int q = 0; q < 4; ++q) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(w_lane + t * 16 + q * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part = __fmaf_rn(w[j], h[t][q * 4 + j], part);
+            for (int j = 0; j < 4; ++j) {
+                const float x = h[t][q * 4 + j];
+                part = __fmaf_rn(w[j], RELU ? fmaxf(x, 0.0f) : x, part);
+            }
         }
     return part;
 }
@@ -239,37 +331,77 @@ struct EncFill {
 // ------------------------------------------------------------------------------------------ the kernel
 template <int SEM, bool RAYS>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x 32 KiB weight buffers
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // 3 x 36 KiB weight slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pj = lane & 31, hi = lane >> 5;
     constexpr int NCH = chunks_per_net(SEM);
     constexpr int C = SEM ? 6 : 4;
 
-    // ---- weight stream: chunk `cur` is consumed from buffer `par`; chunk cur+1 is DMA'd into par^1 meanwhile
-    int cur = 0, par = 0;
-    const float* const src_lane = P.chunks + wave * 256 + lane * 4;  // + chunk*8192 + i*1024 floats
-    auto dma_piece = [&](int chunk, int buf, int i) {  // 32 pieces of 1 KiB per chunk; this wave copies 8
-        const float* src = src_lane + (size_t)chunk * kChunkFloats + i * 1024;
-        float* dst = lds + buf * kChunkFloats + (i * 4 + wave) * 256;  // wave-uniform; HW adds lane*16 B
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
+    // ---- weight stream (see "A-operand pipeline" above).  State, all advanced by register rotation in tail():
+    //   c0/c1/c2 : this lane's LDS byte address of the slot holding chunk cur / cur+1 / cur+2 (being filled)
+    //   d2..     : wave-uniform LDS byte address (slot base + wave*1 KiB) of the same slots, for the DMA
+    //   src2     : global address of chunk cur+2 in the packed stream (wraps at the end of the net)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
-    // stage protocol: the barrier proves (a) chunk `cur` has landed (every wave drained its own DMA before
-    // arriving) and (b) every wave is done reading buffer par^1, which this stage's DMA pieces overwrite.
-    auto stage_begin = [&]() -> unsigned {  // LDS byte address of this lane's first A operand
-        __syncthreads();
-        return lds_base + (unsigned)(par * kChunkFloats + lane * 4) * 4u;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);        // provably wave-uniform copy
+    const unsigned voff = (unsigned)(wave * kGroupFloats + lane * 4) * 4u;  // lane's byte offset in a 4 KiB piece row
+    auto lane_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotFloats + lane * 4) * 4u; };
+    auto wave_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotFloats + wave_s * kGroupFloats) * 4u; };
+    unsigned c0 = lane_addr(0), c1 = lane_addr(1), c2 = lane_addr(2);
+    unsigned d0 = wave_addr(0), d1 = wave_addr(1), d2 = wave_addr(2);
+    const float* const src_end = P.chunks + (size_t)NCH * kSlotFloats;
+    const float* src2 = P.chunks + (size_t)(2 % NCH) * kSlotFloats;
+    // one 1 KiB piece: this wave copies pieces i*4+wave of a chunk, i < kDmaPieces.  Inline asm so that the
+    // whole issue is a few SALU + 1 VMEM instruction with wave-uniform (SGPR) addressing (through the builtin
+    // hipcc spends ~10 VALU/readfirstlane instructions per piece, ~110 cycles, of which only 64 hide under an
+    // MFMA).  M0 (LDS destination) is saved/restored inside the statement.
+    auto dma_piece = [&](const float* src_chunk, unsigned dst_wave, int i) {
+        const float* src = src_chunk + i * 4 * kGroupFloats;  // uniform
+        const unsigned dst = dst_wave + (unsigned)i * 4096u;   // uniform
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(voff), "s"(src) : "memory");
     };
-    auto side = [&](int i) { dma_piece(cur + 1 == NCH ? 0 : cur + 1, par ^ 1, i); };
-    auto stage_end = [&]() {
-        cur = (cur + 1 == NCH) ? 0 : cur + 1;
-        par ^= 1;
+#ifdef NSOS_EXP_NODMA  // timing experiment only (results are garbage): how much does the DMA issue cost?
+    auto side = [&](int) {};
+#else
+    auto side = [&](int i) { dma_piece(src2, d2, i); };
+#endif
+    auto mid = [&]() {
+#ifndef NSOS_EXP_NOBARRIER  // timing experiment only (racy): how much does the per-chunk barrier cost?
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#endif
     };
+    auto tail = [&]() {  // chunk cur -> cur+1
+        const unsigned tc = c0, td = d0;
+        c0 = c1; c1 = c2; c2 = tc;
+        d0 = d1; d1 = d2; d2 = td;
+        src2 += kSlotFloats;
+        if (src2 == src_end) src2 = P.chunks;
+    };
+    auto stage_begin = [&]() { return ChunkCtx{c0, c1}; };
+    // prologue: chunks 0 and 1 resident, ring = first groups of chunk 0
+    f32x4 ring[kRing];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(0, 0, i);
+    for (int i = 0; i < kDmaPieces; ++i) dma_piece(P.chunks, d0, i);
+#pragma unroll
+    for (int i = 0; i < kDmaPieces; ++i) dma_piece(P.chunks + (size_t)(1 % NCH) * kSlotFloats, d1, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the asm DMAs are invisible to hipcc's own counting
+    __syncthreads();
+    static_for<0, kRing>([&](auto ic) { lds_read_a<decltype(ic)::value * 1024>(ring[decltype(ic)::value], lane_addr(0)); });
+    lgkm_wait<0>();
+    NSOS_PIN();
 
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        int stamp_k = 0;
+        auto stamp = [&]() {  // diagnostics only: one s_memtime per phase of the first tile of blocks 0..3
+            if (P.prof && tile == (int)blockIdx.x && blockIdx.x < 4) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                if (lane == 0 && stamp_k < kProfSlots) P.prof[(blockIdx.x * 4 + wave) * kProfSlots + stamp_k] = t;
+            }
+            ++stamp_k;
+        };
+        stamp();  // 0: tile start
         // ---- this lane's point (both half-waves of a column hold the same point)
         const long long gp = (long long)tile * kTilePts + wave * 32 + pj;
         const bool valid = gp < P.n_pts;
@@ -297,94 +429,66 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         EncFill<NSOS_XYZ_FREQS, 16, 16>::run(ex[1], x, hi);
         EncFill<NSOS_DIR_FREQS, 0, 16>::run(ed, dv, hi);
 
-        f32x16 acc[8], hin[8];
+        // Z: accumulators of the layer being computed; H: previous layer's activations (VGPRs, MFMA srcB)
+        f32x16 Z[8], H[8];
         float sigma = 0.0f, sem_out[2] = {0.0f, 0.0f};
+        stamp();  // 1: inputs loaded + encoded
 
-        // ---- trunk: pts_linears.0..7 (l = 0..7) and feature_linear (l = 8)
+        // the 63 encoded-xyz features enter (layer 0; skip connection into layer 5): 2 chunks
+        auto enc_part = [&](auto with_bias) {
+            constexpr bool WB = decltype(with_bias)::value;
+            chunk8<WB>(Z, ring, stage_begin(), ex[0], side, mid, tail);
+            chunk8<false>(Z, ring, stage_begin(), ex[1], side, mid, tail);
+        };
+        enc_part(std::true_type{});  // pts_linears.0
+        const float relu = 0.0f, pass = -__builtin_inff();
+        activate(H, Z, relu);
+        stamp();  // 2
+        // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8): Z = bias + W * H
 #pragma unroll 1
-        for (int l = 0; l <= 8; ++l) {
-            load_bias<8>(acc, P.aux + kAuxBias + l * 256 + hi * 128);
-            if (l == 0 || l == 5) {  // encoded xyz enters (layer 0; skip connection, input-first cat)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const unsigned wl = stage_begin();
-                    chunk8(acc, wl, ex[c], side);
-                    stage_end();
-                }
-            }
-            if (l != 0) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const unsigned wl = stage_begin();
-                    chunk8(acc, wl, hin[c], side);
-                    stage_end();
-                }
-            }
-            if (l < 8) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) hin[t][r] = fmaxf(acc[t][r], 0.0f);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) hin[t] = acc[t];  // feature_linear has no activation
-            }
+        for (int l = 1; l <= 8; ++l) {
+            static_for<0, 8>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                chunk8<(c == 0)>(Z, ring, stage_begin(), H[c], side, mid, tail);
+            });
+            if (l == 5) enc_part(std::false_type{});  // skip: layer 5 = bias + W_h h4 + W_x x63
+            activate(H, Z, l < 8 ? relu : pass);          // feature_linear's output is used without activation
+            stamp();                                      // 2 + l
             if (l == 7) {
-                // sigma head (models/nerf_mlp.py:77), on the vector ALU
-                const float pa = head_partial<8>(hin, P.aux + kAuxAlphaW + hi * 128, hi ? 0.0f : P.aux[kAuxScalars]);
+                // H = h7.  sigma head (models/nerf_mlp.py:77), on the vector ALU
+                const float pa = head_partial<8, false>(H, P.aux + kAuxAlphaW + hi * 128, hi ? 0.0f : P.aux[kAuxScalars]);
                 sigma = both_halves(pa);
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80), cat([h, x63]): h first
                     f32x16 sacc[4];
-                    load_bias<4>(sacc, P.aux + kAuxSem0B + hi * 64);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const unsigned wl = stage_begin();
-                        chunk4<32>(sacc, wl, hin[2 * c], hin[2 * c + 1], side);
-                        stage_end();
-                    }
-                    if constexpr (SEM == 2) {
-                        const unsigned wl = stage_begin();
-                        chunk4<32>(sacc, wl, ex[0], ex[1], side);
-                        stage_end();
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sacc[t][r] = fmaxf(sacc[t][r], 0.0f);
+                    static_for<0, 4>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        chunk4<32, (c == 0)>(sacc, ring, stage_begin(), H[2 * c], H[2 * c + 1], side, mid, tail);
+                    });
+                    if constexpr (SEM == 2) chunk4<32, false>(sacc, ring, stage_begin(), ex[0], ex[1], side, mid, tail);
 #pragma unroll
                     for (int o = 0; o < 2; ++o) {
-                        const float ps = head_partial<4>(sacc, P.aux + kAuxSem2W + o * 128 + hi * 64,
-                                                         hi ? 0.0f : P.aux[kAuxScalars + 4 + o]);
+                        const float ps = head_partial<4, true>(sacc, P.aux + kAuxSem2W + o * 128 + hi * 64,
+                                                               hi ? 0.0f : P.aux[kAuxScalars + 4 + o]);
                         sem_out[o] = both_halves(ps);
                     }
                 }
             }
         }
-        // ---- view branch (models/nerf_mlp.py:87-92): cat([feature, dir27]) -> 128 -> rgb
+        // ---- view branch (models/nerf_mlp.py:87-92): cat([feature, dir27]) -> 128 -> rgb.  H = feature.
         f32x16 vacc[4];
-        load_bias<4>(vacc, P.aux + kAuxViewsB + hi * 64);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const unsigned wl = stage_begin();
-            chunk4<32>(vacc, wl, hin[2 * c], hin[2 * c + 1], side);
-            stage_end();
-        }
-        {
-            const unsigned wl = stage_begin();
-            chunk4<16>(vacc, wl, ed, ed, side);
-            stage_end();
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) vacc[t][r] = fmaxf(vacc[t][r], 0.0f);
+        static_for<0, 4>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            chunk4<32, (c == 0)>(vacc, ring, stage_begin(), H[2 * c], H[2 * c + 1], side, mid, tail);
+        });
+        chunk4<16, false>(vacc, ring, stage_begin(), ed, ed, side, mid, tail);
         float rgb[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-            const float pr = head_partial<4>(vacc, P.aux + kAuxRgbW + o * 128 + hi * 64,
-                                             hi ? 0.0f : P.aux[kAuxScalars + 1 + o]);
+            const float pr = head_partial<4, true>(vacc, P.aux + kAuxRgbW + o * 128 + hi * 64,
+                                                   hi ? 0.0f : P.aux[kAuxScalars + 1 + o]);
             rgb[o] = both_halves(pr);
         }
+        stamp();  // 11: view branch + rgb head done
         // ---- raw = [r, g, b, sigma, (sem0, sem1)]   (models/nerf_mlp.py:93-96)
         if (valid) {
             float* out = P.raw + gp * C;
@@ -399,14 +503,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
                 }
             }
         }
+        stamp();  // 12: outputs stored
     }
-    // the cyclic prefetch leaves one DMA in flight: drain it before the LDS allocation is released
+    // the cyclic prefetch leaves DMAs in flight: drain them before the LDS allocation is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------ packing
 struct PackSeg {
     const float* w;
+    const float* bias;  // leading bias k-step of the segment's first chunk, or NULL
     int in_dim;
     int col_base;
     int kind;
@@ -416,9 +523,6 @@ struct PackParams {
     PackSeg seg[16];
     int n_seg;
     int n_chunks;
-    const float* bias256[9];  // pts_linears.0..7 bias, feature bias
-    const float* views_b;
-    const float* sem0_b;
     const float* alpha_w;
     const float* alpha_b;
     const float* rgb_w;
@@ -436,10 +540,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams P) {
         float v = 0.0f;
         auto feat256 = [](int rem) { return acc_feature((rem & 127) >> 4, rem & 15, rem >> 7); };
         auto feat128 = [](int rem) { return acc_feature((rem & 63) >> 4, rem & 15, rem >> 6); };
-        if (a < kAuxViewsB) v = P.bias256[a >> 8][feat256(a & 255)];
-        else if (a < kAuxSem0B) v = P.views_b[feat128(a - kAuxViewsB)];
-        else if (a < kAuxAlphaW) v = P.sem0_b ? P.sem0_b[feat128(a - kAuxSem0B)] : 0.0f;
-        else if (a < kAuxRgbW) v = P.alpha_w[feat256(a - kAuxAlphaW)];
+        if (a < kAuxRgbW) v = P.alpha_w[feat256(a - kAuxAlphaW)];
         else if (a < kAuxSem2W) { const int rem = a - kAuxRgbW; v = P.rgb_w[(rem >> 7) * 128 + feat128(rem & 127)]; }
         else if (a < kAuxScalars) { const int rem = a - kAuxSem2W; v = P.sem2_w ? P.sem2_w[(rem >> 7) * 128 + feat128(rem & 127)] : 0.0f; }
         else {
@@ -450,24 +551,37 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams P) {
         }
         P.aux[a] = v;
     }
-    if (gid >= (long long)P.n_chunks * kChunkFloats) return;
-    int chunk = (int)(gid >> 13);
+    if (gid >= (long long)P.n_chunks * kSlotFloats) return;
+    int chunk = (int)(gid / kSlotFloats);
     int s = 0;
     while (chunk >= P.seg[s].n_chunks) { chunk -= P.seg[s].n_chunks; ++s; }
     const PackSeg sg = P.seg[s];
-    const int within = (int)(gid & (kChunkFloats - 1));
-    const int g = within >> 8, lane = (within >> 2) & 63, j = within & 3;
+    const int within = (int)(gid % kSlotFloats);
+    int g = within >> 8;
+    const int lane = (within >> 2) & 63, j = within & 3;
     const int hi = lane >> 5, i = lane & 31;
-    int t, ks, f = -1;
-    if (sg.kind == kHid8 || sg.kind == kEnc8) { ks = chunk * 16 + (g >> 1); t = 4 * (g & 1) + j; }
-    else { ks = chunk * 32 + g; t = j; }
-    switch (sg.kind) {
-        case kHid8: case kHid4: f = acc_feature(ks >> 4, ks & 15, hi); break;
-        case kEnc8: case kEnc4: f = 2 * ks + hi; if (f >= NSOS_XYZ_DIM) f = -1; break;
-        case kDir4: f = (ks < 16) ? 2 * ks + hi : -1; if (f >= NSOS_DIR_DIM) f = -1; break;
+    const bool eight = (sg.kind == kHid8 || sg.kind == kEnc8);
+    float v = 0.0f;
+    const int nb = (sg.bias && chunk == 0) ? (eight ? 2 : 1) : 0;  // leading bias groups of this chunk
+    if (g < nb) {
+        const int t = eight ? 4 * g + j : j;
+        v = hi == 0 ? sg.bias[32 * t + i] : 0.0f;  // k = 0: bias * 1.0 ;  k = 1: 0 * 1.0
+    } else {
+        g -= nb;
+        const int groups = sg.kind == kDir4 ? 16 : 32;
+        if (g < groups) {
+            int t, ks, f = -1;
+            if (eight) { ks = chunk * 16 + (g >> 1); t = 4 * (g & 1) + j; }
+            else { ks = chunk * 32 + g; t = j; }
+            switch (sg.kind) {
+                case kHid8: case kHid4: f = acc_feature(ks >> 4, ks & 15, hi); break;
+                case kEnc8: case kEnc4: f = 2 * ks + hi; if (f >= NSOS_XYZ_DIM) f = -1; break;
+                case kDir4: f = 2 * ks + hi; if (f >= NSOS_DIR_DIM) f = -1; break;
+            }
+            if (f >= 0) v = sg.w[(long long)(32 * t + i) * sg.in_dim + sg.col_base + f];
+        }
     }
-    const int out = 32 * t + i;
-    P.chunks[gid] = (f >= 0) ? sg.w[(long long)out * sg.in_dim + sg.col_base + f] : 0.0f;
+    P.chunks[gid] = v;
 }
 
 int g_num_cus = 0;
@@ -483,17 +597,19 @@ int num_cus() {
     return g_num_cus;
 }
 
+constexpr int kLdsBytes = 3 * kSlotFloats * 4;
+
 template <int SEM, bool RAYS>
 int32_t launch_mlp(const MlpParams& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<SEM, RAYS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkFloats * 4);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
     const int grid = p.n_tiles < num_cus() ? p.n_tiles : num_cus();
-    hipLaunchKernelGGL((mlp_fused_kernel<SEM, RAYS>), dim3(grid), dim3(256), 2 * kChunkFloats * 4, stream, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<SEM, RAYS>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();
 }
 
@@ -507,12 +623,28 @@ int32_t dispatch_mlp(int sem_mode, const MlpParams& p, hipStream_t stream) {
     return NSOS_ERR_UNSUPPORTED;
 }
 
+int32_t fill_ray_params(MlpParams& p, const void* packed, const float* rays_o, const float* rays_d,
+                        const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples, float* raw) {
+    NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
+    const long long n_pts = (long long)n_rays * n_samples;
+    NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    p = MlpParams{};
+    p.aux = static_cast<const float*>(packed);
+    p.chunks = p.aux + kAuxFloats;
+    p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
+    p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
+    p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
+    return NSOS_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" size_t nsos_mlp_packed_bytes(int32_t sem_mode) {
     if (sem_mode < 0 || sem_mode > 2) return 0;
-    return sizeof(float) * ((size_t)kAuxFloats + (size_t)chunks_per_net(sem_mode) * kChunkFloats);
+    return sizeof(float) * ((size_t)kAuxFloats + (size_t)chunks_per_net(sem_mode) * kSlotFloats);
 }
 
 extern "C" int32_t nsos_mlp_pack(const nsos_mlp_tensors* T, int32_t sem_mode, void* packed, size_t packed_bytes,
@@ -528,35 +660,34 @@ extern "C" int32_t nsos_mlp_pack(const nsos_mlp_tensors* T, int32_t sem_mode, vo
 
     PackParams P = {};
     int n = 0;
-    auto add = [&](const float* w, int in_dim, int col, int kind, int nch) { P.seg[n++] = PackSeg{w, in_dim, col, kind, nch}; };
+    auto add = [&](const float* w, const float* bias, int in_dim, int col, int kind, int nch) {
+        P.seg[n++] = PackSeg{w, bias, in_dim, col, kind, nch};
+    };
     const int X = NSOS_XYZ_DIM, W = NSOS_NET_WIDTH;
-    add(T->pts_w[0], X, 0, kEnc8, 2);
-    for (int l = 1; l <= 4; ++l) add(T->pts_w[l], W, 0, kHid8, 8);
-    add(T->pts_w[5], X + W, 0, kEnc8, 2);  // skip layer input = cat([x63, h]) (models/nerf_mlp.py:73-74)
-    add(T->pts_w[5], X + W, X, kHid8, 8);
-    add(T->pts_w[6], W, 0, kHid8, 8);
-    add(T->pts_w[7], W, 0, kHid8, 8);
+    add(T->pts_w[0], T->pts_b[0], X, 0, kEnc8, 2);
+    for (int l = 1; l <= 4; ++l) add(T->pts_w[l], T->pts_b[l], W, 0, kHid8, 8);
+    // skip layer: input = cat([x63, h]) (models/nerf_mlp.py:73-74); the kernel contracts h first, then x63
+    add(T->pts_w[5], T->pts_b[5], X + W, X, kHid8, 8);
+    add(T->pts_w[5], nullptr, X + W, 0, kEnc8, 2);
+    add(T->pts_w[6], T->pts_b[6], W, 0, kHid8, 8);
+    add(T->pts_w[7], T->pts_b[7], W, 0, kHid8, 8);
     if (sem_mode) {
         const int in_dim = sem_mode == NSOS_SEM_COORD ? W + X : W;  // cat([h, x63]) (models/nerf_mlp.py:79)
-        add(T->sem0_w, in_dim, 0, kHid4, 4);
-        if (sem_mode == NSOS_SEM_COORD) add(T->sem0_w, in_dim, W, kEnc4, 1);
+        add(T->sem0_w, T->sem0_b, in_dim, 0, kHid4, 4);
+        if (sem_mode == NSOS_SEM_COORD) add(T->sem0_w, nullptr, in_dim, W, kEnc4, 1);
     }
-    add(T->feature_w, W, 0, kHid8, 8);
-    add(T->views_w, W + NSOS_DIR_DIM, 0, kHid4, 4);  // cat([feature, dir27]) (models/nerf_mlp.py:87)
-    add(T->views_w, W + NSOS_DIR_DIM, W, kDir4, 1);
+    add(T->feature_w, T->feature_b, W, 0, kHid8, 8);
+    add(T->views_w, T->views_b, W + NSOS_DIR_DIM, 0, kHid4, 4);  // cat([feature, dir27]) (models/nerf_mlp.py:87)
+    add(T->views_w, nullptr, W + NSOS_DIR_DIM, W, kDir4, 1);
     P.n_seg = n;
     P.n_chunks = chunks_per_net(sem_mode);
-    for (int l = 0; l < 8; ++l) P.bias256[l] = T->pts_b[l];
-    P.bias256[8] = T->feature_b;
-    P.views_b = T->views_b;
-    P.sem0_b = sem_mode ? T->sem0_b : nullptr;
     P.alpha_w = T->alpha_w; P.alpha_b = T->alpha_b;
     P.rgb_w = T->rgb_w; P.rgb_b = T->rgb_b;
     P.sem2_w = sem_mode ? T->sem2_w : nullptr;
     P.sem2_b = sem_mode ? T->sem2_b : nullptr;
     P.aux = static_cast<float*>(packed);
     P.chunks = P.aux + kAuxFloats;
-    const long long total = (long long)P.n_chunks * kChunkFloats;
+    const long long total = (long long)P.n_chunks * kSlotFloats;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
     return nsos_launch_status();
 }
@@ -565,18 +696,22 @@ extern "C" int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, c
                                          const float* rays_d, const float* viewdirs, const float* z_vals,
                                          int64_t n_rays, int32_t n_samples, float* raw, void* stream) {
     if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
-    NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
-    NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
+    MlpParams p;
+    const int32_t rc = fill_ray_params(p, packed, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw);
+    if (rc != NSOS_OK) return rc;
+    return dispatch_mlp<true>(sem_mode, p, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float* rays_o,
+                                         const float* rays_d, const float* viewdirs, const float* z_vals,
+                                         int64_t n_rays, int32_t n_samples, float* raw, uint64_t* stamps,
+                                         void* stream) {
     if (n_rays == 0) return NSOS_OK;
-    const long long n_pts = (long long)n_rays * n_samples;
-    NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
-    MlpParams p = {};
-    p.aux = static_cast<const float*>(packed);
-    p.chunks = p.aux + kAuxFloats;
-    p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
-    p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
-    p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
+    NSOS_REQUIRE(stamps, NSOS_ERR_NULL_POINTER);
+    MlpParams p;
+    const int32_t rc = fill_ray_params(p, packed, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw);
+    if (rc != NSOS_OK) return rc;
+    p.prof = reinterpret_cast<unsigned long long*>(stamps);
     return dispatch_mlp<true>(sem_mode, p, (hipStream_t)stream);
 }
 
@@ -586,7 +721,6 @@ extern "C" int32_t nsos_mlp_forward_points(const void* packed, int32_t sem_mode,
     NSOS_REQUIRE(packed && pts && dirs && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_pts >= 0, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
-    if (n_pts == 0) return NSOS_OK;
     NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     MlpParams p = {};
     p.aux = static_cast<const float*>(packed);

@@ -156,9 +156,9 @@ static void mlp_point(const oracle_mlp_weights* w, const float* pt, const float*
             const float* row = w->pts_w[l] + (int64_t)o * in_dim;
             float acc = w->pts_b[l][o];
             if (l == 0) acc = dot_natural(row, ex, XD, acc);
-            else if (l == 5) { /* cat([x63, h]) : models/nerf_mlp.py:73-74 */
-                acc = dot_natural(row, ex, XD, acc);
+            else if (l == 5) { /* input cat([x63, h]) (models/nerf_mlp.py:73-74); canonical order: h part, then x63 */
                 acc = dot_chain(row + XD, h, W, acc);
+                acc = dot_natural(row, ex, XD, acc);
             } else acc = dot_chain(row, h, W, acc);
             t[o] = acc > 0.0f ? acc : 0.0f;
         }

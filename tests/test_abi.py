@@ -32,10 +32,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_packed_sizes_and_error_strings():
     lib = _lib.lib()
-    # aux (3584 floats) + 73 / 77 / 78 chunks of 32 KiB (DESIGN.md "HBM layout")
-    assert lib.nsos_mlp_packed_bytes(0) == 4 * 3584 + 73 * 32768
-    assert lib.nsos_mlp_packed_bytes(1) == 4 * 3584 + 77 * 32768
-    assert lib.nsos_mlp_packed_bytes(2) == 4 * 3584 + 78 * 32768
+    # aux (1024 floats) + 73 / 77 / 78 chunk slots of 36 KiB (DESIGN.md "HBM layout")
+    assert lib.nsos_mlp_packed_bytes(0) == 4 * 1024 + 73 * 36864
+    assert lib.nsos_mlp_packed_bytes(1) == 4 * 1024 + 77 * 36864
+    assert lib.nsos_mlp_packed_bytes(2) == 4 * 1024 + 78 * 36864
     assert lib.nsos_mlp_packed_bytes(7) == 0
     assert lib.nsos_error_string(0) == b"ok"
     assert b"NULL" in lib.nsos_error_string(-1)
