@@ -119,6 +119,11 @@ def main():
     fine_flop = 2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE)
     achieved = fine_flop / (fine_ms * 1e-3) / 1e12 if fine else 0.0
 
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")   # PMC passes of this same command (separate runs)
+    if os.path.exists(tj):
+        traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+
     if rank == 0:
         value = world * N_RAYS * args.steps / dt
         line = {
@@ -132,7 +137,8 @@ def main():
                        "rays_per_gpu": N_RAYS, "parallelism": f"ray-sharded x{world}, no collective in the path",
                        "flop_per_ray": FLOP_PER_RAY},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per fine-pass launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01/traffic.json",
                          "kernel": "mlp_fused_kernel<0,true> (fine pass, 786432 points)",
                          "kernel_ms": round(fine_ms, 4), "launches_timed": len(fine),
                          "whole_path_frac": round(value / world * FLOP_PER_RAY / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},

@@ -39,8 +39,17 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_tcc"):
     for f in find(f"{d}/**/*counter_collection.csv"):
         rows = list(csv.DictReader(open(f)))
         agg = defaultdict(lambda: defaultdict(list))
-        for r in rows:
-            agg[(short(r["Kernel_Name"]), r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # the coarse (262144-point) and fine (786432-point) MLP launches share kernel name and grid: they
+        # alternate, so split them by dispatch parity within the kernel (warm-up pack/first launches are even)
+        seen = defaultdict(dict)
+        for r in sorted(rows, key=lambda r: int(r.get("Dispatch_Id", 0))):
+            name = short(r["Kernel_Name"])
+            if "mlp_fused" in name:
+                d = seen[name]
+                if r["Dispatch_Id"] not in d:
+                    d[r["Dispatch_Id"]] = len(d)
+                name += " [fine]" if d[r["Dispatch_Id"]] % 2 else " [coarse]"
+            agg[(name, r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"== {d}: mean counter value per dispatch")
         for k, cs in sorted(agg.items(), key=lambda kv: -len(kv[1]))[:40]:
             if "mlp_fused" not in k[0] and "composite" not in k[0] and "importance" not in k[0]:
