@@ -109,6 +109,22 @@ int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, const float*
 int32_t nsos_mlp_forward_points(const void* packed, int32_t sem_mode, const float* pts, const float* dirs,
                                 int64_t n_pts, float* raw, void* stream);
 
+/* ---- K5: training with a frozen backbone (run_nerf.py:307-318, --fix_backbone) -------------------------------
+ * nsos_mlp_forward_rays_save = nsos_mlp_forward_rays that also stores, per point, what the semantic head's
+ * backward needs: sem_in out [R*S,320] = [relu(h7) (256) | x63 (63) | 1.0] (the input of semantic_linear.0,
+ * models/nerf_mlp.py:79-80, plus a ones column that turns the bias gradient into the same GEMM) and
+ * sem_hid out [R*S,128] = relu(semantic_linear.0(...)).  sem_mode must be PLAIN or COORD.
+ * nsos_sem_head_backward: the element-wise part of d(semantics)/d(semantic_linear.*) (models/renderer.py:64-66,
+ * models/nerf_mlp.py:61): g_logits out [R*S,2] = weights * g_semantics[ray], g_hid out [R*S,128] =
+ * (sem_hid > 0) * (g_logits @ semantic_linear.2.weight).  The weight gradients are then plain GEMMs of these
+ * with sem_hid / sem_in (done by the host with the BLAS library). */
+int32_t nsos_mlp_forward_rays_save(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                   const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                   float* raw, float* sem_in, float* sem_hid, void* stream);
+int32_t nsos_sem_head_backward(const float* weights, const float* g_semantics, const float* sem2_w,
+                               const float* sem_hid, int64_t n_rays, int32_t n_samples, float* g_hid,
+                               float* g_logits, void* stream);
+
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).
  * Not on the product path; used to attribute the kernel's non-MFMA cycles (profiles/). */

@@ -82,6 +82,8 @@ struct MlpParams {
     int n_samples;
     int n_tiles;
     unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays): per-wave shader-clock stamps, or NULL
+    float* sem_in;   // SAVE: [P,320] = [h7 (256) | x63 (63) | 1.0]  inputs of semantic_linear.0 (+ ones column for the bias grad)
+    float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...))   inputs of semantic_linear.2
 };
 
 // ------------------------------------------------------------------------------------------ device helpers
@@ -329,7 +331,8 @@ struct EncFill {
 };
 
 // ------------------------------------------------------------------------------------------ the kernel
-template <int SEM, bool RAYS>
+// SAVE: training-mode variant that additionally stores what the semantic head's backward needs (K5).
+template <int SEM, bool RAYS, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // 3 x 36 KiB weight slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -465,6 +468,28 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
                         chunk4<32, (c == 0)>(sacc, ring, stage_begin(), H[2 * c], H[2 * c + 1], side, mid, tail);
                     });
                     if constexpr (SEM == 2) chunk4<32, false>(sacc, ring, stage_begin(), ex[0], ex[1], side, mid, tail);
+                    if constexpr (SAVE) {
+                        if (valid) {
+                            float* row = P.sem_in + gp * 320;   // H = relu(h7): 4 consecutive features per (tile, reg quad)
+                            float* hrow = P.sem_hid + gp * 128;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q + 4 * hi) =
+                                        f32x4{H[t][4 * q], H[t][4 * q + 1], H[t][4 * q + 2], H[t][4 * q + 3]};
+#pragma unroll
+                            for (int k = 0; k < 32; ++k)  // x63 feature 2k+hi; the pad slot (feature 63) carries the 1.0
+                                row[256 + 2 * k + hi] = (k == 31 && hi == 1) ? 1.0f : ex[k >> 4][k & 15];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * hi) =
+                                        f32x4{fmaxf(sacc[t][4 * q], 0.0f), fmaxf(sacc[t][4 * q + 1], 0.0f),
+                                              fmaxf(sacc[t][4 * q + 2], 0.0f), fmaxf(sacc[t][4 * q + 3], 0.0f)};
+                        }
+                    }
 #pragma unroll
                     for (int o = 0; o < 2; ++o) {
                         const float ps = head_partial<4, true>(sacc, P.aux + kAuxSem2W + o * 128 + hi * 64,
@@ -599,17 +624,17 @@ int num_cus() {
 
 constexpr int kLdsBytes = 3 * kSlotFloats * 4;
 
-template <int SEM, bool RAYS>
+template <int SEM, bool RAYS, bool SAVE = false>
 int32_t launch_mlp(const MlpParams& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<SEM, RAYS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<SEM, RAYS, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
     const int grid = p.n_tiles < num_cus() ? p.n_tiles : num_cus();
-    hipLaunchKernelGGL((mlp_fused_kernel<SEM, RAYS>), dim3(grid), dim3(256), kLdsBytes, stream, p);
+    hipLaunchKernelGGL((mlp_fused_kernel<SEM, RAYS, SAVE>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();
 }
 
@@ -700,6 +725,23 @@ extern "C" int32_t nsos_mlp_forward_rays(const void* packed, int32_t sem_mode, c
     const int32_t rc = fill_ray_params(p, packed, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw);
     if (rc != NSOS_OK) return rc;
     return dispatch_mlp<true>(sem_mode, p, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_save(const void* packed, int32_t sem_mode, const float* rays_o,
+                                              const float* rays_d, const float* viewdirs, const float* z_vals,
+                                              int64_t n_rays, int32_t n_samples, float* raw, float* sem_in,
+                                              float* sem_hid, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(sem_in && sem_hid, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(sem_mode == NSOS_SEM_PLAIN || sem_mode == NSOS_SEM_COORD, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
+    MlpParams p;
+    const int32_t rc = fill_ray_params(p, packed, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw);
+    if (rc != NSOS_OK) return rc;
+    p.sem_in = sem_in;
+    p.sem_hid = sem_hid;
+    return sem_mode == NSOS_SEM_COORD ? launch_mlp<2, true, true>(p, (hipStream_t)stream)
+                                      : launch_mlp<1, true, true>(p, (hipStream_t)stream);
 }
 
 extern "C" int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float* rays_o,

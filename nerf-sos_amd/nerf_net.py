@@ -104,11 +104,64 @@ class NeRFMLP(nn.Module):
         return raw.reshape(list(lead) + [raw.shape[-1]])
 
 
+def _trainable(module: nn.Module):
+    if not torch.is_grad_enabled():
+        return []
+    return [n for n, p in module.named_parameters() if p.requires_grad]
+
+
 def _no_autograd(module: nn.Module, what: str):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+    if _trainable(module):
         raise NotImplementedError(
-            f"{what}: the backward kernels (SURVEY.md K5) are not built yet -- call under torch.no_grad() "
-            "or freeze the parameters.  (No autograd fallback on purpose.)")
+            f"{what}: no backward kernel for this call -- run it under torch.no_grad() or freeze the parameters.  "
+            "(Gradients are implemented for NeRFNet.forward/render_rays with the reference's frozen-backbone recipe; "
+            "there is no autograd fallback on purpose.)")
+
+
+_SEM_KEYS = ("semantic_linear.0.weight", "semantic_linear.0.bias", "semantic_linear.2.weight", "semantic_linear.2.bias")
+
+
+class _FrozenBackboneRender(torch.autograd.Function):
+    """render_rays with gradients for the semantic heads only -- the reference's shipped training recipe
+    (run_nerf.py:307-318 + scripts/train_*_node0.sh --fix_backbone; engines/trainer.py:201).
+
+    forward : the normal kernel sequence, with the SAVE variant of the fused MLP kernel that also stores the
+              head's inputs; every output except `semantics` / `semantics0` is non-differentiable (they do not
+              depend on the semantic parameters: weights/rgb/depth come from the frozen backbone).
+    backward: nsos_sem_head_backward (element-wise) + four plain GEMMs (rocBLAS through torch.matmul) per net:
+              dW2 = g_logits^T hid, db2 = g_logits^T 1, [dW1 | db1] = g_hid^T [h7, x63, 1]."""
+
+    @staticmethod
+    def forward(ctx, net, args, kwargs, *sem_params):
+        with torch.no_grad():
+            ret, saved = net._render_rays_impl(*args, save=True, **kwargs)
+        keys = list(ret.keys())
+        outs = tuple(ret[k] for k in keys)
+        ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if k not in ("semantics", "semantics0")])
+        ctx.keys, ctx.saved, ctx.net = keys, saved, net
+        net._last_keys = keys
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        net, saved = ctx.net, ctx.saved
+        g = dict(zip(ctx.keys, gouts))
+        grads = []
+        has_fine = "fine" in saved  # then the coarse pass's outputs carry the '0' suffix (models/nerf_net.py:126-128)
+        for tag, mlp in net._sem_nets():
+            sv = saved.get(tag)
+            gs = g.get("semantics" if (tag == "fine" or not has_fine) else "semantics0") if sv else None
+            if sv is None or gs is None:
+                grads += [None] * 4
+                continue
+            w2 = mlp.mlp.semantic_linear[2].weight.detach()
+            g_hid, g_logits = ops.sem_head_backward(sv["weights"], gs.reshape(-1, 2).contiguous(), w2, sv["sem_hid"])
+            gw1_aug = g_hid.t() @ sv["sem_in"]                           # [128,320] = [dW1 | (pad) | db1]
+            in_dim = mlp.mlp.semantic_linear[0].weight.shape[1]
+            ones = torch.ones((g_logits.shape[0], 1), device=g_logits.device, dtype=torch.float32)
+            grads += [gw1_aug[:, :in_dim].contiguous(), gw1_aug[:, 319].contiguous(),
+                      g_logits.t() @ sv["sem_hid"], (g_logits.t() @ ones).reshape(2)]
+        return (None, None, None) + tuple(grads)
 
 
 class NeRFNet(nn.Module):
@@ -138,22 +191,58 @@ class NeRFNet(nn.Module):
         self.render_kwargs_test = dict(self.render_kwargs_train, perturb=0., raw_noise_std=0.)
 
     # ---------------------------------------------------------------------------------------------
+    def _sem_nets(self):
+        """(tag, NeRFMLP) pairs whose semantic heads can receive gradients, in the order their parameters are
+        passed to _FrozenBackboneRender."""
+        nets = [("coarse", self.nerf)]
+        if self.nerf_fine is not self.nerf:
+            nets.append(("fine", self.nerf_fine))
+        return nets
+
     def render_rays(self, rays_o, rays_d, near, far, viewdirs=None, raw_noise_std=0., verbose=False,
                     retraw=False, retpts=False, pytest=False, **kwargs) -> Dict[str, torch.Tensor]:
         """One ray chunk: coarse sample -> MLP -> composite -> importance sample -> fine MLP -> composite
         (models/nerf_net.py:71-130).  Random tensors are drawn on the rays' device in the reference's
-        order (rand[R,S], randn[R,S], rand[R,N], randn[R,S+N]) and handed to the kernels."""
-        _no_autograd(self, "NeRFNet.render_rays")
+        order (rand[R,S], randn[R,S], rand[R,N], randn[R,S+N]) and handed to the kernels.
+        Under autograd, gradients flow to the semantic heads (frozen-backbone recipe); any other trainable
+        parameter raises."""
+        args = (rays_o, rays_d, near, far, viewdirs, raw_noise_std, retraw, retpts)
+        trainable = _trainable(self)
+        if not trainable:
+            return self._render_rays_impl(*args, save=False, **kwargs)[0]
+        other = [n for n in trainable if "semantic_linear" not in n]
+        if other or not self.use_semantics:
+            raise NotImplementedError(
+                "NeRFNet: gradients are implemented for the semantic heads only (the reference's --fix_backbone "
+                f"recipe, run_nerf.py:307-318); freeze these first: {other[:4]}{' ...' if len(other) > 4 else ''}")
+        params = [dict(m.mlp.named_parameters())[k] for _, m in self._sem_nets() for k in _SEM_KEYS]
+        outs = _FrozenBackboneRender.apply(self, args, kwargs, *params)
+        return dict(zip(self._last_keys, outs))
+
+    def _render_rays_impl(self, rays_o, rays_d, near, far, viewdirs, raw_noise_std, retraw, retpts, save=False,
+                          **kwargs):
         perturb = kwargs.get('perturb', self.perturb)
         n_samples = kwargs.get('N_samples', self.N_samples)
         R, dev = rays_d.shape[0], rays_d.device
+        saved = {}
+
+        def query(net, z, tag):
+            if not save:
+                return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
+            raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(), net.sem_mode, rays_o, rays_d,
+                                                             viewdirs, z)
+            saved[tag] = dict(sem_in=sem_in, sem_hid=sem_hid)
+            return raw
+
         t_rand = torch.rand((R, n_samples), device=dev) if perturb > 0. else None          # sampler.py:61
         z_vals, unit_dirs = ops.ray_setup(rays_d, near, far, n_samples, t_rand)
         if viewdirs is None:
             viewdirs = unit_dirs
-        raw = ops.mlp_forward_rays(self.nerf.packed_weights(), self.nerf.sem_mode, rays_o, rays_d, viewdirs, z_vals)
+        raw = query(self.nerf, z_vals, "coarse")
         noise = torch.randn((R, n_samples), device=dev) if raw_noise_std > 0. else None    # renderer.py:47
         ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
+        if save:
+            saved["coarse"]["weights"] = ret['weights']
         if retraw:
             ret['raw'] = raw
         if retpts:
@@ -166,10 +255,11 @@ class NeRFNet(nn.Module):
             N = self.N_importance
             u = torch.rand((R, N), device=dev) if perturb != 0.0 else None                 # sampler.py:103,158
             z_fine, z_samples, z_std = ops.importance_sample(z_vals, ret0['weights'], N, u)
-            raw = ops.mlp_forward_rays(self.nerf_fine.packed_weights(), self.nerf_fine.sem_mode, rays_o, rays_d,
-                                       viewdirs, z_fine)
+            raw = query(self.nerf_fine, z_fine, "fine")
             noise = torch.randn((R, n_samples + N), device=dev) if raw_noise_std > 0. else None
             ret = ops.composite(raw, z_fine, rays_d, noise, raw_noise_std, self.white_bkgd)
+            if save:
+                saved["fine"]["weights"] = ret['weights']
             if retraw:
                 ret['raw'] = raw
             if retpts:
@@ -177,7 +267,7 @@ class NeRFNet(nn.Module):
             ret['z_std'] = z_std
             for k in ret0:
                 ret[k + '0'] = ret0[k]
-        return ret
+        return ret, saved
 
     def forward(self, ray_batch, bound_batch, **kwargs) -> Dict[str, torch.Tensor]:
         """models/nerf_net.py:132-195: kwargs selection by mode, flatten, per-chunk render, un-flatten.

@@ -135,6 +135,40 @@ def mlp_forward_rays(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, 
     return raw
 
 
+def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
+                          viewdirs: torch.Tensor, z_vals: torch.Tensor):
+    """Training-mode K2 (frozen backbone): raw [R,S,6] plus the semantic head's saved inputs
+    sem_in [R*S,320] = [relu(h7) | x63 | 1] and sem_hid [R*S,128] (see nsos_mlp_forward_rays_save)."""
+    if sem_mode == SEM_NONE:
+        raise ValueError("mlp_forward_rays_save needs a semantic head")
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
+    R, S = z_vals.shape
+    dev = z_vals.device
+    raw = torch.empty((R, S, 6), device=dev, dtype=torch.float32)
+    sem_in = torch.empty((R * S, 320), device=dev, dtype=torch.float32)
+    sem_hid = torch.empty((R * S, 128), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
+                                                     _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
+               "nsos_mlp_forward_rays_save")
+    return raw, sem_in, sem_hid
+
+
+def sem_head_backward(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: torch.Tensor,
+                      sem_hid: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Element-wise part of the semantic head's backward: (g_hid [P,128], g_logits [P,2])."""
+    weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
+    sem2_w, sem_hid = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid")
+    R, S = weights.shape
+    if tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (R * S, 128) or tuple(sem2_w.shape) != (2, 128):
+        raise ValueError("sem_head_backward: inconsistent shapes")
+    g_hid = torch.empty((R * S, 128), device=weights.device, dtype=torch.float32)
+    g_logits = torch.empty((R * S, 2), device=weights.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_sem_head_backward(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), R, S,
+                                                 _p(g_hid), _p(g_logits), _stream()), "nsos_sem_head_backward")
+    return g_hid, g_logits
+
+
 def mlp_forward_points(packed: torch.Tensor, sem_mode: int, pts: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
     """raw [P,C] for explicit points / per-point directions  (NeRFMLP.forward, models/nerf_mlp.py:179)."""
     pts, dirs = _dev(pts, "pts"), _dev(dirs, "viewdirs")

@@ -114,6 +114,8 @@ def main():
         manifest.setdefault("state_keys", {})[name] = list(sd.keys())
     _, _, sd1 = build_ref("nosem", n_importance=0)
     manifest["state_sha256"]["nosem_coarse_only"] = state_sha(sd1)
+    _, _, sd2 = build_ref("semcoord", n_importance=0)
+    manifest["state_sha256"]["semcoord_coarse_only"] = state_sha(sd2)
 
     g = torch.Generator().manual_seed(1234)
 
@@ -297,6 +299,36 @@ def main():
         for i, t in enumerate(dr):
             out[f"{tag}_train_draw{i}"] = np32(t)
     np.savez_compressed(os.path.join(HERE, "end_to_end.npz"), **out)
+
+    # ---------------------------------------------------------------- K5: frozen-backbone gradients
+    torch.set_grad_enabled(True)
+    out = {}
+    rays_g = tp.synthetic_rays(12, seed=11)
+    out["rays"] = np32(rays_g)
+    gg = torch.Generator().manual_seed(4321)
+    for name, peaky, white, n_imp in (("semcoord", True, False, 128), ("sem", True, True, 128), ("semcoord", False, False, 0)):
+        tag = f"{name}_{'peaky' if peaky else 'default'}{'_white' if white else ''}{'_coarse' if n_imp == 0 else ''}"
+        net, pc, sd = build_ref(name, n_importance=n_imp, white_bkgd=white, peaky=peaky)
+        for n_, p_ in net.named_parameters():           # run_nerf.py:307-318 (--fix_backbone)
+            p_.requires_grad = 'semantic_linear' in n_
+        net.eval()
+        ret = net(rays_g, (tp.NEAR, tp.FAR), radii=None)
+        G = torch.randn(ret["semantics"].shape, generator=gg)
+        loss = (ret["semantics"] * G).sum()
+        out[f"{tag}_G"] = np32(G)
+        if n_imp:
+            G0 = torch.randn(ret["semantics0"].shape, generator=gg)
+            loss = loss + (ret["semantics0"] * G0).sum()
+            out[f"{tag}_G0"] = np32(G0)
+        loss.backward()
+        seen = set()
+        for n_, p_ in net.named_parameters():
+            if p_.requires_grad and id(p_) not in seen:
+                seen.add(id(p_))
+                out[f"{tag}_grad_{n_}"] = np32(p_.grad)
+        out[f"{tag}_semantics"] = np32(ret["semantics"])
+    np.savez_compressed(os.path.join(HERE, "sem_grads.npz"), **out)
+    torch.set_grad_enabled(False)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

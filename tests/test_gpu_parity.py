@@ -290,3 +290,69 @@ def test_empty_batch():
         out = net.render_rays(torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV),
                               torch.zeros(0, device=DEV), torch.zeros(0, device=DEV))
     assert out["rgb"].shape == (0, 3) and out["weights"].shape == (0, 192)
+
+
+# ------------------------------------------------------------------------------------------ K5 (training)
+GRAD_CASES = [("semcoord", True, False, 128), ("sem", True, True, 128), ("semcoord", False, False, 0)]
+
+
+def _frozen(net):
+    for n, p in net.named_parameters():  # run_nerf.py:307-318 (--fix_backbone)
+        p.requires_grad = 'semantic_linear' in n
+    return net
+
+
+@pytest.mark.parametrize("name,peaky,white,n_imp", GRAD_CASES)
+def test_frozen_backbone_gradients(golden, manifest, name, peaky, white, n_imp):
+    """loss.backward() through NeRFNet with the shipped frozen-backbone recipe: semantic-head gradients equal
+    the reference's (captured from the real reference by the golden generator)."""
+    g = golden("sem_grads")
+    tag = tag_of(name, peaky, white, n_imp == 0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=n_imp, white_bkgd=white, **CFGS[name]).to(DEV)
+    net.load_state_dict(ref_state(name, manifest, peaky, n_imp))
+    _frozen(net).eval()
+    ret = net(T(g["rays"]), (tp.NEAR, tp.FAR), radii=None)
+    assert ret["semantics"].requires_grad and not ret["rgb"].requires_grad and not ret["weights"].requires_grad
+    close(N(ret["semantics"]), g[f"{tag}_semantics"], what="semantics (training-mode kernel variant)")
+    loss = (ret["semantics"] * T(g[f"{tag}_G"])).sum()
+    if n_imp:
+        loss = loss + (ret["semantics0"] * T(g[f"{tag}_G0"])).sum()
+    loss.backward()
+    sd = dict(net.named_parameters())
+    keys = [k[len(tag) + 6:] for k in g if k.startswith(tag + "_grad_")]
+    assert len(keys) == (8 if n_imp else 4)
+    for k in keys:
+        want = g[f"{tag}_grad_{k}"]
+        got = N(sd[k].grad)
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() <= 1e-4 * scale + 1e-6, f"grad {k}: max err {np.abs(got - want).max():.3e} (scale {scale:.3e})"
+    for n, p in net.named_parameters():
+        assert (p.grad is None) == ('semantic_linear' not in n)
+
+
+def test_training_variant_matches_inference_and_optimizer_step(manifest):
+    """The SAVE kernel variant produces bit-identical outputs; an Adam step on the heads changes only semantics."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True,
+                               perturb=0., raw_noise_std=0.).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    _frozen(net).train()
+    rays = tp.synthetic_rays(300, seed=5).to(DEV)
+    with torch.no_grad():
+        a = net(rays, (tp.NEAR, tp.FAR))
+    b = net(rays, (tp.NEAR, tp.FAR))
+    for k in a:
+        assert torch.equal(a[k], b[k].detach()), k
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-5)  # tiny step along -sign(grad)
+    (b["semantics"].square().mean() + b["semantics0"].square().mean()).backward()
+    opt.step()
+    with torch.no_grad():
+        c = net(rays, (tp.NEAR, tp.FAR))
+    assert torch.equal(c["rgb"], a["rgb"]) and torch.equal(c["weights"], a["weights"])
+    assert not torch.equal(c["semantics"], a["semantics"])
+    assert c["semantics"].square().mean() < a["semantics"].square().mean()
+
+
+def test_unfrozen_backbone_raises():
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True).to(DEV)
+    with pytest.raises(NotImplementedError, match="fix_backbone"):
+        net(tp.synthetic_rays(8).to(DEV), (tp.NEAR, tp.FAR))

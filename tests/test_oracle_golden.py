@@ -134,3 +134,28 @@ def test_end_to_end(golden, manifest, name, peaky, white, n_imp, mode):
             assert (err > tol).mean() < 5e-3, f"{tag} {k}: {(err > tol).mean():.4f} outside tol"
         else:
             close(got, want, what=f"{tag} {k}")
+
+
+GRAD_CASES = [("semcoord", True, False, 128), ("sem", True, True, 128), ("semcoord", False, False, 0)]
+
+
+@pytest.mark.parametrize("name,peaky,white,n_imp", GRAD_CASES)
+def test_frozen_backbone_gradients_port(golden, manifest, name, peaky, white, n_imp):
+    """K5 oracle: autograd through the torch port reproduces the reference's semantic-head gradients
+    (run_nerf.py:307-318 recipe) captured by the golden generator."""
+    g = golden("sem_grads")
+    tag = tag_of(name, peaky, white, n_imp == 0)
+    sd = {k: v.clone() for k, v in ref_state(name, manifest, peaky, n_imp).items()}
+    for k, v in sd.items():
+        v.requires_grad_("semantic_linear" in k)
+    cfg = tp.PortConfig(n_importance=n_imp, white_bkgd=white, **CFGS[name])
+    rays = torch.as_tensor(g["rays"])
+    ret = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR))
+    loss = (ret["semantics"] * torch.as_tensor(g[f"{tag}_G"])).sum()
+    if n_imp:
+        loss = loss + (ret["semantics0"] * torch.as_tensor(g[f"{tag}_G0"])).sum()
+    loss.backward()
+    keys = [k[len(tag) + 6:] for k in g if k.startswith(tag + "_grad_")]
+    assert len(keys) == (8 if n_imp else 4)
+    for k in keys:
+        close(sd[k].grad.numpy(), g[f"{tag}_grad_{k}"], atol=1e-6, rtol=1e-5, what=f"grad {k}")
