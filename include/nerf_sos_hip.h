@@ -82,6 +82,15 @@ size_t nsos_mlp_packed_bytes(int32_t sem_mode);
 int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
                       void* stream);
 
+/* ---- K0: pinhole ray generation (SURVEY.md section 8f "next", rank 1) ------------------------------------
+ * get_persp_rays (utils/ray.py:12-22; callers data/gen_dataset.py:189,202) for the pixels
+ * [pix_begin, pix_end) of an H x W image in row-major order (pixel = j*W + i):
+ *   dirs = [(i-cx)/fx, -(j-cy)/fy, -1];  rays_d = dirs @ c2w[:3,:3]^T (unnormalised);  rays_o = c2w[:3,3].
+ * c2w_host: HOST pointer to the 12 floats of c2w[:3,:4] row-major (poses are tiny and live on the host);
+ * rays_o, rays_d out: device [pix_end-pix_begin, 3].  Removes the [N,H,W,2,3] ray tensors from disk / PCIe. */
+int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w_host,
+                           int64_t pix_begin, int64_t pix_end, float* rays_o, float* rays_d, void* stream);
+
 /* ---- K1: ray set-up -----------------------------------------------------------------------
  * viewdirs = d/|d| (models/nerf_net.py:163-166) and the stratified depths z
  * (StratifiedSampler.forward, models/sampler.py:46-68): z = near(1-t)+far*t, t=linspace(0,1,S);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "nsos_error_string": (C.c_char_p, [_i32]),
     "nsos_mlp_packed_bytes": (_sz, [_i32]),
     "nsos_mlp_pack": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
+    "nsos_generate_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, C.POINTER(C.c_float), _i64, _i64, _fp, _fp, _fp]),
     "nsos_ray_setup": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_ray_points": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),

@@ -301,32 +301,77 @@ __host__ __device__ constexpr EncSlot enc_slot(int idx, int L) {
     return {j % 3, k, j >= 3};
 }
 
-// Feature pair (2s, 2s+1) of an encoding: the lo half-wave needs 2s, the hi half-wave 2s+1.  One
-// sincos per lane: select the argument by half, evaluate, select sin or cos by half.
-template <int L, int S0>
-__device__ __forceinline__ float enc_pair(const float (&x)[3], int hi) {
-    constexpr EncSlot e0 = enc_slot(2 * S0, L), e1 = enc_slot(2 * S0 + 1, L);
-    float v0 = 0.0f, v1 = 0.0f;
-    constexpr bool t0 = e0.octave >= 0, t1 = e1.octave >= 0;
-    if constexpr (e0.octave == -1) v0 = x[e0.coord];
-    if constexpr (e1.octave == -1) v1 = x[e1.coord];
-    if constexpr (t0 || t1) {
-        const float a0 = t0 ? x[e0.coord] * (float)(1 << (t0 ? e0.octave : 0)) : 0.0f;
-        const float a1 = t1 ? x[e1.coord] * (float)(1 << (t1 ? e1.octave : 0)) : 0.0f;
-        const float arg = hi ? a1 : a0;
-        float sn, cs;
-        sincosf(arg, &sn, &cs);
-        if constexpr (t0) v0 = e0.is_cos ? cs : sn;
-        if constexpr (t1) v1 = e1.is_cos ? cs : sn;
+// sin and cos of a positional-encoding argument (|a| = |coordinate| * 2^k, a few thousand radians at most).
+// Branch-free three-term Cody-Waite reduction with fmaf (each step rounds once; the partial remainders are
+// O(1), so the reduced argument is good to ~1 ulp for |a| < 2^15) + the Cephes minimax polynomials on
+// [-pi/4, pi/4] (~1 ulp).  ocml's sincosf takes its Payne-Hanek branch for arguments this large, which made the
+// encoding 10k cycles per tile AND desynchronised the four waves (the next barrier waits for the slowest).
+// Arguments >= 2^15 (never produced by a scene-normalised NeRF) fall back to ocml.
+__device__ __forceinline__ void sincos_pe(float a, float& sn, float& cs) {
+    if (__builtin_expect(!(fabsf(a) < 32768.0f), 0)) {
+        sincosf(a, &sn, &cs);
+        return;
     }
-    return hi ? v1 : v0;
+    const float q = __builtin_rintf(a * 0.636619772367581343f);          // 2/pi
+    float r = __fmaf_rn(q, -1.57079637050628662109375f, a);              // pi/2 split into three fp32 terms
+    r = __fmaf_rn(q, 4.37113900018624283e-8f, r);
+    r = __fmaf_rn(q, 1.71512451613343730e-15f, r);
+    const int n = (int)q;
+    const float r2 = r * r;
+    float ps = __fmaf_rn(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __fmaf_rn(r2, ps, -1.6666654611e-1f);
+    ps = __fmaf_rn(r * r2, ps, r);                                       // sin(r)
+    float pc = __fmaf_rn(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __fmaf_rn(r2, pc, 4.166664568298827e-2f);
+    pc = __fmaf_rn(r2 * r2, pc, __fmaf_rn(r2, -0.5f, 1.0f));             // cos(r)
+    const float s0 = (n & 1) ? pc : ps, c0 = (n & 1) ? ps : pc;
+    sn = (n & 2) ? -s0 : s0;
+    cs = ((n + 1) & 2) ? -c0 : c0;
 }
 
-template <int L, int S0, int N>
-struct EncFill {
-    __device__ __forceinline__ static void run(f32x16& out, const float (&x)[3], int hi) {
-        out[S0 & 15] = enc_pair<L, S0>(x, hi);
-        if constexpr ((S0 & 15) + 1 < N) EncFill<L, S0 + 1, N>::run(out, x, hi);
+// Encoding of a 3-vector with L octaves, directly in B-operand form: k-step s of lane (j, hi) = feature 2s+hi.
+// The sin and cos of one (octave, coordinate) pair always belong to DIFFERENT half-waves (feature indices
+// 3+6k+c and 6+6k+c differ in parity), so pair p = 3k+c is evaluated once, by half p&1 (job t = p>>1 evaluates
+// pair 2t in the lo half and 2t+1 in the hi half with one instruction stream); each lane keeps the value its
+// own half needs and hands the other to its partner lane (lane ^ 32): 3L/2 sincos evaluations per lane instead
+// of 3L.  All index bookkeeping below is compile-time.
+template <int L>
+struct Enc {
+    static constexpr int kPairs = 3 * L, kJobs = (kPairs + 1) / 2;
+    // does half h need the sin (vs the cos) of pair p = 3k+c ?   sin feature 3+6k+c has parity (c+1)&1
+    __host__ __device__ static constexpr bool half_needs_sin(int p, int h) { return (((p % 3) + 1) & 1) == h; }
+
+    float own_sn[kJobs], own_cs[kJobs], recv[kJobs];
+
+    __device__ __forceinline__ void evaluate(const float (&x)[3], int hi) {
+#pragma unroll
+        for (int t = 0; t < kJobs; ++t) {
+            const int pl = 2 * t, ph = (2 * t + 1 < kPairs) ? 2 * t + 1 : 2 * t;  // pair of the lo / hi half
+            const float al = x[pl % 3] * (float)(1 << (pl / 3)), ah = x[ph % 3] * (float)(1 << (ph / 3));
+            sincos_pe(hi ? ah : al, own_sn[t], own_cs[t]);
+            // what the PARTNER half needs from my pair: half 1-h of pair (2t+h)
+            const bool send_sin_l = half_needs_sin(pl, 1), send_sin_h = half_needs_sin(ph, 0);
+            const float send = (hi ? send_sin_h : send_sin_l) ? own_sn[t] : own_cs[t];
+            recv[t] = __shfl_xor(send, 32, NSOS_WAVE);
+        }
+    }
+    // value of feature idx for a lane of half h (h compile-time)
+    template <int IDX, int H>
+    __device__ __forceinline__ float feature(const float (&x)[3]) const {
+        constexpr EncSlot e = enc_slot(IDX, L);
+        if constexpr (e.octave == -1) return x[e.coord];
+        else if constexpr (e.octave == -2) return 0.0f;
+        else {
+            constexpr int p = 3 * e.octave + e.coord, t = p >> 1;
+            if constexpr ((p & 1) == H || 2 * t + 1 >= kPairs) return e.is_cos ? own_cs[t] : own_sn[t];  // my half evaluated it
+            else return recv[t];
+        }
+    }
+    template <int S0, int N>
+    __device__ __forceinline__ void fill(f32x16& out, const float (&x)[3], int hi) const {
+        const float lo_v = feature<2 * S0, 0>(x), hi_v = feature<2 * S0 + 1, 1>(x);
+        out[S0 & 15] = hi ? hi_v : lo_v;
+        if constexpr ((S0 & 15) + 1 < N) fill<S0 + 1, N>(out, x, hi);
     }
 };
 
@@ -428,9 +473,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         }
         // ---- encodings, directly in B-operand form: k-step s of lane (j,hi) = feature 2s+hi
         f32x16 ex[2], ed;
-        EncFill<NSOS_XYZ_FREQS, 0, 16>::run(ex[0], x, hi);
-        EncFill<NSOS_XYZ_FREQS, 16, 16>::run(ex[1], x, hi);
-        EncFill<NSOS_DIR_FREQS, 0, 16>::run(ed, dv, hi);
+        {
+            Enc<NSOS_XYZ_FREQS> e;
+            e.evaluate(x, hi);
+            e.fill<0, 16>(ex[0], x, hi);
+            e.fill<16, 16>(ex[1], x, hi);
+        }
+        {
+            Enc<NSOS_DIR_FREQS> e;
+            e.evaluate(dv, hi);
+            e.fill<0, 16>(ed, dv, hi);
+        }
 
         // Z: accumulators of the layer being computed; H: previous layer's activations (VGPRs, MFMA srcB)
         f32x16 Z[8], H[8];

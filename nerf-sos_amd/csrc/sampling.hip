@@ -10,6 +10,27 @@
 //     the bisection and the merge never leave the wave (no block barriers).
 #include "common.h"
 
+// ------------------------------------------------------------------------------------------ K0
+// Pinhole ray generation on device: utils/ray.py:12-22 get_persp_rays.
+//   dirs = [(i-cx)/fx, -(j-cy)/fy, -1];  rays_d[c] = (dirs0*R[c][0] + dirs1*R[c][1]) + dirs2*R[c][2];  rays_o = t
+// (ATen sums the three products left to right: verified bitwise).  One thread per pixel of [pix_begin, pix_end).
+struct Pose { float m[12]; };  // c2w[:3,:4] row-major, by value in the kernel arguments
+__global__ __launch_bounds__(256) void generate_rays_kernel(int W, float fx, float fy, float cx, float cy,
+                                                            const Pose c2w, int64_t pix_begin, int64_t n,
+                                                            float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const int64_t pix = pix_begin + gid;
+    const float i = (float)(pix % W), j = (float)(pix / W);
+    const float d0 = (i - cx) / fx, d1 = -((j - cy) / fy), d2 = -1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float p0 = d0 * c2w.m[4 * c], p1 = d1 * c2w.m[4 * c + 1], p2 = d2 * c2w.m[4 * c + 2];
+        rays_d[3 * gid + c] = (p0 + p1) + p2;
+        rays_o[3 * gid + c] = c2w.m[4 * c + 3];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ K1
 // models/nerf_net.py:163-166 + models/sampler.py:46-68.   grid: one thread per (ray, sample).
 __global__ __launch_bounds__(256) void ray_setup_kernel(const float* __restrict__ rays_d,
@@ -177,6 +198,23 @@ __global__ __launch_bounds__(256) void importance_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
+extern "C" int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy,
+                                      const float* c2w_host, int64_t pix_begin, int64_t pix_end, float* rays_o,
+                                      float* rays_d, void* stream) {
+    NSOS_REQUIRE(c2w_host, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(H > 0 && W > 0 && pix_begin >= 0 && pix_end >= pix_begin && pix_end <= (int64_t)H * W, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(fx != 0.0f && fy != 0.0f, NSOS_ERR_BAD_SHAPE);
+    const int64_t n = pix_end - pix_begin;
+    if (n == 0) return NSOS_OK;
+    NSOS_REQUIRE(rays_o && rays_d, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE((n + 255) / 256 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    Pose pose;
+    for (int k = 0; k < 12; ++k) pose.m[k] = c2w_host[k];
+    hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       fx, fy, cx, cy, pose, pix_begin, n, rays_o, rays_d);
+    return nsos_launch_status();
+}
+
 extern "C" int32_t nsos_ray_setup(const float* rays_d, const float* near, const float* far, const float* t_rand,
                                   int64_t n_rays, int32_t n_samples, float* z_vals, float* viewdirs,
                                   void* stream) {

@@ -40,6 +40,27 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ------------------------------------------------------------------------------------------ K0
+def generate_rays(H: int, W: int, K, c2w, device, pix_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """get_persp_rays (utils/ray.py:12-22) on device.  K: 3x3 intrinsics, c2w: [3,4] (or [4,4]) pose -- host
+    tensors / arrays.  Returns [2, H, W, 3] like the reference, or [2, n, 3] for the flat pixel range given."""
+    Kf = torch.as_tensor(K, dtype=torch.float32).cpu()
+    pose = torch.as_tensor(c2w, dtype=torch.float32).cpu()[:3, :4].contiguous()
+    b, e = (0, H * W) if pix_range is None else pix_range
+    n = e - b
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("nerf_sos_amd: `device` must be a GPU -- this package has no CPU path")
+    with torch.cuda.device(dev):
+        ro = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        rd = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        arr = (C.c_float * 12)(*pose.reshape(-1).tolist())
+        _lib.check(_lib.lib().nsos_generate_rays(H, W, float(Kf[0, 0]), float(Kf[1, 1]), float(Kf[0, 2]), float(Kf[1, 2]),
+                                                 arr, b, e, _p(ro), _p(rd), _stream()), "nsos_generate_rays")
+    rays = torch.stack([ro, rd], 0)
+    return rays.reshape(2, H, W, 3) if pix_range is None else rays
+
+
 # ------------------------------------------------------------------------------------------ K1
 def ray_setup(rays_d: torch.Tensor, near: torch.Tensor, far: torch.Tensor, n_samples: int,
               t_rand: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:

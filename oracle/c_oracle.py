@@ -66,6 +66,15 @@ def num_threads() -> int:
     return int(lib().oracle_num_threads())
 
 
+def generate_rays(H: int, W: int, K, c2w):
+    K, pose = _f(K), np.ascontiguousarray(_f(c2w)[:3, :4])
+    o = np.empty((H, W, 3), np.float32)
+    d = np.empty((H, W, 3), np.float32)
+    lib().oracle_generate_rays(C.c_int32(H), C.c_int32(W), C.c_float(K[0, 0]), C.c_float(K[1, 1]), C.c_float(K[0, 2]),
+                               C.c_float(K[1, 2]), _p(pose), _p(o), _p(d))
+    return np.stack([o, d], 0)
+
+
 def ray_setup(rays_o, rays_d, near, far, t_rand, n_samples: int):
     o, d, n, f, t = _f(rays_o), _f(rays_d), _f(near).reshape(-1), _f(far).reshape(-1), _f(t_rand)
     R = d.shape[0]

@@ -56,6 +56,23 @@ static inline int chain_feature(int j) {
     return (j & ~7) + (q >> 1) + 4 * (q & 1);
 }
 
+/* ---------------------------------------------------------------------------- ray generation
+ * utils/ray.py:12-22 get_persp_rays: pixel (i, j) of an H x W image, intrinsics fx, fy, cx, cy, pose c2w[3][4]. */
+void oracle_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w,
+                          float* rays_o, float* rays_d) {
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < W; ++i) {
+            const float d0 = ((float)i - cx) / fx, d1 = -(((float)j - cy) / fy), d2 = -1.0f;
+            float* o = rays_o + 3 * ((int64_t)j * W + i);
+            float* d = rays_d + 3 * ((int64_t)j * W + i);
+            for (int c = 0; c < 3; ++c) {
+                const float p0 = d0 * c2w[4 * c], p1 = d1 * c2w[4 * c + 1], p2 = d2 * c2w[4 * c + 2];
+                d[c] = (p0 + p1) + p2; /* torch.sum over the 3 products, left to right (verified bitwise) */
+                o[c] = c2w[4 * c + 3];
+            }
+        }
+}
+
 /* ---------------------------------------------------------------------------- ray setup
  * models/nerf_net.py:164-165 (viewdirs = d/|d|) and models/sampler.py:46-68 (stratified z). */
 void oracle_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far,

@@ -36,6 +36,8 @@ typedef struct {
     float* sem_hidden;  /* [P,128] */
 } oracle_mlp_taps;
 
+void oracle_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w,
+                          float* rays_o, float* rays_d);
 void oracle_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far,
                       const float* t_rand, int64_t n_rays, int32_t n_samples, float* z_vals, float* viewdirs);
 void oracle_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int64_t n_rays,

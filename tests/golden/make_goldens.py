@@ -300,6 +300,18 @@ def main():
             out[f"{tag}_train_draw{i}"] = np32(t)
     np.savez_compressed(os.path.join(HERE, "end_to_end.npz"), **out)
 
+    # ---------------------------------------------------------------- K0: ray generation (utils/ray.py)
+    from utils.ray import get_persp_rays, get_persp_intrinsic
+    out = {}
+    for idx, (H_, W_, f_) in enumerate(((37, 53, 41.7), (63, 84, 70.83), (8, 5, 3.0))):
+        K_ = get_persp_intrinsic(H_, W_, f_)
+        c2w = torch.cat([torch.linalg.qr(torch.randn(3, 3, generator=g))[0], torch.randn(3, 1, generator=g) * 3], 1)
+        out[f"case{idx}_HWf"] = np.array([H_, W_, f_], np.float64)
+        out[f"case{idx}_K"] = np32(K_)
+        out[f"case{idx}_c2w"] = np32(c2w)
+        out[f"case{idx}_rays"] = np32(get_persp_rays(H_, W_, K_, c2w))
+    np.savez_compressed(os.path.join(HERE, "rays.npz"), **out)
+
     # ---------------------------------------------------------------- K5: frozen-backbone gradients
     torch.set_grad_enabled(True)
     out = {}

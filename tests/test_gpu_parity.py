@@ -356,3 +356,17 @@ def test_unfrozen_backbone_raises():
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True).to(DEV)
     with pytest.raises(NotImplementedError, match="fix_backbone"):
         net(tp.synthetic_rays(8).to(DEV), (tp.NEAR, tp.FAR))
+
+
+# ------------------------------------------------------------------------------------------ K0 (section 8f)
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_generate_rays(golden, case):
+    g = golden("rays")
+    H, W, _ = (int(v) for v in g[f"case{case}_HWf"])
+    K, c2w, want = g[f"case{case}_K"], g[f"case{case}_c2w"], g[f"case{case}_rays"]
+    rays = ops.generate_rays(H, W, K, c2w, DEV)
+    assert rays.shape == (2, H, W, 3) and np.array_equal(N(rays), want), "rays must equal the REFERENCE bit for bit"
+    b, e = W + 3, H * W - 2   # a ragged flat pixel range, as a ray-sharded rank would request
+    part = ops.generate_rays(H, W, K, c2w, DEV, pix_range=(b, e))
+    assert np.array_equal(N(part), want.reshape(2, -1, 3)[:, b:e])
+    assert ops.generate_rays(H, W, K, c2w, DEV, pix_range=(5, 5)).shape == (2, 0, 3)

@@ -159,3 +159,11 @@ def test_frozen_backbone_gradients_port(golden, manifest, name, peaky, white, n_
     assert len(keys) == (8 if n_imp else 4)
     for k in keys:
         close(sd[k].grad.numpy(), g[f"{tag}_grad_{k}"], atol=1e-6, rtol=1e-5, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_generate_rays(golden, case):
+    g = golden("rays")
+    H, W, _ = g[f"case{case}_HWf"]
+    rays = co.generate_rays(int(H), int(W), g[f"case{case}_K"], g[f"case{case}_c2w"])
+    assert np.array_equal(rays, g[f"case{case}_rays"]), "get_persp_rays must be reproduced bit for bit"
