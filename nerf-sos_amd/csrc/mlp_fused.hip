@@ -31,17 +31,12 @@
 //   * Persistent grid (one workgroup per CU); the chunk stream is cyclic so the DMA of the next tile's
 //     first chunks overlaps the current tile's tail.
 // Compiled with -ffp-contract=off (x = o + d*z must stay a separately rounded multiply and add).
-#include "common.h"
+#include "mlp_common.h"
 
-#include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+using namespace nsos;
 
 namespace {
 
-constexpr int kGroupFloats = 256;                 // one group = A operands of 4 MFMAs = 64 lanes x 16 B = 1 KiB
 constexpr int kSlotGroups = 36;                   // LDS slot / packed-stream stride per chunk (34 used at most)
 constexpr int kSlotFloats = kSlotGroups * kGroupFloats;  // 36 KiB
 constexpr int kDmaPieces = kSlotGroups / 4;       // 1 KiB pieces per wave per chunk
@@ -63,9 +58,6 @@ __host__ __device__ constexpr int chunks_per_net(int sem) {
     // L0 enc(2) + L1-4 (4x8) + L5 hid(8)+enc(2) + L6,L7 (2x8) + [sem0 hid(4) (+enc 1)] + feature(8) + views hid(4)+dir(1)
     return 2 + 32 + 10 + 16 + (sem ? 4 + (sem == 2 ? 1 : 0) : 0) + 8 + 5;
 }
-
-// feature index held by (tile t, reg r, half hi) in the 32x32 accumulator layout
-__host__ __device__ constexpr int acc_feature(int t, int r, int hi) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 constexpr int kProfSlots = 64;
 struct MlpParams {
@@ -91,121 +83,13 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-#define NSOS_PIN() __builtin_amdgcn_sched_barrier(0)
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ---- A-operand pipeline -------------------------------------------------------------------------
-// One ds_read_b128 feeds a group of 4 MFMAs (256 cycles of matrix pipe).  hipcc, left alone, issues each
-// read right before its use and waits lgkmcnt(0), and with source-level prefetching it still waits for the
-// YOUNGEST read.  So the reads are inline asm, invisible to the compiler's wait-count pass, with hand-counted
-// waits (cdna_hip_programming.md section 5.7, form iii):
-//   * a ring of kRing slots: slot g%kRing is re-loaded for group g+kRing right after group g's MFMAs were
-//     issued, so while group g computes, the reads of the next kRing-1 groups are in flight (LDS returns in
-//     order, so "lgkmcnt(n)" with n = number of younger reads == "group g has landed");
-//   * the ring never drains at a chunk boundary: during groups NG-6..NG-4 the first kRing groups of the
-//     NEXT chunk (already resident in the next LDS slot) are read into `nxt`, and become the ring at the
-//     chunk's end (lgkmcnt(0) there is free: those reads are >= 3 groups old);
-//   * extra outstanding LGKM/VM operations the compiler may issue can only make a counted wait stricter
-//     (in-order return within a class), never looser, so the counts are safe.
-// Three LDS slots: chunk c is consumed from slot c%3 while chunk c+1 is resident in the next one and chunk
-// c+2 is being DMA'd into the third.  ONE workgroup barrier per chunk, before group kMidGroup: every wave
-// drains its own DMA (vmcnt(0), issued a whole chunk earlier) and arrives; passing it proves (a) chunk c+1
-// has landed for every wave and (b) every wave has finished chunk c-1, whose slot the DMA pieces issued right
-// after the barrier (one per MFMA shadow) overwrite.  The ring reads simply continue across the barrier.
-#ifdef NSOS_EXP_RING
-constexpr int kRing = NSOS_EXP_RING;
-#else
-constexpr int kRing = 3;
-#endif
-constexpr int kMidGroup = 4;
-
-template <int OFF_BYTES>
-__device__ __forceinline__ void lds_read_a(f32x4& dst, unsigned lds_addr) {
-#ifdef NSOS_EXP_NOLDS  // timing experiment only (garbage results)
-    asm volatile("" : "+v"(dst));
-    return;
-#endif
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF_BYTES) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait() {
-#ifdef NSOS_EXP_NOWAIT  // timing experiment only (racy)
-    return;
-#endif
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
-}
-
-// Issue schedule of one chunk's LDS reads, in program order: after the MFMAs of group g:
-//   R(g+kRing) if g+kRing < NG   (ring reload),   then   N(g-(NG-6)) if NG-6 <= g < NG-6+kRing  (next chunk).
-// younger_reads(NG, g) = number of reads issued after R(g) and before group g's MFMAs (0 for g < kRing,
-// whose data was waited for at the previous chunk's end).
-__host__ __device__ constexpr int reads_after_group(int NG, int g) {
-    return (g + kRing < NG ? 1 : 0) + ((g >= NG - 6 && g < NG - 6 + kRing) ? 1 : 0);
-}
-__host__ __device__ constexpr int younger_reads(int NG, int g) {
-    if (g < kRing) return 0;
-    int n = reads_after_group(NG, g - kRing) - 1;  // R(g) is the first read issued after group g-kRing
-    for (int h = g - kRing + 1; h < g; ++h) n += reads_after_group(NG, h);
-    return n;
-}
-
-struct ChunkCtx {     // what a chunk needs from the weight stream
-    unsigned wl_cur;  // LDS byte address of this lane's A operands in the current chunk's slot
-    unsigned wl_nxt;  // same for the next chunk's slot
-};
-
-// NG groups of 4 MFMAs; group g's A operands are the f32x4 at byte offset g*1024 from ctx.wl_cur (which
-// already includes lane*16).  mfma4(g, a) issues the 4 MFMAs of group g plus whatever rides in their shadows.
-// tail() advances the weight stream's bookkeeping (slot rotation, DMA source pointer): it runs in the MFMA
-// shadow after group NG-3, i.e. after the last use of the current values, so nothing is left to compute
-// between two chunks (measured: ~150 exposed cycles per chunk boundary otherwise).
-template <int NG, class M, class B, class T>
-__device__ __forceinline__ void a_pipeline(f32x4 (&ring)[kRing], const ChunkCtx ctx, M&& mfma4, B&& mid, T&& tail) {
-    static_assert(NG >= kMidGroup + 3 + 6 && NG <= kSlotGroups, "chunk length outside the barrier/DMA/preload schedule");
-    f32x4 nxt[kRing];
-    static_for<0, NG>([&](auto ic) {
-        constexpr int g = decltype(ic)::value;
-        if constexpr (g == kMidGroup) {
-            NSOS_PIN();
-            mid();
-            NSOS_PIN();
-        }
-        if constexpr (g >= kRing) lgkm_wait<younger_reads(NG, g)>();
-        NSOS_PIN();
-        mfma4(ic, ring[g % kRing]);
-        NSOS_PIN();
-        if constexpr (g + kRing < NG) lds_read_a<(g + kRing) * 1024>(ring[g % kRing], ctx.wl_cur);
-        if constexpr (g >= NG - 6 && g < NG - 6 + kRing) lds_read_a<(g - (NG - 6)) * 1024>(nxt[g - (NG - 6)], ctx.wl_nxt);
-        if constexpr (g == NG - 3) {
-            NSOS_PIN();
-            tail();
-            NSOS_PIN();
-        }
-    });
-    lgkm_wait<0>();
-    NSOS_PIN();
-    // The next chunk starts at group 0, which uses slot 0: re-assignment in order is right for every NG.
-#pragma unroll
-    for (int i = 0; i < kRing; ++i) ring[i] = nxt[i];
-}
-
-// The DMA of chunk c+2 (kDmaPieces x 1 KiB per wave) is issued from inside chunk c: one piece after each of
-// the first kDmaPieces MFMAs that follow the barrier, so its issue slots are covered by the 64-cycle MFMAs.
+// A-operand pipeline geometry of this kernel (machinery + rationale: mlp_common.h): one group = 4 MFMAs
+// (256 cycles); ring of 3; next chunk's first groups pre-read during groups NG-6..NG-4; three 36 KiB LDS
+// slots (chunk c consumed, c+1 resident, c+2 in flight); barrier before group 4, vmcnt(0) at it.
+constexpr int kRing = 3, kPre = 6, kMidGroup = 4;
 template <int G, int J, class S>
-__device__ __forceinline__ void dma_slot(S&& side) {
-    constexpr int i = (G - kMidGroup) * 4 + J;
-    if constexpr (G >= kMidGroup && i < kDmaPieces) {
-        NSOS_PIN();
-        side(i);
-        NSOS_PIN();
-    }
+__device__ __forceinline__ void dma_after_mfma(S&& side) {  // piece i rides behind the i-th MFMA after the barrier
+    dma_slot<(G - kMidGroup) * 4 + J, kDmaPieces>(side);
 }
 
 // One chunk of an 8-tile layer: 16 k-steps x 8 tiles (+ a leading bias k-step if BIAS).
@@ -214,7 +98,7 @@ template <bool BIAS, class S, class B, class T>
 __device__ __forceinline__ void chunk8(f32x16 (&acc)[8], f32x4 (&ring)[kRing], const ChunkCtx ctx, const f32x16& b,
                                        S&& side, B&& mid, T&& tail) {
     constexpr int NB = BIAS ? 2 : 0;
-    a_pipeline<32 + NB>(ring, ctx, [&](auto ic, const f32x4& a) {
+    a_pipeline<32 + NB, kRing, kPre, kMidGroup>(ring, ctx, [&](auto ic, const f32x4& a) {
         constexpr int g = decltype(ic)::value;
         static_for<0, 4>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -225,7 +109,7 @@ __device__ __forceinline__ void chunk8(f32x16 (&acc)[8], f32x4 (&ring)[kRing], c
                 constexpr int gr = g - NB, q = gr & 1;
                 acc[4 * q + j] = mfma(a[j], b[gr >> 1], acc[4 * q + j]);
             }
-            dma_slot<g, j>(side);
+            dma_after_mfma<g, j>(side);
         });
     }, mid, tail);
 }
@@ -236,7 +120,7 @@ template <int NKS, bool BIAS, class S, class B, class T>
 __device__ __forceinline__ void chunk4(f32x16 (&acc)[4], f32x4 (&ring)[kRing], const ChunkCtx ctx, const f32x16& b0,
                                        const f32x16& b1, S&& side, B&& mid, T&& tail) {
     constexpr int NB = BIAS ? 1 : 0;
-    a_pipeline<NKS + NB>(ring, ctx, [&](auto ic, const f32x4& a) {
+    a_pipeline<NKS + NB, kRing, kPre, kMidGroup>(ring, ctx, [&](auto ic, const f32x4& a) {
         constexpr int g = decltype(ic)::value;
         static_for<0, 4>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -247,7 +131,7 @@ __device__ __forceinline__ void chunk4(f32x16 (&acc)[4], f32x4 (&ring)[kRing], c
                 constexpr int ks = g - NB;
                 acc[j] = mfma(a[j], ks < 16 ? b0[ks & 15] : b1[ks & 15], acc[j]);
             }
-            dma_slot<g, j>(side);
+            dma_after_mfma<g, j>(side);
         });
     }, mid, tail);
 }
@@ -285,95 +169,16 @@ __device__ __forceinline__ float head_partial(const f32x16 (&h)[NT], const float
     return part;
 }
 
-__device__ __forceinline__ float both_halves(float part) { return part + __shfl_xor(part, 32, NSOS_WAVE); }
-
-// positional-encoding feature idx of a 3-vector with L octaves (models/embedder.py:34-48):
-//   [x y z | sin(2^0 x..z) cos(2^0 x..z) | sin(2^1 ..) ...];   idx >= 3+6L is zero padding.
-struct EncSlot {
-    int coord;   // 0..2
-    int octave;  // 0..L-1, or -1 = raw coordinate, -2 = pad
-    bool is_cos;
+// encoded feature idx lives in half-wave idx & 1 (k-step s of lane (j, hi) = feature 2s+hi)
+struct ParityHalf {
+    __host__ __device__ static constexpr int of(int idx) { return idx & 1; }
 };
-__host__ __device__ constexpr EncSlot enc_slot(int idx, int L) {
-    if (idx < 3) return {idx, -1, false};
-    if (idx >= 3 + 6 * L) return {0, -2, false};
-    const int k = (idx - 3) / 6, j = (idx - 3) % 6;
-    return {j % 3, k, j >= 3};
+template <int L, int S0, int N>
+__device__ __forceinline__ void enc_fill(f32x16& out, const Enc<L, ParityHalf>& e, const float (&x)[3], int hi) {
+    const float lo_v = e.template feature<2 * S0, 0>(x), hi_v = e.template feature<2 * S0 + 1, 1>(x);
+    out[S0 & 15] = hi ? hi_v : lo_v;
+    if constexpr ((S0 & 15) + 1 < N) enc_fill<L, S0 + 1, N>(out, e, x, hi);
 }
-
-// sin and cos of a positional-encoding argument (|a| = |coordinate| * 2^k, a few thousand radians at most).
-// Branch-free three-term Cody-Waite reduction with fmaf (each step rounds once; the partial remainders are
-// O(1), so the reduced argument is good to ~1 ulp for |a| < 2^15) + the Cephes minimax polynomials on
-// [-pi/4, pi/4] (~1 ulp).  ocml's sincosf takes its Payne-Hanek branch for arguments this large, which made the
-// encoding 10k cycles per tile AND desynchronised the four waves (the next barrier waits for the slowest).
-// Arguments >= 2^15 (never produced by a scene-normalised NeRF) fall back to ocml.
-__device__ __forceinline__ void sincos_pe(float a, float& sn, float& cs) {
-    if (__builtin_expect(!(fabsf(a) < 32768.0f), 0)) {
-        sincosf(a, &sn, &cs);
-        return;
-    }
-    const float q = __builtin_rintf(a * 0.636619772367581343f);          // 2/pi
-    float r = __fmaf_rn(q, -1.57079637050628662109375f, a);              // pi/2 split into three fp32 terms
-    r = __fmaf_rn(q, 4.37113900018624283e-8f, r);
-    r = __fmaf_rn(q, 1.71512451613343730e-15f, r);
-    const int n = (int)q;
-    const float r2 = r * r;
-    float ps = __fmaf_rn(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = __fmaf_rn(r2, ps, -1.6666654611e-1f);
-    ps = __fmaf_rn(r * r2, ps, r);                                       // sin(r)
-    float pc = __fmaf_rn(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = __fmaf_rn(r2, pc, 4.166664568298827e-2f);
-    pc = __fmaf_rn(r2 * r2, pc, __fmaf_rn(r2, -0.5f, 1.0f));             // cos(r)
-    const float s0 = (n & 1) ? pc : ps, c0 = (n & 1) ? ps : pc;
-    sn = (n & 2) ? -s0 : s0;
-    cs = ((n + 1) & 2) ? -c0 : c0;
-}
-
-// Encoding of a 3-vector with L octaves, directly in B-operand form: k-step s of lane (j, hi) = feature 2s+hi.
-// The sin and cos of one (octave, coordinate) pair always belong to DIFFERENT half-waves (feature indices
-// 3+6k+c and 6+6k+c differ in parity), so pair p = 3k+c is evaluated once, by half p&1 (job t = p>>1 evaluates
-// pair 2t in the lo half and 2t+1 in the hi half with one instruction stream); each lane keeps the value its
-// own half needs and hands the other to its partner lane (lane ^ 32): 3L/2 sincos evaluations per lane instead
-// of 3L.  All index bookkeeping below is compile-time.
-template <int L>
-struct Enc {
-    static constexpr int kPairs = 3 * L, kJobs = (kPairs + 1) / 2;
-    // does half h need the sin (vs the cos) of pair p = 3k+c ?   sin feature 3+6k+c has parity (c+1)&1
-    __host__ __device__ static constexpr bool half_needs_sin(int p, int h) { return (((p % 3) + 1) & 1) == h; }
-
-    float own_sn[kJobs], own_cs[kJobs], recv[kJobs];
-
-    __device__ __forceinline__ void evaluate(const float (&x)[3], int hi) {
-#pragma unroll
-        for (int t = 0; t < kJobs; ++t) {
-            const int pl = 2 * t, ph = (2 * t + 1 < kPairs) ? 2 * t + 1 : 2 * t;  // pair of the lo / hi half
-            const float al = x[pl % 3] * (float)(1 << (pl / 3)), ah = x[ph % 3] * (float)(1 << (ph / 3));
-            sincos_pe(hi ? ah : al, own_sn[t], own_cs[t]);
-            // what the PARTNER half needs from my pair: half 1-h of pair (2t+h)
-            const bool send_sin_l = half_needs_sin(pl, 1), send_sin_h = half_needs_sin(ph, 0);
-            const float send = (hi ? send_sin_h : send_sin_l) ? own_sn[t] : own_cs[t];
-            recv[t] = __shfl_xor(send, 32, NSOS_WAVE);
-        }
-    }
-    // value of feature idx for a lane of half h (h compile-time)
-    template <int IDX, int H>
-    __device__ __forceinline__ float feature(const float (&x)[3]) const {
-        constexpr EncSlot e = enc_slot(IDX, L);
-        if constexpr (e.octave == -1) return x[e.coord];
-        else if constexpr (e.octave == -2) return 0.0f;
-        else {
-            constexpr int p = 3 * e.octave + e.coord, t = p >> 1;
-            if constexpr ((p & 1) == H || 2 * t + 1 >= kPairs) return e.is_cos ? own_cs[t] : own_sn[t];  // my half evaluated it
-            else return recv[t];
-        }
-    }
-    template <int S0, int N>
-    __device__ __forceinline__ void fill(f32x16& out, const float (&x)[3], int hi) const {
-        const float lo_v = feature<2 * S0, 0>(x), hi_v = feature<2 * S0 + 1, 1>(x);
-        out[S0 & 15] = hi ? hi_v : lo_v;
-        if constexpr ((S0 & 15) + 1 < N) fill<S0 + 1, N>(out, x, hi);
-    }
-};
 
 // ------------------------------------------------------------------------------------------ the kernel
 // SAVE: training-mode variant that additionally stores what the semantic head's backward needs (K5).
@@ -405,9 +210,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
     auto dma_piece = [&](const float* src_chunk, unsigned dst_wave, int i) {
         const float* src = src_chunk + i * 4 * kGroupFloats;  // uniform
         const unsigned dst = dst_wave + (unsigned)i * 4096u;   // uniform
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(dst), "v"(voff), "s"(src) : "memory");
+        dma_1k(src, dst, voff);
     };
 #ifdef NSOS_EXP_NODMA  // timing experiment only (results are garbage): how much does the DMA issue cost?
     auto side = [&](int) {};
@@ -474,15 +277,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         // ---- encodings, directly in B-operand form: k-step s of lane (j,hi) = feature 2s+hi
         f32x16 ex[2], ed;
         {
-            Enc<NSOS_XYZ_FREQS> e;
+            Enc<NSOS_XYZ_FREQS, ParityHalf> e;
             e.evaluate(x, hi);
-            e.fill<0, 16>(ex[0], x, hi);
-            e.fill<16, 16>(ex[1], x, hi);
+            enc_fill<NSOS_XYZ_FREQS, 0, 16>(ex[0], e, x, hi);
+            enc_fill<NSOS_XYZ_FREQS, 16, 16>(ex[1], e, x, hi);
         }
         {
-            Enc<NSOS_DIR_FREQS> e;
+            Enc<NSOS_DIR_FREQS, ParityHalf> e;
             e.evaluate(dv, hi);
-            e.fill<0, 16>(ed, dv, hi);
+            enc_fill<NSOS_DIR_FREQS, 0, 16>(ed, e, dv, hi);
         }
 
         // Z: accumulators of the layer being computed; H: previous layer's activations (VGPRs, MFMA srcB)
