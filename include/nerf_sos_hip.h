@@ -134,6 +134,18 @@ int32_t nsos_sem_head_backward(const float* weights, const float* g_semantics, c
                                const float* sem_hid, int64_t n_rays, int32_t n_samples, float* g_hid,
                                float* g_logits, void* stream);
 
+/* ---- K2-LP: the same fused network with 16-bit MFMA inputs and fp32 accumulation (reduced-precision configs) ----
+ * For BASELINE configs C3 (bf16) and C5 (fp16, eval-only).  NOT bit/1e-4-comparable with the reference's fp32
+ * arithmetic (fp16: ~1e-3 relative, bf16: ~1e-2); never used by the fp32 parity path.  Weights are packed to 16
+ * bit by nsos_mlp_pack_lp into their own stream layout (nsos_mlp_packed_bytes_lp bytes).  raw out is fp32. */
+enum { NSOS_DTYPE_F32 = 0, NSOS_DTYPE_F16 = 1, NSOS_DTYPE_BF16 = 2 };
+size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode);
+int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* tensors, int32_t sem_mode, int32_t dtype, void* packed,
+                         size_t packed_bytes, void* stream);
+int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                 const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
+                                 int32_t n_samples, float* raw, void* stream);
+
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).
  * Not on the product path; used to attribute the kernel's non-MFMA cycles (profiles/). */

@@ -1,0 +1,594 @@
+// K2-LP: the fused positional-encoding + MLP kernel with 16-bit (fp16 or bf16) MFMA inputs and fp32
+// accumulation, for the reduced-precision configurations (BASELINE C3 bf16, C5 fp16 eval-only).  Same network,
+// same replaced reference code as mlp_fused.hip (models/embedder.py:34-48, models/nerf_mlp.py:67-100,179-215);
+// NOT used by the fp32 parity path or by bench.py's headline number.
+//
+// What changes against the exact-fp32 kernel (DESIGN.md "K2-LP"):
+//   * v_mfma_f32_32x32x16_{f16,bf16}: 32 cycles, K = 16 -> 16x the MAC rate, so everything that was free next to a
+//     64-cycle fp32 MFMA now matters: A operands are 16 B per lane per MFMA, so each wave owns TWO column tiles
+//     (64 points) and every ds_read_b128 feeds two MFMAs; a 256 x 256 layer is only 8192 cycles of matrix pipe.
+//   * Accumulator -> B-operand feedback still works: a K-slice of 16 features is (tile t, reg half u): lane half kg
+//     supplies k-slots 8kg..8kg+7 = accumulator regs 8u..8u+7 = features 32t + 16u + {0,1,2,3,8,9,10,11} + 4kg, so
+//     after each layer ONE batched pass converts Z (fp32, AGPRs) to packed 16-bit pairs (v_cvt_pk) with the ReLU as
+//     v_pk_max_i16(x, 0) (sign bit set <=> negative int16), 4 VGPRs per slice, named directly as MFMA srcB.
+//   * Weights are packed to 16 bit in MFMA order; chunks are <= 34 A operands (1 KiB each) in 36 KiB slots, FOUR
+//     LDS slots (144 KiB): chunk c consumed, c+1 resident, c+2 landing, c+3 being issued; the per-chunk barrier
+//     waits with a COUNTED vmcnt (the 9 newest DMA pieces stay in flight), giving the DMA two chunks of lead.
+//   * Bias: leading K-slice with B = 1.0 (hidden layers, heads); layer 0 carries it in the encoding's pad slot.
+//   * sigma head: v_dot2c on the packed activations; rgb / semantics heads: fp32 VALU on the fp32 accumulators.
+// Compiled with -ffp-contract=off (x = o + d*z stays a separately rounded multiply and add).
+#include "mlp_common.h"
+
+using namespace nsos;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int kSlotGroups = 36;                          // LDS slot / stream stride per chunk, in 1 KiB A operands
+constexpr int kSlotBytes = kSlotGroups * 1024;
+constexpr int kSlots = 4;
+constexpr int kDmaPieces = kSlotGroups / 4;              // 1 KiB pieces per wave per chunk
+constexpr int kTilePts = 256;                            // 4 waves x 2 column tiles x 32 points
+#ifdef NSOS_LP_RING
+constexpr int kRing = NSOS_LP_RING, kPre = NSOS_LP_RING + 3, kMid = 2;
+#else
+constexpr int kRing = 5, kPre = 8, kMid = 2;
+#endif
+
+// aux stream, offsets in 4-byte words
+constexpr int kAuxAlphaW = 0;     // 128 words: sigma-head weights packed 16-bit, [kg][slice 0..15][q 0..3]
+constexpr int kAuxRgbW = 128;     // 3 x 128 fp32, accumulator layout [hi][t 0..3][r 0..15]
+constexpr int kAuxSem2W = 512;    // 2 x 128 fp32
+constexpr int kAuxScalars = 768;  // alpha_b, rgb_b[3], sem2_b[2]
+constexpr int kAuxWords = 1024;
+
+enum ChunkKind { kHid8 = 0, kEnc8 = 1, kHid4 = 2, kEnc4 = 3, kDir4 = 4 };
+
+__host__ __device__ constexpr int lp_chunks(int sem) {
+    // L0 enc(1) + 8 hidden layers x 4 + L5 enc(1) + [sem0 hid(2) (+enc 1)] + views hid(2) + dir(1)
+    return 1 + 32 + 1 + (sem ? 2 + (sem == 2 ? 1 : 0) : 0) + 3;
+}
+
+struct F16 {
+    static constexpr unsigned kOnes = 0x3C003C00u;  // {1.0h, 1.0h}
+    __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
+        unsigned r;
+        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
+    // pack two accumulator elements straight out of the AGPR file (VALU cannot source AGPRs; doing the two
+    // v_accvgpr_reads inside the asm keeps hipcc from hoisting hundreds of them ahead of the pass and spilling)
+    template <bool RELU>
+    __device__ static __forceinline__ unsigned pack2_acc(float lo, float hi) {
+        unsigned r, t;
+        if constexpr (RELU)
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
+                         "v_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
+        else
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
+                         "v_cvt_pk_f16_f32 %0, %0, %1" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
+        return r;
+    }
+    __device__ static __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
+        asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+        return acc;
+    }
+    __device__ static __forceinline__ unsigned short bits(float x) {
+        const _Float16 h = (_Float16)x;  // round to nearest even
+        return __builtin_bit_cast(unsigned short, h);
+    }
+};
+struct BF16 {
+    static constexpr unsigned kOnes = 0x3F803F80u;
+    __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
+        unsigned r;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
+    template <bool RELU>
+    __device__ static __forceinline__ unsigned pack2_acc(float lo, float hi) {
+        unsigned r, t;
+        if constexpr (RELU)
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
+                         "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
+        else
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
+                         "v_cvt_pk_bf16_f32 %0, %0, %1" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
+        return r;
+    }
+    __device__ static __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
+        asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+        return acc;
+    }
+    __device__ static __forceinline__ unsigned short bits(float x) {  // round to nearest even
+        unsigned u = __builtin_bit_cast(unsigned, x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // quiet NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    }
+};
+
+struct LpParams {
+    const unsigned* aux;
+    const unsigned char* chunks;
+    const float* rays_o;
+    const float* rays_d;
+    const float* viewdirs;
+    const float* z_vals;
+    float* raw;
+    long long n_pts;
+    int n_samples;
+    int n_tiles;
+};
+
+// encoded feature idx lives in half-wave (idx >> 3) & 1: a K-slice of 16 consecutive features, lane half kg
+// supplying k-slots 8kg .. 8kg+7
+struct SliceHalf {
+    __host__ __device__ static constexpr int of(int idx) { return (idx >> 3) & 1; }
+};
+
+// one K-slice (4 packed words) of an encoding: word q of lane half kg = features 16s + 8kg + 2q, +1
+template <class T, int L, int S, bool ONE_AT_63>
+__device__ __forceinline__ u32x4 enc_slice(const Enc<L, SliceHalf>& e, const float (&x)[3], int kg) {
+    u32x4 out;
+    static_for<0, 4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, f0 = 16 * S + 2 * q, f1 = 16 * S + 8 + 2 * q;
+        const float lo_a = e.template feature<f0, 0>(x), lo_b = e.template feature<f0 + 1, 0>(x);
+        const float hi_a = e.template feature<f1, 1>(x);
+        const float hi_b = (ONE_AT_63 && f1 + 1 == 63) ? 1.0f : e.template feature<f1 + 1, 1>(x);
+        out[q] = T::pack2(kg ? hi_a : lo_a, kg ? hi_b : lo_b);
+    });
+    return out;
+}
+
+__device__ __forceinline__ unsigned relu_pk16(unsigned p) {  // works for fp16 and bf16 bit patterns alike
+    unsigned r;
+    asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(p));
+    return r;
+}
+
+// H[c][2t+u] = pack16(relu?(Z[c][t][8u .. 8u+7]))   -- one batched VALU pass per layer
+template <class T, int NT, bool RELU>
+__device__ __forceinline__ void activate(u32x4 (&H)[2][2 * NT], const f32x16 (&Z)[2][NT]) {
+    // the asm below reads the accumulators behind hipcc's hazard tracking: an 8-pass MFMA result needs up to
+    // 11 wait states before a VALU read (the compiler itself emits s_nop 6 after other filler here)
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    H[c][2 * t + u][q] = T::template pack2_acc<RELU>(Z[c][t][8 * u + 2 * q], Z[c][t][8 * u + 2 * q + 1]);
+}
+
+// fp32 vector-ALU head on fp32 accumulators (rgb, semantics): this half-wave's partial chain
+//   part = fma(w, relu(h), part), h read straight from its AGPR (see pack2_acc for why this is asm)
+template <int NT>
+__device__ __forceinline__ float head_partial_f32(const f32x16 (&h)[NT], const float* w_lane, float init) {
+    float part = init;
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(w_lane + t * 16 + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float tmp;
+                asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_max_f32 %1, 0, %1\n\tv_fmac_f32 %0, %3, %1"
+                             : "+v"(part), "=&v"(tmp) : "a"(h[t][q * 4 + j]), "v"(w[j]));
+            }
+        }
+    return part;
+}
+
+// ------------------------------------------------------------------------------------------ the kernel
+template <class T, int SEM>
+__global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pj = lane & 31, kg = lane >> 5;
+    constexpr int NCH = lp_chunks(SEM);
+    constexpr int C = SEM ? 6 : 4;
+
+    // ---- weight stream: slots rotate (c0 = chunk cur, c1 = cur+1, c2 = cur+2, c3 = being filled with cur+3)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
+    auto lane_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotBytes + lane * 16); };
+    auto wave_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotBytes + wave_s * 1024); };
+    unsigned c0 = lane_addr(0), c1 = lane_addr(1), c2 = lane_addr(2), c3 = lane_addr(3);
+    unsigned d0 = wave_addr(0), d1 = wave_addr(1), d2 = wave_addr(2), d3 = wave_addr(3);
+    const unsigned char* const src_end = P.chunks + (size_t)NCH * kSlotBytes;
+    const unsigned char* src3 = P.chunks + (size_t)(3 % NCH) * kSlotBytes;
+    auto dma_piece = [&](const unsigned char* src_chunk, unsigned dst_wave, int i) {
+        dma_1k(src_chunk + i * 4096, dst_wave + (unsigned)i * 4096u, voff);
+    };
+    auto side = [&](int i) { dma_piece(src3, d3, i); };
+    auto mid = [&]() {
+        // all DMA pieces except the newest kDmaPieces (chunk cur+2, issued one chunk ago) must have landed:
+        // that is chunk cur+1, which the end of this chunk starts to read.  (Extra outstanding VM operations
+        // of the compiler only make this counted wait stricter.)
+#ifdef NSOS_EXP_VM0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kDmaPieces) : "memory");
+#endif
+        __builtin_amdgcn_s_barrier();
+    };
+    auto tail = [&]() {
+        const unsigned tc = c0, td = d0;
+        c0 = c1; c1 = c2; c2 = c3; c3 = tc;
+        d0 = d1; d1 = d2; d2 = d3; d3 = td;
+        src3 += kSlotBytes;
+        if (src3 == src_end) src3 = P.chunks;
+    };
+    auto ctx = [&]() { return ChunkCtx{c0, c1}; };
+
+    f32x4 ring[kRing];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < kDmaPieces; ++i)
+            dma_piece(P.chunks + (size_t)(k % NCH) * kSlotBytes, k == 0 ? d0 : (k == 1 ? d1 : d2), i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    static_for<0, kRing>([&](auto ic) { lds_read_a<decltype(ic)::value * 1024>(ring[decltype(ic)::value], c0); });
+    lgkm_wait<0>();
+    NSOS_PIN();
+
+    // one chunk: NG groups, group g = A operand `a0 + g` of a part with NT output tiles and NB leading bias
+    // A operands; the K-slice of A operand a >= NB is (a - NB) / NT, its tile (a - NB) % NT.
+    // zf_c != 0: the part starts the accumulation (slice 0 uses C = 0 instead of the old accumulator contents).
+    auto run_chunk = [&](auto ng_c, auto nt_c, auto nb_c, auto a0_c, auto nwork_c, auto zf_c, auto& acc, auto&& bsel) {
+        constexpr int NG = decltype(ng_c)::value, NT = decltype(nt_c)::value, NB = decltype(nb_c)::value;
+        constexpr int A0 = decltype(a0_c)::value, NWORK = decltype(nwork_c)::value;
+        constexpr bool ZF = decltype(zf_c)::value != 0;
+        a_pipeline<NG, kRing, kPre, kMid>(ring, ctx(), [&](auto ic, const f32x4& a32) {
+            constexpr int g = decltype(ic)::value, a = A0 + g;
+            const u32x4 aop = __builtin_bit_cast(u32x4, a32);
+            static_for<0, 2>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (g < NWORK) {
+                    if constexpr (a < NB) {
+                        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        const u32x4 ones = {T::kOnes, T::kOnes, T::kOnes, T::kOnes};
+                        acc[c][a] = T::mfma(aop, ones, zero);
+                    } else {
+                        constexpr int s = (a - NB) / NT, t = (a - NB) % NT;
+                        if constexpr (ZF && s == 0) {
+                            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                            acc[c][t] = T::mfma(aop, bsel(cc, std::integral_constant<int, s>{}), zero);
+                        } else {
+                            acc[c][t] = T::mfma(aop, bsel(cc, std::integral_constant<int, s>{}), acc[c][t]);
+                        }
+                    }
+                }
+                dma_slot<(g - kMid) * 2 + c, kDmaPieces>(side);
+            });
+        }, mid, tail);
+    };
+#define IC(n) std::integral_constant<int, (n)> {}
+
+    for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        // ---- this lane's two points (column tile c: point tile*256 + wave*64 + c*32 + pj)
+        long long gp[2], ray_of[2];
+        bool valid[2];
+        u32x4 ex[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            gp[c] = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
+            valid[c] = gp[c] < P.n_pts;
+            const long long gc = valid[c] ? gp[c] : P.n_pts - 1;
+            const long long ray = gc / P.n_samples;
+            const float z = P.z_vals[gc];
+            float x[3];
+            ray_of[c] = ray;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float m = P.rays_d[3 * ray + k] * z;  // models/sampler.py:70,166 (mul, then add)
+                x[k] = P.rays_o[3 * ray + k] + m;
+            }
+            {
+                Enc<NSOS_XYZ_FREQS, SliceHalf> e;
+                e.evaluate(x, kg);
+                ex[c][0] = enc_slice<T, NSOS_XYZ_FREQS, 0, true>(e, x, kg);
+                ex[c][1] = enc_slice<T, NSOS_XYZ_FREQS, 1, true>(e, x, kg);
+                ex[c][2] = enc_slice<T, NSOS_XYZ_FREQS, 2, true>(e, x, kg);
+                ex[c][3] = enc_slice<T, NSOS_XYZ_FREQS, 3, true>(e, x, kg);  // feature 63 (pad) = 1.0: layer-0 bias
+            }
+        }
+
+        f32x16 Z[2][8];
+        u32x4 H[2][16];
+        float sigma[2] = {0.0f, 0.0f}, sem_out[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        auto from_ex = [&](auto cc, auto sc) { return ex[decltype(cc)::value][decltype(sc)::value]; };
+        auto from_H = [&](auto cc, auto sc) { return H[decltype(cc)::value][decltype(sc)::value]; };
+
+        // pts_linears.0: 4 encoded slices x 8 tiles; the first slice of every tile starts from C = 0
+        run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), Z, from_ex);
+        activate<T, 8, true>(H, Z);
+        // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8)
+#pragma unroll 1
+        for (int l = 1; l <= 8; ++l) {
+            run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), Z, from_H);
+            run_chunk(IC(34), IC(8), IC(8), IC(34), IC(34), IC(0), Z, from_H);
+            run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), Z, from_H);
+            run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), Z, from_H);
+            if (l == 5) run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), Z, from_ex);  // skip connection
+            if (l < 8) activate<T, 8, true>(H, Z); else activate<T, 8, false>(H, Z);
+            if (l == 7) {
+                // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
+                const unsigned* aw = P.aux + kAuxAlphaW + kg * 64;
+                float pa[2] = {kg ? 0.0f : __builtin_bit_cast(float, P.aux[kAuxScalars]), 0.0f};
+                pa[1] = pa[0];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(aw + 4 * s);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pa[0] = T::dot2(H[0][s][q], w[q], pa[0]);
+                        pa[1] = T::dot2(H[1][s][q], w[q], pa[1]);
+                    }
+                }
+                sigma[0] = both_halves(pa[0]);
+                sigma[1] = both_halves(pa[1]);
+                if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
+                    f32x16 sacc[2][4];
+                    run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), sacc, from_H);
+                    run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), sacc, from_H);
+                    if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sacc, from_ex);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int o = 0; o < 2; ++o) {
+                            const float ps = head_partial_f32<4>(
+                                sacc[c], reinterpret_cast<const float*>(P.aux) + kAuxSem2W + o * 128 + kg * 64,
+                                kg ? 0.0f : __builtin_bit_cast(float, P.aux[kAuxScalars + 4 + o]));
+                            sem_out[c][o] = both_halves(ps);
+                        }
+                }
+            }
+        }
+        // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
+        f32x16 vacc[2][4];
+        run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), vacc, from_H);
+        run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), vacc, from_H);
+        // the direction encoding is evaluated only now (12 sincos per column): keeping its 16 VGPRs alive through
+        // the trunk pushes the kernel into spilling, and a spilled "pending" ring register is a race
+        u32x4 ed[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float dv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3 * ray_of[c] + k];
+            Enc<NSOS_DIR_FREQS, SliceHalf> e;
+            e.evaluate(dv, kg);
+            ed[c][0] = enc_slice<T, NSOS_DIR_FREQS, 0, false>(e, dv, kg);
+            ed[c][1] = enc_slice<T, NSOS_DIR_FREQS, 1, false>(e, dv, kg);
+        }
+        auto from_ed = [&](auto cc, auto sc) { return ed[decltype(cc)::value][decltype(sc)::value]; };
+        run_chunk(IC(16), IC(4), IC(0), IC(0), IC(8), IC(0), vacc, from_ed);  // 2 slices x 4 tiles; groups 8..15 are padding
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float rgb[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float pr = head_partial_f32<4>(vacc[c], reinterpret_cast<const float*>(P.aux) + kAuxRgbW + o * 128 + kg * 64,
+                                                     kg ? 0.0f : __builtin_bit_cast(float, P.aux[kAuxScalars + 1 + o]));
+                rgb[o] = both_halves(pr);
+            }
+            if (valid[c]) {
+                float* out = P.raw + gp[c] * C;
+                if constexpr (C == 4) {
+                    if (kg == 0) *reinterpret_cast<f32x4*>(out) = f32x4{rgb[0], rgb[1], rgb[2], sigma[c]};
+                } else {
+                    if (kg == 0) {
+                        *reinterpret_cast<f32x2*>(out) = f32x2{rgb[0], rgb[1]};
+                        *reinterpret_cast<f32x2*>(out + 2) = f32x2{rgb[2], sigma[c]};
+                    } else {
+                        *reinterpret_cast<f32x2*>(out + 4) = f32x2{sem_out[c][0], sem_out[c][1]};
+                    }
+                }
+            }
+        }
+    }
+#undef IC
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ packing
+struct LpChunk {
+    const float* w;
+    const float* bias;  // leading bias A operands of the part (a < NB), or the pad-slot bias (kEnc8 of layer 0), or NULL
+    int in_dim, col_base, kind, a0, n_groups;
+};
+struct LpPackParams {
+    LpChunk ch[40];
+    int n_chunks;
+    const float* alpha_w; const float* alpha_b;
+    const float* rgb_w; const float* rgb_b;
+    const float* sem2_w; const float* sem2_b;
+    unsigned* aux;
+    unsigned short* chunks;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams P) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < kAuxWords) {
+        const int a = (int)gid;
+        unsigned v = 0;
+        auto feat128 = [](int rem) { return acc_feature((rem & 63) >> 4, rem & 15, rem >> 6); };
+        if (a < kAuxRgbW) {  // sigma head weights, packed pairs in H order: word = [kg][s][q] -> features of slice s
+            const int kgl = a >> 6, s = (a & 63) >> 2, q = a & 3;
+            const int f0 = acc_feature(s >> 1, 8 * (s & 1) + 2 * q, kgl), f1 = acc_feature(s >> 1, 8 * (s & 1) + 2 * q + 1, kgl);
+            v = (unsigned)T::bits(P.alpha_w[f0]) | ((unsigned)T::bits(P.alpha_w[f1]) << 16);
+        } else if (a < kAuxSem2W) { const int rem = a - kAuxRgbW; v = __builtin_bit_cast(unsigned, P.rgb_w[(rem >> 7) * 128 + feat128(rem & 127)]); }
+        else if (a < kAuxScalars) { const int rem = a - kAuxSem2W; v = P.sem2_w ? __builtin_bit_cast(unsigned, P.sem2_w[(rem >> 7) * 128 + feat128(rem & 127)]) : 0u; }
+        else {
+            const int i = a - kAuxScalars;
+            float f = 0.0f;
+            if (i == 0) f = P.alpha_b[0];
+            else if (i < 4) f = P.rgb_b[i - 1];
+            else if (i < 6) f = P.sem2_b ? P.sem2_b[i - 4] : 0.0f;
+            v = __builtin_bit_cast(unsigned, f);
+        }
+        P.aux[a] = v;
+    }
+    const long long per_chunk = kSlotBytes / 2;  // 16-bit elements per slot
+    if (gid >= (long long)P.n_chunks * per_chunk) return;
+    const LpChunk ck = P.ch[gid / per_chunk];
+    const int within = (int)(gid % per_chunk);
+    const int g = within >> 9, lane = (within >> 3) & 63, e = within & 7;  // 512 elements per A operand
+    const int i = lane & 31, kgl = lane >> 5, m = 8 * kgl + e;
+    float v = 0.0f;
+    if (g < ck.n_groups) {
+        const int a = ck.a0 + g;
+        const bool eight = ck.kind == kHid8 || ck.kind == kEnc8;
+        const int nt = eight ? 8 : 4;
+        const int nb = (ck.kind == kHid8 || ck.kind == kHid4) ? nt : 0;
+        if (a < nb) {
+            v = (m == 0) ? ck.bias[32 * a + i] : 0.0f;
+        } else {
+            const int s = (a - nb) / nt, t = (a - nb) % nt;
+            int f = -1;
+            switch (ck.kind) {
+                case kHid8: case kHid4: f = acc_feature(s >> 1, 8 * (s & 1) + e, kgl); break;
+                case kEnc8: case kEnc4: f = 16 * s + m; if (f >= NSOS_XYZ_DIM) f = (f == 63 && ck.bias) ? -2 : -1; break;
+                case kDir4: f = 16 * s + m; if (f >= NSOS_DIR_DIM || s > 1) f = -1; break;
+            }
+            if (f >= 0) v = ck.w[(long long)(32 * t + i) * ck.in_dim + ck.col_base + f];
+            else if (f == -2) v = ck.bias[32 * t + i];  // layer-0 bias rides in the encoding's pad slot (input 1.0)
+        }
+    }
+    P.chunks[gid] = T::bits(v);
+}
+
+int lp_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 256;
+}
+
+constexpr int kLdsBytes = kSlots * kSlotBytes;
+
+template <class T, int SEM>
+int32_t launch_lp(const LpParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_lp_kernel<T, SEM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) return (int32_t)e;
+        configured = true;
+    }
+    static const int cus = lp_num_cus();
+    const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+    hipLaunchKernelGGL((mlp_lp_kernel<T, SEM>), dim3(grid), dim3(256), kLdsBytes, stream, p);
+    return nsos_launch_status();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode) {
+    if (sem_mode < 0 || sem_mode > 2) return 0;
+    return (size_t)kAuxWords * 4 + (size_t)lp_chunks(sem_mode) * kSlotBytes;
+}
+
+extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
+                                    size_t packed_bytes, void* stream) {
+    NSOS_REQUIRE(T_ && packed, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(sem_mode >= 0 && sem_mode <= 2 && (dtype == NSOS_DTYPE_F16 || dtype == NSOS_DTYPE_BF16), NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(packed_bytes >= nsos_mlp_packed_bytes_lp(sem_mode), NSOS_ERR_BUFFER_TOO_SMALL);
+    NSOS_REQUIRE(((uintptr_t)packed & 15) == 0, NSOS_ERR_MISALIGNED);
+    for (int l = 0; l < NSOS_NET_DEPTH; ++l) NSOS_REQUIRE(T_->pts_w[l] && T_->pts_b[l], NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(T_->alpha_w && T_->alpha_b && T_->feature_w && T_->feature_b && T_->views_w && T_->views_b &&
+                     T_->rgb_w && T_->rgb_b, NSOS_ERR_NULL_POINTER);
+    if (sem_mode) NSOS_REQUIRE(T_->sem0_w && T_->sem0_b && T_->sem2_w && T_->sem2_b, NSOS_ERR_NULL_POINTER);
+
+    LpPackParams P = {};
+    int n = 0;
+    auto add = [&](const float* w, const float* bias, int in_dim, int col, int kind, int a0, int ng) {
+        P.ch[n++] = LpChunk{w, bias, in_dim, col, kind, a0, ng};
+    };
+    auto hidden8 = [&](const float* w, const float* b, int in_dim, int col) {
+        for (int c = 0; c < 4; ++c) add(w, b, in_dim, col, kHid8, 34 * c, 34);
+    };
+    auto hidden4 = [&](const float* w, const float* b, int in_dim, int col) {
+        for (int c = 0; c < 2; ++c) add(w, b, in_dim, col, kHid4, 34 * c, 34);
+    };
+    const int X = NSOS_XYZ_DIM, W = NSOS_NET_WIDTH;
+    add(T_->pts_w[0], T_->pts_b[0], X, 0, kEnc8, 0, 32);  // bias in the pad slot
+    for (int l = 1; l <= 4; ++l) hidden8(T_->pts_w[l], T_->pts_b[l], W, 0);
+    hidden8(T_->pts_w[5], T_->pts_b[5], X + W, X);         // skip layer: h part (with its bias slice) ...
+    add(T_->pts_w[5], nullptr, X + W, 0, kEnc8, 0, 32);    // ... then the x63 part
+    hidden8(T_->pts_w[6], T_->pts_b[6], W, 0);
+    hidden8(T_->pts_w[7], T_->pts_b[7], W, 0);
+    if (sem_mode) {
+        const int in_dim = sem_mode == NSOS_SEM_COORD ? W + X : W;
+        hidden4(T_->sem0_w, T_->sem0_b, in_dim, 0);
+        if (sem_mode == NSOS_SEM_COORD) add(T_->sem0_w, nullptr, in_dim, W, kEnc4, 0, 16);
+    }
+    hidden8(T_->feature_w, T_->feature_b, W, 0);
+    hidden4(T_->views_w, T_->views_b, W + NSOS_DIR_DIM, 0);
+    add(T_->views_w, nullptr, W + NSOS_DIR_DIM, W, kDir4, 0, 8);
+    NSOS_REQUIRE(n == lp_chunks(sem_mode), NSOS_ERR_UNSUPPORTED);
+    P.n_chunks = n;
+    P.alpha_w = T_->alpha_w; P.alpha_b = T_->alpha_b;
+    P.rgb_w = T_->rgb_w; P.rgb_b = T_->rgb_b;
+    P.sem2_w = sem_mode ? T_->sem2_w : nullptr;
+    P.sem2_b = sem_mode ? T_->sem2_b : nullptr;
+    P.aux = static_cast<unsigned*>(packed);
+    P.chunks = reinterpret_cast<unsigned short*>(P.aux + kAuxWords);
+    const long long total = (long long)n * (kSlotBytes / 2);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dtype == NSOS_DTYPE_F16) hipLaunchKernelGGL(lp_pack_kernel<F16>, grid, block, 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(lp_pack_kernel<BF16>, grid, block, 0, (hipStream_t)stream, P);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                            const float* rays_d, const float* viewdirs, const float* z_vals,
+                                            int64_t n_rays, int32_t n_samples, float* raw, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(sem_mode >= 0 && sem_mode <= 2 && (dtype == NSOS_DTYPE_F16 || dtype == NSOS_DTYPE_BF16), NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
+    const long long n_pts = (long long)n_rays * n_samples;
+    NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    LpParams p = {};
+    p.aux = static_cast<const unsigned*>(packed);
+    p.chunks = reinterpret_cast<const unsigned char*>(p.aux + kAuxWords);
+    p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
+    p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
+    p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
+    const hipStream_t st = (hipStream_t)stream;
+    if (dtype == NSOS_DTYPE_F16) {
+        switch (sem_mode) {
+            case 0: return launch_lp<F16, 0>(p, st);
+            case 1: return launch_lp<F16, 1>(p, st);
+            default: return launch_lp<F16, 2>(p, st);
+        }
+    }
+    switch (sem_mode) {
+        case 0: return launch_lp<BF16, 0>(p, st);
+        case 1: return launch_lp<BF16, 1>(p, st);
+        default: return launch_lp<BF16, 2>(p, st);
+    }
+}

@@ -76,22 +76,22 @@ class NeRFMLP(nn.Module):
         self.mlp = MLP(net_depth, net_width, skips=skips, input_ch=3 + 6 * multires, output_ch=output_dim,
                        input_ch_views=3 + 6 * multires_views, use_viewdirs=viewdirs, use_semantics=use_semantics,
                        sem_layer=sem_layer, sem_dim=sem_dim, sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
-        self._packed: Optional[torch.Tensor] = None
-        self._packed_key = None
+        self._packed = {}      # precision -> packed stream
+        self._packed_key = {}  # precision -> (data_ptr, version) of every parameter when it was packed
 
     @property
     def sem_mode(self) -> int:
         return self.mlp.sem_mode
 
-    def packed_weights(self) -> torch.Tensor:
-        """The MFMA-order weight stream, re-packed on device whenever a parameter changed
+    def packed_weights(self, precision: str = "fp32") -> torch.Tensor:
+        """The MFMA-order weight stream for `precision`, re-packed on device whenever a parameter changed
         (optimizer steps and load_state_dict bump ``Tensor._version``)."""
         params = dict(self.mlp.named_parameters())
         key = tuple((p.data_ptr(), p._version) for p in params.values())
-        if self._packed is None or key != self._packed_key:
-            self._packed = ops.pack_mlp(params, self.sem_mode, self._packed)
-            self._packed_key = key
-        return self._packed
+        if precision not in self._packed or key != self._packed_key.get(precision):
+            self._packed[precision] = ops.pack_mlp(params, self.sem_mode, self._packed.get(precision), precision)
+            self._packed_key[precision] = key
+        return self._packed[precision]
 
     def forward(self, inputs, viewdirs=None):
         if viewdirs is None:
@@ -189,6 +189,9 @@ class NeRFNet(nn.Module):
         self.render_kwargs_train = {'N_importance': N_importance, 'N_samples': N_samples, 'perturb': perturb,
                                     'raw_noise_std': raw_noise_std, 'retraw': True, 'retpts': False}
         self.render_kwargs_test = dict(self.render_kwargs_train, perturb=0., raw_noise_std=0.)
+        # Not in the reference (which is fp32 only): "fp32" = exact-fp32 MFMA (parity path, default);
+        # "fp16" / "bf16" = 16-bit MFMA inputs with fp32 accumulation (BASELINE configs C5 / C3), inference only.
+        self.mlp_precision = "fp32"
 
     # ---------------------------------------------------------------------------------------------
     def _sem_nets(self):
@@ -228,6 +231,9 @@ class NeRFNet(nn.Module):
 
         def query(net, z, tag):
             if not save:
+                if self.mlp_precision != "fp32":
+                    return ops.mlp_forward_rays_lp(net.packed_weights(self.mlp_precision), net.sem_mode,
+                                                   self.mlp_precision, rays_o, rays_d, viewdirs, z)
                 return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
             raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(), net.sem_mode, rays_o, rays_d,
                                                              viewdirs, z)

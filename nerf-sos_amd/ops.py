@@ -97,12 +97,21 @@ _MLP_FIELDS = (("alpha", "alpha_linear"), ("feature", "feature_linear"), ("views
                ("rgb", "rgb_linear"))
 
 
-def packed_bytes(sem_mode: int) -> int:
-    return int(_lib.lib().nsos_mlp_packed_bytes(sem_mode))
+DTYPES = {"fp32": 0, "fp16": 1, "bf16": 2}
 
 
-def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Gather one net's state-dict tensors (keys relative to `<net>.mlp.`) into the MFMA-order stream."""
+def packed_bytes(sem_mode: int, precision: str = "fp32") -> int:
+    if precision == "fp32":
+        return int(_lib.lib().nsos_mlp_packed_bytes(sem_mode))
+    return int(_lib.lib().nsos_mlp_packed_bytes_lp(sem_mode))
+
+
+def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch.Tensor] = None,
+             precision: str = "fp32") -> torch.Tensor:
+    """Gather one net's state-dict tensors (keys relative to `<net>.mlp.`) into the MFMA-order stream
+    (fp32 exact-MFMA layout, or the 16-bit layout of the reduced-precision kernel)."""
+    if precision not in DTYPES:
+        raise ValueError(f"precision must be one of {list(DTYPES)}, got {precision!r}")
     keep = []
 
     def g(name):
@@ -128,11 +137,15 @@ def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch
     for k, shp in shapes.items():
         if tuple(params[k].shape) != shp:
             raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
-    nbytes = packed_bytes(sem_mode)
+    nbytes = packed_bytes(sem_mode, precision)
     dev = keep[0].device
     if out is None or out.numel() * 4 < nbytes or out.device != dev:
         out = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-    _lib.check(_lib.lib().nsos_mlp_pack(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
+    if precision == "fp32":
+        _lib.check(_lib.lib().nsos_mlp_pack(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
+    else:
+        _lib.check(_lib.lib().nsos_mlp_pack_lp(C.byref(T), sem_mode, DTYPES[precision], _p(out), nbytes, _stream()),
+                   "nsos_mlp_pack_lp")
     return out
 
 
@@ -150,6 +163,28 @@ def mlp_forward_rays(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, 
         ev[0].record()
     _lib.check(_lib.lib().nsos_mlp_forward_rays(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
                                                 _p(z_vals), R, S, _p(raw), _stream()), "nsos_mlp_forward_rays")
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append((R * S, ev[0], ev[1]))
+    return raw
+
+
+def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, rays_o: torch.Tensor,
+                        rays_d: torch.Tensor, viewdirs: torch.Tensor, z_vals: torch.Tensor) -> torch.Tensor:
+    """Reduced-precision K2 (fp16 / bf16 MFMA inputs, fp32 accumulation): raw [R,S,C] fp32.  `packed` must come
+    from pack_mlp(..., precision=precision)."""
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
+    R, S = z_vals.shape
+    Cn = 4 if sem_mode == SEM_NONE else 6
+    raw = torch.empty((R, S, Cn), device=z_vals.device, dtype=torch.float32)
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(_lib.lib().nsos_mlp_forward_rays_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o), _p(rays_d),
+                                                   _p(viewdirs), _p(z_vals), R, S, _p(raw), _stream()),
+               "nsos_mlp_forward_rays_lp")
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append((R * S, ev[0], ev[1]))

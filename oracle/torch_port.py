@@ -192,6 +192,44 @@ def point_query(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Tenso
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
 
 
+def point_query_lp(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Tensor, cfg: PortConfig,
+                   dtype: torch.dtype) -> Tensor:
+    """Emulation of the reduced-precision kernel (nerf-sos_amd/csrc/mlp_lp.hip), NOT of the reference: everything
+    that enters an MFMA is rounded to `dtype` (encodings, MFMA weights and biases, activations after ReLU, the
+    feature vector), products are accumulated in fp64 here (fp32 on the GPU); the sigma head uses 16-bit weights on
+    the 16-bit activations, the rgb / semantic output heads are fp32 on the un-rounded fp32 hidden layers."""
+    q = lambda t: t.to(dtype).double()  # noqa: E731
+    W = lambda n: sd[f"{prefix}.mlp.{n}.weight"]  # noqa: E731
+    B = lambda n: sd[f"{prefix}.mlp.{n}.bias"]  # noqa: E731
+    flat = pts.reshape(-1, 3)
+    dirs = viewdirs.reshape(-1, 3)
+    ex, ed = q(posenc(flat, cfg.multires)), q(posenc(dirs, cfg.multires_views))
+    X = cfg.xyz_dim
+    h = q(torch.relu(ex @ q(W("pts_linears.0")).T + q(B("pts_linears.0"))).float())
+    for i in range(1, cfg.net_depth):
+        w = q(W(f"pts_linears.{i}"))
+        if i == cfg.skip + 1:
+            z = h @ w[:, X:].T + ex @ w[:, :X].T + q(B(f"pts_linears.{i}"))
+        else:
+            z = h @ w.T + q(B(f"pts_linears.{i}"))
+        h = q(torch.relu(z).float())
+    sigma = h @ q(W("alpha_linear")).T + B("alpha_linear").double()
+    outs = []
+    if cfg.use_semantics:
+        w = q(W("semantic_linear.0"))
+        z = h @ w[:, :cfg.net_width].T + q(B("semantic_linear.0"))
+        if cfg.sem_with_coord:
+            z = z + ex @ w[:, cfg.net_width:].T
+        sem = torch.relu(z).float().double() @ W("semantic_linear.2").double().T + B("semantic_linear.2").double()
+        outs = [sem]
+    feat = q((h @ q(W("feature_linear")).T + q(B("feature_linear"))).float())
+    w = q(W("views_linears.0"))
+    z = feat @ w[:, :cfg.net_width].T + ed @ w[:, cfg.net_width:].T + q(B("views_linears.0"))
+    rgb = torch.relu(z).float().double() @ W("rgb_linear").double().T + B("rgb_linear").double()
+    out = torch.cat([rgb, sigma] + outs, -1).float()
+    return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
+
+
 def composite(raw: Tensor, z_vals: Tensor, rays_d: Tensor, noise: Optional[Tensor], cfg: PortConfig) -> Dict[str, Tensor]:
     """models/renderer.py:35-85.  ``noise`` is the already-scaled additive sigma noise
     (``randn * raw_noise_std``) or None."""

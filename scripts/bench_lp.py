@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""GPU box: throughput and accuracy of the reduced-precision (fp16 / bf16 MFMA) render path vs the fp32 path,
+on the bench workload (4096 rays x (64+192)) and a full 1008x756 image.  Secondary numbers for DESIGN.md; the
+headline bench (bench.py) is fp32."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import nerf_sos_amd
+from nerf_sos_amd import ops
+from oracle import torch_port as tp
+
+dev = torch.device("cuda:0")
+out = {}
+for sem in (False, True):
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=sem, sem_with_coord=sem,
+                               ray_chunk=65536).to(dev).eval()
+    net.load_state_dict(tp.make_peaky({k: v.cpu() for k, v in net.state_dict().items()}, gain=40.0, shift=1.0))
+    rays = tp.synthetic_rays(4096, seed=0).to(dev)
+    ref = None
+    for prec in ("fp32", "fp16", "bf16"):
+        net.mlp_precision = prec
+        with torch.no_grad():
+            for _ in range(3):
+                o = net(rays, (tp.NEAR, tp.FAR))
+            torch.cuda.synchronize()
+            ops.KERNEL_EVENTS = []
+            t0 = time.perf_counter()
+            for _ in range(20):
+                o = net(rays, (tp.NEAR, tp.FAR))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+        fine = [a.elapsed_time(b) for n, a, b in ev if n == 4096 * 192]
+        fine_ms = sum(fine) / len(fine)
+        mac = 634496 if sem else 593408
+        tf = 2 * mac * 4096 * 192 / (fine_ms * 1e-3) / 1e12
+        rec = {"rays_per_s": round(4096 / dt), "ms_per_step": round(dt * 1e3, 3), "fine_kernel_ms": round(fine_ms, 3),
+               "fine_kernel_tflops": round(tf, 1)}
+        if prec == "fp32":
+            ref = {k: v.clone() for k, v in o.items()}
+        else:
+            mse = (o["rgb"] - ref["rgb"]).square().mean().item()
+            rec["psnr_rgb_vs_fp32_db"] = round(-10 * np.log10(max(mse, 1e-30)), 1)
+            rec["max_abs_rgb"] = float((o["rgb"] - ref["rgb"]).abs().max())
+            rec["frac_of_lp_peak_2500TF"] = round(tf / 2500, 3)
+        out[f"{'semcoord' if sem else 'nosem'}_{prec}"] = rec
+        print(f"{'semcoord' if sem else 'nosem':9s} {prec}: {json.dumps(rec)}", flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/bench_lp.json", "w"), indent=1)

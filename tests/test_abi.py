@@ -73,3 +73,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dp, f)).read()
                 assert not banned.search(txt), f"{f} references oracle/"
+
+
+def test_lds_ring_protocol_holds_in_the_built_code():
+    """The MLP kernels wait for their inline-asm LDS reads with hand-counted lgkmcnt; hipcc may spill or copy a
+    destination before its data lands (it did once, in the reduced-precision kernel).  Replay the protocol over the
+    disassembled gfx950 code of the built library: no instruction may touch a still-pending read's register, and the
+    kernels must stay free of scratch traffic."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_lds_ring.py")
+    spec = importlib.util.spec_from_file_location("check_lds_ring", path)
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    kernels = {k: v for k, v in chk.disassemble(_lib.LIB_PATH).items() if "mlp_" in k and "pack" not in k}
+    assert len(kernels) >= 14, sorted(kernels)
+    for name, ins in kernels.items():
+        bad, n_reads, n_scratch = chk.check_kernel(ins)
+        assert n_reads > 100, name
+        assert not bad, (name, bad[:3])
+        assert n_scratch == 0, (name, n_scratch)

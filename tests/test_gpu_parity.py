@@ -393,3 +393,53 @@ def test_full_image_chunked_eval_flow():
         mine = net(part, (tp.NEAR, tp.FAR), retraw=False)
     for k in ("rgb", "depth", "acc", "weights"):
         assert torch.equal(mine[k], full[k].reshape(H * W, -1)[b:e].reshape(mine[k].shape)), k
+
+
+# ------------------------------------------------------------------------------------------ K2-LP (reduced precision)
+@pytest.mark.parametrize("precision,tol", [("fp16", 3e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("name", list(CFGS))
+def test_mlp_lp_vs_emulation(manifest, name, precision, tol):
+    """16-bit-input MFMA kernel vs its torch emulation (same roundings, fp64 accumulation): agreement is limited
+    by rare 1-ulp rounding flips of 16-bit activations, far below the format's own error against fp32."""
+    sd = ref_state(name, manifest, peaky=False)
+    cfg = tp.PortConfig(**CFGS[name])
+    mode = ops.sem_mode_of(**CFGS[name])
+    rays = tp.synthetic_rays(70, seed=2)
+    o, d = T(rays[0]), T(rays[1])
+    near, far = torch.full((70,), tp.NEAR, device=DEV), torch.full((70,), tp.FAR, device=DEV)
+    for S in (64, 192, 50):  # 50: ragged tail inside a 256-point tile
+        z, v = ops.ray_setup(d, near, far, S, torch.rand(70, S, device=DEV))
+        params = {k[len("nerf_fine") + 5:]: t.to(DEV) for k, t in sd.items() if k.startswith("nerf_fine.mlp.")}
+        packed = ops.pack_mlp(params, mode, precision=precision)
+        raw = ops.mlp_forward_rays_lp(packed, mode, precision, o, d, v, z)
+        again = ops.mlp_forward_rays_lp(packed, mode, precision, o, d, v, z)
+        assert torch.equal(raw, again), "reduced-precision kernel is not deterministic"
+        pts = tp.ray_points(rays[0], rays[1], z.cpu())
+        dirs = v.cpu()[:, None, :].expand(70, S, 3)
+        dt = torch.float16 if precision == "fp16" else torch.bfloat16
+        ref = tp.point_query_lp(sd, "nerf_fine", pts, dirs, cfg, dt)
+        err = (raw.cpu() - ref).abs()
+        scale = 1.0 + ref.abs()
+        assert (err / scale).max() < tol, f"{precision} {name} S={S}: max rel err {(err / scale).max():.3e}"
+        assert (err / scale).mean() < tol / 4, f"{precision} {name} S={S}: mean rel err {(err / scale).mean():.3e}"
+        # and against the exact fp32 kernel: the format's own error
+        raw32 = ops.mlp_forward_rays(ops.pack_mlp(params, mode), mode, o, d, v, z)
+        fmt = ((raw - raw32).abs() / (1.0 + raw32.abs())).max().item()
+        assert fmt < (2e-2 if precision == "fp16" else 1.5e-1), f"{precision} vs fp32 kernel: {fmt:.3e}"
+
+
+@pytest.mark.parametrize("precision,min_psnr", [("fp16", 55.0), ("bf16", 38.0)])
+def test_render_lp_end_to_end(manifest, precision, min_psnr):
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
+    net.load_state_dict(tp.make_peaky(ref_state("semcoord", manifest), gain=40.0, shift=1.0))
+    rays = tp.synthetic_rays(2048, seed=4).to(DEV)
+    with torch.no_grad():
+        a = net(rays, (tp.NEAR, tp.FAR))
+        net.mlp_precision = precision
+        b = net(rays, (tp.NEAR, tp.FAR))
+    assert set(a) == set(b) and b["rgb"].dtype == torch.float32
+    for k in ("rgb", "rgb0"):
+        mse = (a[k] - b[k]).square().mean().item()
+        psnr = -10 * np.log10(max(mse, 1e-30))
+        assert psnr > min_psnr, f"{precision} {k}: PSNR vs the fp32 path {psnr:.1f} dB"
+    assert a["acc"].max() > 0.5
