@@ -53,6 +53,7 @@ __host__ __device__ constexpr int lp_chunks(int sem) {
 }
 
 struct F16 {
+    static constexpr bool kIsF16 = true;
     static constexpr unsigned kOnes = 0x3C003C00u;  // {1.0h, 1.0h}
     __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -60,19 +61,6 @@ struct F16 {
     __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
         unsigned r;
         asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
-    }
-    // pack two accumulator elements straight out of the AGPR file (VALU cannot source AGPRs; doing the two
-    // v_accvgpr_reads inside the asm keeps hipcc from hoisting hundreds of them ahead of the pass and spilling)
-    template <bool RELU>
-    __device__ static __forceinline__ unsigned pack2_acc(float lo, float hi) {
-        unsigned r, t;
-        if constexpr (RELU)
-            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
-                         "v_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
-        else
-            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
-                         "v_cvt_pk_f16_f32 %0, %0, %1" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
         return r;
     }
     __device__ static __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
@@ -85,6 +73,7 @@ struct F16 {
     }
 };
 struct BF16 {
+    static constexpr bool kIsF16 = false;
     static constexpr unsigned kOnes = 0x3F803F80u;
     __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -92,17 +81,6 @@ struct BF16 {
     __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
         unsigned r;
         asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
-    }
-    template <bool RELU>
-    __device__ static __forceinline__ unsigned pack2_acc(float lo, float hi) {
-        unsigned r, t;
-        if constexpr (RELU)
-            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
-                         "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
-        else
-            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\t"
-                         "v_cvt_pk_bf16_f32 %0, %0, %1" : "=&v"(r), "=&v"(t) : "a"(lo), "a"(hi));
         return r;
     }
     __device__ static __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
@@ -117,6 +95,31 @@ struct BF16 {
     }
 };
 
+// four packed words (one u32x4 B operand) from eight accumulator elements, straight out of the AGPR file.  VALU
+// cannot source AGPRs; doing the v_accvgpr_reads inside the asm keeps hipcc from hoisting hundreds of them ahead of
+// the pass and spilling (a spilled "pending" ring register is a race, scripts/check_lds_ring.py).  Reads first,
+// then converts, then clamps: no instruction depends on the one just before it.  Measured: ~5.8 cycles per VALU
+// instruction, dominated by the AGPR reads.
+#define NSOS_LP_QUAD(CVT, RELU_OPS)                                                                                  \
+    asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %4, %9\n\t"                                        \
+                 "v_accvgpr_read_b32 %1, %10\n\tv_accvgpr_read_b32 %5, %11\n\t"                                      \
+                 "v_accvgpr_read_b32 %2, %12\n\tv_accvgpr_read_b32 %6, %13\n\t"                                      \
+                 "v_accvgpr_read_b32 %3, %14\n\tv_accvgpr_read_b32 %7, %15\n\t" CVT " %0, %0, %4\n\t" CVT          \
+                 " %1, %1, %5\n\t" CVT " %2, %2, %6\n\t" CVT " %3, %3, %7" RELU_OPS                                 \
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)            \
+                 : "a"(z[0]), "a"(z[1]), "a"(z[2]), "a"(z[3]), "a"(z[4]), "a"(z[5]), "a"(z[6]), "a"(z[7]))
+#define NSOS_LP_RELU4 "\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_max_i16 %1, %1, 0\n\tv_pk_max_i16 %2, %2, 0\n\tv_pk_max_i16 %3, %3, 0"
+template <class T, bool RELU>
+__device__ __forceinline__ u32x4 pack8_acc(const float (&z)[8]) {
+    unsigned r0, r1, r2, r3, t0, t1, t2, t3;
+    if constexpr (T::kIsF16) {
+        if constexpr (RELU) NSOS_LP_QUAD("v_cvt_pk_f16_f32", NSOS_LP_RELU4); else NSOS_LP_QUAD("v_cvt_pk_f16_f32", "");
+    } else {
+        if constexpr (RELU) NSOS_LP_QUAD("v_cvt_pk_bf16_f32", NSOS_LP_RELU4); else NSOS_LP_QUAD("v_cvt_pk_bf16_f32", "");
+    }
+    return u32x4{r0, r1, r2, r3};
+}
+
 struct LpParams {
     const unsigned* aux;
     const unsigned char* chunks;
@@ -128,7 +131,9 @@ struct LpParams {
     long long n_pts;
     int n_samples;
     int n_tiles;
+    unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays_lp): per-wave shader-clock stamps, or NULL
 };
+constexpr int kProfSlots = 64;
 
 // encoded feature idx lives in half-wave (idx >> 3) & 1: a K-slice of 16 consecutive features, lane half kg
 // supplying k-slots 8kg .. 8kg+7
@@ -150,11 +155,6 @@ __device__ __forceinline__ u32x4 enc_slice(const Enc<L, SliceHalf>& e, const flo
     return out;
 }
 
-__device__ __forceinline__ unsigned relu_pk16(unsigned p) {  // works for fp16 and bf16 bit patterns alike
-    unsigned r;
-    asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(p));
-    return r;
-}
 
 // H[c][2t+u] = pack16(relu?(Z[c][t][8u .. 8u+7]))   -- one batched VALU pass per layer
 template <class T, int NT, bool RELU>
@@ -167,37 +167,41 @@ __device__ __forceinline__ void activate(u32x4 (&H)[2][2 * NT], const f32x16 (&Z
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                float z[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    H[c][2 * t + u][q] = T::template pack2_acc<RELU>(Z[c][t][8 * u + 2 * q], Z[c][t][8 * u + 2 * q + 1]);
+                for (int i = 0; i < 8; ++i) z[i] = Z[c][t][8 * u + i];
+                H[c][2 * t + u] = pack8_acc<T, RELU>(z);
+            }
 }
 
-// fp32 vector-ALU head on fp32 accumulators (rgb, semantics): this half-wave's partial chain
-//   part = fma(w, relu(h), part), h read straight from its AGPR (see pack2_acc for why this is asm)
-template <int NT>
-__device__ __forceinline__ float head_partial_f32(const f32x16 (&h)[NT], const float* w_lane, float init) {
-    float part = init;
+// fp32 vector-ALU heads on fp32 accumulators (rgb: NO = 3, semantics: NO = 2): this half-wave's partial chains
+//   part[o] = fma(w[o][f], relu(h[f]), part[o]) over the lane's NT*16 features, weights from the LDS copy of aux.
+// Each accumulator element is read from its AGPR and clamped ONCE (asm, see pack8_acc) and feeds all NO chains.
+template <int NT, int NO>
+__device__ __forceinline__ void heads_partial_f32(const f32x16 (&h)[NT], const float* w_lane, float (&part)[NO]) {
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(w_lane + t * 16 + q * 4);
+            f32x4 w[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) w[o] = *reinterpret_cast<const f32x4*>(w_lane + o * 128 + t * 16 + q * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float tmp;
-                asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_max_f32 %1, 0, %1\n\tv_fmac_f32 %0, %3, %1"
-                             : "+v"(part), "=&v"(tmp) : "a"(h[t][q * 4 + j]), "v"(w[j]));
+                float x;
+                asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_max_f32 %0, 0, %0" : "=v"(x) : "a"(h[t][q * 4 + j]));
+#pragma unroll
+                for (int o = 0; o < NO; ++o) part[o] = __fmaf_rn(w[o][j], x, part[o]);
             }
         }
-    return part;
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
 template <class T, int SEM>
 __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pj = lane & 31, kg = lane >> 5;
     constexpr int NCH = lp_chunks(SEM);
@@ -243,6 +247,10 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #pragma unroll
         for (int i = 0; i < kDmaPieces; ++i)
             dma_piece(P.chunks + (size_t)(k % NCH) * kSlotBytes, k == 0 ? d0 : (k == 1 ? d1 : d2), i);
+    // head weights and biases (aux, 4 KiB) live in LDS behind the slots: a global load per use would put an L2
+    // round trip in front of every few VALU instructions of the heads
+    const unsigned* const aux_l = reinterpret_cast<const unsigned*>(lds + kSlots * kSlotBytes);
+    *reinterpret_cast<u32x4*>(lds + kSlots * kSlotBytes + threadIdx.x * 16) = reinterpret_cast<const u32x4*>(P.aux)[threadIdx.x];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     static_for<0, kRing>([&](auto ic) { lds_read_a<decltype(ic)::value * 1024>(ring[decltype(ic)::value], c0); });
@@ -283,19 +291,26 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #define IC(n) std::integral_constant<int, (n)> {}
 
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        int stamp_k = 0;
+        auto stamp = [&]() {  // diagnostics only: one s_memtime per phase of the second tile of blocks 0..3
+            if (P.prof && tile == (int)(blockIdx.x + gridDim.x) && blockIdx.x < 4) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                if (lane == 0 && stamp_k < kProfSlots) P.prof[(blockIdx.x * 4 + wave) * kProfSlots + stamp_k] = t;
+            }
+            ++stamp_k;
+        };
+        stamp();  // 0: tile start
         // ---- this lane's two points (column tile c: point tile*256 + wave*64 + c*32 + pj)
-        long long gp[2], ray_of[2];
-        bool valid[2];
+        int ray_of[2];  // n_rays <= n_pts < 2^31 * 256, rays themselves < 2^31 (checked at the entry point)
         u32x4 ex[2][4];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            gp[c] = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
-            valid[c] = gp[c] < P.n_pts;
-            const long long gc = valid[c] ? gp[c] : P.n_pts - 1;
+            const long long gp = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
+            const long long gc = gp < P.n_pts ? gp : P.n_pts - 1;
             const long long ray = gc / P.n_samples;
             const float z = P.z_vals[gc];
             float x[3];
-            ray_of[c] = ray;
+            ray_of[c] = (int)ray;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float m = P.rays_d[3 * ray + k] * z;  // models/sampler.py:70,166 (mul, then add)
@@ -318,8 +333,11 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
         auto from_H = [&](auto cc, auto sc) { return H[decltype(cc)::value][decltype(sc)::value]; };
 
         // pts_linears.0: 4 encoded slices x 8 tiles; the first slice of every tile starts from C = 0
+        stamp();  // 1: inputs + xyz encoding
         run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), Z, from_ex);
+        stamp();  // 2: L0 MFMAs
         activate<T, 8, true>(H, Z);
+        stamp();  // 3: L0 activation
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8)
 #pragma unroll 1
         for (int l = 1; l <= 8; ++l) {
@@ -328,11 +346,13 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
             run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), Z, from_H);
             run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), Z, from_H);
             if (l == 5) run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), Z, from_ex);  // skip connection
+            stamp();  // 2 + 2l: MFMAs of layer l
             if (l < 8) activate<T, 8, true>(H, Z); else activate<T, 8, false>(H, Z);
+            stamp();  // 3 + 2l: activation pass
             if (l == 7) {
                 // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
-                const unsigned* aw = P.aux + kAuxAlphaW + kg * 64;
-                float pa[2] = {kg ? 0.0f : __builtin_bit_cast(float, P.aux[kAuxScalars]), 0.0f};
+                const unsigned* aw = aux_l + kAuxAlphaW + kg * 64;
+                float pa[2] = {kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]), 0.0f};
                 pa[1] = pa[0];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
@@ -351,21 +371,23 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                     run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), sacc, from_H);
                     if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sacc, from_ex);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < 2; ++c) {
+                        float ps[2];
 #pragma unroll
-                        for (int o = 0; o < 2; ++o) {
-                            const float ps = head_partial_f32<4>(
-                                sacc[c], reinterpret_cast<const float*>(P.aux) + kAuxSem2W + o * 128 + kg * 64,
-                                kg ? 0.0f : __builtin_bit_cast(float, P.aux[kAuxScalars + 4 + o]));
-                            sem_out[c][o] = both_halves(ps);
-                        }
+                        for (int o = 0; o < 2; ++o) ps[o] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars + 4 + o]);
+                        heads_partial_f32<4, 2>(sacc[c], reinterpret_cast<const float*>(aux_l) + kAuxSem2W + kg * 64, ps);
+#pragma unroll
+                        for (int o = 0; o < 2; ++o) sem_out[c][o] = both_halves(ps[o]);
+                    }
                 }
+                stamp();  // 18 (l == 7 only; the later slots shift by one): sigma + semantic heads
             }
         }
         // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
         f32x16 vacc[2][4];
         run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), vacc, from_H);
         run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), vacc, from_H);
+        stamp();  // 21: view-branch MFMAs on the feature
         // the direction encoding is evaluated only now (12 sincos per column): keeping its 16 VGPRs alive through
         // the trunk pushes the kernel into spilling, and a spilled "pending" ring register is a race
         u32x4 ed[2][2];
@@ -373,25 +395,27 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
         for (int c = 0; c < 2; ++c) {
             float dv[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3 * ray_of[c] + k];
+            for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3ll * ray_of[c] + k];
             Enc<NSOS_DIR_FREQS, SliceHalf> e;
             e.evaluate(dv, kg);
             ed[c][0] = enc_slice<T, NSOS_DIR_FREQS, 0, false>(e, dv, kg);
             ed[c][1] = enc_slice<T, NSOS_DIR_FREQS, 1, false>(e, dv, kg);
         }
         auto from_ed = [&](auto cc, auto sc) { return ed[decltype(cc)::value][decltype(sc)::value]; };
+        stamp();  // 22: direction encoding
         run_chunk(IC(16), IC(4), IC(0), IC(0), IC(8), IC(0), vacc, from_ed);  // 2 slices x 4 tiles; groups 8..15 are padding
+        stamp();  // 23: direction MFMAs
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             float rgb[3];
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const float pr = head_partial_f32<4>(vacc[c], reinterpret_cast<const float*>(P.aux) + kAuxRgbW + o * 128 + kg * 64,
-                                                     kg ? 0.0f : __builtin_bit_cast(float, P.aux[kAuxScalars + 1 + o]));
-                rgb[o] = both_halves(pr);
-            }
-            if (valid[c]) {
-                float* out = P.raw + gp[c] * C;
+            for (int o = 0; o < 3; ++o) rgb[o] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars + 1 + o]);
+            heads_partial_f32<4, 3>(vacc[c], reinterpret_cast<const float*>(aux_l) + kAuxRgbW + kg * 64, rgb);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) rgb[o] = both_halves(rgb[o]);
+            const long long gp = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
+            if (gp < P.n_pts) {
+                float* out = P.raw + gp * C;
                 if constexpr (C == 4) {
                     if (kg == 0) *reinterpret_cast<f32x4*>(out) = f32x4{rgb[0], rgb[1], rgb[2], sigma[c]};
                 } else {
@@ -404,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                 }
             }
         }
+        stamp();  // 24: rgb head + stores
     }
 #undef IC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -485,7 +510,7 @@ int lp_num_cus() {
     return 256;
 }
 
-constexpr int kLdsBytes = kSlots * kSlotBytes;
+constexpr int kLdsBytes = kSlots * kSlotBytes + kAuxWords * 4;
 
 template <class T, int SEM>
 int32_t launch_lp(const LpParams& p, hipStream_t stream) {
@@ -562,12 +587,13 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
     return nsos_launch_status();
 }
 
-extern "C" int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
-                                            const float* rays_d, const float* viewdirs, const float* z_vals,
-                                            int64_t n_rays, int32_t n_samples, float* raw, void* stream) {
+static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                               const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
+                               int32_t n_samples, float* raw, unsigned long long* prof, void* stream) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_rays < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(sem_mode >= 0 && sem_mode <= 2 && (dtype == NSOS_DTYPE_F16 || dtype == NSOS_DTYPE_BF16), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
     const long long n_pts = (long long)n_rays * n_samples;
@@ -578,6 +604,7 @@ extern "C" int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
+    p.prof = prof;
     const hipStream_t st = (hipStream_t)stream;
     if (dtype == NSOS_DTYPE_F16) {
         switch (sem_mode) {
@@ -591,4 +618,20 @@ extern "C" int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode
         case 1: return launch_lp<BF16, 1>(p, st);
         default: return launch_lp<BF16, 2>(p, st);
     }
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                            const float* rays_d, const float* viewdirs, const float* z_vals,
+                                            int64_t n_rays, int32_t n_samples, float* raw, void* stream) {
+    return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, stream);
+}
+
+extern "C" int32_t nsos_mlp_profile_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                            const float* rays_d, const float* viewdirs, const float* z_vals,
+                                            int64_t n_rays, int32_t n_samples, float* raw, uint64_t* stamps,
+                                            void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(stamps, NSOS_ERR_NULL_POINTER);
+    return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw,
+                           reinterpret_cast<unsigned long long*>(stamps), stream);
 }

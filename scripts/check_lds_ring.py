@@ -76,7 +76,11 @@ def check_kernel(ins_list):
                 keep = int(m.group(1))
                 pending = pending[len(pending) - keep:] if keep else []
             continue
-        if op in ("s_endpgm", "s_barrier") or op.startswith("s_"):
+        if op.startswith("s_"):
+            # divergent control flow: hipcc's own LDS reads under an exec mask are its business (it waits at the join
+            # point, which a linear replay cannot see).  The hand-written rings never span a branch or an exec change.
+            if op.startswith(("s_cbranch", "s_branch")) or re.search(r"\bexec\b", rest.split(",")[0]) or "saveexec" in op:
+                pending = []
             continue
         is_lds_read = op.startswith("ds_read") or op.startswith("ds_load")
         # a later LDS read may overwrite a pending destination (returns are in order: plain WAW on a dead value,
