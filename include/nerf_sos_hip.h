@@ -180,6 +180,44 @@ int32_t nsos_importance_sample(const float* z_vals, const float* weights, const 
                                int64_t n_rays, int32_t n_coarse, int32_t n_importance, float* z_fine,
                                float* z_samples, float* z_std, float* cdf_out, int64_t* inds_out, void* stream);
 
+/* ---- evaluation post-processing ---------------------------------------------
+ * What engines/eval.py:44-57,79-86 computes on the host after copying every output off the device:
+ *   sem_prob = softmax(semantics, -1); sem_pred = argmax(sem_prob, -1)   (first maximal index, int32)
+ *   metrics[0] = img2mse(rgb, target) (utils/image.py:125-128), metrics[1] = mse2psnr(.) (utils/image.py:134-137)
+ * semantics [R,sem_dim] may be NULL (no semantic outputs); rgb/target [R,3] may be NULL (no metrics);
+ * sem_prob [R,sem_dim] / sem_pred [R] may each be NULL.  workspace: nsos_eval_workspace_bytes() bytes, 8-byte
+ * aligned, contents undefined on return except ws[0] = the fp64 sum of per-ray mean squared errors.
+ * The reduction order is fixed (no atomics): results are bit-identical run to run. */
+size_t nsos_eval_workspace_bytes(void);
+int32_t nsos_eval_postprocess(const float* semantics, const float* rgb, const float* target, int64_t n_rays,
+                              int32_t sem_dim, float* sem_prob, int32_t* sem_pred, float* metrics, void* workspace,
+                              void* stream);
+
+/* ---- correlation losses on the rendered patches --------------------------------
+ * CorrelationLoss.forward (utils/image.py:335-370) and GeoCorrelationLoss.forward (utils/image.py:448-487) for one
+ * batch of B patches, with the random choices made by the caller:
+ *   neg_indx int64 [B]   the negative patch of each patch (reference: torch.min(sim_matrix, 0)[1], or a permutation)
+ *   rand1, rand2 [B,S,S,2] the two torch.rand draws (values in [0,1); the kernel applies the reference's *2-1)
+ * loss out [1].  grad_code out (may be NULL): d loss / d code, same shape as code -- the only input that carries
+ * gradient in the reference (feats / depth sides are under no_grad).  Nothing of size (H*W)^2 is materialised for the
+ * geometric loss.  workspace: nsos_corr_workspace_bytes(kind, B, n_points, feat_dim) bytes, 16-byte aligned
+ * (kind 0 = appearance: n_points = S*S; kind 1 = geometric: n_points = H*W <= 4096, feat_dim ignored).
+ * code_dim (sem_dim) <= 4.  Deterministic (fixed-order fp64 reductions, no atomics).
+ * nsos_geo_correlation_loss: depth [B,1,H,W] is filtered as the reference does (values > max_depth become the
+ * largest value < max_depth); with filter_in_place != 0 the filtered values are also written back, which is what
+ * the reference does to the caller's tensor (utils/image.py:455). */
+size_t nsos_corr_workspace_bytes(int32_t kind, int32_t batch, int32_t n_points, int32_t feat_dim);
+int32_t nsos_app_correlation_loss(const float* feats, const float* code, const int64_t* neg_indx, const float* rand1,
+                                  const float* rand2, int32_t batch, int32_t feat_dim, int32_t feat_h, int32_t feat_w,
+                                  int32_t code_dim, int32_t code_h, int32_t code_w, int32_t feature_samples,
+                                  float self_shift, float self_weight, float neg_shift, float neg_weight, float* loss,
+                                  float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
+int32_t nsos_geo_correlation_loss(float* depth, const float* code, const float* ray_o, const float* ray_d,
+                                  const int64_t* neg_indx, int32_t batch, int32_t code_dim, int32_t height,
+                                  int32_t width, float self_shift, float self_weight, float neg_shift,
+                                  float neg_weight, float max_depth, int32_t filter_in_place, float* loss,
+                                  float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

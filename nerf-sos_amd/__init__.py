@@ -7,5 +7,7 @@ eager-PyTorch fallback: every op raises if the HIP library is missing or the ten
 from .nerf_net import MLP, NeRFMLP, NeRFNet  # noqa: F401
 from . import ops  # noqa: F401
 from . import sharding  # noqa: F401
+from . import losses  # noqa: F401
+from .losses import CorrelationLoss, GeoCorrelationLoss  # noqa: F401
 
-__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding"]
+__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding", "losses", "CorrelationLoss", "GeoCorrelationLoss"]

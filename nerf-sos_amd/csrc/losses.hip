@@ -1,0 +1,655 @@
+// Correlation losses on the render path's outputs for gfx950:
+//   CorrelationLoss.forward     utils/image.py:335-370  (appearance: DINO features vs rendered semantic logits)
+//   GeoCorrelationLoss.forward  utils/image.py:448-487  (geometry: back-projected depth vs rendered semantic logits)
+// Both reduce, for a "self" pair set (patch n with itself) and a "negative" pair set (patch n with patch neg[n]),
+//   fd[n,p,q]  feature affinity of row point p and column point q      (no gradient)
+//   cd[n,p,q]  affinity of the L2-normalised semantic codes of p and q (gradient -> semantics)
+//   pointwise (utils/image.py:316-319): fd1 = fd - mean_q fd;  fd2 = (fd1 - mean(fd1)) + mean(fd)
+//   loss = mean( -max(cd, 0) * (fd2 - shift) );  total = neg_weight * L_neg + self_weight * L_self.
+// The reference materialises every [B,N,N] tensor (N = P*P = 4096 for the geometric loss: 537 MB each, an O(P^4)
+// HBM-bound chain of ~20 element-wise kernels).  Here nothing of size N^2 exists for the geometric loss: fd and cd
+// are recomputed from LDS-resident points in each of four passes
+//   1 row sums of fd            -> row means, mean(fd)
+//   2 sum of fl32(fd - rowmean) -> mean(fd1)
+//   3 loss sum + gradient w.r.t. the row codes       (thread = row point p, loop over q)
+//   4 gradient w.r.t. the column codes               (thread = column point q, loop over p)
+// so the kernel is VALU-bound (~25 flop per pair per pass) and reads O(N) bytes.  All reductions are fp64 in a fixed
+// order (no atomics): results are bit-identical run to run.  The appearance loss has N = 121 sample points; its fd
+// (a 384-channel dot product) is materialised once ([2,B,121,121]) and the same four passes read it back.
+// The forward call also produces d(loss)/d(code) (the loss is only ever back-propagated with a scalar upstream
+// gradient), so autograd's backward is one scaling.
+// Compiled with -ffp-contract=off: element-wise fp32 expressions follow the reference's op order.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxC = 4;        // semantic code channels supported (sem_dim; the shipped recipes use 2)
+constexpr int kRedBlocks = 1024;  // upper bound on partial sums per reduction
+
+struct CorrParams {
+    float self_shift, self_weight, neg_shift, neg_weight;
+};
+
+// ---- workspace layout (doubles first, then floats), shared by both losses ----------------------------------------
+struct Ws {
+    double* rowsum;    // [2][B][N]
+    double* partial;   // [2][kRedBlocks]  scratch for block partials
+    double* scal;      // [16]: 0,1 sum fd (neg,self)  2,3 sum fd1  4,5 loss sums  6 depth max (as double)
+    float* pts;        // geo: xyz [B][N][4]           app: unused
+    float* cn;         // normalised codes, row side    [B][N][kMaxC]
+    float* cn2;        // app only: column-side codes of the negative set [B][N][kMaxC]
+    float* dinv;       // 1 / max(||c||, eps) and the norm itself, row side [B][N][2]
+    float* dinv2;      // app only, negative column side
+    float* grow;       // [2][B][N][kMaxC] gradient w.r.t. normalised row codes
+    float* gcol;       // [2][B][N][kMaxC] gradient w.r.t. normalised column codes
+    float* fdmat;      // app only: [2][B][N][N]
+    float* fn;         // app only: normalised sampled features [2][B][N][Cf]  (0: coords1 of n, 1: coords2 of neg[n])
+};
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+inline size_t ws_layout(Ws* w, void* base, int B, int N, int Cf, bool app) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return base ? (char*)base + o : (char*)nullptr; };
+    double* rowsum = (double*)take(sizeof(double) * 2 * B * N);
+    double* partial = (double*)take(sizeof(double) * 2 * kRedBlocks);
+    double* scal = (double*)take(sizeof(double) * 16);
+    float* pts = (float*)take(app ? 0 : sizeof(float) * B * N * 4);
+    float* cn = (float*)take(sizeof(float) * B * N * kMaxC);
+    float* cn2 = (float*)take(app ? sizeof(float) * B * N * kMaxC : 0);
+    float* dinv = (float*)take(sizeof(float) * B * N * 2);
+    float* dinv2 = (float*)take(app ? sizeof(float) * B * N * 2 : 0);
+    float* grow = (float*)take(sizeof(float) * 2 * B * N * kMaxC);
+    float* gcol = (float*)take(sizeof(float) * 2 * B * N * kMaxC);
+    float* fdmat = (float*)take(app ? sizeof(float) * 2 * B * N * N : 0);
+    float* fn = (float*)take(app ? sizeof(float) * 2 * B * N * Cf : 0);
+    if (w) *w = Ws{rowsum, partial, scal, pts, cn, cn2, dinv, dinv2, grow, gcol, fdmat, fn};
+    return off;
+}
+
+// block-wide fp64 sum in a fixed order; valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* smem) {
+    v = nsos_wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) smem[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) s += smem[i];
+    __syncthreads();
+    return s;
+}
+
+// clamped inverse L1 distance, GeoCorrelationLoss.tensor_correlation (utils/image.py:404-413)
+template <int D>
+__device__ __forceinline__ float inv_l1(const float (&a)[D], const float* b, float max_depth, bool* clamped = nullptr) {
+    float s = fabsf(a[0] - b[0]);
+#pragma unroll
+    for (int k = 1; k < D; ++k) s = s + fabsf(a[k] - b[k]);   // torch.sum over dim 1, in order
+    const float r = 1.0f / (s + 5e-2f);
+    if (clamped) *clamped = r > max_depth;
+    return r > max_depth ? max_depth : r;
+}
+
+// ------------------------------------------------------------------------------------------ geometric loss: prep
+__global__ __launch_bounds__(256) void depth_max_kernel(const float* __restrict__ depth, long long n, float max_depth,
+                                                        double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double m = -1.0e300;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = depth[i];
+        if (d < max_depth && (double)d > m) m = (double)d;   // orig_feats[orig_feats < max_depth].max(), :455
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off, NSOS_WAVE); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = sm[i] > m ? sm[i] : m;
+        partial[blockIdx.x] = m;
+    }
+}
+__global__ void depth_max_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal) {
+    double m = -1.0e300;
+    for (int i = 0; i < nb; ++i) m = partial[i] > m ? partial[i] : m;
+    scal[6] = m;   // -1e300 if no element was below max_depth (torch raises on the empty max; here the filter yields NaN-free -inf)
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void geo_prep_kernel(float* __restrict__ depth, const float* __restrict__ code,
+                                                       const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                       int B, int N, float max_depth, int write_back,
+                                                       const double* __restrict__ scal, float* __restrict__ pts,
+                                                       float* __restrict__ cn, float* __restrict__ dinv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N) return;
+    const int n = (int)(i / N), p = (int)(i % N);
+    float d = depth[i];
+    if (d > max_depth) {  // :455
+        d = (float)scal[6];
+        if (write_back) depth[i] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const long long j = ((long long)n * 3 + k) * N + p;
+        const float m = ray_d[j] * d;
+        pts[i * 4 + k] = ray_o[j] + m;   // depth2pts, :443
+    }
+    pts[i * 4 + 3] = 0.0f;
+    float v[C], ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        v[c] = code[((long long)n * C + c) * N + p];
+        ss = c == 0 ? v[c] * v[c] : ss + v[c] * v[c];
+    }
+    const float nrm = sqrtf(ss), den = fmaxf(nrm, 1e-10f);  // F.normalize(dim=1, eps=1e-10), :301
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) cn[i * kMaxC + c] = c < C ? v[c] / den : 0.0f;
+    dinv[i * 2] = den;
+    dinv[i * 2 + 1] = nrm;
+}
+
+// ------------------------------------------------------------------------------------------ the four pair passes
+// grid = (ceil(N / 256), B, 2 sets); set 0 = negative pairs (patch n rows, patch neg[n] columns), set 1 = self.
+// GEO: fd from LDS-resident xyz; otherwise fd from the materialised matrix.
+struct PairArgs {
+    int B, N, C;
+    const long long* neg;
+    const float* pts;      // [B][N][4]
+    const float* cn;       // row codes [B][N][kMaxC]
+    const float* cn2;      // app: negative-set column codes (indexed by n); geo: NULL (columns are cn[neg[n]])
+    const float* fdmat;    // app
+    double* rowsum;
+    double* partial;
+    double* scal;
+    float* grow;
+    float* gcol;
+    float max_depth;
+    CorrParams prm;
+};
+
+template <bool GEO>
+__device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, int n) {
+    if (GEO) return A.cn + (size_t)(set == 0 ? (int)A.neg[n] : n) * A.N * kMaxC;
+    return (set == 0 ? A.cn2 : A.cn) + (size_t)n * A.N * kMaxC;
+}
+
+// PASS 1: row sums.  PASS 2: sum fl32(fd - rowmean).  PASS 3: loss + row-code gradient.
+template <bool GEO, int C, int PASS>
+__global__ __launch_bounds__(256) void pair_rows_kernel(const PairArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // columns: GEO xyz [N][4] then codes [N][kMaxC]
+    __shared__ double red[4];
+    const int set = blockIdx.z, n = blockIdx.y, N = A.N;
+    const int m = set == 0 ? (int)A.neg[n] : n;
+    float* lx = lds;
+    float* lc = lds + (GEO ? (size_t)N * 4 : 0);
+    if (GEO)
+        for (int i = threadIdx.x; i < N * 4; i += blockDim.x) lx[i] = A.pts[(size_t)m * N * 4 + i];
+    if (PASS == 3) {
+        const float* cc = col_codes<GEO>(A, set, n);
+        for (int i = threadIdx.x; i < N * kMaxC; i += blockDim.x) lc[i] = cc[i];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < N;
+    const int pc = live ? p : N - 1;
+    const size_t row = (size_t)n * N + pc;
+    float x[3] = {0, 0, 0}, c1[C];
+    if (GEO) { x[0] = A.pts[row * 4]; x[1] = A.pts[row * 4 + 1]; x[2] = A.pts[row * 4 + 2]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) c1[c] = A.cn[row * kMaxC + c];
+    const float* fdrow = GEO ? nullptr : A.fdmat + (((size_t)set * A.B + n) * N + pc) * N;
+    const double cnt = (double)A.B * N * N;
+    float rm = 0.0f, m1 = 0.0f, old_mean = 0.0f;
+    if (PASS >= 2) rm = (float)(A.rowsum[((size_t)set * A.B + n) * N + pc] / (double)N);   // fd.mean([3,4]), :318
+    if (PASS == 3) { old_mean = (float)(A.scal[set] / cnt); m1 = (float)(A.scal[2 + set] / cnt); }
+    const float shift = set == 0 ? A.prm.neg_shift : A.prm.self_shift;
+    const float gscale = -(set == 0 ? A.prm.neg_weight : A.prm.self_weight) / (float)cnt;
+    double acc = 0.0;
+    double g[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = 0.0;
+    for (int q = 0; q < N; ++q) {
+        const float fd = GEO ? inv_l1<3>(x, lx + q * 4, A.max_depth) : fdrow[q];
+        if (PASS == 1) { acc += (double)fd; continue; }
+        const float fd1 = fd - rm;                         // fd -= fd.mean([3,4]), :318
+        if (PASS == 2) { acc += (double)fd1; continue; }
+        const float fd2 = (fd1 - m1) + old_mean;           // fd - fd.mean() + old_mean, :319
+        const float t = fd2 - shift;
+        float cd;
+        bool clamped = false;
+        if (GEO) cd = inv_l1<C>(c1, lc + q * kMaxC, A.max_depth, &clamped);   // overridden tensor_correlation, :427
+        else {
+            cd = c1[0] * lc[q * kMaxC];
+#pragma unroll
+            for (int c = 1; c < C; ++c) cd = cd + c1[c] * lc[q * kMaxC + c];
+        }
+        const float cdc = cd < 0.0f ? 0.0f : cd;           // cd.clamp(0), :330
+        acc += (double)(-cdc * t);
+        if (cd >= 0.0f && !clamped) {
+            const float gcd = gscale * t;                  // d total / d cd
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float dc;
+                if (GEO) {
+                    const float df = c1[c] - lc[q * kMaxC + c];
+                    dc = -(cd * cd) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+                } else dc = lc[q * kMaxC + c];
+                g[c] += (double)(gcd * dc);
+            }
+        }
+    }
+    if (PASS == 1 && live) A.rowsum[((size_t)set * A.B + n) * N + p] = acc;
+    if (PASS == 3 && live)
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) A.grow[(((size_t)set * A.B + n) * N + p) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
+    const double s = block_sum(live ? acc : 0.0, red);
+    if (threadIdx.x == 0) A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// scal[slot + set] = sum of the block partials, fixed order
+__global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, int slot) {
+    const int set = threadIdx.x;
+    if (set >= 2) return;
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += partial[(size_t)set * kRedBlocks + i];
+    scal[slot + set] = s;
+}
+
+// PASS 4: gradient w.r.t. the column codes: thread = column point q of pair (n -> m), loop over the row points p.
+template <bool GEO, int C>
+__global__ __launch_bounds__(256) void pair_cols_kernel(const PairArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // rows: xyz [N][4] (GEO), codes [N][kMaxC], rowmean [N]
+    const int set = blockIdx.z, n = blockIdx.y, N = A.N;
+    const int m = set == 0 ? (int)A.neg[n] : n;
+    float* lx = lds;
+    float* lc = lds + (GEO ? (size_t)N * 4 : 0);
+    float* lr = lc + (size_t)N * kMaxC;
+    if (GEO)
+        for (int i = threadIdx.x; i < N * 4; i += blockDim.x) lx[i] = A.pts[(size_t)n * N * 4 + i];
+    for (int i = threadIdx.x; i < N * kMaxC; i += blockDim.x) lc[i] = A.cn[(size_t)n * N * kMaxC + i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) lr[i] = (float)(A.rowsum[((size_t)set * A.B + n) * N + i] / (double)N);
+    __syncthreads();
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    float y[3] = {0, 0, 0}, c2[C];
+    if (GEO) { const size_t col = (size_t)m * N + q; y[0] = A.pts[col * 4]; y[1] = A.pts[col * 4 + 1]; y[2] = A.pts[col * 4 + 2]; }
+    const float* cc = col_codes<GEO>(A, set, n);
+#pragma unroll
+    for (int c = 0; c < C; ++c) c2[c] = cc[(size_t)q * kMaxC + c];
+    const double cnt = (double)A.B * N * N;
+    const float old_mean = (float)(A.scal[set] / cnt), m1 = (float)(A.scal[2 + set] / cnt);
+    const float shift = set == 0 ? A.prm.neg_shift : A.prm.self_shift;
+    const float gscale = -(set == 0 ? A.prm.neg_weight : A.prm.self_weight) / (float)cnt;
+    const float* fdcol = GEO ? nullptr : A.fdmat + ((size_t)set * A.B + n) * N * N + q;
+    double g[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = 0.0;
+    for (int p = 0; p < N; ++p) {
+        // fd(p, q) with the ROW point first, exactly as the row passes evaluate it
+        float fd;
+        if (GEO) { const float xp[3] = {lx[p * 4], lx[p * 4 + 1], lx[p * 4 + 2]}; fd = inv_l1<3>(xp, y, A.max_depth); }
+        else fd = fdcol[(size_t)p * N];
+        const float fd2 = ((fd - lr[p]) - m1) + old_mean;
+        const float t = fd2 - shift;
+        float cd;
+        bool clamped = false;
+        float c1[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) c1[c] = lc[p * kMaxC + c];
+        if (GEO) cd = inv_l1<C>(c1, c2, A.max_depth, &clamped);
+        else {
+            cd = c1[0] * c2[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) cd = cd + c1[c] * c2[c];
+        }
+        if (cd >= 0.0f && !clamped) {
+            const float gcd = gscale * t;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float dc;
+                if (GEO) {
+                    const float df = c1[c] - c2[c];
+                    dc = (cd * cd) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+                } else dc = c1[c];
+                g[c] += (double)(gcd * dc);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) A.gcol[(((size_t)set * A.B + n) * N + q) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
+}
+
+__global__ void loss_finish_kernel(const double* __restrict__ scal, double cnt, CorrParams prm, float* __restrict__ loss) {
+    const float l_neg = (float)(scal[4] / cnt), l_self = (float)(scal[5] / cnt);   // .mean(), :370
+    loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
+}
+
+// backward of F.normalize for one point: g_v = (g - y (g.y)) / d  if ||v|| >= eps, else g / eps
+template <int C>
+__device__ __forceinline__ void normalize_backward(const float (&gy)[C], const float* y, float den, float nrm, float (&gv)[C]) {
+    if (nrm >= 1e-10f) {
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) dot += gy[c] * y[c];
+#pragma unroll
+        for (int c = 0; c < C; ++c) gv[c] = (gy[c] - y[c] * dot) / den;
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) gv[c] = gy[c] / den;
+    }
+}
+
+// geo: gradient w.r.t. code[m,:,pixel] = normalize_backward( rows(neg,m) + rows(self,m) + cols(self,m) + sum_{n: neg[n]=m} cols(neg,n) )
+template <int C>
+__global__ __launch_bounds__(256) void geo_grad_kernel(int B, int N, const long long* __restrict__ neg, const float* __restrict__ cn,
+                                                       const float* __restrict__ dinv, const float* __restrict__ grow,
+                                                       const float* __restrict__ gcol, float* __restrict__ grad_code) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N) return;
+    const int m = (int)(i / N), p = (int)(i % N);
+    float gy[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float s = grow[((size_t)(0 * B + m) * N + p) * kMaxC + c];
+        s += grow[((size_t)(1 * B + m) * N + p) * kMaxC + c];
+        s += gcol[((size_t)(1 * B + m) * N + p) * kMaxC + c];
+        gy[c] = s;
+    }
+    for (int n = 0; n < B; ++n)
+        if ((int)neg[n] == m)
+#pragma unroll
+            for (int c = 0; c < C; ++c) gy[c] += gcol[((size_t)(0 * B + n) * N + p) * kMaxC + c];
+    float gv[C];
+    normalize_backward<C>(gy, cn + i * kMaxC, dinv[i * 2], dinv[i * 2 + 1], gv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) grad_code[((long long)m * C + c) * N + p] = gv[c];
+}
+
+// ------------------------------------------------------------------------------------------ appearance loss pieces
+// F.grid_sample(bilinear, padding_mode='border', align_corners=True) geometry for one sample (utils/image.py:303-304)
+struct Bilinear {
+    int x0, y0;           // north-west corner
+    float w[4];           // nw, ne, sw, se
+};
+__device__ __forceinline__ Bilinear bilinear_of(float gx, float gy, int W, int H) {
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    const float fx = floorf(ix), fy = floorf(iy);
+    Bilinear b;
+    b.x0 = (int)fx; b.y0 = (int)fy;
+    const float ex = fx + 1.0f, ey = fy + 1.0f;   // south-east corner
+    b.w[0] = (ex - ix) * (ey - iy);
+    b.w[1] = (ix - fx) * (ey - iy);
+    b.w[2] = (ex - ix) * (iy - fy);
+    b.w[3] = (ix - fx) * (iy - fy);
+    return b;
+}
+// sample point p = i*S + j of patch n reads coords[n, j, i, :] (coords.permute(0,2,1,3)); coords = rand*2-1 (:343-344)
+__device__ __forceinline__ void sample_coord(const float* rnd, int n, int p, int S, float& gx, float& gy) {
+    const int i = p / S, j = p % S;
+    const float* r = rnd + (((size_t)n * S + j) * S + i) * 2;
+    gx = r[0] * 2.0f - 1.0f;
+    gy = r[1] * 2.0f - 1.0f;
+}
+__device__ __forceinline__ float bilinear_fetch(const float* img, int W, int H, const Bilinear& b) {
+    float out = 0.0f;
+    const bool xin = b.x0 + 1 <= W - 1, yin = b.y0 + 1 <= H - 1;
+    out = img[(size_t)b.y0 * W + b.x0] * b.w[0];
+    if (xin) out = out + img[(size_t)b.y0 * W + b.x0 + 1] * b.w[1];
+    if (yin) out = out + img[(size_t)(b.y0 + 1) * W + b.x0] * b.w[2];
+    if (xin && yin) out = out + img[(size_t)(b.y0 + 1) * W + b.x0 + 1] * b.w[3];
+    return out;
+}
+
+// one workgroup per (sample point p, patch n, side): side 0 = patch n at coords1, side 1 = patch neg[n] at coords2.
+// Samples all Cf feature channels, L2-normalises them, and (thread 0) samples + normalises the code.
+template <int C>
+__global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict__ feats, const float* __restrict__ code,
+                                                         const long long* __restrict__ neg, const float* __restrict__ rnd1,
+                                                         const float* __restrict__ rnd2, int B, int Cf, int Hf, int Wf, int Hc,
+                                                         int Wc, int S, float* __restrict__ fn, float* __restrict__ cn,
+                                                         float* __restrict__ cn2, float* __restrict__ dinv, float* __restrict__ dinv2) {
+    __shared__ double red[2];
+    const int p = blockIdx.x, n = blockIdx.y, side = blockIdx.z, N = S * S;
+    const int src = side == 0 ? n : (int)neg[n];
+    float gx, gy;
+    sample_coord(side == 0 ? rnd1 : rnd2, n, p, S, gx, gy);
+    const Bilinear bf = bilinear_of(gx, gy, Wf, Hf);
+    float* out = fn + (((size_t)side * B + n) * N + p) * Cf;
+    double ss = 0.0;
+    for (int c = threadIdx.x; c < Cf; c += blockDim.x) {
+        const float v = bilinear_fetch(feats + ((size_t)src * Cf + c) * Hf * Wf, Wf, Hf, bf);
+        out[c] = v;
+        ss += (double)v * v;
+    }
+    const double tot = block_sum(ss, red);
+    __shared__ float den_s;
+    if (threadIdx.x == 0) den_s = fmaxf((float)sqrt(tot), 1e-10f);
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cf; c += blockDim.x) out[c] = out[c] / den_s;
+    if (threadIdx.x == 0) {
+        const Bilinear bc = bilinear_of(gx, gy, Wc, Hc);
+        float v[C], s2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            v[c] = bilinear_fetch(code + ((size_t)src * C + c) * Hc * Wc, Wc, Hc, bc);
+            s2 = c == 0 ? v[c] * v[c] : s2 + v[c] * v[c];
+        }
+        const float nrm = sqrtf(s2), den = fmaxf(nrm, 1e-10f);
+        float* co = (side == 0 ? cn : cn2) + ((size_t)n * N + p) * kMaxC;
+        float* dv = (side == 0 ? dinv : dinv2) + ((size_t)n * N + p) * 2;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) co[c] = c < C ? v[c] / den : 0.0f;
+        dv[0] = den;
+        dv[1] = nrm;
+    }
+}
+
+// fd[set][n][p][q] = <f1n[n][p], f2n[q]>, f2n = side 1 for the negative set, side 0 (the same patch) for the self set
+__global__ __launch_bounds__(256) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat) {
+    const int set = blockIdx.z, n = blockIdx.y, p = blockIdx.x;
+    const float* a = fn + (((size_t)0 * B + n) * N + p) * Cf;
+    const float* bb = fn + (((size_t)(set == 0 ? 1 : 0) * B + n) * N) * Cf;
+    for (int q = threadIdx.x; q < N; q += blockDim.x) {
+        const float* b = bb + (size_t)q * Cf;
+        double s = 0.0;
+        for (int c = 0; c < Cf; ++c) s += (double)(a[c] * b[c]);
+        fdmat[(((size_t)set * B + n) * N + p) * N + q] = (float)s;
+    }
+}
+
+// gradient w.r.t. the SAMPLED codes, back through F.normalize:  out g1[n][p][C] (coords1 of n), g2[n][p][C] (coords2)
+template <int C>
+__global__ __launch_bounds__(128) void app_point_grad_kernel(int B, int N, const float* __restrict__ cn, const float* __restrict__ cn2,
+                                                             const float* __restrict__ dinv, const float* __restrict__ dinv2,
+                                                             const float* __restrict__ grow, const float* __restrict__ gcol,
+                                                             float* __restrict__ g1, float* __restrict__ g2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N) return;
+    float gy[C], gv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)   // rows of both sets + columns of the self set all are code(coords1) of patch n
+        gy[c] = (grow[((size_t)0 * B * N + i) * kMaxC + c] + grow[((size_t)1 * B * N + i) * kMaxC + c]) + gcol[((size_t)1 * B * N + i) * kMaxC + c];
+    normalize_backward<C>(gy, cn + i * kMaxC, dinv[i * 2], dinv[i * 2 + 1], gv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) g1[i * kMaxC + c] = gv[c];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gy[c] = gcol[((size_t)0 * B * N + i) * kMaxC + c];
+    normalize_backward<C>(gy, cn2 + i * kMaxC, dinv2[i * 2], dinv2[i * 2 + 1], gv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) g2[i * kMaxC + c] = gv[c];
+}
+
+// grid_sample backward as a gather (deterministic): thread = one pixel of patch m; it collects the bilinear weights
+// of the coords1 samples of m and of the coords2 samples of every n whose negative is m
+template <int C>
+__global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, int Hc, int Wc, const long long* __restrict__ neg,
+                                                          const float* __restrict__ rnd1, const float* __restrict__ rnd2,
+                                                          const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          float* __restrict__ grad_code) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * Hc * Wc) return;
+    const int m = (int)(i / (Hc * Wc)), y = (int)((i / Wc) % Hc), x = (int)(i % Wc);
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    for (int side = 0; side < 2; ++side)
+        for (int n = 0; n < B; ++n) {
+            if (side == 0 ? n != m : (int)neg[n] != m) continue;
+            const float* gsrc = (side == 0 ? g1 : g2) + (size_t)n * N * kMaxC;
+            for (int p = 0; p < N; ++p) {
+                float gx, gy;
+                sample_coord(side == 0 ? rnd1 : rnd2, n, p, S, gx, gy);
+                const Bilinear b = bilinear_of(gx, gy, Wc, Hc);
+                const int dx = x - b.x0, dy = y - b.y0;
+                if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
+                const float w = b.w[dy * 2 + dx];
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += gsrc[(size_t)p * kMaxC + c] * w;
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < C; ++c) grad_code[((size_t)m * C + c) * Hc * Wc + (size_t)y * Wc + x] = acc[c];
+}
+
+// ------------------------------------------------------------------------------------------ host side
+template <bool GEO, int C>
+int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st) {
+    const int N = A.N, B = A.B;
+    const int tb = GEO ? 256 : 128;
+    const dim3 grid((N + tb - 1) / tb, B, 2);
+    const int nb = (int)(grid.x * grid.y);
+    if (nb > kRedBlocks) return NSOS_ERR_UNSUPPORTED;
+    const size_t lds_rows12 = GEO ? (size_t)N * 4 * 4 : 0;
+    const size_t lds_rows3 = lds_rows12 + (size_t)N * kMaxC * 4;
+    const size_t lds_cols = lds_rows3 + (size_t)N * 4;
+    constexpr int kLdsCap = 150 * 1024;   // dynamic part; the kernels also hold a few bytes of static LDS (160 KiB per CU)
+    if (lds_cols > (size_t)kLdsCap) return NSOS_ERR_UNSUPPORTED;
+    static bool configured = false;
+    if (!configured) {
+        const int cap = kLdsCap;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_cols_kernel<GEO, C>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e != hipSuccess) return (int32_t)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1>), grid, dim3(tb), lds_rows12, st, A);
+    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, 0);
+    hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 2>), grid, dim3(tb), lds_rows12, st, A);
+    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, 2);
+    hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3>), grid, dim3(tb), lds_rows3, st, A);
+    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, 4);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss);
+    if (want_grad) hipLaunchKernelGGL((pair_cols_kernel<GEO, C>), grid, dim3(tb), lds_cols, st, A);
+    return nsos_launch_status();
+}
+
+template <int C>
+int32_t geo_impl(float* depth, const float* code, const float* ray_o, const float* ray_d, const long long* neg, int B, int N,
+                 CorrParams prm, float max_depth, int write_back, float* loss, float* grad_code, void* workspace, hipStream_t st) {
+    Ws w;
+    ws_layout(&w, workspace, B, N, 0, false);
+    const long long tot = (long long)B * N;
+    const int rb = (int)((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256);
+    hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot, max_depth, w.partial);
+    hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
+    hipLaunchKernelGGL((geo_prep_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, depth, code, ray_o, ray_d, B, N,
+                       max_depth, write_back, w.scal, w.pts, w.cn, w.dinv);
+    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm};
+    const int32_t rc = run_pair_passes<true, C>(A, grad_code != nullptr, loss, st);
+    if (rc != NSOS_OK) return rc;
+    if (grad_code)
+        hipLaunchKernelGGL((geo_grad_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, neg, w.cn, w.dinv, w.grow,
+                           w.gcol, grad_code);
+    return nsos_launch_status();
+}
+
+template <int C>
+int32_t app_impl(const float* feats, const float* code, const long long* neg, const float* rnd1, const float* rnd2, int B, int Cf,
+                 int Hf, int Wf, int Hc, int Wc, int S, CorrParams prm, float* loss, float* grad_code, void* workspace, hipStream_t st) {
+    const int N = S * S;
+    Ws w;
+    ws_layout(&w, workspace, B, N, Cf, true);
+    hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, B, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
+                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2);
+    hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(256), 0, st, w.fn, B, N, Cf, w.fdmat);
+    PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm};
+    const int32_t rc = run_pair_passes<false, C>(A, grad_code != nullptr, loss, st);
+    if (rc != NSOS_OK) return rc;
+    if (grad_code) {
+        // g1/g2 reuse the (now consumed) feature buffer
+        float* g1 = w.fn;
+        float* g2 = w.fn + (size_t)B * N * kMaxC;
+        const long long tot = (long long)B * N;
+        hipLaunchKernelGGL((app_point_grad_kernel<C>), dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, st, B, N, w.cn, w.cn2, w.dinv,
+                           w.dinv2, w.grow, w.gcol, g1, g2);
+        const long long px = (long long)B * Hc * Wc;
+        hipLaunchKernelGGL((app_scatter_kernel<C>), dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, B, N, S, Hc, Wc, neg, rnd1, rnd2,
+                           g1, g2, grad_code);
+    }
+    return nsos_launch_status();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" size_t nsos_corr_workspace_bytes(int32_t kind, int32_t batch, int32_t n_points, int32_t feat_dim) {
+    if (batch <= 0 || n_points <= 0 || (kind != 0 && kind != 1)) return 0;
+    const int cf = kind == 0 ? (feat_dim < 2 * kMaxC ? 2 * kMaxC : feat_dim) : 0;
+    return ws_layout(nullptr, nullptr, batch, n_points, cf, kind == 0);
+}
+
+extern "C" int32_t nsos_geo_correlation_loss(float* depth, const float* code, const float* ray_o, const float* ray_d,
+                                             const int64_t* neg_indx, int32_t batch, int32_t code_dim, int32_t height,
+                                             int32_t width, float self_shift, float self_weight, float neg_shift,
+                                             float neg_weight, float max_depth, int32_t filter_in_place, float* loss,
+                                             float* grad_code, void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch == 0) return NSOS_OK;
+    NSOS_REQUIRE(depth && code && ray_o && ray_d && neg_indx && loss && workspace, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(batch > 0 && height > 0 && width > 0, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
+    const long long N = (long long)height * width;
+    NSOS_REQUIRE(N <= 4096, NSOS_ERR_UNSUPPORTED);   // one patch's points + codes + row means stay resident in LDS
+    NSOS_REQUIRE(((uintptr_t)workspace & 15) == 0, NSOS_ERR_MISALIGNED);
+    NSOS_REQUIRE(workspace_bytes >= nsos_corr_workspace_bytes(1, batch, (int32_t)N, 0), NSOS_ERR_BUFFER_TOO_SMALL);
+    const CorrParams prm = {self_shift, self_weight, neg_shift, neg_weight};
+    const long long* neg = reinterpret_cast<const long long*>(neg_indx);
+    const hipStream_t st = (hipStream_t)stream;
+    switch (code_dim) {
+        case 1: return geo_impl<1>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        case 2: return geo_impl<2>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        case 3: return geo_impl<3>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        default: return geo_impl<4>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+    }
+}
+
+extern "C" int32_t nsos_app_correlation_loss(const float* feats, const float* code, const int64_t* neg_indx,
+                                             const float* rand1, const float* rand2, int32_t batch, int32_t feat_dim,
+                                             int32_t feat_h, int32_t feat_w, int32_t code_dim, int32_t code_h,
+                                             int32_t code_w, int32_t feature_samples, float self_shift,
+                                             float self_weight, float neg_shift, float neg_weight, float* loss,
+                                             float* grad_code, void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch == 0) return NSOS_OK;
+    NSOS_REQUIRE(feats && code && neg_indx && rand1 && rand2 && loss && workspace, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(batch > 0 && feat_dim > 0 && feat_h > 0 && feat_w > 0 && code_h > 0 && code_w > 0 && feature_samples > 0,
+                 NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
+    const int N = feature_samples * feature_samples;
+    NSOS_REQUIRE(N <= 1024, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(((uintptr_t)workspace & 15) == 0, NSOS_ERR_MISALIGNED);
+    NSOS_REQUIRE(workspace_bytes >= nsos_corr_workspace_bytes(0, batch, N, feat_dim), NSOS_ERR_BUFFER_TOO_SMALL);
+    const CorrParams prm = {self_shift, self_weight, neg_shift, neg_weight};
+    const long long* neg = reinterpret_cast<const long long*>(neg_indx);
+    const hipStream_t st = (hipStream_t)stream;
+    switch (code_dim) {
+        case 1: return app_impl<1>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
+        case 2: return app_impl<2>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
+        case 3: return app_impl<3>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
+        default: return app_impl<4>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
+    }
+}

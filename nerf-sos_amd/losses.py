@@ -1,0 +1,148 @@
+"""Correlation losses on the rendered patches -- host-side mirror of the reference's loss modules
+(utils/image.py:263-487) over `nsos_app_correlation_loss` / `nsos_geo_correlation_loss`.
+
+Same constructor (`args` namespace with `rand_neg`, `self_corr_w`, `use_sim_matrix`, `app_corr_params` /
+`geo_corr_params`, `patch_stride`), same `forward` signatures, same random draws in the same order from torch's
+global generator on the inputs' device (`rand` for coords1 then coords2; `randperm` for `super_perm` / `rand_neg`).
+Only `orig_code` carries gradient, as in the reference (the feature / depth side is under `no_grad` there).
+No CPU path: inputs must be GPU tensors and the HIP library must be present.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import _dev, _p, _stream
+
+
+def _params_of(values: Sequence, defaults):
+    vals = [d if v is None else float(v) for v, d in zip(values, defaults)]
+    return tuple(vals)
+
+
+class _CorrFn(torch.autograd.Function):
+    """loss = f(code); the forward launch already produces d loss / d code, backward only scales it."""
+
+    @staticmethod
+    def forward(ctx, code, launch):
+        loss, grad = launch(code, code.requires_grad)
+        ctx.save_for_backward(grad if grad is not None else torch.empty(0, device=code.device))
+        ctx.has_grad = grad is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g if ctx.has_grad else None), None
+
+
+class CorrelationLoss(nn.Module):
+    """utils/image.py:263-370.  forward(orig_feats [B,Cf,Hf,Wf], orig_code [B,C,P,P], sim_matrix [B,B] or None)."""
+
+    _DEFAULTS = (0.18, 0.67, 0.46, 0.63)   # self_shift, self_weight, neg_shift, neg_weight (:271-274)
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.zero_clamp = True
+        self.stabalize = False
+        self.pointwise = True
+        self.feature_samples = 11
+        self.rand_neg = bool(getattr(args, "rand_neg", False))
+        self.self_corr_w = getattr(args, "self_corr_w", 1)
+        self.use_sim_matrix = getattr(args, "use_sim_matrix", True)
+        raw = getattr(args, self._PARAM_ATTR, None) if args is not None else None
+        self.self_shift, self.self_weight, self.neg_shift, self.neg_weight = _params_of(raw or [None] * 4, self._DEFAULTS)
+
+    _PARAM_ATTR = "app_corr_params"
+
+    def super_perm(self, size: int, device: torch.device):
+        perm = torch.randperm(size, device=device, dtype=torch.long)          # :306-309
+        perm[perm == torch.arange(size, device=device)] += 1
+        return perm % size
+
+    def _neg_index(self, sim_matrix: Optional[torch.Tensor], B: int, device) -> torch.Tensor:
+        if sim_matrix is None:
+            neg = self.super_perm(B, device)                                   # :351-352
+        else:
+            assert len(sim_matrix.shape) == 2
+            neg = torch.min(sim_matrix, dim=0)[1]                              # :354
+        if self.rand_neg:
+            neg = torch.randperm(sim_matrix.shape[0], device=device, dtype=torch.long)   # :357
+        return neg.to(device=device, dtype=torch.int64).contiguous()
+
+    def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor]):
+        feats = _dev(orig_feats.detach(), "orig_feats")
+        B, Cf, Hf, Wf = feats.shape
+        Bc, C, Hc, Wc = orig_code.shape
+        if Bc != B:
+            raise ValueError(f"orig_feats has {B} patches, orig_code {Bc}")
+        S = self.feature_samples
+        dev = feats.device
+        rand1 = torch.rand([B, S, S, 2], device=dev)                           # :343 (the kernel applies *2-1)
+        rand2 = torch.rand([B, S, S, 2], device=dev)                           # :344
+        neg = self._neg_index(sim_matrix, B, dev)
+        lib = _lib.lib()
+        prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
+
+        def launch(code, want_grad):
+            code = _dev(code.detach(), "orig_code")
+            nbytes = lib.nsos_corr_workspace_bytes(0, B, S * S, Cf)
+            ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            grad = torch.empty_like(code) if want_grad else None
+            _lib.check(lib.nsos_app_correlation_loss(_p(feats), _p(code), neg.data_ptr(), _p(rand1), _p(rand2), B, Cf, Hf, Wf, C,
+                                                     Hc, Wc, S, *prm, _p(loss), _p(grad), ws.data_ptr(), ws.numel() * 8,
+                                                     _stream()), "nsos_app_correlation_loss")
+            return loss, grad
+
+        return _CorrFn.apply(orig_code, launch)
+
+
+class GeoCorrelationLoss(CorrelationLoss):
+    """utils/image.py:373-487.  forward(orig_feats = depth [B,1,P,P], orig_code [B,C,P,P],
+    batch_rays = [ray_o, ray_d, rgbs] each [B,3,P,P], sim_matrix).  As in the reference, depth values above
+    `max_depth` are replaced IN PLACE (the caller's tensor changes) before back-projection."""
+
+    _DEFAULTS = (3.0, 0.67, 10.0, 0.63)    # :379-382
+    _PARAM_ATTR = "geo_corr_params"
+
+    def __init__(self, args=None):
+        super().__init__(args)
+        self.max_depth = 15
+        self.ps = getattr(args, "patch_stride", 8)
+
+    def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, batch_rays, sim_matrix: Optional[torch.Tensor]):
+        depth = orig_feats
+        B, one, H, W = depth.shape
+        if one != 1:
+            raise ValueError("depth must be [B,1,P,P]")
+        ray_o, ray_d = batch_rays[0], batch_rays[1]
+        dev = depth.device
+        inplace = depth.is_contiguous() and depth.dtype == torch.float32
+        dbuf = depth if inplace else _dev(depth.detach().float().contiguous(), "depth")
+        _dev(dbuf, "depth")
+        ro = _dev(ray_o.detach().expand(B, 3, H, W), "ray_o")
+        rd = _dev(ray_d.detach().expand(B, 3, H, W), "ray_d")
+        neg = self._neg_index(sim_matrix, B, dev)
+        C = orig_code.shape[1]
+        lib = _lib.lib()
+        prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
+
+        def launch(code, want_grad):
+            code = _dev(code.detach(), "orig_code")
+            nbytes = lib.nsos_corr_workspace_bytes(1, B, H * W, 0)
+            ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            grad = torch.empty_like(code) if want_grad else None
+            _lib.check(lib.nsos_geo_correlation_loss(dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(), B, C, H, W, *prm,
+                                                     float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
+                                                     ws.numel() * 8, _stream()), "nsos_geo_correlation_loss")
+            return loss, grad
+
+        out = _CorrFn.apply(orig_code, launch)
+        if not inplace:   # a permuted view (engines/trainer.py:156): put the filtered values back through the view
+            depth.copy_(dbuf)
+        return out

@@ -288,3 +288,43 @@ def importance_sample(z_vals: torch.Tensor, weights: torch.Tensor, n_importance:
     if debug:
         return z_fine, z_samples, z_std, cdf, inds
     return z_fine, z_samples, z_std
+
+
+# ------------------------------------------------------------------------------------------ evaluation post-processing
+def eval_postprocess(semantics: Optional[torch.Tensor] = None, rgb: Optional[torch.Tensor] = None,
+                     target: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """engines/eval.py:44-57,79-86 without the trip to the host: ``sem_prob = softmax(semantics, -1)``,
+    ``sem = argmax(sem_prob, -1)[..., None]`` (int32, as the reference's ``astype(np.int32)``), and
+    ``mse = img2mse(rgb, target)``, ``psnr = mse2psnr(mse)`` (utils/image.py:125-137) as 1-element tensors.
+    Leading dimensions are kept ([H,W,C] images or [R,C] ray lists)."""
+    if semantics is None and (rgb is None or target is None):
+        raise ValueError("eval_postprocess needs semantics and/or (rgb, target)")
+    out: Dict[str, torch.Tensor] = {}
+    first = semantics if semantics is not None else rgb
+    dev = first.device
+    lead = tuple(first.shape[:-1])
+    n = 1
+    for d in lead:
+        n *= int(d)
+    sem2d = prob = pred = None
+    C_ = 0
+    if semantics is not None:
+        C_ = int(semantics.shape[-1])
+        sem2d = _dev(semantics.reshape(n, C_), "semantics")
+        prob = torch.empty((n, C_), device=dev, dtype=torch.float32)
+        pred = torch.empty((n,), device=dev, dtype=torch.int32)
+    rgb2d = tgt2d = metrics = None
+    if rgb is not None and target is not None:
+        if tuple(rgb.shape) != tuple(target.shape) or rgb.shape[-1] != 3 or tuple(rgb.shape[:-1]) != lead:
+            raise ValueError(f"rgb {tuple(rgb.shape)} and target {tuple(target.shape)} must both be [..., 3] over the same rays")
+        rgb2d, tgt2d = _dev(rgb.reshape(n, 3), "rgb"), _dev(target.reshape(n, 3), "target")
+        metrics = torch.empty((2,), device=dev, dtype=torch.float32)
+    ws = torch.empty((_lib.lib().nsos_eval_workspace_bytes() // 8,), device=dev, dtype=torch.float64)
+    _lib.check(_lib.lib().nsos_eval_postprocess(_p(sem2d), _p(rgb2d), _p(tgt2d), n, C_, _p(prob), _p(pred), _p(metrics),
+                                                _p(ws), _stream()), "nsos_eval_postprocess")
+    if semantics is not None:
+        out["sem_prob"] = prob.reshape(*lead, C_)
+        out["sem"] = pred.reshape(*lead, 1)
+    if metrics is not None:
+        out["mse"], out["psnr"] = metrics[0:1], metrics[1:2]
+    return out

@@ -96,3 +96,24 @@ def test_lds_ring_protocol_holds_in_the_built_code():
         # the fp32 kernels are spill-free; the sem+coord reduced-precision variant keeps one 64-bit value in scratch
         # outside its MFMA chunks (harmless as long as no pending register is involved, which `bad` checks)
         assert n_scratch <= (8 if "mlp_lp_kernel" in name else 0), (name, n_scratch)
+
+
+def test_next_row_entry_points_validate_without_a_gpu():
+    lib = _lib.lib()
+    assert lib.nsos_eval_workspace_bytes() == 257 * 8
+    assert lib.nsos_eval_postprocess(None, None, None, 0, 2, None, None, None, None, None) == 0       # empty batch
+    assert lib.nsos_eval_postprocess(None, None, None, 5, 2, None, None, None, None, None) == -1      # NULL
+    assert lib.nsos_corr_workspace_bytes(1, 8, 4096, 0) > 8 * 4096 * 4 * 4
+    assert lib.nsos_corr_workspace_bytes(0, 8, 121, 384) > 2 * 8 * 121 * 121 * 4
+    assert lib.nsos_corr_workspace_bytes(2, 8, 121, 384) == 0
+    one = C.c_float(0)
+    buf = (C.c_double * 4)()
+    p = C.cast(buf, C.c_void_p)
+    # geometric loss: more than 4096 points per patch does not fit the LDS-resident design
+    assert lib.nsos_geo_correlation_loss(p, p, p, p, p, 2, 2, 65, 64, 0.5, 1, 3, 1, 15, 1, C.byref(one), None, p, 32, None) == -3
+    assert lib.nsos_geo_correlation_loss(p, p, p, p, p, 2, 5, 8, 8, 0.5, 1, 3, 1, 15, 1, C.byref(one), None, p, 32, None) == -3
+    assert lib.nsos_geo_correlation_loss(p, p, p, p, p, 2, 2, 8, 8, 0.5, 1, 3, 1, 15, 1, C.byref(one), None, p, 32, None) == -4
+    assert lib.nsos_app_correlation_loss(p, p, p, p, None, 2, 16, 5, 5, 2, 8, 8, 11, 0.18, 1, 0.46, 1, C.byref(one), None, p, 32, None) == -1
+    assert lib.nsos_app_correlation_loss(p, p, p, p, p, 2, 16, 5, 5, 2, 8, 8, 11, 0.18, 1, 0.46, 1, C.byref(one), None, p, 32, None) == -4
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        nerf_sos_amd.CorrelationLoss(None)(torch.zeros(2, 4, 3, 3), torch.zeros(2, 2, 8, 8), torch.zeros(2, 2))

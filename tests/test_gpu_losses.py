@@ -1,0 +1,147 @@
+"""GPU parity of the rows next to the render path against goldens captured from the real
+reference classes (tests/golden/make_goldens_losses.py): evaluation post-processing and the two correlation losses.
+Tolerance: 1e-4 of the quantity's scale (fp32); predicted labels and the in-place depth filter are exact."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_sos_amd
+from nerf_sos_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses.npz"))
+APP, GEO = (0.18, 1, 0.46, 1), (0.5, 1, 3, 1)   # scripts/train_fortress_node0.sh
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+def ref_args():
+    a = types.SimpleNamespace()
+    a.rand_neg, a.self_corr_w, a.use_sim_matrix, a.patch_stride = False, 0, True, 6
+    a.app_corr_params = [str(x) for x in APP]
+    a.geo_corr_params = [str(x) for x in GEO]
+    return a
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(np.asarray(b)).float()
+    return float((a.reshape(b.shape) - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_eval_postprocess_golden():
+    out = ops.eval_postprocess(T(GOLD["post_sem"]), T(GOLD["post_rgb"]), T(GOLD["post_tgt"]))
+    assert out["sem"].dtype == torch.int32 and tuple(out["sem"].shape) == (9, 13, 1)
+    assert np.array_equal(out["sem"].cpu().numpy(), GOLD["post_pred"])          # labels: exact (incl. the tie -> 0)
+    assert np.abs(out["sem_prob"].cpu().numpy() - GOLD["post_prob"]).max() < 1e-6
+    assert abs(out["mse"].item() - GOLD["post_mse"][0]) < 1e-6 * GOLD["post_mse"][0]
+    assert abs(out["psnr"].item() - GOLD["post_psnr"][0]) < 1e-5
+    again = ops.eval_postprocess(T(GOLD["post_sem"]), T(GOLD["post_rgb"]), T(GOLD["post_tgt"]))
+    assert torch.equal(out["mse"], again["mse"])                                  # fixed-order reduction
+    out5 = ops.eval_postprocess(T(GOLD["post5_sem"]))
+    assert set(out5) == {"sem_prob", "sem"} and np.array_equal(out5["sem"].cpu().numpy(), GOLD["post5_pred"])
+    assert np.abs(out5["sem_prob"].cpu().numpy() - GOLD["post5_prob"]).max() < 1e-6
+    only = ops.eval_postprocess(rgb=T(GOLD["post_rgb"]), target=T(GOLD["post_tgt"]))
+    assert set(only) == {"mse", "psnr"} and torch.equal(only["mse"], out["mse"])
+
+
+def test_eval_postprocess_on_a_render():
+    """The C5 flow: render, post-process on device, only labels + two scalars leave the GPU."""
+    from oracle import torch_port as tp
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
+    rays = tp.synthetic_rays(512, seed=1).to(DEV)
+    with torch.no_grad():
+        ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+    tgt = torch.rand_like(ret["rgb"])
+    out = ops.eval_postprocess(ret["semantics"], ret["rgb"], tgt)
+    prob = ret["semantics"].softmax(-1)
+    assert torch.equal(out["sem"][..., 0].long(), prob.argmax(-1)) and (out["sem_prob"] - prob).abs().max() < 1e-6
+    mse = ((ret["rgb"] - tgt) ** 2).mean()
+    assert abs(out["mse"].item() - mse.item()) < 1e-6 and abs(out["psnr"].item() + 10 * np.log10(mse.item())) < 1e-4
+
+
+class InjectRand:
+    def __init__(self, *arrays):
+        self.q = [T(a) for a in arrays]
+
+    def __enter__(self):
+        self._rand = torch.rand
+        torch.rand = lambda *a, **k: self.q.pop(0)
+
+    def __exit__(self, *exc):
+        torch.rand = self._rand
+
+
+@pytest.mark.parametrize("tag", ["app_small", "app_full"])
+def test_correlation_loss_golden(tag):
+    mod = nerf_sos_amd.CorrelationLoss(ref_args())
+    assert (mod.self_shift, mod.self_weight, mod.neg_shift, mod.neg_weight) == APP
+    feats, sim = T(GOLD[f"{tag}_feats"]), T(GOLD[f"{tag}_sim"])
+    code = T(GOLD[f"{tag}_code"]).requires_grad_(True)
+    with InjectRand(GOLD[f"{tag}_rand1"], GOLD[f"{tag}_rand2"]):
+        loss = mod(feats, code, sim)
+    assert loss.shape == () and loss.dtype == torch.float32
+    assert abs(loss.item() - GOLD[f"{tag}_loss"][0]) < 1e-4 * (1 + abs(GOLD[f"{tag}_loss"][0])), (loss.item(), GOLD[f"{tag}_loss"][0])
+    (3.0 * loss).backward()
+    assert rel(code.grad / 3.0, GOLD[f"{tag}_grad"]) < 1e-4
+    code2 = T(GOLD[f"{tag}_code"]).requires_grad_(True)
+    with InjectRand(GOLD[f"{tag}_rand1"], GOLD[f"{tag}_rand2"]):
+        loss2 = mod(feats, code2, sim)
+    loss2.backward()
+    assert torch.equal(loss2, loss.detach()) and torch.equal(code2.grad * 3.0, code.grad)   # deterministic
+    with torch.no_grad(), InjectRand(GOLD[f"{tag}_rand1"], GOLD[f"{tag}_rand2"]):
+        assert torch.equal(mod(feats, code.detach(), sim), loss.detach())                      # no-grad path
+
+
+@pytest.mark.parametrize("tag", ["geo_small", "geo_full"])
+def test_geo_correlation_loss_golden(tag):
+    mod = nerf_sos_amd.GeoCorrelationLoss(ref_args())
+    assert (mod.self_shift, mod.self_weight, mod.neg_shift, mod.neg_weight, mod.max_depth) == GEO + (15,)
+    depth, sim = T(GOLD[f"{tag}_depth"]), T(GOLD[f"{tag}_sim"])
+    B, _, P, _ = depth.shape
+    ray_o = T(GOLD[f"{tag}_ray_o"])[:, :, None, None].expand(B, 3, P, P)
+    ray_d = T(GOLD[f"{tag}_ray_d"])
+    code = T(GOLD[f"{tag}_code"]).requires_grad_(True)
+    loss = mod(depth, code, [ray_o, ray_d, None], sim)
+    assert abs(loss.item() - GOLD[f"{tag}_loss"][0]) < 1e-4 * (1 + abs(GOLD[f"{tag}_loss"][0])), (loss.item(), GOLD[f"{tag}_loss"][0])
+    assert np.array_equal(depth.cpu().numpy(), GOLD[f"{tag}_depth_after"])     # in-place depth filter, exact
+    loss.backward()
+    assert rel(code.grad, GOLD[f"{tag}_grad"]) < 1e-4
+    # trainer layout (engines/trainer.py:151-160): channel-last tensors permuted to [B,C,P,P] views
+    depth_cl = T(GOLD[f"{tag}_depth"]).permute(0, 2, 3, 1).contiguous()
+    code_cl = T(GOLD[f"{tag}_code"]).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    loss2 = mod(depth_cl.permute(0, 3, 1, 2), code_cl.permute(0, 3, 1, 2), [ray_o, ray_d, None], sim)
+    loss2.backward()
+    assert torch.equal(loss2, loss.detach())
+    assert torch.equal(code_cl.grad.permute(0, 3, 1, 2), code.grad)
+    assert np.array_equal(depth_cl.permute(0, 3, 1, 2).cpu().numpy(), GOLD[f"{tag}_depth_after"])
+
+
+def test_losses_on_rendered_patches_train_the_semantic_head():
+    """The training step right after the path (engines/trainer.py:127-166, 201-203): rendered semantics -> both
+    correlation losses -> backward through the frozen-backbone render -> the semantic head's gradients."""
+    from oracle import torch_port as tp
+    B, P = 2, 16
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV)
+    for n_, p_ in net.named_parameters():
+        p_.requires_grad = "semantic_linear" in n_
+    net.eval()
+    rays = tp.synthetic_rays(B * P * P, seed=5).to(DEV).reshape(2, B, P, P, 3)
+    ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+    sem = ret["semantics"].permute(0, 3, 1, 2)
+    depth = ret["depth"].permute(0, 3, 1, 2)
+    feat = torch.randn(B, 384, 14, 14, device=DEV)
+    sim = torch.rand(B, B, device=DEV)
+    ro, rd = rays[0].permute(0, 3, 1, 2), rays[1].permute(0, 3, 1, 2)
+    a = ref_args()
+    loss = nerf_sos_amd.CorrelationLoss(a)(feat, sem, sim) + 0.01 * nerf_sos_amd.GeoCorrelationLoss(a)(depth, sem, [ro, rd, None], sim)
+    loss.backward()
+    g = net.nerf_fine.mlp.semantic_linear[2].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    assert net.nerf_fine.mlp.pts_linears[0].weight.grad is None
