@@ -13,8 +13,8 @@
 //   2 sum of fl32(fd - rowmean) -> mean(fd1)
 //   3 loss sum + gradient w.r.t. the row codes       (thread = row point p, loop over q)
 //   4 gradient w.r.t. the column codes               (thread = column point q, loop over p)
-// so the kernel is VALU-bound (~25 flop per pair per pass) and reads O(N) bytes.  All reductions are fp64 in a fixed
-// order (no atomics): results are bit-identical run to run.  The appearance loss has N = 121 sample points; its fd
+// so the kernel is VALU-bound (~25 flop per pair per pass) and reads O(N) bytes.  All reductions run in a fixed order
+// (fp32 over 32 consecutive pairs, fp64 across those blocks; no atomics): results are bit-identical run to run.  The appearance loss has N = 121 sample points; its fd
 // (a 384-channel dot product) is materialised once ([2,B,121,121]) and the same four passes read it back.
 // The forward call also produces d(loss)/d(code) (the loss is only ever back-propagated with a scalar upstream
 // gradient), so autograd's backward is one scaling.
@@ -80,13 +80,20 @@ __device__ __forceinline__ double block_sum(double v, double* smem) {
     return s;
 }
 
+// 1/x for x in [0.05, 1e11]: hardware reciprocal + one Newton step (<= 1 ulp from the correctly rounded quotient the
+// reference computes; the IEEE division sequence costs 3x more and the pair passes are VALU-bound)
+__device__ __forceinline__ float recip(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __fmaf_rn(r, __fmaf_rn(-x, r, 1.0f), r);
+}
+
 // clamped inverse L1 distance, GeoCorrelationLoss.tensor_correlation (utils/image.py:404-413)
 template <int D>
 __device__ __forceinline__ float inv_l1(const float (&a)[D], const float* b, float max_depth, bool* clamped = nullptr) {
     float s = fabsf(a[0] - b[0]);
 #pragma unroll
     for (int k = 1; k < D; ++k) s = s + fabsf(a[k] - b[k]);   // torch.sum over dim 1, in order
-    const float r = 1.0f / (s + 5e-2f);
+    const float r = recip(s + 5e-2f);
     if (clamped) *clamped = r > max_depth;
     return r > max_depth ? max_depth : r;
 }
@@ -205,39 +212,49 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(const PairArgs A) {
     if (PASS == 3) { old_mean = (float)(A.scal[set] / cnt); m1 = (float)(A.scal[2 + set] / cnt); }
     const float shift = set == 0 ? A.prm.neg_shift : A.prm.self_shift;
     const float gscale = -(set == 0 ? A.prm.neg_weight : A.prm.self_weight) / (float)cnt;
+    // sums: fp32 over blocks of kBlk consecutive q (fixed order), blocks folded into fp64
+    constexpr int kBlk = 32;
     double acc = 0.0;
     double g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = 0.0;
-    for (int q = 0; q < N; ++q) {
-        const float fd = GEO ? inv_l1<3>(x, lx + q * 4, A.max_depth) : fdrow[q];
-        if (PASS == 1) { acc += (double)fd; continue; }
-        const float fd1 = fd - rm;                         // fd -= fd.mean([3,4]), :318
-        if (PASS == 2) { acc += (double)fd1; continue; }
-        const float fd2 = (fd1 - m1) + old_mean;           // fd - fd.mean() + old_mean, :319
-        const float t = fd2 - shift;
-        float cd;
-        bool clamped = false;
-        if (GEO) cd = inv_l1<C>(c1, lc + q * kMaxC, A.max_depth, &clamped);   // overridden tensor_correlation, :427
-        else {
-            cd = c1[0] * lc[q * kMaxC];
+    for (int q0 = 0; q0 < N; q0 += kBlk) {
+        const int qe = q0 + kBlk < N ? q0 + kBlk : N;
+        float acc32 = 0.0f, g32[C];
 #pragma unroll
-            for (int c = 1; c < C; ++c) cd = cd + c1[c] * lc[q * kMaxC + c];
-        }
-        const float cdc = cd < 0.0f ? 0.0f : cd;           // cd.clamp(0), :330
-        acc += (double)(-cdc * t);
-        if (cd >= 0.0f && !clamped) {
-            const float gcd = gscale * t;                  // d total / d cd
+        for (int c = 0; c < C; ++c) g32[c] = 0.0f;
+#pragma unroll 4
+        for (int q = q0; q < qe; ++q) {
+            const float fd = GEO ? inv_l1<3>(x, lx + q * 4, A.max_depth) : fdrow[q];
+            if (PASS == 1) { acc32 += fd; continue; }
+            const float fd1 = fd - rm;                         // fd -= fd.mean([3,4]), :318
+            if (PASS == 2) { acc32 += fd1; continue; }
+            const float fd2 = (fd1 - m1) + old_mean;           // fd - fd.mean() + old_mean, :319
+            const float t = fd2 - shift;
+            float cd;
+            bool clamped = false;
+            if (GEO) cd = inv_l1<C>(c1, lc + q * kMaxC, A.max_depth, &clamped);   // overridden tensor_correlation, :427
+            else {
+                cd = c1[0] * lc[q * kMaxC];
+#pragma unroll
+                for (int c = 1; c < C; ++c) cd = cd + c1[c] * lc[q * kMaxC + c];
+            }
+            const float cdc = cd < 0.0f ? 0.0f : cd;           // cd.clamp(0), :330
+            acc32 += -cdc * t;
+            const float gcd = (cd >= 0.0f && !clamped) ? gscale * t : 0.0f;   // d total / d cd
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 float dc;
                 if (GEO) {
                     const float df = c1[c] - lc[q * kMaxC + c];
-                    dc = -(cd * cd) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+                    dc = df == 0.0f ? 0.0f : copysignf(cd * cd, -df);   // d cd / d c1 = -cd^2 sign(c1 - c2)
                 } else dc = lc[q * kMaxC + c];
-                g[c] += (double)(gcd * dc);
+                g32[c] += gcd * dc;
             }
         }
+        acc += (double)acc32;
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
     }
     if (PASS == 1 && live) A.rowsum[((size_t)set * A.B + n) * N + p] = acc;
     if (PASS == 3 && live)
@@ -282,39 +299,47 @@ __global__ __launch_bounds__(256) void pair_cols_kernel(const PairArgs A) {
     const float shift = set == 0 ? A.prm.neg_shift : A.prm.self_shift;
     const float gscale = -(set == 0 ? A.prm.neg_weight : A.prm.self_weight) / (float)cnt;
     const float* fdcol = GEO ? nullptr : A.fdmat + ((size_t)set * A.B + n) * N * N + q;
+    constexpr int kBlk = 32;
     double g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = 0.0;
-    for (int p = 0; p < N; ++p) {
-        // fd(p, q) with the ROW point first, exactly as the row passes evaluate it
-        float fd;
-        if (GEO) { const float xp[3] = {lx[p * 4], lx[p * 4 + 1], lx[p * 4 + 2]}; fd = inv_l1<3>(xp, y, A.max_depth); }
-        else fd = fdcol[(size_t)p * N];
-        const float fd2 = ((fd - lr[p]) - m1) + old_mean;
-        const float t = fd2 - shift;
-        float cd;
-        bool clamped = false;
-        float c1[C];
+    for (int p0 = 0; p0 < N; p0 += kBlk) {
+        const int pe = p0 + kBlk < N ? p0 + kBlk : N;
+        float g32[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) c1[c] = lc[p * kMaxC + c];
-        if (GEO) cd = inv_l1<C>(c1, c2, A.max_depth, &clamped);
-        else {
-            cd = c1[0] * c2[0];
+        for (int c = 0; c < C; ++c) g32[c] = 0.0f;
+#pragma unroll 4
+        for (int p = p0; p < pe; ++p) {
+            // fd(p, q) with the ROW point first, exactly as the row passes evaluate it
+            float fd;
+            if (GEO) { const float xp[3] = {lx[p * 4], lx[p * 4 + 1], lx[p * 4 + 2]}; fd = inv_l1<3>(xp, y, A.max_depth); }
+            else fd = fdcol[(size_t)p * N];
+            const float fd2 = ((fd - lr[p]) - m1) + old_mean;
+            const float t = fd2 - shift;
+            float cd;
+            bool clamped = false;
+            float c1[C];
 #pragma unroll
-            for (int c = 1; c < C; ++c) cd = cd + c1[c] * c2[c];
-        }
-        if (cd >= 0.0f && !clamped) {
-            const float gcd = gscale * t;
+            for (int c = 0; c < C; ++c) c1[c] = lc[p * kMaxC + c];
+            if (GEO) cd = inv_l1<C>(c1, c2, A.max_depth, &clamped);
+            else {
+                cd = c1[0] * c2[0];
+#pragma unroll
+                for (int c = 1; c < C; ++c) cd = cd + c1[c] * c2[c];
+            }
+            const float gcd = (cd >= 0.0f && !clamped) ? gscale * t : 0.0f;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 float dc;
                 if (GEO) {
                     const float df = c1[c] - c2[c];
-                    dc = (cd * cd) * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+                    dc = df == 0.0f ? 0.0f : copysignf(cd * cd, df);   // d cd / d c2 = +cd^2 sign(c1 - c2)
                 } else dc = c1[c];
-                g[c] += (double)(gcd * dc);
+                g32[c] += gcd * dc;
             }
         }
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
     }
 #pragma unroll
     for (int c = 0; c < kMaxC; ++c) A.gcol[(((size_t)set * A.B + n) * N + q) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
@@ -451,13 +476,15 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
 // fd[set][n][p][q] = <f1n[n][p], f2n[q]>, f2n = side 1 for the negative set, side 0 (the same patch) for the self set
 __global__ __launch_bounds__(256) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat) {
     const int set = blockIdx.z, n = blockIdx.y, p = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const float* a = fn + (((size_t)0 * B + n) * N + p) * Cf;
     const float* bb = fn + (((size_t)(set == 0 ? 1 : 0) * B + n) * N) * Cf;
-    for (int q = threadIdx.x; q < N; q += blockDim.x) {
+    for (int q = wave; q < N; q += nw) {   // one wave per column point, lanes across channels (coalesced)
         const float* b = bb + (size_t)q * Cf;
         double s = 0.0;
-        for (int c = 0; c < Cf; ++c) s += (double)(a[c] * b[c]);
-        fdmat[(((size_t)set * B + n) * N + p) * N + q] = (float)s;
+        for (int c = lane; c < Cf; c += 64) s += (double)(a[c] * b[c]);
+        s = nsos_wave_sum(s);
+        if (lane == 0) fdmat[(((size_t)set * B + n) * N + p) * N + q] = (float)s;
     }
 }
 
