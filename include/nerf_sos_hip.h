@@ -133,6 +133,15 @@ int32_t nsos_mlp_forward_rays_save(const void* packed, int32_t sem_mode, const f
 int32_t nsos_sem_head_backward(const float* weights, const float* g_semantics, const float* sem2_w,
                                const float* sem_hid, int64_t n_rays, int32_t n_samples, float* g_hid,
                                float* g_logits, void* stream);
+/* The whole backward of the semantic head in one pass over the points (what NeRFNet uses): the element-wise part
+ * above fused into the weight-gradient reductions, on the exact-fp32 MFMA.  Out: gw1_aug [128,320] =
+ * [d semantic_linear.0.weight (first in_dim columns) | unused | d semantic_linear.0.bias (column 319)],
+ * gw2 [2,128] = d semantic_linear.2.weight, gb2 [2] = d semantic_linear.2.bias.  g_hid / g_logits are never
+ * materialised.  workspace: nsos_sem_head_wgrad_workspace_bytes() bytes.  Deterministic (block-ordered reduction). */
+size_t nsos_sem_head_wgrad_workspace_bytes(void);
+int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+                            const float* sem_in, int64_t n_rays, int32_t n_samples, float* gw1_aug, float* gw2,
+                            float* gb2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2-LP: the same fused network with 16-bit MFMA inputs and fp32 accumulation (reduced-precision configs) ----
  * For BASELINE configs C3 (bf16) and C5 (fp16, eval-only).  NOT bit/1e-4-comparable with the reference's fp32
@@ -145,6 +154,12 @@ int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* tensors, int32_t sem_mode, int3
 int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                  const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                  int32_t n_samples, float* raw, void* stream);
+/* Training with a frozen backbone at reduced precision (config C3): as nsos_mlp_forward_rays_save, with sem_in
+ * holding the 16-bit values the semantic head actually consumed (widened to fp32) and sem_hid its fp32 hidden
+ * activations; nsos_sem_head_backward and the weight-gradient GEMMs are the same as for the fp32 path. */
+int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                      const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
+                                      int32_t n_samples, float* raw, float* sem_in, float* sem_hid, void* stream);
 
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).

@@ -31,9 +31,12 @@ SIGNATURES = {
     "nsos_mlp_forward_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays_save": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
     "nsos_sem_head_backward": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
+    "nsos_sem_head_wgrad_workspace_bytes": (_sz, []),
+    "nsos_sem_head_wgrad": (_i32, [_fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
     "nsos_mlp_packed_bytes_lp": (_sz, [_i32]),
     "nsos_mlp_pack_lp": (_i32, [C.POINTER(MlpTensors), _i32, _i32, _fp, _sz, _fp]),
     "nsos_mlp_forward_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "nsos_mlp_forward_rays_save_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
     "nsos_mlp_profile_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_profile_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),

@@ -54,3 +54,131 @@ extern "C" int32_t nsos_sem_head_backward(const float* weights, const float* g_s
                        (hipStream_t)stream, weights, g_semantics, sem2_w, sem_hid, n_pts, n_samples, g_hid, g_logits);
     return nsos_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// K5 (second part): the weight gradients themselves, fused with the element-wise part above.
+//   [dW1 | db1] [128,320] = sum_p g_hid[p,:]^T sem_in[p,:]      dW2 [2,128] = sum_p g_logits[p,:]^T hid[p,:]
+//   db2 [2] = sum_p g_logits[p,:]
+// These are reductions over millions of points into tiny outputs (M = 128 or 2, N = 320 or 128, K = R*S): the BLAS
+// library picks 16x16 macro-tiles for that shape and runs at ~3 % of the fp32 MFMA rate (19 ms per pass for the 6.3 M
+// points of a 32 768-ray step).  Here: persistent grid, workgroup b owns a contiguous block of points; wave w owns
+// the 32 hidden features [32w, 32w+32) x all 320 columns = 10 accumulator tiles of v_mfma_f32_32x32x2_f32 (exact
+// fp32), K = points, two per MFMA.  The A operand (g_hid) is formed in registers from sem_hid, the compositing
+// weight and dL/dsemantics -- g_hid and g_logits are never written.  MFMA-bound: 81 920 MAC per point.
+// Partials [n_blocks][128*320 + 2*128 + 2] are then summed in block order (fp64): deterministic, no atomics.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int kWgradOut = 128 * 320 + 2 * 128 + 2;
+
+struct WgradIn {
+    float a;        // g_hid of (feature 32w+i, point pt0+k)
+    float b[10];    // sem_in columns 32nt+i of that point
+};
+
+__global__ __launch_bounds__(256, 1) void sem_head_wgrad_kernel(const float* __restrict__ weights, const float* __restrict__ g_sem,
+                                                                const float* __restrict__ w2, const float* __restrict__ hid,
+                                                                const float* __restrict__ sem_in, long long n_pts, int S,
+                                                                float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
+    long long chunk = (n_pts + gridDim.x - 1) / gridDim.x;
+    chunk += chunk & 1;
+    const long long start = (long long)blockIdx.x * chunk;
+    const long long end = start + chunk < n_pts ? start + chunk : n_pts;
+    const float w2a = w2[32 * wave + i], w2b = w2[128 + 32 * wave + i];
+    f32x16 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float gw2[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f};
+
+    auto fetch = [&](long long pt0, WgradIn& in) {
+        const long long pt = pt0 + k;
+        const bool valid = pt < end;
+        const long long pc = valid ? pt : (n_pts - 1);
+        const float w = valid ? weights[pc] : 0.0f;
+        const long long r = pc / S;
+        const float gl0 = w * g_sem[2 * r], gl1 = w * g_sem[2 * r + 1];   // g_logits (models/renderer.py:64-66)
+        const float h = hid[pc * 128 + 32 * wave + i];
+        in.a = h > 0.0f ? gl0 * w2a + gl1 * w2b : 0.0f;                    // g_hid (models/nerf_mlp.py:61)
+        gw2[0] += gl0 * h;                                                 // hid is stored after its ReLU
+        gw2[1] += gl1 * h;
+        gb2[0] += gl0;
+        gb2[1] += gl1;
+        const float* row = sem_in + pc * 320 + i;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) in.b[t] = row[32 * t];
+    };
+    WgradIn cur, nxt;
+    if (start < end) fetch(start, cur);
+    for (long long pt0 = start; pt0 < end; pt0 += 2) {
+        const bool more = pt0 + 2 < end;
+        if (more) fetch(pt0 + 2, nxt);   // next pair's loads in flight under this pair's 10 MFMAs
+#pragma unroll
+        for (int t = 0; t < 10; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a, cur.b[t], acc[t], 0, 0, 0);
+        if (more) cur = nxt;
+    }
+    float* out = partial + (size_t)blockIdx.x * kWgradOut;
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)   // accumulator element r of lane (i, k): row (r&3) + 8(r>>2) + 4k, column i
+            out[(size_t)(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * k) * 320 + 32 * t + i] = acc[t][r];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const float s = gw2[o] + __shfl_xor(gw2[o], 32, NSOS_WAVE);
+        if (k == 0) out[128 * 320 + o * 128 + 32 * wave + i] = s;
+        const float sb = gb2[o] + __shfl_xor(gb2[o], 32, NSOS_WAVE);
+        if (wave == 0 && lane == 0) out[128 * 320 + 256 + o] = sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks,
+                                                                    float* __restrict__ gw1, float* __restrict__ gw2,
+                                                                    float* __restrict__ gb2) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kWgradOut) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += (double)partial[(size_t)b * kWgradOut + e];
+    if (e < 128 * 320) gw1[e] = (float)s;
+    else if (e < 128 * 320 + 256) gw2[e - 128 * 320] = (float)s;
+    else gb2[e - 128 * 320 - 256] = (float)s;
+}
+
+int wgrad_blocks() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        n = cus;
+    }
+    return n;
+}
+}  // namespace
+
+extern "C" size_t nsos_sem_head_wgrad_workspace_bytes(void) { return (size_t)1024 * kWgradOut * sizeof(float); }
+
+extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w,
+                                       const float* sem_hid, const float* sem_in, int64_t n_rays, int32_t n_samples,
+                                       float* gw1_aug, float* gw2, float* gb2, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    NSOS_REQUIRE(gw1_aug && gw2 && gb2, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_rays == 0 || (weights && g_semantics && sem2_w && sem_hid && sem_in && workspace), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(workspace_bytes >= nsos_sem_head_wgrad_workspace_bytes(), NSOS_ERR_BUFFER_TOO_SMALL);
+    const long long n_pts = (long long)n_rays * n_samples;
+    int blocks = wgrad_blocks();
+    if (blocks > 1024) blocks = 1024;
+    const long long pairs = (n_pts + 1) / 2;
+    if (pairs < blocks) blocks = (int)(pairs > 0 ? pairs : 1);
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sem_head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in,
+                       n_pts, (int)n_samples, static_cast<float*>(workspace));
+    hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 255) / 256), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
+    return nsos_launch_status();
+}

@@ -54,6 +54,8 @@ __host__ __device__ constexpr int lp_chunks(int sem) {
 
 struct F16 {
     static constexpr bool kIsF16 = true;
+    __device__ static __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+    __device__ static __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
     static constexpr unsigned kOnes = 0x3C003C00u;  // {1.0h, 1.0h}
     __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -74,6 +76,8 @@ struct F16 {
 };
 struct BF16 {
     static constexpr bool kIsF16 = false;
+    __device__ static __forceinline__ float lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+    __device__ static __forceinline__ float hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
     static constexpr unsigned kOnes = 0x3F803F80u;
     __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -132,6 +136,8 @@ struct LpParams {
     int n_samples;
     int n_tiles;
     unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays_lp): per-wave shader-clock stamps, or NULL
+    float* sem_in;   // SAVE: [P,320] = [relu(h7) | x63 | 1.0] as the 16-bit values the semantic head consumed, widened to fp32
+    float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
 };
 constexpr int kProfSlots = 64;
 
@@ -199,7 +205,8 @@ __device__ __forceinline__ void heads_partial_f32(const f32x16 (&h)[NT], const f
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-template <class T, int SEM>
+// SAVE: training-mode variant that also stores what the semantic head's backward needs (K5, frozen backbone)
+template <class T, int SEM, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -370,6 +377,46 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                     run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), sacc, from_H);
                     run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), sacc, from_H);
                     if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sacc, from_ex);
+                    if constexpr (SAVE) {
+                        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
+                        auto relu_acc = [](float a) {   // AGPR read inside asm: see pack8_acc
+                            float x;
+                            asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_max_f32 %0, 0, %0" : "=v"(x) : "a"(a));
+                            return x;
+                        };
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const long long gp = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
+                            if (gp < P.n_pts) {
+                                float* row = P.sem_in + gp * 320;
+                                float* hrow = P.sem_hid + gp * 128;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) {   // word = accumulator elements 8u+2q, +1 of tile t
+                                            const unsigned w = H[c][2 * t + u][q];
+                                            *reinterpret_cast<f32x2*>(row + 32 * t + 2 * (q & 1) + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                                                f32x2{T::lo(w), T::hi(w)};
+                                        }
+#pragma unroll
+                                for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {       // slice word = features 16s + 8kg + 2q, +1; 63 is the 1.0 pad
+                                        const unsigned w = ex[c][sl][q];
+                                        *reinterpret_cast<f32x2*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x2{T::lo(w), T::hi(w)};
+                                    }
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
+                                            f32x4{relu_acc(sacc[c][t][4 * q]), relu_acc(sacc[c][t][4 * q + 1]),
+                                                  relu_acc(sacc[c][t][4 * q + 2]), relu_acc(sacc[c][t][4 * q + 3])};
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         float ps[2];
@@ -512,18 +559,18 @@ int lp_num_cus() {
 
 constexpr int kLdsBytes = kSlots * kSlotBytes + kAuxWords * 4;
 
-template <class T, int SEM>
+template <class T, int SEM, bool SAVE = false>
 int32_t launch_lp(const LpParams& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_lp_kernel<T, SEM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_lp_kernel<T, SEM, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
     static const int cus = lp_num_cus();
     const int grid = p.n_tiles < cus ? p.n_tiles : cus;
-    hipLaunchKernelGGL((mlp_lp_kernel<T, SEM>), dim3(grid), dim3(256), kLdsBytes, stream, p);
+    hipLaunchKernelGGL((mlp_lp_kernel<T, SEM, SAVE>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();
 }
 
@@ -589,7 +636,8 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
 
 static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
-                               int32_t n_samples, float* raw, unsigned long long* prof, void* stream) {
+                               int32_t n_samples, float* raw, unsigned long long* prof, float* sem_in, float* sem_hid,
+                               void* stream) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
@@ -605,7 +653,14 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
     p.prof = prof;
+    p.sem_in = sem_in;
+    p.sem_hid = sem_hid;
     const hipStream_t st = (hipStream_t)stream;
+    if (sem_in) {
+        NSOS_REQUIRE(sem_hid && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
+        if (dtype == NSOS_DTYPE_F16) return sem_mode == 1 ? launch_lp<F16, 1, true>(p, st) : launch_lp<F16, 2, true>(p, st);
+        return sem_mode == 1 ? launch_lp<BF16, 1, true>(p, st) : launch_lp<BF16, 2, true>(p, st);
+    }
     if (dtype == NSOS_DTYPE_F16) {
         switch (sem_mode) {
             case 0: return launch_lp<F16, 0>(p, st);
@@ -623,7 +678,19 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
 extern "C" int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                             const float* rays_d, const float* viewdirs, const float* z_vals,
                                             int64_t n_rays, int32_t n_samples, float* raw, void* stream) {
-    return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, stream);
+    return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr,
+                           nullptr, stream);
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                                 const float* rays_d, const float* viewdirs, const float* z_vals,
+                                                 int64_t n_rays, int32_t n_samples, float* raw, float* sem_in,
+                                                 float* sem_hid, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(sem_in && sem_hid, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
+    return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, sem_in,
+                           sem_hid, stream);
 }
 
 extern "C" int32_t nsos_mlp_profile_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
@@ -633,5 +700,5 @@ extern "C" int32_t nsos_mlp_profile_rays_lp(const void* packed, int32_t sem_mode
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(stamps, NSOS_ERR_NULL_POINTER);
     return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw,
-                           reinterpret_cast<unsigned long long*>(stamps), stream);
+                           reinterpret_cast<unsigned long long*>(stamps), nullptr, nullptr, stream);
 }

@@ -155,12 +155,10 @@ class _FrozenBackboneRender(torch.autograd.Function):
                 grads += [None] * 4
                 continue
             w2 = mlp.mlp.semantic_linear[2].weight.detach()
-            g_hid, g_logits = ops.sem_head_backward(sv["weights"], gs.reshape(-1, 2).contiguous(), w2, sv["sem_hid"])
-            gw1_aug = g_hid.t() @ sv["sem_in"]                           # [128,320] = [dW1 | (pad) | db1]
+            gw1_aug, gw2, gb2 = ops.sem_head_wgrad(sv["weights"], gs.reshape(-1, 2).contiguous(), w2, sv["sem_hid"],
+                                                   sv["sem_in"])           # [128,320] = [dW1 | (pad) | db1]
             in_dim = mlp.mlp.semantic_linear[0].weight.shape[1]
-            ones = torch.ones((g_logits.shape[0], 1), device=g_logits.device, dtype=torch.float32)
-            grads += [gw1_aug[:, :in_dim].contiguous(), gw1_aug[:, 319].contiguous(),
-                      g_logits.t() @ sv["sem_hid"], (g_logits.t() @ ones).reshape(2)]
+            grads += [gw1_aug[:, :in_dim].contiguous(), gw1_aug[:, 319].contiguous(), gw2, gb2]
         return (None, None, None) + tuple(grads)
 
 
@@ -235,8 +233,8 @@ class NeRFNet(nn.Module):
                     return ops.mlp_forward_rays_lp(net.packed_weights(self.mlp_precision), net.sem_mode,
                                                    self.mlp_precision, rays_o, rays_d, viewdirs, z)
                 return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
-            raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(), net.sem_mode, rays_o, rays_d,
-                                                             viewdirs, z)
+            raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,
+                                                             rays_d, viewdirs, z, self.mlp_precision)
             saved[tag] = dict(sem_in=sem_in, sem_hid=sem_hid)
             return raw
 

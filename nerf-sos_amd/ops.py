@@ -192,9 +192,10 @@ def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, ray
 
 
 def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
-                          viewdirs: torch.Tensor, z_vals: torch.Tensor):
+                          viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32"):
     """Training-mode K2 (frozen backbone): raw [R,S,6] plus the semantic head's saved inputs
-    sem_in [R*S,320] = [relu(h7) | x63 | 1] and sem_hid [R*S,128] (see nsos_mlp_forward_rays_save)."""
+    sem_in [R*S,320] = [relu(h7) | x63 | 1] and sem_hid [R*S,128] (see nsos_mlp_forward_rays_save[_lp]).
+    `packed` must have been packed for the same `precision`."""
     if sem_mode == SEM_NONE:
         raise ValueError("mlp_forward_rays_save needs a semantic head")
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
@@ -204,9 +205,15 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     raw = torch.empty((R, S, 6), device=dev, dtype=torch.float32)
     sem_in = torch.empty((R * S, 320), device=dev, dtype=torch.float32)
     sem_hid = torch.empty((R * S, 128), device=dev, dtype=torch.float32)
-    _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
-                                                     _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
-               "nsos_mlp_forward_rays_save")
+    if precision == "fp32":
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
+                                                         _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
+                   "nsos_mlp_forward_rays_save")
+    else:
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_save_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o),
+                                                            _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
+                                                            _p(sem_in), _p(sem_hid), _stream()),
+                   "nsos_mlp_forward_rays_save_lp")
     return raw, sem_in, sem_hid
 
 
@@ -223,6 +230,32 @@ def sem_head_backward(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: 
     _lib.check(_lib.lib().nsos_sem_head_backward(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), R, S,
                                                  _p(g_hid), _p(g_logits), _stream()), "nsos_sem_head_backward")
     return g_hid, g_logits
+
+
+_WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
+
+
+def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: torch.Tensor, sem_hid: torch.Tensor,
+                   sem_in: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Backward of the semantic head in one pass (nsos_sem_head_wgrad): returns
+    (gw1_aug [128,320] = [dW1 | . | db1 in column 319], dW2 [2,128], db2 [2])."""
+    weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
+    sem2_w, sem_hid, sem_in = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid"), _dev(sem_in, "sem_in")
+    R, S = weights.shape
+    if (tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (R * S, 128) or tuple(sem2_w.shape) != (2, 128)
+            or tuple(sem_in.shape) != (R * S, 320)):
+        raise ValueError("sem_head_wgrad: inconsistent shapes")
+    dev = weights.device
+    if dev not in _WGRAD_WS:
+        _WGRAD_WS[dev] = torch.empty(_lib.lib().nsos_sem_head_wgrad_workspace_bytes() // 4, device=dev, dtype=torch.float32)
+    ws = _WGRAD_WS[dev]
+    gw1 = torch.empty((128, 320), device=dev, dtype=torch.float32)
+    gw2 = torch.empty((2, 128), device=dev, dtype=torch.float32)
+    gb2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_sem_head_wgrad(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,
+                                              _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4, _stream()),
+               "nsos_sem_head_wgrad")
+    return gw1, gw2, gb2
 
 
 def mlp_forward_points(packed: torch.Tensor, sem_mode: int, pts: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:

@@ -95,7 +95,10 @@ def test_lds_ring_protocol_holds_in_the_built_code():
         assert not bad, (name, bad[:3])
         # the fp32 kernels are spill-free; the sem+coord reduced-precision variant keeps one 64-bit value in scratch
         # outside its MFMA chunks (harmless as long as no pending register is involved, which `bad` checks)
-        assert n_scratch <= (8 if "mlp_lp_kernel" in name else 0), (name, n_scratch)
+        limit = 0
+        if "mlp_lp_kernel" in name:   # ...ELi<SEM>ELb<SAVE>E...: the training (SAVE) variant unpacks 128 words for its stores
+            limit = 160 if "ELb1EEE" in name else 8
+        assert n_scratch <= limit, (name, n_scratch)
 
 
 def test_next_row_entry_points_validate_without_a_gpu():

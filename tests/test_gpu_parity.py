@@ -443,3 +443,63 @@ def test_render_lp_end_to_end(manifest, precision, min_psnr):
         psnr = -10 * np.log10(max(mse, 1e-30))
         assert psnr > min_psnr, f"{precision} {k}: PSNR vs the fp32 path {psnr:.1f} dB"
     assert a["acc"].max() > 0.5
+
+
+@pytest.mark.parametrize("precision,tol", [("fp16", 2e-2), ("bf16", 1.5e-1)])
+def test_lp_training_variant(golden, manifest, precision, tol):
+    """Config C3: frozen-backbone training at reduced precision.  The SAVE variant of the 16-bit kernel (a) renders
+    bit-identically to the inference variant, (b) stores exactly the operands the head consumed -- a torch head with
+    the 16-bit-rounded first-layer weights on `sem_in` reproduces `sem_hid` and the logits -- and (c) yields
+    semantic-head gradients within the format's error of the reference's fp32 gradients (default-init network; with
+    the spiky test field a 16-bit sigma moves the compositing weights themselves, so there only sanity is checked)."""
+    g = golden("sem_grads")
+    rays = T(g["rays"])
+    # (a) two-pass spiky field: identical to inference, finite gradients on the heads only
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, True, 128))
+    _frozen(net).eval()
+    net.mlp_precision = precision
+    with torch.no_grad():
+        a = net(rays, (tp.NEAR, tp.FAR))
+    b = net(rays, (tp.NEAR, tp.FAR))
+    for k in a:
+        assert torch.equal(a[k], b[k].detach()), k
+    (b["semantics"].square().sum() + b["semantics0"].square().sum()).backward()
+    for n, p in net.named_parameters():
+        assert (p.grad is None) == ('semantic_linear' not in n)
+        assert p.grad is None or (torch.isfinite(p.grad).all() and p.grad.abs().max() > 0)
+    # (c) coarse-only default-init network against the reference's fp32 gradients
+    tag = tag_of("semcoord", False, False, True)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=0, **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, False, 0))
+    _frozen(net).eval()
+    net.mlp_precision = precision
+    ret = net(rays, (tp.NEAR, tp.FAR))
+    (ret["semantics"] * T(g[f"{tag}_G"])).sum().backward()
+    sd = dict(net.named_parameters())
+    keys = [k[len(tag) + 6:] for k in g if k.startswith(tag + "_grad_")]
+    assert len(keys) == 4
+    for k in keys:
+        want = g[f"{tag}_grad_{k}"]
+        got = N(sd[k].grad)
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() <= tol * scale, f"{precision} grad {k}: {np.abs(got - want).max() / scale:.3e} of scale"
+    # (b) the saved operands, straight from the kernel
+    mode = ops.sem_mode_of(**CFGS["semcoord"])
+    R = rays.shape[1]
+    near, far = torch.full((R,), tp.NEAR, device=DEV), torch.full((R,), tp.FAR, device=DEV)
+    z, v = ops.ray_setup(rays[1], near, far, 64, None)
+    mlp = net.nerf.mlp
+    raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.nerf.packed_weights(precision), mode, rays[0].contiguous(),
+                                                     rays[1].contiguous(), v, z, precision)
+    raw_inf = ops.mlp_forward_rays_lp(net.nerf.packed_weights(precision), mode, precision, rays[0].contiguous(),
+                                      rays[1].contiguous(), v, z)
+    assert torch.equal(raw, raw_inf)
+    dt = torch.float16 if precision == "fp16" else torch.bfloat16
+    assert torch.equal(sem_in, sem_in.to(dt).float()) and (sem_in[:, 319] == 1).all() and (sem_in[:, :256] >= 0).all()
+    W1 = mlp.semantic_linear[0].weight.detach().to(dt).double()
+    b1 = mlp.semantic_linear[0].bias.detach().to(dt).double()
+    hid = torch.relu(sem_in[:, :W1.shape[1]].double() @ W1.T + b1).float()
+    assert (hid - sem_hid).abs().max() < 1e-4 * (1 + sem_hid.abs().max())
+    logits = sem_hid @ mlp.semantic_linear[2].weight.detach().T + mlp.semantic_linear[2].bias.detach()
+    assert (logits - raw[..., 4:6].reshape(-1, 2)).abs().max() < 1e-4 * (1 + logits.abs().max())
