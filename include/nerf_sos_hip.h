@@ -183,6 +183,14 @@ int32_t nsos_composite(const float* raw, const float* z_vals, const float* rays_
                        float* weights, float* rgb, float* sem, float* depth, float* acc, float* disp,
                        void* stream);
 
+/* Backward of nsos_composite w.r.t. raw (autograd of models/renderer.py:35-85; z_vals, rays_d and the noise carry no
+ * gradient in the reference).  Upstream gradients g_rgb [R,3], g_sem [R,C-4], g_depth [R], g_acc [R], g_disp [R],
+ * g_weights [R,S] may each be NULL (= zero).  g_raw out [R,S,C].  alpha / transmittance / weights are recomputed. */
+int32_t nsos_composite_backward(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
+                                float noise_std, int64_t n_rays, int32_t n_samples, int32_t n_ch, int32_t white_bkgd,
+                                const float* g_rgb, const float* g_sem, const float* g_depth, const float* g_acc,
+                                const float* g_disp, const float* g_weights, float* g_raw, void* stream);
+
 /* ---- K4: hierarchical sampling ----------------------------------------------------------------
  * ImportanceSampler.forward / sample_pdf (models/sampler.py:91-167) + z_std (models/nerf_net.py:124):
  * pdf over the inner 62 coarse weights, cdf (fp64-accumulated), right-bisect search of u,

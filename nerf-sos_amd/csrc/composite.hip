@@ -138,3 +138,162 @@ extern "C" int32_t nsos_composite(const float* raw, const float* z_vals, const f
 #undef NSOS_LAUNCH_COMPOSITE
     return nsos_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the compositing (autograd of models/renderer.py:35-85 w.r.t. `raw`): one wave per ray, same sample
+// ownership as the forward kernel.  alpha / T / weights are recomputed from `raw` (cheaper than storing them), then
+//   gw_j     = dL/dw_j = g_weights_j + g_rgb.sigmoid(c_j) + g_sem.s_j + G_depth z_j + G_acc
+//   dL/da_i  = gw_i T_i - (1/t_i) sum_{j>i} gw_j w_j          (w_j = a_j prod_{i<j} t_i,  t_i = 1 - a_i + 1e-10)
+//   g_sigma_i = dL/da_i * dist_i * exp(-relu(sigma_i) dist_i) * [sigma_i > 0]
+//   g_c_i    = g_rgb * w_i * sig (1 - sig),   g_s_i = g_sem * w_i
+// with G_depth / G_acc collecting the per-ray terms (white background, the depth -> 1e10 replacement for empty rays,
+// disp = 1/max(1e-10, depth/acc)).  The suffix sum is a lane-local reverse pass + one wave-level scan, in fp64.
+// z_vals, rays_d and the noise carry no gradient in the reference (samples are detached, models/sampler.py:159).
+// Any of the upstream gradients may be NULL (= zero).  Rays with acc <= 1e-10 take no gradient through disp (the
+// reference's autograd produces NaN there: -0 * inf).
+template <int IPL>
+__global__ __launch_bounds__(256) void composite_backward_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d,
+    const float* __restrict__ noise, float noise_std, int64_t n_rays, int S, int C, int white_bkgd,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_sem, const float* __restrict__ g_depth,
+    const float* __restrict__ g_acc, const float* __restrict__ g_disp, const float* __restrict__ g_weights,
+    float* __restrict__ g_raw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float norm = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+    const float* zr = z_vals + r * S;
+    const float* rr = raw + r * (int64_t)S * C;
+    const int s0 = lane * IPL;
+    const int nsem = C - 4;
+
+    float z[IPL + 1], alpha[IPL], tt[IPL], dexp[IPL], col[IPL][3], smv[IPL][2];
+#pragma unroll
+    for (int i = 0; i <= IPL; ++i) z[i] = (s0 + i < S) ? zr[s0 + i] : 0.0f;
+    double prod = 1.0, tloc[IPL];
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        const int s = s0 + i;
+        const bool live = s < S;
+        const float* c = rr + (int64_t)(live ? s : 0) * C;
+        float dist = (s + 1 < S) ? (z[i + 1] - z[i]) : 1e10f;
+        dist = dist * norm;
+        float sigma = c[3];
+        if (noise) sigma = sigma + noise[r * S + (live ? s : 0)] * noise_std;
+        const float relu = sigma > 0.0f ? sigma : 0.0f;
+        const float e = expf(-relu * dist);
+        const float a = live ? (1.0f - e) : 0.0f;
+        alpha[i] = a;
+        dexp[i] = (live && sigma > 0.0f) ? dist * e : 0.0f;   // d alpha / d sigma
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[i][k] = 1.0f / (1.0f + expf(-c[k]));
+        smv[i][0] = nsem > 0 ? c[4] : 0.0f;
+        smv[i][1] = nsem > 1 ? c[5] : 0.0f;
+        tloc[i] = prod;
+        tt[i] = (1.0f - a) + 1e-10f;
+        if (live) prod *= (double)tt[i];
+    }
+    double incl = prod;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off, NSOS_WAVE);
+        if (lane >= off) incl *= o;
+    }
+    double excl = __shfl_up(incl, 1, NSOS_WAVE);
+    if (lane == 0) excl = 1.0;
+    float T[IPL], w[IPL];
+    double s_depth = 0, s_acc = 0;
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        T[i] = (float)(excl * tloc[i]);
+        w[i] = (s0 + i < S) ? alpha[i] * T[i] : 0.0f;
+        s_depth += (double)(w[i] * z[i]);
+        s_acc += (double)w[i];
+    }
+    s_depth = nsos_wave_sum(s_depth);
+    s_acc = nsos_wave_sum(s_acc);
+    const float a_ray = (float)s_acc, dep = (float)s_depth;
+    const bool empty = a_ray <= 1e-10f;   // depth replaced by 1e10: no gradient through the sum (:72)
+
+    float grgb[3] = {0, 0, 0}, gsem[2] = {0, 0};
+    if (g_rgb)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) grgb[k] = g_rgb[3 * r + k];
+    if (g_sem && nsem > 0) { gsem[0] = g_sem[nsem * r]; if (nsem > 1) gsem[1] = g_sem[nsem * r + 1]; }
+    float G_acc = g_acc ? g_acc[r] : 0.0f;
+    float G_dep = (g_depth && !empty) ? g_depth[r] : 0.0f;
+    if (g_disp && !empty) {
+        const float q = dep / a_ray;
+        if (q > 1e-10f) {                           // disp = 1/q (:74)
+            const float gq = -g_disp[r] / (q * q);
+            G_dep += gq / a_ray;
+            G_acc += -gq * dep / (a_ray * a_ray);
+        }
+    }
+    if (white_bkgd) G_acc -= (grgb[0] + grgb[1] + grgb[2]) + (gsem[0] + gsem[1]);   // rgb, sem += 1 - acc (:77-81)
+
+    float gw[IPL];
+    double suf_loc[IPL], tail = 0.0;   // suf_loc[i] = sum over this lane's samples j > i of gw_j w_j
+#pragma unroll
+    for (int i = IPL - 1; i >= 0; --i) {
+        const int s = s0 + i;
+        float g = g_weights && s < S ? g_weights[r * S + s] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g += grgb[k] * col[i][k];
+        g += gsem[0] * smv[i][0] + gsem[1] * smv[i][1];
+        g += G_dep * z[i] + G_acc;
+        gw[i] = s < S ? g : 0.0f;
+        suf_loc[i] = tail;
+        tail += (double)(gw[i] * w[i]);
+    }
+    // exclusive suffix scan of the lane totals (lanes above this one)
+    double incl_s = tail;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_down(incl_s, off, NSOS_WAVE);
+        if (lane + off < 64) incl_s += o;
+    }
+    double above = __shfl_down(incl_s, 1, NSOS_WAVE);
+    if (lane == 63) above = 0.0;
+#pragma unroll
+    for (int i = 0; i < IPL; ++i) {
+        const int s = s0 + i;
+        if (s >= S) continue;
+        const double suffix = above + suf_loc[i];
+        const float ga = (float)((double)(gw[i] * T[i]) - suffix / (double)tt[i]);
+        float* o = g_raw + (r * S + s) * (int64_t)C;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = grgb[k] * w[i] * (col[i][k] * (1.0f - col[i][k]));
+        o[3] = ga * dexp[i];
+        if (nsem > 0) o[4] = gsem[0] * w[i];
+        if (nsem > 1) o[5] = gsem[1] * w[i];
+    }
+}
+
+extern "C" int32_t nsos_composite_backward(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
+                                           float noise_std, int64_t n_rays, int32_t n_samples, int32_t n_ch,
+                                           int32_t white_bkgd, const float* g_rgb, const float* g_sem,
+                                           const float* g_depth, const float* g_acc, const float* g_disp,
+                                           const float* g_weights, float* g_raw, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(raw && z_vals && rays_d && g_raw, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_ch == 4 || n_ch == 5 || n_ch == 6, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_samples <= 512, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE((n_rays + 3) / 4 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+    const int ipl = (n_samples + 63) / 64;
+#define NSOS_LAUNCH_CB(I)                                                                                              \
+    hipLaunchKernelGGL(composite_backward_kernel<I>, grid, block, 0, (hipStream_t)stream, raw, z_vals, rays_d, noise, \
+                       noise_std, n_rays, n_samples, n_ch, white_bkgd, g_rgb, g_sem, g_depth, g_acc, g_disp, g_weights, g_raw)
+    switch (ipl) {
+        case 1: NSOS_LAUNCH_CB(1); break;
+        case 2: NSOS_LAUNCH_CB(2); break;
+        case 3: NSOS_LAUNCH_CB(3); break;
+        case 4: NSOS_LAUNCH_CB(4); break;
+        default: NSOS_LAUNCH_CB(8); break;
+    }
+#undef NSOS_LAUNCH_CB
+    return nsos_launch_status();
+}

@@ -294,6 +294,24 @@ def composite(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noi
     return ret
 
 
+def composite_backward(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                       noise_std: float = 0.0, white_bkgd: bool = False, g_rgb=None, g_sem=None, g_depth=None, g_acc=None,
+                       g_disp=None, g_weights=None) -> torch.Tensor:
+    """d loss / d raw [R,S,C] given the gradients of VolumetricRenderer.forward's outputs (any may be None)."""
+    raw, z_vals, rays_d = _dev(raw, "raw"), _dev(z_vals, "z_vals"), _dev(rays_d, "rays_d")
+    R, S, Cn = raw.shape
+    opt = lambda t, n, shape: None if t is None else _dev(t.reshape(shape), n)  # noqa: E731
+    noise = opt(noise, "noise", (R, S))
+    g_rgb, g_sem = opt(g_rgb, "g_rgb", (R, 3)), (opt(g_sem, "g_sem", (R, Cn - 4)) if Cn > 4 else None)
+    g_depth, g_acc, g_disp = opt(g_depth, "g_depth", (R,)), opt(g_acc, "g_acc", (R,)), opt(g_disp, "g_disp", (R,))
+    g_weights = opt(g_weights, "g_weights", (R, S))
+    g_raw = torch.empty_like(raw)
+    _lib.check(_lib.lib().nsos_composite_backward(_p(raw), _p(z_vals), _p(rays_d), _p(noise), float(noise_std), R, S, Cn,
+                                                  int(bool(white_bkgd)), _p(g_rgb), _p(g_sem), _p(g_depth), _p(g_acc),
+                                                  _p(g_disp), _p(g_weights), _p(g_raw), _stream()), "nsos_composite_backward")
+    return g_raw
+
+
 # ------------------------------------------------------------------------------------------ K4
 def importance_sample(z_vals: torch.Tensor, weights: torch.Tensor, n_importance: int,
                       u: Optional[torch.Tensor] = None, cdf_in: Optional[torch.Tensor] = None,
