@@ -130,6 +130,32 @@ int32_t nsos_mlp_forward_points(const void* packed, int32_t sem_mode, const floa
 int32_t nsos_mlp_forward_rays_save(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                    const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                    float* raw, float* sem_in, float* sem_hid, void* stream);
+/* ---- K7: full backward (every parameter trainable) --------------------------------------------------
+ * nsos_mlp_forward_rays_save_all = nsos_mlp_forward_rays that also stores every layer's activations, row-major
+ * acts out [R*S, NSOS_ACTS_DIM] fp32, so that the backward is GEMMs + masks over saved data:
+ *   [256 l, 256 l + 256)  relu(pts_linears.l(...)), l = 0..7        NSOS_ACTS_FEAT   feature_linear output (no activation)
+ *   NSOS_ACTS_VIEWS  relu(views_linears.0(...)) [128]              NSOS_ACTS_SEM    relu(semantic_linear.0(...)) [128]
+ *   NSOS_ACTS_X      encoded xyz [63] then 1.0                     NSOS_ACTS_D      encoded view direction [27], zero pad
+ * (10.4 KB per point; training only).  Outputs are bit-identical to nsos_mlp_forward_rays. */
+#define NSOS_ACTS_FEAT 2048
+#define NSOS_ACTS_VIEWS 2304
+#define NSOS_ACTS_SEM 2432
+#define NSOS_ACTS_X 2560
+#define NSOS_ACTS_D 2624
+#define NSOS_ACTS_DIM 2656
+int32_t nsos_mlp_forward_rays_save_all(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                       const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                       float* raw, float* acts, void* stream);
+/* Building blocks of the full backward over saved activations (the input-gradient GEMMs g_in = g_out W are plain
+ * [P,256]x[256,256] products and go through the BLAS library):
+ * nsos_wgrad: dW [M, N] (row stride ldw) = sum_p G[p, 0:M]^T X[p, 0:N], db [M] = sum_p G[p, 0:M] (db may be NULL);
+ *   G, X row-major with row strides ldg, ldx (slices of larger buffers); M, N in {32, 64, 128, 256}.  Exact-fp32 MFMA
+ *   with K = points; deterministic.  workspace: nsos_wgrad_workspace_bytes().
+ * nsos_relu_mask: g[p, c] = h[p, c] > 0 ? g[p, c] : 0 in place over n_cols (multiple of 4) columns. */
+size_t nsos_wgrad_workspace_bytes(void);
+int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
+                   float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t ldh, int64_t n_pts, int32_t n_cols, void* stream);
 int32_t nsos_sem_head_backward(const float* weights, const float* g_semantics, const float* sem2_w,
                                const float* sem_hid, int64_t n_rays, int32_t n_samples, float* g_hid,
                                float* g_logits, void* stream);

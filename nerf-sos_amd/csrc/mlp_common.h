@@ -109,6 +109,13 @@ __device__ __forceinline__ void a_pipeline(f32x4 (&ring)[RING], const ChunkCtx c
     });
     lgkm_wait<0>();
     NSOS_PIN();
+    // The preloaded operands have landed only NOW, but hipcc considers an asm output defined where the asm statement
+    // ends: with the value live across the (register-hungry) code between two chunks it would spill or copy the
+    // register right after the ds_read, i.e. before the data arrives.  Re-defining the values here, after the wait,
+    // gives the long-lived value a definition point at which the data is valid (scripts/check_lds_ring.py verifies).
+#pragma unroll
+    for (int i = 0; i < RING; ++i) asm volatile("" : "+v"(nxt[i]));
+    NSOS_PIN();
     // The next chunk starts at group 0, which uses slot 0: re-assignment in order is right for every NG.
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = nxt[i];

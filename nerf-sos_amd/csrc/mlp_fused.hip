@@ -76,6 +76,7 @@ struct MlpParams {
     unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays): per-wave shader-clock stamps, or NULL
     float* sem_in;   // SAVE: [P,320] = [h7 (256) | x63 (63) | 1.0]  inputs of semantic_linear.0 (+ ones column for the bias grad)
     float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...))   inputs of semantic_linear.2
+    float* acts;     // SAVE == 2 (full backward): [P, NSOS_ACTS_DIM] every layer's activations, see nerf_sos_hip.h
 };
 
 // ------------------------------------------------------------------------------------------ device helpers
@@ -181,8 +182,9 @@ __device__ __forceinline__ void enc_fill(f32x16& out, const Enc<L, ParityHalf>& 
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-// SAVE: training-mode variant that additionally stores what the semantic head's backward needs (K5).
-template <int SEM, bool RAYS, bool SAVE = false>
+// SAVE: training-mode variants that additionally store what a backward pass needs --
+//   1: the semantic head's operands only (frozen backbone, K5);  2: every layer's activations (full backward, K7).
+template <int SEM, bool RAYS, int SAVE = 0>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // 3 x 36 KiB weight slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -290,6 +292,27 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
 
         // Z: accumulators of the layer being computed; H: previous layer's activations (VGPRs, MFMA srcB)
         f32x16 Z[8], H[8];
+        auto save_layer = [&](int col0) {   // SAVE == 2: H (4 consecutive features per (tile, register quad)) -> acts
+            if (valid) {
+                float* row = P.acts + gp * NSOS_ACTS_DIM + col0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q + 4 * hi) =
+                            f32x4{H[t][4 * q], H[t][4 * q + 1], H[t][4 * q + 2], H[t][4 * q + 3]};
+            }
+        };
+        if constexpr (SAVE == 2) {
+            if (valid) {
+                float* row = P.acts + gp * NSOS_ACTS_DIM;
+#pragma unroll
+                for (int k = 0; k < 32; ++k)   // x63 feature 2k+hi (slot 63 = 1.0), dir27 feature 2k+hi (k < 16)
+                    row[NSOS_ACTS_X + 2 * k + hi] = (k == 31 && hi == 1) ? 1.0f : ex[k >> 4][k & 15];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) row[NSOS_ACTS_D + 2 * k + hi] = (2 * k + hi < NSOS_DIR_DIM) ? ed[k] : 0.0f;
+            }
+        }
         float sigma = 0.0f, sem_out[2] = {0.0f, 0.0f};
         stamp();  // 1: inputs loaded + encoded
 
@@ -302,6 +325,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         enc_part(std::true_type{});  // pts_linears.0
         const float relu = 0.0f, pass = -__builtin_inff();
         activate(H, Z, relu);
+        if constexpr (SAVE == 2) save_layer(0);
         stamp();  // 2
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8): Z = bias + W * H
 #pragma unroll 1
@@ -312,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
             });
             if (l == 5) enc_part(std::false_type{});  // skip: layer 5 = bias + W_h h4 + W_x x63
             activate(H, Z, l < 8 ? relu : pass);          // feature_linear's output is used without activation
+            if constexpr (SAVE == 2) save_layer(256 * l);  // l == 8: the (linear) feature vector at NSOS_ACTS_FEAT
             stamp();                                      // 2 + l
             if (l == 7) {
                 // H = h7.  sigma head (models/nerf_mlp.py:77), on the vector ALU
@@ -324,7 +349,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
                         chunk4<32, (c == 0)>(sacc, ring, stage_begin(), H[2 * c], H[2 * c + 1], side, mid, tail);
                     });
                     if constexpr (SEM == 2) chunk4<32, false>(sacc, ring, stage_begin(), ex[0], ex[1], side, mid, tail);
-                    if constexpr (SAVE) {
+                    if constexpr (SAVE == 2) {
+                        if (valid) {
+                            float* hrow = P.acts + gp * NSOS_ACTS_DIM + NSOS_ACTS_SEM;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * hi) =
+                                        f32x4{fmaxf(sacc[t][4 * q], 0.0f), fmaxf(sacc[t][4 * q + 1], 0.0f),
+                                              fmaxf(sacc[t][4 * q + 2], 0.0f), fmaxf(sacc[t][4 * q + 3], 0.0f)};
+                        }
+                    }
+                    if constexpr (SAVE == 1) {
                         if (valid) {
                             float* row = P.sem_in + gp * 320;   // H = relu(h7): 4 consecutive features per (tile, reg quad)
                             float* hrow = P.sem_hid + gp * 128;
@@ -362,6 +399,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
             chunk4<32, (c == 0)>(vacc, ring, stage_begin(), H[2 * c], H[2 * c + 1], side, mid, tail);
         });
         chunk4<16, false>(vacc, ring, stage_begin(), ed, ed, side, mid, tail);
+        if constexpr (SAVE == 2) {
+            if (valid) {
+                float* vrow = P.acts + gp * NSOS_ACTS_DIM + NSOS_ACTS_VIEWS;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(vrow + 32 * t + 8 * q + 4 * hi) =
+                            f32x4{fmaxf(vacc[t][4 * q], 0.0f), fmaxf(vacc[t][4 * q + 1], 0.0f),
+                                  fmaxf(vacc[t][4 * q + 2], 0.0f), fmaxf(vacc[t][4 * q + 3], 0.0f)};
+            }
+        }
         float rgb[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
@@ -480,7 +529,7 @@ int num_cus() {
 
 constexpr int kLdsBytes = 3 * kSlotFloats * 4;
 
-template <int SEM, bool RAYS, bool SAVE = false>
+template <int SEM, bool RAYS, int SAVE = 0>
 int32_t launch_mlp(const MlpParams& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
@@ -598,6 +647,24 @@ extern "C" int32_t nsos_mlp_forward_rays_save(const void* packed, int32_t sem_mo
     p.sem_hid = sem_hid;
     return sem_mode == NSOS_SEM_COORD ? launch_mlp<2, true, true>(p, (hipStream_t)stream)
                                       : launch_mlp<1, true, true>(p, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_save_all(const void* packed, int32_t sem_mode, const float* rays_o,
+                                                  const float* rays_d, const float* viewdirs, const float* z_vals,
+                                                  int64_t n_rays, int32_t n_samples, float* raw, float* acts, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(acts, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
+    MlpParams p;
+    const int32_t rc = fill_ray_params(p, packed, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw);
+    if (rc != NSOS_OK) return rc;
+    p.acts = acts;
+    switch (sem_mode) {
+        case NSOS_SEM_NONE: return launch_mlp<0, true, 2>(p, (hipStream_t)stream);
+        case NSOS_SEM_PLAIN: return launch_mlp<1, true, 2>(p, (hipStream_t)stream);
+        case NSOS_SEM_COORD: return launch_mlp<2, true, 2>(p, (hipStream_t)stream);
+    }
+    return NSOS_ERR_UNSUPPORTED;
 }
 
 extern "C" int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float* rays_o,

@@ -1,0 +1,155 @@
+// K7 (full backward): weight-gradient reductions and the ReLU mask for gfx950.
+//
+//   dW[m][n] = sum_p G[p][m] * X[p][n]      db[m] = sum_p G[p][m]           (autograd of y = x W^T + b over P points)
+// G [P, ldg] = gradient w.r.t. a layer's pre-activation output, X [P, ldx] = that layer's input; both row-major
+// slices of larger buffers (the saved activations of nsos_mlp_forward_rays_save_all, gradient ping-pong buffers).
+// The shape is a reduction over millions of points into a tiny output -- M, N <= 256 and K = P -- for which the BLAS
+// library's heuristics pick 16x16 macro-tiles (measured ~3 % of the fp32 MFMA rate).  Here: persistent
+// grid; a workgroup owns a contiguous block of points; v_mfma_f32_32x32x2_f32 (exact fp32) with K = points, two per
+// MFMA; the 4 waves split the 32-row tiles of the output (RW = min(M/32, 4) row groups) and, when M/32 < 4, also the
+// points (KW = 4/RW interleaved subsets).  A operand = G[pt][32 mt + i], B operand = X[pt][32 nt + j]: both are
+// coalesced 128 B rows.  Per-(workgroup, k-subset) partials are summed in a fixed order in fp64: deterministic.
+// MFMA-bound for M = N = 256 (65 536 MAC per point per layer).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int kWgradMaxBlocks = 256;
+
+// RT = row tiles per wave (1 or 2), NT = column tiles (1..8)
+template <int RT, int NT>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                       long long n_pts, int M, int N, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
+    const int MT = M >> 5;
+    const int RW = MT < 4 ? MT : 4, KW = 4 / RW;            // MT in {1,2,4,8}
+    const int rw = wave % RW, kw = wave / RW;
+    long long chunk = (n_pts + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + 2 * KW - 1) / (2 * KW) * (2 * KW);
+    const long long start = (long long)blockIdx.x * chunk;
+    const long long end = start + chunk < n_pts ? start + chunk : n_pts;
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.0f;
+    float bsum[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) bsum[r] = 0.0f;
+
+    struct In { float a[RT]; float b[NT]; };
+    auto fetch = [&](long long pt0, In& in) {
+        const long long pt = pt0 + k;
+        const bool valid = pt < end;
+        const long long pc = valid ? pt : (n_pts - 1);
+        const float* grow = G + pc * ldg + 32 * rw + i;
+        const float* xrow = X + pc * ldx + i;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            in.a[r] = valid ? grow[32 * RW * r] : 0.0f;      // row tile rw + RW*r
+            bsum[r] += in.a[r];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) in.b[t] = xrow[32 * t];
+    };
+    const long long step = 2 * KW;
+    In cur, nxt;
+    long long pt0 = start + 2 * kw;
+    if (pt0 < end) fetch(pt0, cur);
+    for (; pt0 < end; pt0 += step) {
+        const bool more = pt0 + step < end;
+        if (more) fetch(pt0 + step, nxt);
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[r], cur.b[t], acc[r][t], 0, 0, 0);
+        if (more) cur = nxt;
+    }
+    // partial [(block * KW + kw)][M*N + M]
+    float* out = partial + ((size_t)blockIdx.x * KW + kw) * ((size_t)M * N + M);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int mt = rw + RW * r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)   // accumulator element e of lane (i, k): row (e&3) + 8(e>>2) + 4k, column i
+                out[(size_t)(32 * mt + (e & 3) + 8 * (e >> 2) + 4 * k) * N + 32 * t + i] = acc[r][t][e];
+        const float s = bsum[r] + __shfl_xor(bsum[r], 32, NSOS_WAVE);
+        if (k == 0) out[(size_t)M * N + 32 * mt + i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_part, int M, int N,
+                                                           float* __restrict__ dW, int ldw, float* __restrict__ db) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, tot = M * N + M;
+    if (e >= tot) return;
+    double s = 0.0;
+    for (int b = 0; b < n_part; ++b) s += (double)partial[(size_t)b * tot + e];
+    if (e < M * N) dW[(size_t)(e / N) * ldw + e % N] = (float)s;
+    else if (db) db[e - M * N] = (float)s;
+}
+
+// g[p][c] = h[p][c] > 0 ? g[p][c] : 0   (ReLU backward), 4 columns per thread
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, int ldg, const float* __restrict__ h, int ldh,
+                                                        long long n_pts, int n_cols) {
+    const int per_row = n_cols >> 2;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_pts * per_row) return;
+    const long long p = gid / per_row;
+    const int c = (int)(gid % per_row) * 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 gv = *reinterpret_cast<f32x4*>(g + p * ldg + c);
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + p * ldh + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gv[j] = hv[j] > 0.0f ? gv[j] : 0.0f;
+    *reinterpret_cast<f32x4*>(g + p * ldg + c) = gv;
+}
+
+template <int RT, int NT>
+void launch_wgrad(int blocks, hipStream_t st, const float* G, int ldg, const float* X, int ldx, long long n_pts, int M, int N, float* ws) {
+    hipLaunchKernelGGL((wgrad_kernel<RT, NT>), dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, n_pts, M, N, ws);
+}
+}  // namespace
+
+// largest case: M = 32 (KW = 4 k-subsets), N = 256, or M = N = 256 (KW = 1)
+extern "C" size_t nsos_wgrad_workspace_bytes(void) { return (size_t)kWgradMaxBlocks * (256 * 256 + 256) * sizeof(float); }
+
+extern "C" int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
+                              float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    NSOS_REQUIRE(dW && workspace, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts >= 0, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_pts == 0 || (G && X), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE((M == 32 || M == 64 || M == 128 || M == 256) && (N == 32 || N == 64 || N == 128 || N == 256), NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(ldg >= M && ldx >= N && ldw >= N, NSOS_ERR_BAD_SHAPE);
+    const int MT = M / 32, RW = MT < 4 ? MT : 4, KW = 4 / RW, RT = MT / RW, NT = N / 32;
+    int blocks = kWgradMaxBlocks;
+    const long long units = (n_pts + 2 * KW - 1) / (2 * KW);
+    if (units < blocks) blocks = (int)(units > 0 ? units : 1);
+    const size_t need = (size_t)blocks * KW * ((size_t)M * N + M) * sizeof(float);
+    NSOS_REQUIRE(workspace_bytes >= need, NSOS_ERR_BUFFER_TOO_SMALL);
+    const hipStream_t st = (hipStream_t)stream;
+    float* ws = static_cast<float*>(workspace);
+#define NSOS_WG(R, T) launch_wgrad<R, T>(blocks, st, G, ldg, X, ldx, (long long)n_pts, M, N, ws)
+    if (RT == 1) { switch (NT) { case 1: NSOS_WG(1, 1); break; case 2: NSOS_WG(1, 2); break; case 4: NSOS_WG(1, 4); break; default: NSOS_WG(1, 8); break; } }
+    else         { switch (NT) { case 1: NSOS_WG(2, 1); break; case 2: NSOS_WG(2, 2); break; case 4: NSOS_WG(2, 4); break; default: NSOS_WG(2, 8); break; } }
+#undef NSOS_WG
+    const int tot = M * N + M;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, blocks * KW, M, N, dW, ldw, db);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t ldh, int64_t n_pts, int32_t n_cols, void* stream) {
+    if (n_pts == 0) return NSOS_OK;
+    NSOS_REQUIRE(g && h, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts > 0 && n_cols > 0 && (n_cols & 3) == 0 && (ldg & 3) == 0 && (ldh & 3) == 0, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE((((uintptr_t)g | (uintptr_t)h) & 15) == 0, NSOS_ERR_MISALIGNED);
+    const long long tot = (long long)n_pts * (n_cols >> 2);
+    NSOS_REQUIRE((tot + 255) / 256 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, h, ldh,
+                       (long long)n_pts, n_cols);
+    return nsos_launch_status();
+}

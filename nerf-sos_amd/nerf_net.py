@@ -162,6 +162,53 @@ class _FrozenBackboneRender(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+class _FullRender(torch.autograd.Function):
+    """render_rays with gradients for every MLP parameter (K7; the reference trains the whole model in
+    configs/*_full.txt unless --fix_backbone is given, engines/trainer.py:201-203).
+
+    forward : the normal kernel sequence with the SAVE==2 variant of the fused MLP kernel, which stores every layer's
+              activations (10.4 KB per point); outputs are bit-identical to inference.  z_std and pts carry no
+              gradient (the importance samples are detached, models/sampler.py:159).
+    backward: per pass, nsos_composite_backward (d loss / d raw from the gradients of all rendered maps) then the MLP
+              backward over the saved activations (backward.mlp_backward: ReLU masks and weight-gradient reductions
+              are HIP kernels, the [P,256]x[256,256] input-gradient products are plain library GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, net, args, kwargs, *params):
+        with torch.no_grad():
+            ret, saved = net._render_rays_impl(*args, save="all", **kwargs)
+        keys = list(ret.keys())
+        outs = tuple(ret[k] for k in keys)
+        ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if k.rstrip("0") in ("z_std", "pts")])
+        ctx.keys, ctx.saved, ctx.net = keys, saved, net
+        net._last_keys = keys
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from .backward import mlp_backward
+        net, saved = ctx.net, ctx.saved
+        g = {k: v for k, v in zip(ctx.keys, gouts) if v is not None}
+        has_fine = "fine" in saved
+        grads = []
+        for tag, mlp in net._sem_nets():
+            sv = saved.get(tag)
+            names = [n for n, _ in mlp.mlp.named_parameters()]
+            if sv is None:
+                grads += [None] * len(names)
+                continue
+            sfx = "0" if (tag == "coarse" and has_fine) else ""
+            get = lambda k: g.get(k + sfx)  # noqa: E731
+            g_raw = ops.composite_backward(sv["raw"], sv["z"], saved["rays_d"], sv["noise"], saved["noise_std"],
+                                           net.white_bkgd, g_rgb=get("rgb"), g_sem=get("semantics"), g_depth=get("depth"),
+                                           g_acc=get("acc"), g_disp=get("disp"), g_weights=get("weights"))
+            if get("raw") is not None:
+                g_raw = g_raw + get("raw").reshape(g_raw.shape)
+            by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]))
+            grads += [by_name.get(n) for n in names]
+        return (None, None, None) + tuple(grads)
+
+
 class NeRFNet(nn.Module):
     """Coarse + fine volumetric renderer with the reference's constructor and call contract
     (models/nerf_net.py:22-195).  Note the reference's spelling ``pts_chuck``."""
@@ -205,17 +252,21 @@ class NeRFNet(nn.Module):
         """One ray chunk: coarse sample -> MLP -> composite -> importance sample -> fine MLP -> composite
         (models/nerf_net.py:71-130).  Random tensors are drawn on the rays' device in the reference's
         order (rand[R,S], randn[R,S], rand[R,N], randn[R,S+N]) and handed to the kernels.
-        Under autograd, gradients flow to the semantic heads (frozen-backbone recipe); any other trainable
-        parameter raises."""
+        Under autograd: only semantic heads trainable (the shipped --fix_backbone recipe) -> _FrozenBackboneRender;
+        anything else trainable -> _FullRender (every parameter, fp32)."""
         args = (rays_o, rays_d, near, far, viewdirs, raw_noise_std, retraw, retpts)
         trainable = _trainable(self)
         if not trainable:
             return self._render_rays_impl(*args, save=False, **kwargs)[0]
         other = [n for n in trainable if "semantic_linear" not in n]
-        if other or not self.use_semantics:
-            raise NotImplementedError(
-                "NeRFNet: gradients are implemented for the semantic heads only (the reference's --fix_backbone "
-                f"recipe, run_nerf.py:307-318); freeze these first: {other[:4]}{' ...' if len(other) > 4 else ''}")
+        if other:
+            # any backbone parameter trainable (e.g. configs/flower_full.txt trains everything): full backward
+            if self.mlp_precision != "fp32":
+                raise NotImplementedError("NeRFNet: the full backward runs on the exact-fp32 path only; set "
+                                          "mlp_precision = 'fp32' or freeze the backbone (run_nerf.py:307-318)")
+            params = [p_ for _, m in self._sem_nets() for _, p_ in m.mlp.named_parameters()]
+            outs = _FullRender.apply(self, args, kwargs, *params)
+            return dict(zip(self._last_keys, outs))
         params = [dict(m.mlp.named_parameters())[k] for _, m in self._sem_nets() for k in _SEM_KEYS]
         outs = _FrozenBackboneRender.apply(self, args, kwargs, *params)
         return dict(zip(self._last_keys, outs))
@@ -233,6 +284,10 @@ class NeRFNet(nn.Module):
                     return ops.mlp_forward_rays_lp(net.packed_weights(self.mlp_precision), net.sem_mode,
                                                    self.mlp_precision, rays_o, rays_d, viewdirs, z)
                 return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
+            if save == "all":   # full backward (K7): every layer's activations, exact-fp32 kernel only
+                raw, acts = ops.mlp_forward_rays_save_all(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
+                saved[tag] = dict(acts=acts, raw=raw, z=z)
+                return raw
             raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,
                                                              rays_d, viewdirs, z, self.mlp_precision)
             saved[tag] = dict(sem_in=sem_in, sem_hid=sem_hid)
@@ -247,6 +302,8 @@ class NeRFNet(nn.Module):
         ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
         if save:
             saved["coarse"]["weights"] = ret['weights']
+            saved["coarse"]["noise"] = noise
+            saved["rays_d"], saved["noise_std"] = rays_d, raw_noise_std
         if retraw:
             ret['raw'] = raw
         if retpts:
@@ -264,6 +321,7 @@ class NeRFNet(nn.Module):
             ret = ops.composite(raw, z_fine, rays_d, noise, raw_noise_std, self.white_bkgd)
             if save:
                 saved["fine"]["weights"] = ret['weights']
+                saved["fine"]["noise"] = noise
             if retraw:
                 ret['raw'] = raw
             if retpts:

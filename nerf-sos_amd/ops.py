@@ -379,3 +379,59 @@ def eval_postprocess(semantics: Optional[torch.Tensor] = None, rgb: Optional[tor
     if metrics is not None:
         out["mse"], out["psnr"] = metrics[0:1], metrics[1:2]
     return out
+
+
+# ------------------------------------------------------------------------------------------ K7: full backward
+ACTS_FEAT, ACTS_VIEWS, ACTS_SEM, ACTS_X, ACTS_D, ACTS_DIM = 2048, 2304, 2432, 2560, 2624, 2656   # nerf_sos_hip.h
+
+
+def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
+                              viewdirs: torch.Tensor, z_vals: torch.Tensor):
+    """Training-mode K2 with every layer's activations stored: (raw [R,S,C], acts [R*S, ACTS_DIM])."""
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
+    R, S = z_vals.shape
+    dev = z_vals.device
+    raw = torch.empty((R, S, 4 if sem_mode == SEM_NONE else 6), device=dev, dtype=torch.float32)
+    acts = torch.empty((R * S, ACTS_DIM), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
+                                                         R, S, _p(raw), _p(acts), _stream()), "nsos_mlp_forward_rays_save_all")
+    return raw, acts
+
+
+_WG_WS: Dict[torch.device, torch.Tensor] = {}
+
+
+def _rows(t: torch.Tensor, name: str):
+    """(pointer-bearing tensor, row stride) of a 2-D row-major slice with unit column stride."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a float32 GPU matrix with contiguous rows, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+    return t, t.stride(0)
+
+
+def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor] = None) -> None:
+    """dW [M,N] = G^T X, db [M] = column sums of G (nsos_wgrad); G [P,M], X [P,N] may be column slices of wider
+    buffers, dW a column slice of a weight-gradient matrix.  M, N in {32,64,128,256}."""
+    G, ldg = _rows(G, "G")
+    X, ldx = _rows(X, "X")
+    dW, ldw = _rows(dW, "dW")
+    P_, M = G.shape
+    N = X.shape[1]
+    if X.shape[0] != P_ or tuple(dW.shape) != (M, N) or (db is not None and (tuple(db.shape) != (M,) or not db.is_contiguous())):
+        raise ValueError("wgrad: inconsistent shapes")
+    dev = G.device
+    if dev not in _WG_WS:
+        _WG_WS[dev] = torch.empty(_lib.lib().nsos_wgrad_workspace_bytes() // 4, device=dev, dtype=torch.float32)
+    ws = _WG_WS[dev]
+    _lib.check(_lib.lib().nsos_wgrad(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, M, N, dW.data_ptr(), ldw, _p(db), _p(ws),
+                                     ws.numel() * 4, _stream()), "nsos_wgrad")
+
+
+def relu_mask_(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """In place g *= (h > 0) for row-major matrices / column slices with the same shape."""
+    g, ldg = _rows(g, "g")
+    h, ldh = _rows(h, "h")
+    if g.shape != h.shape:
+        raise ValueError("relu_mask_: shape mismatch")
+    _lib.check(_lib.lib().nsos_relu_mask(g.data_ptr(), ldg, h.data_ptr(), ldh, g.shape[0], g.shape[1], _stream()), "nsos_relu_mask")
+    return g

@@ -48,3 +48,102 @@ def test_composite_backward_vs_autograd(S, C, white, noisy):
     (ret2["rgb"] * ups["rgb"].double()).sum().backward()
     got2 = ops.composite_backward(T(raw), T(z), T(d), T(noise), 1.0 if noisy else 0.0, white, g_rgb=T(ups["rgb"])).cpu()
     assert (got2 - rd2.grad.float()).abs().max() <= 1e-4 * rd2.grad.abs().max()
+
+
+import os  # noqa: E402
+
+FULL = np.load(os.path.join(os.path.dirname(__file__), "golden", "full_grads.npz"))
+
+
+def _manifest():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "manifest.json")))
+
+
+@pytest.mark.parametrize("name,peaky,white,n_imp", [("semcoord", True, False, 128), ("sem", False, True, 128), ("nosem", True, False, 0)])
+def test_full_backward_vs_reference(name, peaky, white, n_imp):
+    """Every parameter trainable: gradients of a random linear functional of all rendered maps equal the real
+    reference's autograd (tests/golden/make_goldens_fullgrad.py), to 1e-4 of each gradient's scale (big matrices are
+    checked on 24 rows + 24 columns)."""
+    from helpers import CFGS, ref_state, tag_of
+    tag = tag_of(name, peaky, white, n_imp == 0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=n_imp, white_bkgd=white, **CFGS[name]).to(DEV)
+    net.load_state_dict(ref_state(name, _manifest(), peaky, n_imp))
+    net.eval()
+    rays = torch.from_numpy(FULL["rays"]).to(DEV)
+    with torch.no_grad():
+        want = net(rays, (tp.NEAR, tp.FAR), radii=None)
+    ret = net(rays, (tp.NEAR, tp.FAR), radii=None)
+    loss = 0.0
+    for k in ret:
+        assert torch.equal(ret[k].detach(), want[k]), f"training variant changed {k}"
+        gk = f"{tag}_G_{k}"
+        if gk in FULL:
+            assert ret[k].requires_grad, k
+            loss = loss + (ret[k] * torch.from_numpy(FULL[gk]).to(DEV)).sum()
+    assert not ret["z_std"].requires_grad if "z_std" in ret else True
+    loss.backward()
+    worst = {}
+    n_checked = 0
+    for n_, p_ in net.named_parameters():
+        got = p_.grad
+        assert got is not None, n_
+        refs = []
+        if f"{tag}_grad_{n_}" in FULL:
+            refs.append((got, FULL[f"{tag}_grad_{n_}"]))
+        elif f"{tag}_gradrows_{n_}" in FULL:
+            refs.append((got[::max(1, got.shape[0] // 24)], FULL[f"{tag}_gradrows_{n_}"]))
+            refs.append((got[:, ::max(1, got.shape[1] // 24)], FULL[f"{tag}_gradcols_{n_}"]))
+        else:
+            continue   # nerf_fine aliases nerf when N_importance == 0: stored once
+        for a, b in refs:
+            b = torch.from_numpy(b)
+            scale = float(b.abs().max()) + 1e-20
+            err = float((a.detach().cpu() - b).abs().max()) / scale
+            worst[n_] = max(worst.get(n_, 0.0), err)
+        n_checked += 1
+    assert n_checked >= 24, n_checked
+    # Fine pass: ulp-level differences in the coarse weights move a few importance samples across a bin boundary
+    # (SURVEY F7 / A.5: ~0.1-0.2 % of samples, notably at the u = 1 end of the deterministic eval-mode grid), which
+    # with 12 rays shows up as a 1-4 % change of the fine network's gradients.  The coarse network (no resampling
+    # upstream) is held to 1e-4 here; the 192-sample kernels are held to 1e-4 in the test below.
+    tol = lambda n: 6e-2 if (n.startswith("nerf_fine.") and n_imp > 0) else 1e-4  # noqa: E731
+    bad = {k: v for k, v in worst.items() if v > tol(k)}
+    assert not bad, f"gradients off by more than the tolerance (of their scale): {bad}"
+
+
+def test_full_backward_192_samples_train_mode_vs_port_autograd():
+    """Same kernels as a fine pass (192 samples per ray: 3 per lane in the compositing kernels), train mode with
+    injected jitter and sigma noise, white background -- against autograd through the CPU port, 1e-4 of scale."""
+    from helpers import CFGS, ref_state
+    cfg = tp.PortConfig(n_samples=192, n_importance=0, white_bkgd=True, **CFGS["semcoord"])
+    sd = tp.make_peaky(tp.init_state_dict(cfg, seed=0), gain=8.0, shift=0.5)
+    rays = tp.synthetic_rays(10, seed=8)
+    g = torch.Generator().manual_seed(5)
+    t_rand, noise = torch.rand(10, 192, generator=g), torch.randn(10, 192, generator=g)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = tp.render(sdg, cfg, rays, (tp.NEAR, tp.FAR), raw_noise_std=0.7, draws_per_chunk=[tp.Draws(t_rand=t_rand, noise0=noise)])
+    ups = {k: torch.randn(ref[k].shape, generator=g) * (0.05 if k == "raw" else 1.0) for k in ("rgb", "semantics", "acc", "weights", "raw")}
+    sum((ref[k] * ups[k]).sum() for k in ups).backward()
+
+    net = nerf_sos_amd.NeRFNet(N_samples=192, N_importance=0, white_bkgd=True, perturb=1.0, raw_noise_std=0.7, **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(sd)
+    net.train()
+    q = [t_rand.to(DEV), noise.to(DEV)]
+    _rand, _randn = torch.rand, torch.randn
+    torch.rand = lambda *a, **k: q.pop(0)
+    torch.randn = lambda *a, **k: q.pop(0)
+    try:
+        ret = net(rays.to(DEV), (tp.NEAR, tp.FAR))
+    finally:
+        torch.rand, torch.randn = _rand, _randn
+    for k in ups:
+        assert (ret[k].detach().cpu() - ref[k].detach()).abs().max() <= 1e-4 * (1 + ref[k].detach().abs().max()), k
+    sum((ret[k] * ups[k].to(DEV)).sum() for k in ups).backward()
+    bad = {}
+    for n_, p_ in net.named_parameters():
+        want = sdg[n_].grad
+        err = float((p_.grad.cpu() - want).abs().max() / (want.abs().max() + 1e-20))
+        if err > 1e-4:
+            bad[n_] = err
+    assert not bad, bad
