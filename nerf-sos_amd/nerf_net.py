@@ -145,6 +145,8 @@ class _FrozenBackboneRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         net, saved = ctx.net, ctx.saved
+        if saved is None:
+            raise RuntimeError("nerf_sos_amd: backward through the same render twice (the saved operands were released)")
         g = dict(zip(ctx.keys, gouts))
         grads = []
         has_fine = "fine" in saved  # then the coarse pass's outputs carry the '0' suffix (models/nerf_net.py:126-128)
@@ -159,6 +161,7 @@ class _FrozenBackboneRender(torch.autograd.Function):
                                                    sv["sem_in"])           # [128,320] = [dW1 | (pad) | db1]
             in_dim = mlp.mlp.semantic_linear[0].weight.shape[1]
             grads += [gw1_aug[:, :in_dim].contiguous(), gw1_aug[:, 319].contiguous(), gw2, gb2]
+        ctx.saved = None   # release the saved operands now: the node itself lives as long as the caller keeps the loss
         return (None, None, None) + tuple(grads)
 
 
@@ -188,6 +191,8 @@ class _FullRender(torch.autograd.Function):
     def backward(ctx, *gouts):
         from .backward import mlp_backward
         net, saved = ctx.net, ctx.saved
+        if saved is None:
+            raise RuntimeError("nerf_sos_amd: backward through the same render twice (the saved activations were released)")
         g = {k: v for k, v in zip(ctx.keys, gouts) if v is not None}
         has_fine = "fine" in saved
         grads = []
@@ -206,6 +211,7 @@ class _FullRender(torch.autograd.Function):
                 g_raw = g_raw + get("raw").reshape(g_raw.shape)
             by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]))
             grads += [by_name.get(n) for n in names]
+        ctx.saved = None   # release 10 KB/point of activations now (the node lives as long as the caller keeps the loss)
         return (None, None, None) + tuple(grads)
 
 

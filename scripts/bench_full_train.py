@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""GPU box: one full training step of config C2 (configs/flower_full.txt: every parameter trainable, 4096 rays x
+(64+128) samples, fp32): train-mode render -> img2mse on rgb and rgb0 (engines/trainer.py:113-121) -> backward through
+both networks -> Adam step (run_nerf.py:321).  Prints ms/step, rays/s and the forward/backward split."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import nerf_sos_amd
+from oracle import torch_port as tp
+
+dev = torch.device("cuda:0")
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+torch.manual_seed(0)
+net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0).to(dev).train()
+opt = torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.9, 0.999))
+rays = tp.synthetic_rays(R, seed=0).to(dev)
+gt = torch.rand(R, 3, device=dev)
+
+
+def step(timing=None):
+    opt.zero_grad()
+    if timing is not None:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+    loss = ((ret["rgb"] - gt) ** 2).mean() + ((ret["rgb0"] - gt) ** 2).mean()
+    if timing is not None:
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+    loss.backward()
+    if timing is not None:
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    opt.step()
+    if timing is not None:
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        timing.append((t1 - t0, t2 - t1, t3 - t2))
+    return loss
+
+
+losses = [float(step().detach()) for _ in range(3)]
+torch.cuda.synchronize()
+K = 10
+t0 = time.perf_counter()
+for _ in range(K):
+    l = step()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / K * 1e3
+split = []
+for _ in range(5):
+    step(split)
+f, b, o = (sum(x[i] for x in split) / len(split) * 1e3 for i in range(3))
+out = {"rays": R, "ms_per_step": round(ms, 2), "rays_per_s": round(R / ms * 1e3), "forward_ms": round(f, 2), "backward_ms": round(b, 2),
+       "adam_ms": round(o, 2), "loss_first": round(losses[0], 5), "loss_last": round(float(l.detach()), 5),
+       "saved_activations_GB": round(R * 256 * 2656 * 4 / 1e9, 2)}
+print(json.dumps(out))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/bench_full_train.json", "w"), indent=1)

@@ -352,10 +352,21 @@ def test_training_variant_matches_inference_and_optimizer_step(manifest):
     assert c["semantics"].square().mean() < a["semantics"].square().mean()
 
 
-def test_unfrozen_backbone_raises():
+def test_unfrozen_backbone_trains_in_fp32_and_raises_at_16_bit():
+    """Everything trainable (configs/*_full.txt): the full backward runs on the fp32 path; there is no 16-bit full
+    backward and no autograd fallback, so that combination raises.  Backward twice through one render raises too."""
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True).to(DEV)
-    with pytest.raises(NotImplementedError, match="fix_backbone"):
-        net(tp.synthetic_rays(8).to(DEV), (tp.NEAR, tp.FAR))
+    rays = tp.synthetic_rays(8).to(DEV)
+    ret = net(rays, (tp.NEAR, tp.FAR))
+    assert ret["rgb"].requires_grad and ret["rgb0"].requires_grad and not ret["z_std"].requires_grad
+    loss = ret["rgb"].sum() + ret["rgb0"].sum()
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    with pytest.raises(RuntimeError):
+        loss.backward()
+    net.mlp_precision = "bf16"
+    with pytest.raises(NotImplementedError, match="fp32"):
+        net(rays, (tp.NEAR, tp.FAR))
 
 
 # ------------------------------------------------------------------------------------------ K0 (section 8f)
