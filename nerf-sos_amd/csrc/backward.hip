@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_kernel(const float* __r
         const long long pt = pt0 + k;
         const bool valid = pt < end;
         const long long pc = valid ? pt : (n_pts - 1);
-        const float w = valid ? weights[pc] : 0.0f;
+        float w = weights[pc];   // unconditional load of a clamped row, then a select: `valid ? load : 0` compiles to a
+        w = valid ? w : 0.0f;    // branch with a vmcnt wait behind every load, which serialises the prefetch
         const long long r = pc / S;
         const float gl0 = w * g_sem[2 * r], gl1 = w * g_sem[2 * r + 1];   // g_logits (models/renderer.py:64-66)
         const float h = hid[pc * 128 + 32 * wave + i];
@@ -110,14 +111,23 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_kernel(const float* __r
 #pragma unroll
         for (int t = 0; t < 10; ++t) in.b[t] = row[32 * t];
     };
-    WgradIn cur, nxt;
-    if (start < end) fetch(start, cur);
-    for (long long pt0 = start; pt0 < end; pt0 += 2) {
-        const bool more = pt0 + 2 < end;
-        if (more) fetch(pt0 + 2, nxt);   // next pair's loads in flight under this pair's 10 MFMAs
+    constexpr int U = 4;   // fetch runs 4 k-steps (8 points, 2 560 MFMA cycles) ahead: one k-step is shorter than an HBM trip
+    WgradIn bufA[U], bufB[U];   // used alternately: no register copies for hipcc to hoist into the MFMA stream
+    auto compute = [&](const WgradIn (&in)[U]) {
 #pragma unroll
-        for (int t = 0; t < 10; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a, cur.b[t], acc[t], 0, 0, 0);
-        if (more) cur = nxt;
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 10; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(in[u].a, in[u].b[t], acc[t], 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch(start + 2 * u, bufA[u]);       // points >= end contribute zeros (valid == false)
+    for (long long pt0 = start; pt0 < end; pt0 += 4 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(pt0 + 2 * (U + u), bufB[u]);
+        compute(bufA);
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(pt0 + 2 * (2 * U + u), bufA[u]);
+        compute(bufB);
     }
     float* out = partial + (size_t)blockIdx.x * kWgradOut;
 #pragma unroll

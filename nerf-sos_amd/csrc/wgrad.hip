@@ -40,33 +40,67 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < RT; ++r) bsum[r] = 0.0f;
 
+    // Operand fetch runs a group of U k-steps (2U points) ahead of the MFMAs: one k-step is only RT*NT*64 cycles of
+    // MFMA work, far less than an HBM round trip.  Two operand sets are used alternately (no register copies: hipcc
+    // hoists a `cur = nxt` copy -- and the wait for the loads behind it -- up into the MFMA stream), and the hot loop
+    // only touches groups whose points are all in range, so its loads are unconditional (a `valid ? load : 0` becomes a
+    // branch with a vmcnt wait right behind every load and serialises the whole pipeline on the memory latency).
+    constexpr int U = RT * NT >= 16 ? 4 : (RT * NT >= 8 ? 6 : 8);
     struct In { float a[RT]; float b[NT]; };
-    auto fetch = [&](long long pt0, In& in) {
+    const long long step = 2 * KW;
+    const long long base = start + 2 * kw;
+    auto fetch = [&](long long pt0, In& in) {   // both points of the k-step are in range
         const long long pt = pt0 + k;
-        const bool valid = pt < end;
-        const long long pc = valid ? pt : (n_pts - 1);
-        const float* grow = G + pc * ldg + 32 * rw + i;
-        const float* xrow = X + pc * ldx + i;
+        const float* grow = G + pt * ldg + 32 * rw + i;
+        const float* xrow = X + pt * ldx + i;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            in.a[r] = valid ? grow[32 * RW * r] : 0.0f;      // row tile rw + RW*r
-            bsum[r] += in.a[r];
-        }
+        for (int r = 0; r < RT; ++r) in.a[r] = grow[32 * RW * r];      // row tile rw + RW*r
 #pragma unroll
         for (int t = 0; t < NT; ++t) in.b[t] = xrow[32 * t];
     };
-    const long long step = 2 * KW;
-    In cur, nxt;
-    long long pt0 = start + 2 * kw;
-    if (pt0 < end) fetch(pt0, cur);
-    for (; pt0 < end; pt0 += step) {
-        const bool more = pt0 + step < end;
-        if (more) fetch(pt0 + step, nxt);
+    auto compute1 = [&](const In& in) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RT; ++r) {
+            bsum[r] += in.a[r];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[r], cur.b[t], acc[r][t], 0, 0, 0);
-        if (more) cur = nxt;
+            for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(in.a[r], in.b[t], acc[r][t], 0, 0, 0);
+        }
+    };
+    // k-steps of this wave: j = 0, 1, ... at points base + j*step + {0,1}; n_full of them lie completely below `end`
+    const long long n_ks = base < end ? (end - base + step - 1) / step : 0;              // k-steps with at least one point
+    const long long n_full = base + 1 < end ? (end - 2 - base) / step + 1 : 0;           // k-steps with both points
+    const long long n_grp = n_full / U;                                                   // complete groups of U k-steps
+    if (n_grp > 0) {
+        In bufA[U], bufB[U];
+        auto fetch_grp = [&](long long g, In (&buf)[U]) {
+            const long long gg = g < n_grp ? g : n_grp - 1;   // past the end: re-fetch the last group (never computed)
+#pragma unroll
+            for (int u = 0; u < U; ++u) fetch(base + (gg * U + u) * step, buf[u]);
+        };
+        auto compute = [&](const In (&buf)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) compute1(buf[u]);
+        };
+        fetch_grp(0, bufA);
+        long long g = 0;
+        for (; g + 1 < n_grp; g += 2) {
+            fetch_grp(g + 1, bufB);
+            compute(bufA);
+            fetch_grp(g + 2, bufA);
+            compute(bufB);
+        }
+        if (g < n_grp) compute(bufA);
+    }
+    for (long long j = n_grp * U; j < n_ks; ++j) {   // ragged tail: fewer than U k-steps, the last possibly half valid
+        const long long pt = base + j * step + k;
+        const bool valid = pt < end;
+        const long long pc = valid ? pt : (n_pts - 1);
+        In in;
+        fetch(pc - k, in);
+        if (!valid)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) in.a[r] = 0.0f;
+        compute1(in);
     }
     // partial [(block * KW + kw)][M*N + M]
     float* out = partial + ((size_t)blockIdx.x * KW + kw) * ((size_t)M * N + M);
