@@ -100,3 +100,38 @@ def all_gather_patches(local: Dict[str, torch.Tensor], n_patches: int, group=Non
         g = all_gather_rows(local[k].detach(), counts, group)
         out[k] = g[inv.to(g.device)]
     return out
+
+
+def splice_local_patches(gathered: Dict[str, torch.Tensor], local: Dict[str, torch.Tensor], n_patches: int,
+                         group=None) -> Dict[str, torch.Tensor]:
+    """Put this rank's own (gradient-carrying) patches back into the gathered, detached batch.  Every rank then
+    evaluates the batch-wide correlation losses on the same values, and back-propagation reaches exactly the patches the
+    rank rendered -- in both of their roles (as patch n and as the negative of other patches, utils/image.py:359-360).
+    Summing the parameter gradients over the ranks (`all_reduce_grads`) gives the single-process gradient."""
+    rank, world = _world(group)
+    own = torch.tensor(local_patches(n_patches, rank, world), dtype=torch.long)
+    out = dict(gathered)
+    for k, g in gathered.items():
+        if k in local and local[k].requires_grad and len(own):
+            out[k] = g.index_put((own.to(g.device),), local[k])
+    return out
+
+
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
+    """ONE flat all-reduce (sum, or mean with average=True) of the gradients of `params`, in place.  82 436 floats for
+    the frozen-backbone recipe, 1.27 M for the full model: latency-bound, so a single bucket."""
+    ps = [p for p in params if p.requires_grad]
+    if not ps or not (dist.is_available() and dist.is_initialized()):
+        return
+    for p in ps:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n

@@ -51,6 +51,26 @@ def _worker(rank, world, port, q):
         g = sharding.all_gather_patches(local, B, keys=("semantics", "depth", "semantics0"))
         ok = ok and set(g) == {"semantics", "depth"} and all(torch.equal(g[k], allp[k]) for k in g)
         ok = ok and not g["semantics"].requires_grad
+        # training: batch-wide loss on gathered patches, gradient through the rank's own patches, one grad all-reduce
+        torch.manual_seed(1)
+        head = torch.nn.Linear(3, 2)                       # stands in for the semantic head (same init on every rank)
+        feats = torch.randn(B, P, P, 3)
+        neg = torch.tensor([2, 0, 4, 1, 3])
+
+        def batch_loss(sem):                               # couples every patch with its negative, like the losses
+            return (sem * sem[neg].flip(1)).mean() + sem.square().mean()
+
+        ref_head = torch.nn.Linear(3, 2)
+        ref_head.load_state_dict(head.state_dict())
+        batch_loss(ref_head(feats)).backward()
+        mine_sem = head(feats[own])
+        gathered = sharding.all_gather_patches({"semantics": mine_sem}, B, keys=("semantics",))
+        spliced = sharding.splice_local_patches(gathered, {"semantics": mine_sem}, B)
+        loss = batch_loss(spliced["semantics"])
+        loss.backward()
+        sharding.all_reduce_grads(head.parameters())
+        ok = ok and torch.allclose(loss.detach(), batch_loss(ref_head(feats)).detach(), atol=1e-6)
+        ok = ok and all(torch.allclose(a.grad, b.grad, atol=1e-6) for a, b in zip(head.parameters(), ref_head.parameters()))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
