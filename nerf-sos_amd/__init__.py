@@ -8,6 +8,7 @@ from .nerf_net import MLP, NeRFMLP, NeRFNet  # noqa: F401
 from . import ops  # noqa: F401
 from . import sharding  # noqa: F401
 from . import losses  # noqa: F401
+from . import io  # noqa: F401
 from .losses import CorrelationLoss, GeoCorrelationLoss  # noqa: F401
 
-__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding", "losses", "CorrelationLoss", "GeoCorrelationLoss"]
+__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding", "losses", "io", "CorrelationLoss", "GeoCorrelationLoss"]
