@@ -48,15 +48,25 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
     constexpr int U = RT * NT >= 16 ? 4 : (RT * NT >= 8 ? 6 : 8);
     struct In { float a[RT]; float b[NT]; };
     const long long step = 2 * KW;
-    const long long base = start + 2 * kw;
-    auto fetch = [&](long long pt0, In& in) {   // both points of the k-step are in range
-        const long long pt = pt0 + k;
-        const float* grow = G + pt * ldg + 32 * rw + i;
-        const float* xrow = X + pt * ldx + i;
+    const int kw_s = __builtin_amdgcn_readfirstlane(kw), rw_s = __builtin_amdgcn_readfirstlane(rw);
+    const long long base = start + 2 * kw_s;                       // wave-uniform
+    // addressing: wave-uniform base pointers (SGPRs, advanced per group on the scalar unit) + per-lane 32-bit offsets
+    // that never change, so the hot loop carries no address arithmetic on the vector unit (a VALU instruction between
+    // two fp32 MFMAs costs ~12 cycles)
+    int goff[U], xoff[U];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) in.a[r] = grow[32 * RW * r];      // row tile rw + RW*r
+    for (int u = 0; u < U; ++u) {
+        goff[u] = (int)((u * step + k) * ldg) + 32 * rw_s + i;
+        xoff[u] = (int)((u * step + k) * ldx) + i;
+    }
+    auto fetch_grp = [&](const float* gb, const float* xb, In (&buf)[U]) {   // all points of the group are in range
 #pragma unroll
-        for (int t = 0; t < NT; ++t) in.b[t] = xrow[32 * t];
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) buf[u].a[r] = gb[goff[u] + 32 * RW * r];   // row tile rw + RW*r
+#pragma unroll
+            for (int t = 0; t < NT; ++t) buf[u].b[t] = xb[xoff[u] + 32 * t];
+        }
     };
     auto compute1 = [&](const In& in) {
 #pragma unroll
@@ -66,28 +76,33 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
             for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(in.a[r], in.b[t], acc[r][t], 0, 0, 0);
         }
     };
+    auto compute = [&](const In (&buf)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) compute1(buf[u]);
+    };
     // k-steps of this wave: j = 0, 1, ... at points base + j*step + {0,1}; n_full of them lie completely below `end`
     const long long n_ks = base < end ? (end - base + step - 1) / step : 0;              // k-steps with at least one point
     const long long n_full = base + 1 < end ? (end - 2 - base) / step + 1 : 0;           // k-steps with both points
     const long long n_grp = n_full / U;                                                   // complete groups of U k-steps
     if (n_grp > 0) {
         In bufA[U], bufB[U];
-        auto fetch_grp = [&](long long g, In (&buf)[U]) {
-            const long long gg = g < n_grp ? g : n_grp - 1;   // past the end: re-fetch the last group (never computed)
-#pragma unroll
-            for (int u = 0; u < U; ++u) fetch(base + (gg * U + u) * step, buf[u]);
-        };
-        auto compute = [&](const In (&buf)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) compute1(buf[u]);
-        };
-        fetch_grp(0, bufA);
+        const float* const g0 = G + base * ldg;
+        const float* const x0 = X + base * ldx;
+        const long long gstride = (long long)U * step * ldg, xstride = (long long)U * step * ldx;
+        auto grp_ptr = [&](const float* p0, long long stride, long long g) { return p0 + (g < n_grp ? g : n_grp - 1) * stride; };
+        fetch_grp(g0, x0, bufA);
         long long g = 0;
         for (; g + 1 < n_grp; g += 2) {
-            fetch_grp(g + 1, bufB);
+            // loads of the next group, THEN the MFMAs of the current one: the barriers keep hipcc from sinking loads
+            // into the MFMA stream (its in-order vmcnt waits would then stall on the freshest load)
+            fetch_grp(grp_ptr(g0, gstride, g + 1), grp_ptr(x0, xstride, g + 1), bufB);
+            __builtin_amdgcn_sched_barrier(0);
             compute(bufA);
-            fetch_grp(g + 2, bufA);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_grp(grp_ptr(g0, gstride, g + 2), grp_ptr(x0, xstride, g + 2), bufA);   // past the end: re-fetch the last group
+            __builtin_amdgcn_sched_barrier(0);
             compute(bufB);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (g < n_grp) compute(bufA);
     }
@@ -96,10 +111,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
         const bool valid = pt < end;
         const long long pc = valid ? pt : (n_pts - 1);
         In in;
-        fetch(pc - k, in);
-        if (!valid)
+        const float* grow = G + pc * ldg + 32 * rw + i;
+        const float* xrow = X + pc * ldx + i;
 #pragma unroll
-            for (int r = 0; r < RT; ++r) in.a[r] = 0.0f;
+        for (int r = 0; r < RT; ++r) in.a[r] = valid ? grow[32 * RW * r] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) in.b[t] = xrow[32 * t];
         compute1(in);
     }
     // partial [(block * KW + kw)][M*N + M]
@@ -119,12 +136,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_part, int M, int N,
                                                            float* __restrict__ dW, int ldw, float* __restrict__ db) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x, tot = M * N + M;
-    if (e >= tot) return;
+    // 32 output elements per workgroup x 8 slices of the partials; slice sums are combined in slice order (fixed order)
+    __shared__ double sm[8][32];
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5, tot = M * N + M;
+    const int e = blockIdx.x * 32 + x;
     double s = 0.0;
-    for (int b = 0; b < n_part; ++b) s += (double)partial[(size_t)b * tot + e];
-    if (e < M * N) dW[(size_t)(e / N) * ldw + e % N] = (float)s;
-    else if (db) db[e - M * N] = (float)s;
+    if (e < tot) {
+        const int per = (n_part + 7) / 8, b0 = y * per, b1 = b0 + per < n_part ? b0 + per : n_part;
+        for (int b = b0; b < b1; ++b) s += (double)partial[(size_t)b * tot + e];
+    }
+    sm[y][x] = s;
+    __syncthreads();
+    if (y == 0 && e < tot) {
+        double t = sm[0][x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sm[k][x];
+        if (e < M * N) dW[(size_t)(e / N) * ldw + e % N] = (float)t;
+        else if (db) db[e - M * N] = (float)t;
+    }
 }
 
 // g[p][c] = h[p][c] > 0 ? g[p][c] : 0   (ReLU backward), 4 columns per thread
@@ -172,7 +201,7 @@ extern "C" int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32
     else         { switch (NT) { case 1: NSOS_WG(2, 1); break; case 2: NSOS_WG(2, 2); break; case 4: NSOS_WG(2, 4); break; default: NSOS_WG(2, 8); break; } }
 #undef NSOS_WG
     const int tot = M * N + M;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ws, blocks * KW, M, N, dW, ldw, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, ws, blocks * KW, M, N, dW, ldw, db);
     return nsos_launch_status();
 }
 
