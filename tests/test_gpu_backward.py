@@ -147,3 +147,22 @@ def test_full_backward_192_samples_train_mode_vs_port_autograd():
         if err > 1e-4:
             bad[n_] = err
     assert not bad, bad
+
+
+def test_full_backward_is_chunk_invariant():
+    """NeRFNet.forward renders in ray chunks (models/nerf_net.py:177-187); every chunk is its own autograd node.  The
+    gradients must not depend on the chunking (eval mode: no random draws)."""
+    from helpers import CFGS
+    torch.manual_seed(3)
+    rays = tp.synthetic_rays(23, seed=9).to(DEV)
+    G = torch.randn(23, 3, device=DEV)
+    grads = []
+    for chunk in (1 << 15, 7):
+        torch.manual_seed(0)
+        net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, ray_chunk=chunk, **CFGS["semcoord"]).to(DEV).eval()
+        ret = net(rays, (tp.NEAR, tp.FAR))
+        ((ret["rgb"] * G).sum() + ret["semantics0"].sum() + (ret["rgb0"] * G).sum()).backward()
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert (a - b).abs().max() <= 1e-5 * (a.abs().max() + 1e-12), n
