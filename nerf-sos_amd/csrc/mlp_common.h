@@ -87,6 +87,9 @@ struct ChunkCtx {     // what a chunk needs from the weight stream
 template <int NG, int RING, int PRE, int MID, class M, class B, class T>
 __device__ __forceinline__ void a_pipeline(f32x4 (&ring)[RING], const ChunkCtx ctx, M&& work, B&& mid, T&& tail) {
     static_assert(NG >= MID + 1 && NG >= PRE && PRE >= RING + 3, "chunk length outside the barrier/preload schedule");
+    // the barrier before group MID is what proves that the NEXT chunk has landed in LDS: its operands may only be
+    // preloaded (from group NG - PRE on) after it
+    static_assert(NG - PRE > MID, "chunk too short: the next chunk's operands would be preloaded before this chunk's barrier");
     f32x4 nxt[RING];
     static_for<0, NG>([&](auto ic) {
         constexpr int g = decltype(ic)::value;
