@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--semantics", action="store_true")
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"])
+    ap.add_argument("--post", action="store_true", help="also run the on-device eval post-processing (labels, PSNR)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -42,6 +44,7 @@ def main():
     torch.manual_seed(0)  # same weights on every rank (a real run loads one checkpoint everywhere)
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=args.semantics,
                                sem_with_coord=args.semantics, ray_chunk=args.chunk).to(dev).eval()
+    net.mlp_precision = args.precision
     K = [[args.focal, 0, args.W / 2], [0, args.focal, args.H / 2], [0, 0, 1]]
     c2w = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]]
     n_pix = args.H * args.W
@@ -57,6 +60,8 @@ def main():
         with torch.no_grad():
             out = net(rays, (1.2, 14.72), retraw=False)
         out = {k: out[k] for k in keys}
+        if args.post:   # engines/eval.py:44-57,79-86 on device: only labels and two scalars would leave the GPU
+            post = ops.eval_postprocess(out.get("semantics"), out["rgb"], torch.full_like(out["rgb"], 0.5))
         if args.gather and world > 1:
             rows = [sharding.shard_bounds(n_pix, r, world) for r in range(world)]
             out = {k: sharding.all_gather_rows(v, [y - x for x, y in rows]) for k, v in out.items()}
@@ -68,7 +73,8 @@ def main():
     if rank == 0:
         print(json.dumps({"image": f"{args.W}x{args.H}", "rays": n_pix, "n_gpus": world, "chunk": args.chunk,
                           "seconds": round(best, 4), "rays_per_s": round(n_pix / best, 1), "finite": ok,
-                          "rows_on_rank0": int(out["rgb"].shape[0]), "semantics": args.semantics,
+                          "rows_on_rank0": int(out["rgb"].shape[0]), "semantics": args.semantics, "precision": args.precision,
+                          "post": args.post,
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
     if world > 1:
         dist.destroy_process_group()
