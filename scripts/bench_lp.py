@@ -42,6 +42,18 @@ for sem in (False, True):
         tf = 2 * mac * 4096 * 192 / (fine_ms * 1e-3) / 1e12
         rec = {"rays_per_s": round(4096 / dt), "ms_per_step": round(dt * 1e3, 3), "fine_kernel_ms": round(fine_ms, 3),
                "fine_kernel_tflops": round(tf, 1)}
+        # the same step replayed from a captured HIP graph (host launch path out of the way)
+        gr = nerf_sos_amd.GraphedRender(net, 4096, (tp.NEAR, tp.FAR))
+        for _ in range(3):
+            gr(rays)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gr(rays)
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / 20
+        rec["graphed_ms_per_step"] = round(dtg * 1e3, 3)
+        rec["graphed_rays_per_s"] = round(4096 / dtg)
         if prec == "fp32":
             ref = {k: v.clone() for k, v in o.items()}
         else:

@@ -514,3 +514,24 @@ def test_lp_training_variant(golden, manifest, precision, tol):
     assert (hid - sem_hid).abs().max() < 1e-4 * (1 + sem_hid.abs().max())
     logits = sem_hid @ mlp.semantic_linear[2].weight.detach().T + mlp.semantic_linear[2].bias.detach()
     assert (logits - raw[..., 4:6].reshape(-1, 2)).abs().max() < 1e-4 * (1 + logits.abs().max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_graphed_render_equals_eager(manifest, precision):
+    """hipGraph capture of the eval-mode step: replay is bit-identical to the eager launches, for new inputs too."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    net.mlp_precision = precision
+    g = nerf_sos_amd.GraphedRender(net, 300, (tp.NEAR, tp.FAR), retraw=False)
+    for seed in (1, 2):
+        rays = tp.synthetic_rays(300, seed=seed).to(DEV)
+        with torch.no_grad():
+            want = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+        got = g(rays)
+        assert set(got) == set(want)
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    with torch.no_grad():
+        net.nerf.mlp.rgb_linear.bias.add_(0.1)
+    with pytest.raises(RuntimeError, match="re-capture"):
+        g(rays)
