@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
                 dv[c] = P.dirs[3 * gc + c];
             }
         }
+        // NaN / Inf in a point's inputs must come out as NaN (the reference propagates them silently through sin, the
+        // Linears and relu; v_max(0, NaN) = 0 here would quietly launder them at the first ReLU): 0 if all six are finite
+        const float poison = ((x[0] - x[0]) + (x[1] - x[1])) + ((x[2] - x[2]) + (dv[0] - dv[0])) + ((dv[1] - dv[1]) + (dv[2] - dv[2]));
         // ---- encodings, directly in B-operand form: k-step s of lane (j,hi) = feature 2s+hi
         f32x16 ex[2], ed;
         {
@@ -420,6 +423,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         }
         stamp();  // 11: view branch + rgb head done
         // ---- raw = [r, g, b, sigma, (sem0, sem1)]   (models/nerf_mlp.py:93-96)
+        if (poison != poison) {
+            const float qnan = __builtin_nanf("");
+            rgb[0] = rgb[1] = rgb[2] = sigma = sem_out[0] = sem_out[1] = qnan;
+        }
         if (valid) {
             float* out = P.raw + gp * C;
             if constexpr (C == 4) {

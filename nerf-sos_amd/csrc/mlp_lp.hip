@@ -461,6 +461,21 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) rgb[o] = both_halves(rgb[o]);
             const long long gp = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
+            {   // NaN / Inf in the point's inputs must come out as NaN (the reference propagates them; the packed integer
+                // ReLU would launder them).  The inputs are re-read here (L2 hits) rather than kept alive across the tile.
+                const long long gc = gp < P.n_pts ? gp : P.n_pts - 1, ray = ray_of[c];
+                const float z = P.z_vals[gc];
+                float chk = z - z;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float o = P.rays_o[3 * ray + k], d = P.rays_d[3 * ray + k], v = P.viewdirs[3 * ray + k];
+                    chk += ((o - o) + (d - d)) + (v - v);
+                }
+                if (chk != chk) {
+                    const float qnan = __builtin_nanf("");
+                    rgb[0] = rgb[1] = rgb[2] = sigma[c] = sem_out[c][0] = sem_out[c][1] = qnan;
+                }
+            }
             if (gp < P.n_pts) {
                 float* out = P.raw + gp * C;
                 if constexpr (C == 4) {

@@ -535,3 +535,26 @@ def test_graphed_render_equals_eager(manifest, precision):
         net.nerf.mlp.rgb_linear.bias.add_(0.1)
     with pytest.raises(RuntimeError, match="re-capture"):
         g(rays)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_nan_and_inf_inputs_stay_in_their_ray(manifest, precision):
+    """The reference raises nothing on bad numbers: NaN/Inf propagate silently (SURVEY 8b "Errors").  Here too (the
+    kernels poison the outputs of a point whose inputs are not finite: their ReLUs alone would launder a NaN to 0) -- and
+    a bad ray must not disturb its neighbours in the same tile (rays are independent end to end)."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    net.mlp_precision = precision
+    rays = tp.synthetic_rays(70, seed=6).to(DEV)
+    with torch.no_grad():
+        good = net(rays, (tp.NEAR, tp.FAR))
+        bad_rays = rays.clone()
+        bad_rays[1, 5, 0] = float("nan")       # direction of ray 5
+        bad_rays[0, 9, 2] = float("inf")       # origin of ray 9
+        bad = net(bad_rays, (tp.NEAR, tp.FAR))
+    torch.cuda.synchronize()
+    for r in (5, 9):
+        assert torch.isnan(bad["rgb"][r]).all() and torch.isnan(bad["raw"][r]).all() and torch.isnan(bad["semantics0"][r]).all(), r
+    keep = [i for i in range(70) if i not in (5, 9)]
+    for k in ("rgb", "depth", "acc", "weights", "semantics", "rgb0", "weights0"):
+        assert torch.equal(bad[k][keep], good[k][keep]), k
