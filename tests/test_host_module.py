@@ -56,3 +56,21 @@ def test_shape_assert_matches_reference():
     net = nerf_sos_amd.NeRFNet()
     with torch.no_grad(), pytest.raises(AssertionError):
         net((torch.zeros(4, 3), torch.zeros(5, 3)), (1.0, 2.0))
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_tiny_sample():
+    """bench.py's `cpu_baseline` object (the torch port timed on host cores) -- exercised here on 16 rays so that a
+    broken import or signature shows up in the CPU suite, not only on the GPU box."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    threads = torch.get_num_threads()
+    try:
+        rec = bench.cpu_baseline(16, budget_s=3.0)
+    finally:
+        torch.set_num_threads(threads)
+    assert rec["unit"] == "rays/s" and rec["value"] > 0 and rec["kind"] == "port" and 1 <= rec["cores"] <= 64
+    assert bench.FLOP_PER_RAY == 2 * 593408 * 256
