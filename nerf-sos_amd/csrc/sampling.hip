@@ -92,7 +92,7 @@ struct ImportanceLds {
 __global__ __launch_bounds__(256) void importance_kernel(const float* __restrict__ z_vals,
                                                          const float* __restrict__ weights,
                                                          const float* __restrict__ u_in,
-                                                         const float* __restrict__ cdf_in, int64_t n_rays, int N,
+                                                         const float* __restrict__ cdf_in, int64_t n_rays, int S, int N,
                                                          float* __restrict__ z_fine, float* __restrict__ z_samples,
                                                          float* __restrict__ z_std, float* __restrict__ cdf_out,
                                                          int64_t* __restrict__ inds_out) {
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void importance_kernel(const float* __restrict
     const int64_t r = (int64_t)blockIdx.x * 4 + wave;
     if (r >= n_rays) return;  // whole wave exits together; no block-level barrier below
     ImportanceLds& L = lds_all[wave];
-    constexpr int S = 64, NB = 63;
+    const int NB = S - 1;   // 2 <= S <= 64 coarse samples: one per lane, one cdf entry per lane
 
-    const float z = z_vals[r * S + lane];
+    const float z = lane < S ? z_vals[r * S + lane] : 0.0f;
     // bins = mid-points (models/sampler.py:155): lane j holds .5*(z[j+1]+z[j]), j < 63
     const float z_next = __shfl_down(z, 1, NSOS_WAVE);
-    L.vals[lane] = z;
+    if (lane < S) L.vals[lane] = z;
     if (lane < NB) L.bins[lane] = 0.5f * (z_next + z);
 
     // cdf (models/sampler.py:93-97): entry k lives in lane k; entry 0 = 0, entry k>=1 = inclusive
@@ -249,11 +249,11 @@ extern "C" int32_t nsos_importance_sample(const float* z_vals, const float* weig
     if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(z_vals && (weights || cdf_in) && z_fine && z_samples && z_std, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_importance >= 1, NSOS_ERR_BAD_SHAPE);
-    NSOS_REQUIRE(n_coarse == 64 && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(n_coarse >= 2 && n_coarse <= 64 && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE((n_rays + 3) / 4 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
     hipLaunchKernelGGL(importance_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       z_vals, weights, u, cdf_in, n_rays, n_importance, z_fine, z_samples, z_std, cdf_out,
+                       z_vals, weights, u, cdf_in, n_rays, n_coarse, n_importance, z_fine, z_samples, z_std, cdf_out,
                        inds_out);
     return nsos_launch_status();
 }

@@ -130,8 +130,15 @@ def test_importance_other_counts():
             assert np.array_equal(N(inds), ref["inds"]) and np.array_equal(N(zf), ref["z_fine"])
             assert np.array_equal(N(zs), ref["z_samples"])
             close(N(zstd), ref["z_std"], atol=1e-6, rtol=1e-6, what="z_std")
+    for S in (2, 3, 17, 32, 63):   # fewer coarse samples (the per-call N_samples kwarg, models/sampler.py:41)
+        u = rng.random((R, 128), dtype=np.float32)
+        for uu in (None, u):
+            zf, zs, zstd, cdf, inds = ops.importance_sample(T(z[:, :S]), T(w[:, :S]), 128, None if uu is None else T(uu), debug=True)
+            ref = co.importance(z[:, :S], w[:, :S], uu, 128)
+            assert np.array_equal(N(cdf), ref["cdf"]) and np.array_equal(N(inds), ref["inds"]), S
+            assert np.array_equal(N(zf), ref["z_fine"]) and np.array_equal(N(zs), ref["z_samples"]), S
     with pytest.raises(RuntimeError, match="specialised"):
-        ops.importance_sample(T(z[:, :32]), T(w[:, :32]), 128)
+        ops.importance_sample(T(np.repeat(z, 2, 1)[:, :65]), T(np.repeat(w, 2, 1)[:, :65]), 128)
 
 
 # ------------------------------------------------------------------------------------------ K2
@@ -558,3 +565,22 @@ def test_nan_and_inf_inputs_stay_in_their_ray(manifest, precision):
     keep = [i for i in range(70) if i not in (5, 9)]
     for k in ("rgb", "depth", "acc", "weights", "semantics", "rgb0", "weights0"):
         assert torch.equal(bad[k][keep], good[k][keep]), k
+
+
+def test_per_call_sample_count_override(manifest):
+    """`N_samples` is a per-call kwarg in the reference (models/sampler.py:41); the fine pass still draws the
+    constructor's N_importance samples (models/sampler.py:100,103).  32 coarse + 128 new = 160 fine samples."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS["semcoord"]).to(DEV).eval()
+    sd = ref_state("semcoord", manifest)
+    net.load_state_dict(sd)
+    rays = tp.synthetic_rays(40, seed=12)
+    with torch.no_grad():
+        out = net(rays.to(DEV), (tp.NEAR, tp.FAR), N_samples=32)
+    cfg = tp.PortConfig(n_samples=32, n_importance=128, **CFGS["semcoord"])
+    ref = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR))
+    assert out["weights"].shape == (40, 160) and out["weights0"].shape == (40, 32) and out["raw"].shape == (40, 160, 6)
+    for k in ("rgb0", "depth0", "weights0", "semantics0"):
+        close(N(out[k]), ref[k].numpy(), atol=1e-4, rtol=1e-4, what=k)
+    for k in ("rgb", "acc", "semantics"):   # fine pass: bulk agreement (index flips, SURVEY F7)
+        bad = (np.abs(N(out[k]) - ref[k].numpy()) > 1e-4 * (1 + np.abs(ref[k].numpy()))).any(-1).mean()
+        assert bad <= 0.05, (k, bad)
