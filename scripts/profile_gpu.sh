@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMD=${PROFILE_CMD:-"python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"}   # PROFILE_CMD overrides the profiled command
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- $CMD > $OUT/trace.log 2>&1
 # PMC passes, each on its own (no trace domains combined with --pmc)
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o pmc --output-format csv -- $CMD > $OUT/pmc_sq.log 2>&1

@@ -44,14 +44,14 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_tcc"):
         seen = defaultdict(dict)
         for r in sorted(rows, key=lambda r: int(r.get("Dispatch_Id", 0))):
             name = short(r["Kernel_Name"])
-            if "mlp_fused" in name:
+            if "mlp_fused" in name or "mlp_lp_kernel" in name:
                 d = seen[name]
                 if r["Dispatch_Id"] not in d:
                     d[r["Dispatch_Id"]] = len(d)
                 name += " [fine]" if d[r["Dispatch_Id"]] % 2 else " [coarse]"
             agg[(name, r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        print(f"== {d}: mean counter value per dispatch")
+        print(f"== pmc pass: mean counter value per dispatch")
         for k, cs in sorted(agg.items(), key=lambda kv: -len(kv[1]))[:40]:
-            if "mlp_fused" not in k[0] and "composite" not in k[0] and "importance" not in k[0]:
+            if not any(t in k[0] for t in ("mlp_fused", "mlp_lp_kernel", "composite", "importance", "wgrad", "pair_")):
                 continue
             print(f"  {k[0]:60s} grid {k[1]:>8s} " + "  ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(cs.items())))
