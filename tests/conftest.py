@@ -16,7 +16,7 @@ def pytest_configure(config):
     # The HIP library and the C oracle are build products (git-ignored): build them once if this checkout has none and
     # a compiler is around (hipcc cross-compiles without a GPU).  On the GPU box the prebuilt files travel with the tree.
     lib = os.path.join(ROOT, "nerf-sos_amd", "libnerf_sos_hip.so")
-    ora = os.path.join(ROOT, "oracle", "libnerf_oracle.so")
+    ora = os.path.join(ROOT, "oracle", "liboracle.so")
     if not (os.path.exists(lib) and os.path.exists(ora)) and os.path.exists("/opt/rocm/bin/hipcc"):
         import __graft_entry__
         __graft_entry__.build()
