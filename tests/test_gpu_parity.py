@@ -584,3 +584,27 @@ def test_per_call_sample_count_override(manifest):
     for k in ("rgb", "acc", "semantics"):   # fine pass: bulk agreement (index flips)
         bad = (np.abs(N(out[k]) - ref[k].numpy()) > 1e-4 * (1 + np.abs(ref[k].numpy()))).any(-1).mean()
         assert bad <= 0.05, (k, bad)
+
+
+def test_per_call_kwargs_follow_the_reference(manifest):
+    """Per-call kwargs: N_importance=0 disables the fine pass for that call; a different positive value does
+    NOT change the sample count (models/sampler.py:100,103); retpts adds pts / pts0; perturb / raw_noise_std override the
+    mode defaults; unknown kwargs are ignored."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS["semcoord"]).to(DEV).eval()
+    net.load_state_dict(ref_state("semcoord", manifest))
+    rays = tp.synthetic_rays(20, seed=14).to(DEV)
+    with torch.no_grad():
+        full = net(rays, (tp.NEAR, tp.FAR), radii=0.01, some_unknown_flag=True)
+        coarse = net(rays, (tp.NEAR, tp.FAR), N_importance=0)
+        other = net(rays, (tp.NEAR, tp.FAR), N_importance=17)
+        pts = net(rays, (tp.NEAR, tp.FAR), retpts=True, retraw=False)
+        noisy = net(rays, (tp.NEAR, tp.FAR), perturb=1.0, raw_noise_std=1.0)
+    assert "rgb0" in full and "z_std" in full and full["weights"].shape == (20, 192)
+    assert "rgb0" not in coarse and "z_std" not in coarse and coarse["weights"].shape == (20, 64)
+    assert torch.equal(coarse["rgb"], full["rgb0"]) and torch.equal(coarse["raw"], full["raw0"])
+    assert other["weights"].shape == (20, 192) and torch.equal(other["rgb"], full["rgb"])
+    assert pts["pts"].shape == (20, 192, 3) and pts["pts0"].shape == (20, 64, 3) and "raw" not in pts
+    assert torch.equal(pts["rgb"], full["rgb"])
+    assert not torch.equal(noisy["rgb"], full["rgb"]) and noisy["weights"].shape == (20, 192)
+    with pytest.raises(AssertionError):
+        net((rays[0], rays[1][:10]), (tp.NEAR, tp.FAR))
