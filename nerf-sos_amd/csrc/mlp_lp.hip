@@ -292,6 +292,15 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                     }
                 }
                 dma_slot<(g - kMid) * 2 + c, kDmaPieces>(side);
+#ifdef NSOS_LPX_RIDE   // timing experiment only: what does an activation-like word behind every MFMA cost in THIS stream?
+                if constexpr (NT == 8 && a >= NB && g < NWORK) {
+                    constexpr int t2 = ((a - NB) % NT + 4) & 7;
+                    unsigned r_, t_;
+                    asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0"
+                                 : "=&v"(r_), "=&v"(t_) : "a"(acc[c][t2][(g * 2) & 15]), "a"(acc[c][t2][(g * 2 + 1) & 15]));
+                    asm volatile("" :: "v"(r_));
+                }
+#endif
             });
         }, mid, tail);
     };
