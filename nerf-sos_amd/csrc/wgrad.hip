@@ -14,6 +14,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef NSOS_WG_U
+#define NSOS_WG_U 4   // k-steps per operand group of the 16-tile variant (prefetch distance)
+#endif
+
 namespace {
 constexpr int kWgradMaxBlocks = 256;
 
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
     // hoists a `cur = nxt` copy -- and the wait for the loads behind it -- up into the MFMA stream), and the hot loop
     // only touches groups whose points are all in range, so its loads are unconditional (a `valid ? load : 0` becomes a
     // branch with a vmcnt wait right behind every load and serialises the whole pipeline on the memory latency).
-    constexpr int U = RT * NT >= 16 ? 4 : (RT * NT >= 8 ? 6 : 8);
+    constexpr int U = RT * NT >= 16 ? NSOS_WG_U : (RT * NT >= 8 ? 6 : 8);
     struct In { float a[RT]; float b[NT]; };
     const long long step = 2 * KW;
     const int kw_s = __builtin_amdgcn_readfirstlane(kw), rw_s = __builtin_amdgcn_readfirstlane(rw);
