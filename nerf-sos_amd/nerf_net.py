@@ -128,8 +128,10 @@ class _FrozenBackboneRender(torch.autograd.Function):
     forward : the normal kernel sequence, with the SAVE variant of the fused MLP kernel that also stores the
               head's inputs; every output except `semantics` / `semantics0` is non-differentiable (they do not
               depend on the semantic parameters: weights/rgb/depth come from the frozen backbone).
-    backward: nsos_sem_head_backward (element-wise) + four plain GEMMs (rocBLAS through torch.matmul) per net:
+    backward: ONE kernel per pass, nsos_sem_head_wgrad: g_logits = w G and g_hid = (hid > 0) (g_logits W2) are formed in
+              registers and reduced over the points on the exact-fp32 MFMA:
               dW2 = g_logits^T hid, db2 = g_logits^T 1, [dW1 | db1] = g_hid^T [h7, x63, 1]."""
+
 
     @staticmethod
     def forward(ctx, net, args, kwargs, *sem_params):
