@@ -97,12 +97,14 @@ _MLP_FIELDS = (("alpha", "alpha_linear"), ("feature", "feature_linear"), ("views
                ("rgb", "rgb_linear"))
 
 
-DTYPES = {"fp32": 0, "fp16": 1, "bf16": 2}
+DTYPES = {"fp32": 0, "fp16": 1, "bf16": 2, "fp16x3": 3}   # fp16x3: split-fp16 operands, fp32-grade results (K2-X3)
 
 
 def packed_bytes(sem_mode: int, precision: str = "fp32") -> int:
     if precision == "fp32":
         return int(_lib.lib().nsos_mlp_packed_bytes(sem_mode))
+    if precision == "fp16x3":
+        return int(_lib.lib().nsos_mlp_packed_bytes_x3(sem_mode))
     return int(_lib.lib().nsos_mlp_packed_bytes_lp(sem_mode))
 
 
@@ -143,6 +145,8 @@ def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch
         out = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
     if precision == "fp32":
         _lib.check(_lib.lib().nsos_mlp_pack(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
+    elif precision == "fp16x3":
+        _lib.check(_lib.lib().nsos_mlp_pack_x3(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack_x3")
     else:
         _lib.check(_lib.lib().nsos_mlp_pack_lp(C.byref(T), sem_mode, DTYPES[precision], _p(out), nbytes, _stream()),
                    "nsos_mlp_pack_lp")
@@ -171,8 +175,9 @@ def mlp_forward_rays(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, 
 
 def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, rays_o: torch.Tensor,
                         rays_d: torch.Tensor, viewdirs: torch.Tensor, z_vals: torch.Tensor) -> torch.Tensor:
-    """Reduced-precision K2 (fp16 / bf16 MFMA inputs, fp32 accumulation): raw [R,S,C] fp32.  `packed` must come
-    from pack_mlp(..., precision=precision)."""
+    """K2 on the 16-bit matrix pipe: raw [R,S,C] fp32.  precision "fp16" / "bf16": reduced-precision MFMA inputs with
+    fp32 accumulation; "fp16x3": split-fp16 operands, three MFMAs per product, fp32-grade results.  `packed` must
+    come from pack_mlp(..., precision=precision)."""
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
     viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
     R, S = z_vals.shape
@@ -182,9 +187,13 @@ def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, ray
     if KERNEL_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _lib.check(_lib.lib().nsos_mlp_forward_rays_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o), _p(rays_d),
-                                                   _p(viewdirs), _p(z_vals), R, S, _p(raw), _stream()),
-               "nsos_mlp_forward_rays_lp")
+    if precision == "fp16x3":
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
+                                                       _p(z_vals), R, S, _p(raw), _stream()), "nsos_mlp_forward_rays_x3")
+    else:
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o), _p(rays_d),
+                                                       _p(viewdirs), _p(z_vals), R, S, _p(raw), _stream()),
+                   "nsos_mlp_forward_rays_lp")
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append((R * S, ev[0], ev[1]))
@@ -198,6 +207,8 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     `packed` must have been packed for the same `precision`."""
     if sem_mode == SEM_NONE:
         raise ValueError("mlp_forward_rays_save needs a semantic head")
+    if precision == "fp16x3":
+        raise NotImplementedError("the split-fp16 kernel is inference-only; train with precision 'fp32', 'bf16' or 'fp16'")
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
     viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
     R, S = z_vals.shape

@@ -23,7 +23,7 @@ for sem in (False, True):
     net.load_state_dict(tp.make_peaky({k: v.cpu() for k, v in net.state_dict().items()}, gain=40.0, shift=1.0))
     rays = tp.synthetic_rays(4096, seed=0).to(dev)
     ref = None
-    for prec in ("fp32", "fp16", "bf16"):
+    for prec in ("fp32", "fp16x3", "fp16", "bf16"):
         net.mlp_precision = prec
         with torch.no_grad():
             for _ in range(3):
@@ -60,7 +60,8 @@ for sem in (False, True):
             mse = (o["rgb"] - ref["rgb"]).square().mean().item()
             rec["psnr_rgb_vs_fp32_db"] = round(-10 * np.log10(max(mse, 1e-30)), 1)
             rec["max_abs_rgb"] = float((o["rgb"] - ref["rgb"]).abs().max())
-            rec["frac_of_lp_peak_2500TF"] = round(tf / 2500, 3)
+            issued = tf * 3 if prec == "fp16x3" else tf     # the split kernel issues three MFMAs per useful product
+            rec["frac_of_lp_peak_2500TF"] = round(issued / 2500, 3)
         out[f"{'semcoord' if sem else 'nosem'}_{prec}"] = rec
         print(f"{'semcoord' if sem else 'nosem':9s} {prec}: {json.dumps(rec)}", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
