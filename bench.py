@@ -26,6 +26,7 @@ MAC_PER_POINT = 593408            # matmul MACs of one M
 EVALS_PER_RAY = N_COARSE + (N_COARSE + N_IMPORTANCE)   # 64 coarse + 192 fine
 FLOP_PER_RAY = 2 * MAC_PER_POINT * EVALS_PER_RAY       # 303.82 MFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16, dense (the split-fp16 variant issues 3 of them per product)
 
 
 def cpu_baseline(n_rays_sample: int, budget_s: float = 25.0):
@@ -66,6 +67,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=("fp32", "fp16x3"), default="fp32",
+                    help="fp32: exact-fp32 MFMA kernel (the headline).  fp16x3: split-fp16 kernel, fp32-grade results "
+                         "(DESIGN.md 4.6b); without this flag it is measured as a side note under \"variants\"")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,6 +92,7 @@ def main():
     torch.manual_seed(0)
     net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=False,
                                perturb=1.0, raw_noise_std=1.0).to(dev).eval()
+    net.mlp_precision = args.precision
     rays = tp.synthetic_rays(N_RAYS, seed=rank).to(dev)     # resident in HBM before the timed region
 
     def barrier():
@@ -107,6 +112,35 @@ def main():
         dt = time.perf_counter() - t0
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     assert out["rgb"].shape == (N_RAYS, 3)
+
+    variants = None
+    if world == 1 and args.precision == "fp32":
+        # side note, outside the timed region: the same step on the split-fp16 kernel (fp32-grade results, see
+        # tests/test_gpu_parity.py::test_mlp_x3_is_fp32_grade) and how far its coarse pass is from the exact path's
+        net.mlp_precision = "fp16x3"
+        with torch.no_grad():
+            for _ in range(2):
+                alt = net(rays, (tp.NEAR, tp.FAR))
+            ref_c = alt["rgb0"]                            # eval mode: no perturbation, no noise
+            torch.cuda.synchronize()
+            ops.KERNEL_EVENTS = []
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                alt = net(rays, (tp.NEAR, tp.FAR))
+            torch.cuda.synchronize()
+            dt_alt = time.perf_counter() - t1
+            ev_alt, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+            net.mlp_precision = "fp32"
+            exact_c = out["rgb0"]
+        f_alt = [a.elapsed_time(b) for (n_pts, a, b) in ev_alt if n_pts == N_RAYS * (N_COARSE + N_IMPORTANCE)]
+        f_alt_ms = sum(f_alt) / max(1, len(f_alt))
+        variants = {"fp16x3": {
+            "what": "same step, MLP on the 16-bit matrix pipe with split-fp16 operands (3 MFMAs per product, fp32 accumulate)",
+            "value": round(N_RAYS * args.steps / dt_alt, 1), "unit": "rays/s", "ms_per_step": round(1e3 * dt_alt / args.steps, 4),
+            "kernel_ms": round(f_alt_ms, 4),
+            "algorithmic_tflops": round(2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE) / (f_alt_ms * 1e-3) / 1e12, 1),
+            "issued_frac_of_f16_peak": round(3 * 2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE) / (f_alt_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+            "max_abs_rgb0_vs_exact_fp32": float((ref_c - exact_c).abs().max())}}
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -143,6 +177,16 @@ def main():
                          "kernel_ms": round(fine_ms, 4), "launches_timed": len(fine),
                          "whole_path_frac": round(value / world * FLOP_PER_RAY / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
         }
+        if args.precision == "fp16x3":
+            issued = 3 * achieved
+            line["dtype"] = "f16x3 (split-fp16 operands, fp32 accumulate, fp32-grade results)"
+            line["config"]["workload"] = line["config"]["workload"].replace("fp32 exact-MFMA", "split-fp16 MFMA (fp32-grade)")
+            line["roofline"].update({"peak": PEAK_F16_MFMA_TFLOPS, "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
+                                     "issued_frac": round(issued / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+                                     "kernel": "mlp_x3_kernel<0> (fine pass, 786432 points)",
+                                     "whole_path_frac": round(value / world * FLOP_PER_RAY / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)})
+        if variants:
+            line["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(1024)
         print(json.dumps(line), flush=True)
