@@ -191,7 +191,7 @@ int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int3
  * Every weight and activation is carried as hi = fp16(v), lo = fp16(v - hi) and every product as the three MFMAs
  * hi.hi + hi.lo + lo.hi with fp32 accumulation: max relative error against an fp64 evaluation ~3e-7 .. 3e-6 (plain
  * fp32 arithmetic: ~2e-7 .. 2e-6), i.e. well inside the 1e-4 parity tolerance, at ~3x the exact-fp32 kernel's speed.
- * Limits: |activation| must stay below 65504 (fp16 range).  Opt-in; inference only (no SAVE variant).
+ * Limits: |activation| must stay below 65504 (fp16 range).  Opt-in; inference and frozen-backbone training.
  * Weights are packed by nsos_mlp_pack_x3 into their own stream layout (nsos_mlp_packed_bytes_x3 bytes). */
 size_t nsos_mlp_packed_bytes_x3(int32_t sem_mode);
 int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
@@ -199,6 +199,12 @@ int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* tensors, int32_t sem_mode, void
 int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                  const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                  float* raw, void* stream);
+/* Training with a frozen backbone (--fix_backbone, run_nerf.py:307-318) on the split-fp16 kernel: as
+ * nsos_mlp_forward_rays_save, with sem_in holding the fp32 values hi + lo the semantic head consumed and sem_hid its
+ * fp32 hidden activations; the backward kernels are the fp32 path's.  sem_mode must be 1 or 2. */
+int32_t nsos_mlp_forward_rays_save_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                      const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                      float* raw, float* sem_in, float* sem_hid, void* stream);
 
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).

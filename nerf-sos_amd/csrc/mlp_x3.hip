@@ -100,6 +100,15 @@ __device__ __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
     return acc;
 }
 
+// fp32 value hi + lo of one half (SEL = 0: low, 1: high 16 bits) of a split pair of packed words
+template <int SEL>
+__device__ __forceinline__ float join(unsigned hw, unsigned lw) {
+    float r;
+    if constexpr (SEL == 0) asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hw), "v"(lw));
+    else asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hw), "v"(lw));
+    return r;
+}
+
 struct X3Params {
     const unsigned* aux;
     const unsigned char* chunks;
@@ -111,6 +120,8 @@ struct X3Params {
     long long n_pts;
     int n_samples;
     int n_tiles;
+    float* sem_in;   // SAVE: [P,320] = [relu(h7) | x63 | 1.0], the fp32 values hi + lo the semantic head consumed
+    float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
 };
 
 // encoded feature idx lives in half-wave (idx >> 3) & 1: a K-slice of 16 consecutive features, lane half kg
@@ -173,7 +184,8 @@ __device__ __forceinline__ void heads_partial_f32(const f32x16 (&hm)[4], const f
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-template <int SEM>
+// SAVE: training-mode variant that also stores what the semantic head's backward needs (K5, frozen backbone)
+template <int SEM, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,6 +342,40 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                     f32x16 sm[4], sx[4];
                     static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), sm, sx, h_h, h_l); });
                     if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sm, sx, ex_h, ex_l);
+                    if constexpr (SAVE) {
+                        if (gp < P.n_pts) {
+                            float* row = P.sem_in + gp * 320;
+                            float* hrow = P.sem_hid + gp * 128;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)   // word = accumulator elements 8u+2q, +1 of tile t
+                                        *reinterpret_cast<f32x2*>(row + 32 * t + 2 * (q & 1) + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                                            f32x2{join<0>(Hh[2 * t + u][q], Hl[2 * t + u][q]), join<1>(Hh[2 * t + u][q], Hl[2 * t + u][q])};
+#pragma unroll
+                            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)       // slice word = features 16s + 8kg + 2q, +1; 63 is the 1.0 pad
+                                    *reinterpret_cast<f32x2*>(row + 256 + 16 * sl + 8 * kg + 2 * q) =
+                                        f32x2{join<0>(exh[sl][q], exl[sl][q]), join<1>(exh[sl][q], exl[sl][q])};
+                            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
+                            auto relu_acc = [](const float& m, const float& x) {   // AGPR reads inside asm: see split2_acc
+                                float r, y;
+                                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_add_f32 %0, %0, %1\n\tv_max_f32 %0, 0, %0"
+                                             : "=&v"(r), "=&v"(y) : "a"(m), "a"(x));
+                                return r;
+                            };
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
+                                        f32x4{relu_acc(sm[t][4 * q], sx[t][4 * q]), relu_acc(sm[t][4 * q + 1], sx[t][4 * q + 1]),
+                                              relu_acc(sm[t][4 * q + 2], sx[t][4 * q + 2]), relu_acc(sm[t][4 * q + 3], sx[t][4 * q + 3])};
+                        }
+                    }
                     float ps[2];
 #pragma unroll
                     for (int o = 0; o < 2; ++o) ps[o] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars + 4 + o]);
@@ -470,18 +516,18 @@ int x3_num_cus() {
 
 constexpr int kLdsBytes = kSlots * kSlotBytes + kAuxWords * 4;
 
-template <int SEM>
+template <int SEM, bool SAVE = false>
 int32_t launch_x3(const X3Params& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_kernel<SEM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_kernel<SEM, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
     static const int cus = x3_num_cus();
     const int grid = p.n_tiles < cus ? p.n_tiles : cus;
-    hipLaunchKernelGGL((mlp_x3_kernel<SEM>), dim3(grid), dim3(256), kLdsBytes, stream, p);
+    hipLaunchKernelGGL((mlp_x3_kernel<SEM, SAVE>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();
 }
 
@@ -545,15 +591,21 @@ extern "C" int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_mode
     return nsos_launch_status();
 }
 
-extern "C" int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
-                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
-                                            float* raw, void* stream) {
+namespace {
+int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d, const float* viewdirs,
+                   const float* z_vals, int64_t n_rays, int32_t n_samples, float* raw, float* sem_in, float* sem_hid,
+                   bool save, void* stream) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_rays < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(sem_mode >= 0 && sem_mode <= 2, NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
+    if (save) {
+        NSOS_REQUIRE(sem_mode != 0, NSOS_ERR_UNSUPPORTED);
+        NSOS_REQUIRE(sem_in && sem_hid, NSOS_ERR_NULL_POINTER);
+        NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
+    }
     const long long n_pts = (long long)n_rays * n_samples;
     NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     X3Params p = {};
@@ -562,10 +614,25 @@ extern "C" int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
+    p.sem_in = sem_in; p.sem_hid = sem_hid;
     const hipStream_t st = (hipStream_t)stream;
+    if (save) return sem_mode == 1 ? launch_x3<1, true>(p, st) : launch_x3<2, true>(p, st);
     switch (sem_mode) {
         case 0: return launch_x3<0>(p, st);
         case 1: return launch_x3<1>(p, st);
         default: return launch_x3<2>(p, st);
     }
+}
+}  // namespace
+
+extern "C" int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                            float* raw, void* stream) {
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, false, stream);
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_save_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                                 const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                 float* raw, float* sem_in, float* sem_hid, void* stream) {
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, sem_in, sem_hid, true, stream);
 }

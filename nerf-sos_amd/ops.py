@@ -207,8 +207,6 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     `packed` must have been packed for the same `precision`."""
     if sem_mode == SEM_NONE:
         raise ValueError("mlp_forward_rays_save needs a semantic head")
-    if precision == "fp16x3":
-        raise NotImplementedError("the split-fp16 kernel is inference-only; train with precision 'fp32', 'bf16' or 'fp16'")
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
     viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
     R, S = z_vals.shape
@@ -220,6 +218,10 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
                                                          _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
                    "nsos_mlp_forward_rays_save")
+    elif precision == "fp16x3":
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_save_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
+                                                            _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
+                   "nsos_mlp_forward_rays_save_x3")
     else:
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o),
                                                             _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
