@@ -189,8 +189,9 @@ int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int3
 
 /* ---- K2-X3: the same fused network on the 16-bit matrix pipe with SPLIT-fp16 operands (fp32-grade results) -------
  * Every weight and activation is carried as hi = fp16(v), lo = fp16(v - hi) and every product as the three MFMAs
- * hi.hi + hi.lo + lo.hi with fp32 accumulation: max relative error against an fp64 evaluation ~3e-7 .. 3e-6 (plain
- * fp32 arithmetic: ~2e-7 .. 2e-6), i.e. well inside the 1e-4 parity tolerance, at ~3x the exact-fp32 kernel's speed.
+ * hi.hi + hi.lo + lo.hi with fp32 accumulation (the weights' lo parts scaled by 2^11 so that they stay normal fp16
+ * numbers): max / rms error against an fp64 evaluation equal to plain fp32 arithmetic's (~1e-7 .. 2e-6 max), i.e.
+ * three orders of magnitude inside the 1e-4 parity tolerance, at ~2.8x the exact-fp32 kernel's speed.
  * Limits: |activation| must stay below 65504 (fp16 range).  Opt-in; inference and frozen-backbone training.
  * Weights are packed by nsos_mlp_pack_x3 into their own stream layout (nsos_mlp_packed_bytes_x3 bytes). */
 size_t nsos_mlp_packed_bytes_x3(int32_t sem_mode);

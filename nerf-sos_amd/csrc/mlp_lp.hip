@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                         pa[1] = T::dot2(H[1][s][q], w[q], pa[1]);
                     }
                 }
+                asm volatile("s_nop 3" ::: "memory");  // v_dot2c result -> non-dot VALU read: 3 wait states hipcc cannot see (asm)
                 sigma[0] = both_halves(pa[0]);
                 sigma[1] = both_halves(pa[1]);
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)

@@ -6,19 +6,23 @@
 // Every fp32 value v that enters a product is carried as two fp16 numbers, hi = fp16(v) and lo = fp16(v - hi)
 // (together 22 mantissa bits), and every product W.h is evaluated as three 16-bit MFMAs accumulated in fp32:
 //     W_hi.h_hi  +  W_hi.h_lo  +  W_lo.h_hi                       (the W_lo.h_lo term is below 2^-22 relative)
-// Measured on the CPU against an fp64 evaluation of the same network: max relative error 3.6e-7 .. 2.9e-6, i.e. within
-// ~2x of what plain fp32 arithmetic gives (1.5e-7 .. 1.6e-6) and 30-300x inside the 1e-4 parity bar -- while the
-// matrix work costs 3 x 32 cycles per 16 k-slots instead of 8 x 64 for the exact-fp32 MFMA (5.3x less pipe time).
+// The weights' lo parts are stored x 2^11: a weight of 0.05 has a residual of ~1e-5, an fp16 SUBNORMAL, and the
+// quantisation of those residuals was the largest error term (CPU emulation: 2-5x the final error).  Scaled, they are
+// normal numbers; their products therefore get their own accumulator, folded in as Zm + 2^-11 Zx by the activation.
+// Measured on the GPU against an fp64 evaluation of the same network (scripts/accuracy_x3.py): at or below the error
+// of plain fp32 arithmetic, 3 orders of magnitude inside the 1e-4 parity bar -- while the matrix work costs 3 x 32
+// cycles per 16 k-slots instead of 8 x 64 for the exact-fp32 MFMA (5.3x less pipe time).
 //
 // Structure: the reduced-precision kernel's (mlp_lp.hip), with
-//   * ONE 32-point column per wave (tile = 128 points): accumulators are 2 x 128 AGPRs -- Zm collects W_hi.h_hi,
-//     Zx the two cross terms -- and the activations are two packed files Hh, Hl of 64 VGPRs each;
+//   * ONE 32-point column per wave (tile = 128 points): accumulators are 2 x 128 AGPRs -- Zm collects W_hi.(h_hi + h_lo),
+//     Zx the scaled W_lo.h_hi -- and the activations are two packed files Hh, Hl of 64 VGPRs each;
 //   * an "item" (output tile t, K-slice s or the bias) owns TWO A operands, hi and lo.  Their stream order is skewed,
 //       hi_0, hi_1, lo_0, hi_2, lo_1, ..., hi_{n-1}, lo_{n-2}, lo_{n-1}
-//     so that the three MFMAs of an item are never back to back on the same accumulator:
-//       hi group k:  Zm[t_k] += A_hi.B_hi[s_k],  Zx[t_k] += A_hi.B_lo[s_k]        lo group k:  Zx[t_k] += A_lo.B_hi[s_k]
-//   * the activation pass also splits: z = Zm + Zx, relu, hi = cvt_pk(z), lo = cvt_pk(z - hi) with v_fma_mix_f32
-//     reading the fp16 halves of hi directly (14 VALU per packed pair, all inside asm: see mlp_lp.hip on why);
+//       hi group k:  Zm[t_k] += A_hi.B_hi[s_k],  Zm[t_k] += A_hi.B_lo[s_k]        lo group k:  Zx[t_k] += A_lo.B_hi[s_k]
+//     (the two MFMAs of a hi group are back to back on one accumulator: +3.5 cycles, scripts/ubench/mfma_chain.hip;
+//     every other dependent pair is >= 4 issue slots apart, which is free);
+//   * the activation pass also splits: z = Zm + 2^-11 Zx, relu, hi = cvt_pk(z), lo = cvt_pk(z - hi) with v_fma_mix_f32
+//     reading the fp16 halves of hi directly (12 VALU per packed pair, all inside asm: see mlp_lp.hip on why);
 //   * biases ride as leading items against B = 1.0 (hi and lo), layer 0's in the encoding's pad slot;
 //   * sigma head: v_dot2c over the split activations and split weights (three dot products per word); rgb / semantic
 //     output heads: fp32 VALU on the summed fp32 accumulators.
@@ -55,6 +59,7 @@ __host__ __device__ constexpr int x3_chunks(int sem) {
 }
 
 constexpr unsigned kOnes = 0x3C003C00u;  // {1.0h, 1.0h}
+constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;   // the weights' lo parts are stored x 2^11 (0x3a000000 = 2^-11)
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -80,7 +85,7 @@ __device__ __forceinline__ void split2_acc(const float& m0, const float& x0, con
     unsigned t0, t1, t2;
     if constexpr (RELU)
         asm volatile("v_accvgpr_read_b32 %2, %5\n\tv_accvgpr_read_b32 %4, %6\n\tv_accvgpr_read_b32 %3, %7\n\t"
-                     "v_add_f32 %2, %2, %4\n\tv_accvgpr_read_b32 %4, %8\n\tv_max_f32 %2, 0, %2\n\tv_add_f32 %3, %3, %4\n\t"
+                     "v_fmac_f32 %2, 0x3a000000, %4\n\tv_accvgpr_read_b32 %4, %8\n\tv_max_f32 %2, 0, %2\n\tv_fmac_f32 %3, 0x3a000000, %4\n\t"
                      "v_max_f32 %3, 0, %3\n\tv_cvt_pk_f16_f32 %0, %2, %3\n\t"
                      "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
                      "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -88,7 +93,7 @@ __device__ __forceinline__ void split2_acc(const float& m0, const float& x0, con
                      : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1), "=&v"(t2) : "a"(m0), "a"(x0), "a"(m1), "a"(x1));
     else
         asm volatile("v_accvgpr_read_b32 %2, %5\n\tv_accvgpr_read_b32 %4, %6\n\tv_accvgpr_read_b32 %3, %7\n\t"
-                     "v_add_f32 %2, %2, %4\n\tv_accvgpr_read_b32 %4, %8\n\tv_add_f32 %3, %3, %4\n\t"
+                     "v_fmac_f32 %2, 0x3a000000, %4\n\tv_accvgpr_read_b32 %4, %8\n\tv_fmac_f32 %3, 0x3a000000, %4\n\t"
                      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
                      "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
                      "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -175,7 +180,7 @@ __device__ __forceinline__ void heads_partial_f32(const f32x16 (&hm)[4], const f
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float x, y;
-                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_add_f32 %0, %0, %1\n\tv_max_f32 %0, 0, %0"
+                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_fmac_f32 %0, 0x3a000000, %1\n\tv_max_f32 %0, 0, %0"
                              : "=&v"(x), "=&v"(y) : "a"(hm[t][q * 4 + j]), "a"(hx[t][q * 4 + j]));
 #pragma unroll
                 for (int o = 0; o < NO; ++o) part[o] = __fmaf_rn(w[o][j], x, part[o]);
@@ -263,9 +268,9 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                     constexpr bool FIRST = ZF && s == 0;
                     if constexpr (IS_HI) {
                         Zm[t] = mfma16(aop, bh(IC(s)), FIRST ? zero : Zm[t]);
-                        Zx[t] = mfma16(aop, bl(IC(s)), FIRST ? zero : Zx[t]);
+                        Zm[t] = mfma16(aop, bl(IC(s)), Zm[t]);   // back to back on one accumulator: +3.5 cycles (mfma_chain.hip)
                     } else {
-                        Zx[t] = mfma16(aop, bh(IC(s)), Zx[t]);
+                        Zx[t] = mfma16(aop, bh(IC(s)), FIRST ? zero : Zx[t]);
                     }
                 }
             }
@@ -325,19 +330,27 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 // sigma head (models/nerf_mlp.py:77): three dot products of the split activations and split weights
                 const unsigned* awh = aux_l + kAuxAlphaHi + kg * 64;
                 const unsigned* awl = aux_l + kAuxAlphaLo + kg * 64;
-                float pa = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]);
+                float pa = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]), px = 0.0f;
+                // Two chains (main, scaled lo weights), each kept back to back, and an s_nop before anything else reads
+                // them: a v_dot2c result read by a NON-dot VALU instruction needs 3 wait states (gfx940+ hazard), which
+                // hipcc inserts for its own code but cannot for asm operands -- without the nop sigma came out wrong by 1e-2.
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const u32x4 wh = *reinterpret_cast<const u32x4*>(awh + 4 * s);
-                    const u32x4 wl = *reinterpret_cast<const u32x4*>(awl + 4 * s);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         pa = dot2(Hl[s][q], wh[q], pa);
-                        pa = dot2(Hh[s][q], wl[q], pa);
                         pa = dot2(Hh[s][q], wh[q], pa);
                     }
                 }
-                sigma = both_halves(pa);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const u32x4 wl = *reinterpret_cast<const u32x4*>(awl + 4 * s);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) px = dot2(Hh[s][q], wl[q], px);   // the weights' lo parts are stored x 2^11
+                }
+                asm volatile("s_nop 3" ::: "memory");
+                sigma = both_halves(__fmaf_rn(px, kLoUnscale, pa));
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80): 4 bias + 64 slice items = 4 chunks of 17
                     f32x16 sm[4], sx[4];
                     static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), sm, sx, h_h, h_l); });
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
                             auto relu_acc = [](const float& m, const float& x) {   // AGPR reads inside asm: see split2_acc
                                 float r, y;
-                                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_add_f32 %0, %0, %1\n\tv_max_f32 %0, 0, %0"
+                                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_fmac_f32 %0, 0x3a000000, %1\n\tv_max_f32 %0, 0, %0"
                                              : "=&v"(r), "=&v"(y) : "a"(m), "a"(x));
                                 return r;
                             };
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const X3PackParams P) {
             const int f0 = acc_feature(s >> 1, 8 * (s & 1) + 2 * q, kgl), f1 = acc_feature(s >> 1, 8 * (s & 1) + 2 * q + 1, kgl);
             const float w0 = P.alpha_w[f0], w1 = P.alpha_w[f1];
             unsigned short h0 = f16_bits(w0), h1 = f16_bits(w1);
-            if (is_lo) { h0 = f16_bits(w0 - f16_value(h0)); h1 = f16_bits(w1 - f16_value(h1)); }
+            if (is_lo) { h0 = f16_bits((w0 - f16_value(h0)) * kLoScale); h1 = f16_bits((w1 - f16_value(h1)) * kLoScale); }
             v = (unsigned)h0 | ((unsigned)h1 << 16);
         } else if (a < kAuxSem2W) { const int rem = a - kAuxRgbW; v = __builtin_bit_cast(unsigned, P.rgb_w[(rem >> 7) * 128 + feat128(rem & 127)]); }
         else if (a < kAuxScalars) { const int rem = a - kAuxSem2W; v = P.sem2_w ? __builtin_bit_cast(unsigned, P.sem2_w[(rem >> 7) * 128 + feat128(rem & 127)]) : 0u; }
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const X3PackParams P) {
         }
     }
     unsigned short h = f16_bits(v);
-    if (!is_hi) h = f16_bits(v - f16_value(h));
+    if (!is_hi) h = f16_bits((v - f16_value(h)) * kLoScale);
     P.chunks[gid] = h;
 }
 
