@@ -206,6 +206,11 @@ int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode, const flo
 int32_t nsos_mlp_forward_rays_save_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                       const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                       float* raw, float* sem_in, float* sem_hid, void* stream);
+/* Full training (every parameter trainable) on the split-fp16 kernel: as nsos_mlp_forward_rays_save_all, acts holding
+ * the fp32 values hi + lo each layer handed to the next; the backward (K7) is the fp32 path's. */
+int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                          const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                          float* raw, float* acts, void* stream);
 
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).

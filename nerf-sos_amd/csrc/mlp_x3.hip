@@ -127,6 +127,7 @@ struct X3Params {
     int n_tiles;
     float* sem_in;   // SAVE: [P,320] = [relu(h7) | x63 | 1.0], the fp32 values hi + lo the semantic head consumed
     float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
+    float* acts;     // SAVE == 2 (full backward): [P, NSOS_ACTS_DIM] every layer's activations, see nerf_sos_hip.h
 };
 
 // encoded feature idx lives in half-wave (idx >> 3) & 1: a K-slice of 16 consecutive features, lane half kg
@@ -189,8 +190,10 @@ __device__ __forceinline__ void heads_partial_f32(const f32x16 (&hm)[4], const f
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-// SAVE: training-mode variant that also stores what the semantic head's backward needs (K5, frozen backbone)
-template <int SEM, bool SAVE = false>
+// SAVE 1: training-mode variant that also stores what the semantic head's backward needs (K5, frozen backbone);
+// SAVE 2: stores every layer's activations for the full backward (K7).  Stored values are the fp32 numbers hi + lo
+// that the next layer consumed.
+template <int SEM, int SAVE = 0>
 __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -312,11 +315,52 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         auto ex_l = [&](auto sc) { return exl[decltype(sc)::value]; };
         auto h_h = [&](auto sc) { return Hh[decltype(sc)::value]; };
         auto h_l = [&](auto sc) { return Hl[decltype(sc)::value]; };
+        auto store_H = [&](float* row) __attribute__((always_inline)) {   // 256 activations: word q of slice 2t+u = accumulator elements 8u+2q, +1 of tile t
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x2*>(row + 32 * t + 2 * (q & 1) + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                            f32x2{join<0>(Hh[2 * t + u][q], Hl[2 * t + u][q]), join<1>(Hh[2 * t + u][q], Hl[2 * t + u][q])};
+        };
+        auto store_slices = [&](float* row, auto ns_c, const u32x4* sh, const u32x4* sl_) __attribute__((always_inline)) {   // encoded slices: features 16s + 8kg + 2q, +1
+#pragma unroll
+            for (int sl = 0; sl < decltype(ns_c)::value; ++sl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x2*>(row + 16 * sl + 8 * kg + 2 * q) = f32x2{join<0>(sh[sl][q], sl_[sl][q]), join<1>(sh[sl][q], sl_[sl][q])};
+        };
+        auto store_hidden128 = [&](float* hrow, const f32x16 (&am)[4], const f32x16 (&ax)[4]) __attribute__((always_inline)) {   // relu(Zm + 2^-11 Zx) of a 128-wide layer
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
+            auto relu_acc = [](const float& m, const float& x) {   // AGPR reads inside asm: see split2_acc
+                float r, y;
+                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_fmac_f32 %0, 0x3a000000, %1\n\tv_max_f32 %0, 0, %0"
+                             : "=&v"(r), "=&v"(y) : "a"(m), "a"(x));
+                return r;
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
+                        f32x4{relu_acc(am[t][4 * q], ax[t][4 * q]), relu_acc(am[t][4 * q + 1], ax[t][4 * q + 1]),
+                              relu_acc(am[t][4 * q + 2], ax[t][4 * q + 2]), relu_acc(am[t][4 * q + 3], ax[t][4 * q + 3])};
+        };
+        const bool valid = gp < P.n_pts;
+        float* const arow = SAVE == 2 ? P.acts + gc * NSOS_ACTS_DIM : nullptr;
+        if constexpr (SAVE == 2) {
+            if (valid) store_slices(arow + NSOS_ACTS_X, IC(4), exh, exl);   // slot 63 is the 1.0 pad
+        }
 
         // pts_linears.0: 4 encoded slices x 8 tiles = 32 items in 2 chunks; slice 0 starts from C = 0
         run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(1), Zm, Zx, ex_h, ex_l);
         run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(1), Zm, Zx, ex_h, ex_l);
         activate<8, true>(Hh, Hl, Zm, Zx);
+        if constexpr (SAVE == 2) {
+            if (valid) store_H(arow);
+        }
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8): 8 bias + 128 slice items = 8 chunks of 17
 #pragma unroll 1
         for (int l = 1; l <= 8; ++l) {
@@ -326,6 +370,9 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(0), Zm, Zx, ex_h, ex_l);
             }
             if (l < 8) activate<8, true>(Hh, Hl, Zm, Zx); else activate<8, false>(Hh, Hl, Zm, Zx);
+            if constexpr (SAVE == 2) {
+                if (valid) store_H(arow + 256 * l);   // l == 8: the (linear) feature vector at NSOS_ACTS_FEAT
+            }
             if (l == 7) {
                 // sigma head (models/nerf_mlp.py:77): three dot products of the split activations and split weights
                 const unsigned* awh = aux_l + kAuxAlphaHi + kg * 64;
@@ -355,39 +402,16 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                     f32x16 sm[4], sx[4];
                     static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), sm, sx, h_h, h_l); });
                     if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sm, sx, ex_h, ex_l);
-                    if constexpr (SAVE) {
-                        if (gp < P.n_pts) {
+                    if constexpr (SAVE == 1) {
+                        if (valid) {
                             float* row = P.sem_in + gp * 320;
-                            float* hrow = P.sem_hid + gp * 128;
-#pragma unroll
-                            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q)   // word = accumulator elements 8u+2q, +1 of tile t
-                                        *reinterpret_cast<f32x2*>(row + 32 * t + 2 * (q & 1) + 8 * (2 * u + (q >> 1)) + 4 * kg) =
-                                            f32x2{join<0>(Hh[2 * t + u][q], Hl[2 * t + u][q]), join<1>(Hh[2 * t + u][q], Hl[2 * t + u][q])};
-#pragma unroll
-                            for (int sl = 0; sl < 4; ++sl)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)       // slice word = features 16s + 8kg + 2q, +1; 63 is the 1.0 pad
-                                    *reinterpret_cast<f32x2*>(row + 256 + 16 * sl + 8 * kg + 2 * q) =
-                                        f32x2{join<0>(exh[sl][q], exl[sl][q]), join<1>(exh[sl][q], exl[sl][q])};
-                            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
-                            auto relu_acc = [](const float& m, const float& x) {   // AGPR reads inside asm: see split2_acc
-                                float r, y;
-                                asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_fmac_f32 %0, 0x3a000000, %1\n\tv_max_f32 %0, 0, %0"
-                                             : "=&v"(r), "=&v"(y) : "a"(m), "a"(x));
-                                return r;
-                            };
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
-                                        f32x4{relu_acc(sm[t][4 * q], sx[t][4 * q]), relu_acc(sm[t][4 * q + 1], sx[t][4 * q + 1]),
-                                              relu_acc(sm[t][4 * q + 2], sx[t][4 * q + 2]), relu_acc(sm[t][4 * q + 3], sx[t][4 * q + 3])};
+                            store_H(row);
+                            store_slices(row + 256, IC(4), exh, exl);
+                            store_hidden128(P.sem_hid + gp * 128, sm, sx);
                         }
+                    }
+                    if constexpr (SAVE == 2) {
+                        if (valid) store_hidden128(arow + NSOS_ACTS_SEM, sm, sx);
                     }
                     float ps[2];
 #pragma unroll
@@ -414,6 +438,12 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         }
         run_chunk(IC(8), IC(4), IC(0), IC(0), IC(8), IC(0), vm, vx, [&](auto sc) { return edh[decltype(sc)::value & 1]; },
                   [&](auto sc) { return edl[decltype(sc)::value & 1]; });   // 2 slices x 4 tiles = 8 items (16 groups)
+        if constexpr (SAVE == 2) {
+            if (valid) {
+                store_slices(arow + NSOS_ACTS_D, IC(2), edh, edl);   // 27 features, zero pad
+                store_hidden128(arow + NSOS_ACTS_VIEWS, vm, vx);
+            }
+        }
         float rgb[3];
 #pragma unroll
         for (int o = 0; o < 3; ++o) rgb[o] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars + 1 + o]);
@@ -529,7 +559,7 @@ int x3_num_cus() {
 
 constexpr int kLdsBytes = kSlots * kSlotBytes + kAuxWords * 4;
 
-template <int SEM, bool SAVE = false>
+template <int SEM, int SAVE = 0>
 int32_t launch_x3(const X3Params& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
@@ -607,17 +637,21 @@ extern "C" int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_mode
 namespace {
 int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d, const float* viewdirs,
                    const float* z_vals, int64_t n_rays, int32_t n_samples, float* raw, float* sem_in, float* sem_hid,
-                   bool save, void* stream) {
+                   float* acts, int save, void* stream) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_rays < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(sem_mode >= 0 && sem_mode <= 2, NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)raw & 15) == 0, NSOS_ERR_MISALIGNED);
-    if (save) {
+    if (save == 1) {
         NSOS_REQUIRE(sem_mode != 0, NSOS_ERR_UNSUPPORTED);
         NSOS_REQUIRE(sem_in && sem_hid, NSOS_ERR_NULL_POINTER);
         NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
+    }
+    if (save == 2) {
+        NSOS_REQUIRE(acts, NSOS_ERR_NULL_POINTER);
+        NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
     }
     const long long n_pts = (long long)n_rays * n_samples;
     NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
@@ -627,9 +661,10 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
-    p.sem_in = sem_in; p.sem_hid = sem_hid;
+    p.sem_in = sem_in; p.sem_hid = sem_hid; p.acts = acts;
     const hipStream_t st = (hipStream_t)stream;
-    if (save) return sem_mode == 1 ? launch_x3<1, true>(p, st) : launch_x3<2, true>(p, st);
+    if (save == 1) return sem_mode == 1 ? launch_x3<1, 1>(p, st) : launch_x3<2, 1>(p, st);
+    if (save == 2) return sem_mode == 0 ? launch_x3<0, 2>(p, st) : (sem_mode == 1 ? launch_x3<1, 2>(p, st) : launch_x3<2, 2>(p, st));
     switch (sem_mode) {
         case 0: return launch_x3<0>(p, st);
         case 1: return launch_x3<1>(p, st);
@@ -641,11 +676,17 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
 extern "C" int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                             const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                             float* raw, void* stream) {
-    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, false, stream);
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int32_t nsos_mlp_forward_rays_save_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                                  const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                                  float* raw, float* sem_in, float* sem_hid, void* stream) {
-    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, sem_in, sem_hid, true, stream);
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, sem_in, sem_hid, nullptr, 1, stream);
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                                     const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                     float* raw, float* acts, void* stream) {
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, acts, 2, stream);
 }

@@ -269,9 +269,9 @@ class NeRFNet(nn.Module):
         other = [n for n in trainable if "semantic_linear" not in n]
         if other:
             # any backbone parameter trainable (e.g. configs/flower_full.txt trains everything): full backward
-            if self.mlp_precision != "fp32":
-                raise NotImplementedError("NeRFNet: the full backward runs on the exact-fp32 path only; set "
-                                          "mlp_precision = 'fp32' or freeze the backbone (run_nerf.py:307-318)")
+            if self.mlp_precision not in ("fp32", "fp16x3"):
+                raise NotImplementedError("NeRFNet: the full backward needs fp32-accurate activations; set "
+                                          "mlp_precision = 'fp32' or 'fp16x3', or freeze the backbone (run_nerf.py:307-318)")
             params = [p_ for _, m in self._sem_nets() for _, p_ in m.mlp.named_parameters()]
             outs = _FullRender.apply(self, args, kwargs, *params)
             return dict(zip(self._last_keys, outs))
@@ -292,8 +292,9 @@ class NeRFNet(nn.Module):
                     return ops.mlp_forward_rays_lp(net.packed_weights(self.mlp_precision), net.sem_mode,
                                                    self.mlp_precision, rays_o, rays_d, viewdirs, z)
                 return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
-            if save == "all":   # full backward (K7): every layer's activations, exact-fp32 kernel only
-                raw, acts = ops.mlp_forward_rays_save_all(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
+            if save == "all":   # full backward (K7): every layer's activations (exact-fp32 or split-fp16 kernel)
+                raw, acts = ops.mlp_forward_rays_save_all(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o, rays_d,
+                                                          viewdirs, z, self.mlp_precision)
                 saved[tag] = dict(acts=acts, raw=raw, z=z)
                 return raw
             raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,

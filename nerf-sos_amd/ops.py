@@ -399,16 +399,20 @@ ACTS_FEAT, ACTS_VIEWS, ACTS_SEM, ACTS_X, ACTS_D, ACTS_DIM = 2048, 2304, 2432, 25
 
 
 def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
-                              viewdirs: torch.Tensor, z_vals: torch.Tensor):
-    """Training-mode K2 with every layer's activations stored: (raw [R,S,C], acts [R*S, ACTS_DIM])."""
+                              viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32"):
+    """Training-mode K2 with every layer's activations stored: (raw [R,S,C], acts [R*S, ACTS_DIM]).
+    precision "fp32" (exact kernel) or "fp16x3" (split-fp16 kernel, fp32-accurate); `packed` must match."""
+    if precision not in ("fp32", "fp16x3"):
+        raise NotImplementedError("the full backward needs fp32-accurate activations: precision 'fp32' or 'fp16x3'")
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
     viewdirs, z_vals = _dev(viewdirs, "viewdirs"), _dev(z_vals, "z_vals")
     R, S = z_vals.shape
     dev = z_vals.device
     raw = torch.empty((R, S, 4 if sem_mode == SEM_NONE else 6), device=dev, dtype=torch.float32)
     acts = torch.empty((R * S, ACTS_DIM), device=dev, dtype=torch.float32)
-    _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
-                                                         R, S, _p(raw), _p(acts), _stream()), "nsos_mlp_forward_rays_save_all")
+    fn = "nsos_mlp_forward_rays_save_all" + ("_x3" if precision == "fp16x3" else "")
+    _lib.check(getattr(_lib.lib(), fn)(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
+                                       R, S, _p(raw), _p(acts), _stream()), fn)
     return raw, acts
 
 

@@ -112,9 +112,12 @@ def test_full_backward_vs_reference(name, peaky, white, n_imp):
     assert not bad, f"gradients off by more than the tolerance (of their scale): {bad}"
 
 
-def test_full_backward_192_samples_train_mode_vs_port_autograd():
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_full_backward_192_samples_train_mode_vs_port_autograd(precision):
     """Same kernels as a fine pass (192 samples per ray: 3 per lane in the compositing kernels), train mode with
-    injected jitter and sigma noise, white background -- against autograd through the CPU port, 1e-4 of scale."""
+    injected jitter and sigma noise, white background -- against autograd through the CPU port, 1e-4 of scale.
+    The forward (and the activations it saves for the backward) runs on the exact-fp32 or on the split-fp16 kernel:
+    the same bar for both."""
     from helpers import CFGS, ref_state
     cfg = tp.PortConfig(n_samples=192, n_importance=0, white_bkgd=True, **CFGS["semcoord"])
     sd = tp.make_peaky(tp.init_state_dict(cfg, seed=0), gain=8.0, shift=0.5)
@@ -129,6 +132,7 @@ def test_full_backward_192_samples_train_mode_vs_port_autograd():
     net = nerf_sos_amd.NeRFNet(N_samples=192, N_importance=0, white_bkgd=True, perturb=1.0, raw_noise_std=0.7, **CFGS["semcoord"]).to(DEV)
     net.load_state_dict(sd)
     net.train()
+    net.mlp_precision = precision
     q = [t_rand.to(DEV), noise.to(DEV)]
     _rand, _randn = torch.rand, torch.randn
     torch.rand = lambda *a, **k: q.pop(0)
