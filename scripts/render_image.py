@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--semantics", action="store_true")
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3", "fp16", "bf16"])
     ap.add_argument("--post", action="store_true", help="also run the on-device eval post-processing (labels, PSNR)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))

@@ -33,7 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--patches-per-gpu", type=int, default=2)
     ap.add_argument("--patch", type=int, default=64)
-    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16", "fp16"])
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "fp16x3", "bf16", "fp16"])
     ap.add_argument("--steps", type=int, default=10)
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
