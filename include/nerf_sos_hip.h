@@ -212,6 +212,22 @@ int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, 
                                           const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                           float* raw, float* acts, void* stream);
 
+/* ---- K7-X3: the input-gradient chain of the full backward as one fused split-fp16 kernel --------------------------
+ * Replaces the library GEMMs g_in = g_out @ W and the ReLU-mask passes of the full backward (autograd of
+ * models/nerf_mlp.py:67-100): from g_raw [P,C] (C = 4 or 6: d loss / d [r,g,b,sigma,(sem0,sem1)]) and the activations
+ * acts [P,NSOS_ACTS_DIM] saved by nsos_mlp_forward_rays_save_all[_x3] it writes gbuf [P,NSOS_GBUF_DIM], the gradients
+ * with respect to every layer's pre-activation in the column map of acts (256 l: pts_linears.l, NSOS_ACTS_FEAT:
+ * feature_linear output, NSOS_ACTS_VIEWS: views_linears.0, NSOS_ACTS_SEM: semantic_linear.0), each the GEMM input of
+ * nsos_wgrad.  `scale` (device scalar, a power of two bringing max |g_raw| to ~2^8) is applied to g_raw on load: all of
+ * gbuf is scaled by it and the weight gradients must be divided by it.  Weights are packed (transposed, split fp16) by
+ * nsos_mlp_bwd_pack_x3 into nsos_mlp_bwd_packed_bytes_x3 bytes. */
+#define NSOS_GBUF_DIM 2560
+size_t nsos_mlp_bwd_packed_bytes_x3(int32_t sem_mode);
+int32_t nsos_mlp_bwd_pack_x3(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
+                             void* stream);
+int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode, const float* g_raw, const float* acts,
+                                int64_t n_pts, const float* scale, float* gbuf, void* stream);
+
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).
  * Not on the product path; used to attribute the kernel's non-MFMA cycles (profiles/). */

@@ -191,7 +191,7 @@ class _FullRender(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        from .backward import mlp_backward
+        from .backward import mlp_backward, mlp_backward_x3
         net, saved = ctx.net, ctx.saved
         if saved is None:
             raise RuntimeError("nerf_sos_amd: backward through the same render twice (the saved activations were released)")
@@ -211,7 +211,11 @@ class _FullRender(torch.autograd.Function):
                                            g_acc=get("acc"), g_disp=get("disp"), g_weights=get("weights"))
             if get("raw") is not None:
                 g_raw = g_raw + get("raw").reshape(g_raw.shape)
-            by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]))
+            if net.mlp_precision == "fp16x3":   # fused split-fp16 input-gradient chain (K7-X3) instead of GEMMs + mask passes
+                by_name = mlp_backward_x3(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
+                                          mlp.packed_weights("fp16x3_bwd"))
+            else:
+                by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]))
             grads += [by_name.get(n) for n in names]
         ctx.saved = None   # release 10 KB/point of activations now (the node lives as long as the caller keeps the loss)
         return (None, None, None) + tuple(grads)

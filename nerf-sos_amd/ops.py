@@ -97,7 +97,8 @@ _MLP_FIELDS = (("alpha", "alpha_linear"), ("feature", "feature_linear"), ("views
                ("rgb", "rgb_linear"))
 
 
-DTYPES = {"fp32": 0, "fp16": 1, "bf16": 2, "fp16x3": 3}   # fp16x3: split-fp16 operands, fp32-grade results (K2-X3)
+DTYPES = {"fp32": 0, "fp16": 1, "bf16": 2, "fp16x3": 3,   # fp16x3: split-fp16 operands, fp32-accurate results (K2-X3)
+          "fp16x3_bwd": 4}                                  # the transposed stream of the fused input-gradient kernel (K7-X3)
 
 
 def packed_bytes(sem_mode: int, precision: str = "fp32") -> int:
@@ -105,6 +106,8 @@ def packed_bytes(sem_mode: int, precision: str = "fp32") -> int:
         return int(_lib.lib().nsos_mlp_packed_bytes(sem_mode))
     if precision == "fp16x3":
         return int(_lib.lib().nsos_mlp_packed_bytes_x3(sem_mode))
+    if precision == "fp16x3_bwd":
+        return int(_lib.lib().nsos_mlp_bwd_packed_bytes_x3(sem_mode))
     return int(_lib.lib().nsos_mlp_packed_bytes_lp(sem_mode))
 
 
@@ -147,6 +150,8 @@ def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch
         _lib.check(_lib.lib().nsos_mlp_pack(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
     elif precision == "fp16x3":
         _lib.check(_lib.lib().nsos_mlp_pack_x3(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack_x3")
+    elif precision == "fp16x3_bwd":
+        _lib.check(_lib.lib().nsos_mlp_bwd_pack_x3(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_bwd_pack_x3")
     else:
         _lib.check(_lib.lib().nsos_mlp_pack_lp(C.byref(T), sem_mode, DTYPES[precision], _p(out), nbytes, _stream()),
                    "nsos_mlp_pack_lp")
@@ -414,6 +419,25 @@ def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch
     _lib.check(getattr(_lib.lib(), fn)(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
                                        R, S, _p(raw), _p(acts), _stream()), fn)
     return raw, acts
+
+
+GBUF_DIM = 2560
+
+
+def mlp_input_grads_x3(packed_bwd: torch.Tensor, sem_mode: int, g_raw: torch.Tensor, acts: torch.Tensor,
+                       scale: torch.Tensor) -> torch.Tensor:
+    """Fused split-fp16 input-gradient chain of the full backward (K7-X3): gbuf [P, GBUF_DIM] = scale * (d loss / d every
+    layer's pre-activation), columns as in `acts` (256 l | ACTS_FEAT | ACTS_VIEWS | ACTS_SEM).  `packed_bwd` comes from
+    pack_mlp(..., precision="fp16x3_bwd"); `scale` is a 1-element device tensor holding a power of two."""
+    g_raw, acts = _dev(g_raw, "g_raw"), _dev(acts, "acts")
+    P_, C_ = g_raw.shape
+    if C_ != (4 if sem_mode == SEM_NONE else 6) or acts.shape != (P_, ACTS_DIM) or not acts.is_contiguous():
+        raise ValueError(f"mlp_input_grads_x3: g_raw {tuple(g_raw.shape)} / acts {tuple(acts.shape)} do not fit sem_mode {sem_mode}")
+    scale = _dev(scale.reshape(1), "scale")
+    gbuf = torch.empty((P_, GBUF_DIM), device=acts.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_input_grads_x3(_p(packed_bwd), sem_mode, _p(g_raw), _p(acts), P_, _p(scale), _p(gbuf),
+                                                  _stream()), "nsos_mlp_input_grads_x3")
+    return gbuf
 
 
 _WG_WS: Dict[torch.device, torch.Tensor] = {}
