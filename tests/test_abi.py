@@ -122,3 +122,22 @@ def test_next_row_entry_points_validate_without_a_gpu():
     assert lib.nsos_app_correlation_loss(p, p, p, p, p, 2, 16, 5, 5, 2, 8, 8, 11, 0.18, 1, 0.46, 1, C.byref(one), None, p, 32, None) == -4
     with pytest.raises(RuntimeError, match="GPU tensor"):
         nerf_sos_amd.CorrelationLoss(None)(torch.zeros(2, 4, 3, 3), torch.zeros(2, 2, 8, 8), torch.zeros(2, 2))
+
+
+def test_split_fp16_entry_points_validate_without_a_gpu():
+    """K2-X3 / K7-X3: sizes, empty batches and argument validation are host-side (no launch)."""
+    lib = _lib.lib()
+    slot = 36 * 1024
+    assert lib.nsos_mlp_packed_bytes_x3(0) == 4096 + 73 * slot and lib.nsos_mlp_packed_bytes_x3(2) == 4096 + 78 * slot
+    assert lib.nsos_mlp_packed_bytes_x3(3) == 0
+    assert lib.nsos_mlp_bwd_packed_bytes_x3(0) == 4096 + 68 * slot and lib.nsos_mlp_bwd_packed_bytes_x3(1) == 4096 + 72 * slot
+    buf = (C.c_double * 8)()
+    p = C.cast(buf, C.c_void_p)
+    assert lib.nsos_mlp_forward_rays_x3(p, 0, p, p, p, p, 0, 64, p, None) == 0                 # empty batch
+    assert lib.nsos_mlp_forward_rays_x3(p, 0, p, p, None, p, 4, 64, p, None) == -1             # NULL
+    assert lib.nsos_mlp_forward_rays_x3(p, 3, p, p, p, p, 4, 64, p, None) == -3                # unknown semantic mode
+    assert lib.nsos_mlp_forward_rays_save_x3(p, 0, p, p, p, p, 4, 64, p, p, p, None) == -3     # needs a semantic head
+    assert lib.nsos_mlp_forward_rays_save_all_x3(p, 0, p, p, p, p, 4, 64, p, None, None) == -1
+    assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, 0, p, p, None) == 0
+    assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, 5, None, p, None) == -1
+    assert lib.nsos_mlp_bwd_pack_x3(None, 0, p, 1 << 30, None) == -1

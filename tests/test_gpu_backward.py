@@ -170,3 +170,55 @@ def test_full_backward_is_chunk_invariant():
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert (a - b).abs().max() <= 1e-5 * (a.abs().max() + 1e-12), n
+
+
+@pytest.mark.parametrize("name,n_pts_rays", [("semcoord", (37, 64)), ("nosem", (5, 192)), ("sem", (1, 3))])
+def test_fused_input_gradient_chain_vs_gemms(name, n_pts_rays):
+    """nsos_mlp_input_grads_x3 (one split-fp16 kernel) against the chain of fp32 GEMMs and masks it replaces, block by
+    block, on saved activations of the exact forward: 2e-6 of each block's scale (the GEMM reference itself rounds at
+    ~1e-6); ragged tiles; the power-of-two scale only moves exponents."""
+    from helpers import CFGS
+    from nerf_sos_amd.ops import ACTS_FEAT, ACTS_SEM, ACTS_VIEWS
+    cfg = tp.PortConfig(**CFGS[name])
+    sd = tp.make_peaky(tp.init_state_dict(cfg, seed=0))
+    mode = ops.sem_mode_of(**CFGS[name])
+    R, S = n_pts_rays
+    rays = tp.synthetic_rays(R, seed=3)
+    z = tp.stratified_z(torch.full((R, 1), tp.NEAR), torch.full((R, 1), tp.FAR), max(S, 2), torch.rand(R, max(S, 2)))[:, :S]
+    vd = rays[1] / rays[1].norm(dim=-1, keepdim=True)
+    prm = {k[len("nerf_fine") + 5:]: t.to(DEV) for k, t in sd.items() if k.startswith("nerf_fine.mlp.")}
+    args = [t.to(DEV).contiguous() for t in (rays[0], rays[1], vd, z)]
+    raw, acts = ops.mlp_forward_rays_save_all(ops.pack_mlp(prm, mode), mode, *args)
+    P, C = R * S, raw.shape[-1]
+    g_raw = torch.randn(P, C, device=DEV, generator=torch.Generator(DEV).manual_seed(1)) * 3e-4
+    col = lambda a, n: acts[:, a:a + n]  # noqa: E731
+    ref = {}
+    g_v = (g_raw[:, 0:3] @ prm["rgb_linear.weight"]) * (col(ACTS_VIEWS, 128) > 0)
+    ref[(ACTS_VIEWS, 128)] = g_v
+    g_feat = g_v @ prm["views_linears.0.weight"][:, :256]
+    ref[(ACTS_FEAT, 256)] = g_feat
+    g_h = g_feat @ prm["feature_linear.weight"] + g_raw[:, 3:4] @ prm["alpha_linear.weight"]
+    if mode:
+        g_hs = (g_raw[:, 4:6] @ prm["semantic_linear.2.weight"]) * (col(ACTS_SEM, 128) > 0)
+        ref[(ACTS_SEM, 128)] = g_hs
+        g_h = g_h + g_hs @ prm["semantic_linear.0.weight"][:, :256]
+    for l in range(7, -1, -1):
+        g_h = g_h * (col(256 * l, 256) > 0)
+        ref[(256 * l, 256)] = g_h
+        if l > 0:
+            w = prm[f"pts_linears.{l}.weight"]
+            g_h = g_h @ (w[:, 63:] if l == 5 else w)
+    packed = ops.pack_mlp(prm, mode, precision="fp16x3_bwd")
+    guard = torch.full((64,), 777.0, device=DEV)
+    outs = []
+    for k in (8, 5):   # max |g_raw| -> ~2^8 (what backward.py picks) and ~2^5
+        scale = torch.exp2(torch.floor(torch.log2(2.0 ** k / g_raw.abs().max()))).reshape(1)
+        gbuf = ops.mlp_input_grads_x3(packed, mode, g_raw, acts, scale)
+        assert torch.equal(gbuf[:, :ACTS_SEM], ops.mlp_input_grads_x3(packed, mode, g_raw, acts, scale)[:, :ACTS_SEM]), "not deterministic"
+        outs.append(gbuf / scale)
+    for (a, n), want in ref.items():
+        sc = float(want.abs().max()) + 1e-30
+        for got in outs:
+            assert float((got[:, a:a + n] - want).abs().max()) <= 2e-6 * sc, (a, float((got[:, a:a + n] - want).abs().max()) / sc)
+        assert float((outs[0][:, a:a + n] - outs[1][:, a:a + n]).abs().max()) <= 1e-6 * sc
+    assert (guard == 777.0).all()
