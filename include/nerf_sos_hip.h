@@ -212,6 +212,12 @@ int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, 
                                           const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                           float* raw, float* acts, void* stream);
 
+/* nsos_wgrad for M = N = 256 on the 16-bit matrix pipe: both operands split on the fly into fp16 hi + lo, three MFMAs per
+ * product, fp32 accumulation (K7-X3).  |G| and |X| must be within fp16 range (G from nsos_mlp_input_grads_x3 is, by its
+ * scale); same workspace, same deterministic reduction as nsos_wgrad. */
+int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw,
+                      float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K7-X3: the input-gradient chain of the full backward as one fused split-fp16 kernel --------------------------
  * Replaces the library GEMMs g_in = g_out @ W and the ReLU-mask passes of the full backward (autograd of
  * models/nerf_mlp.py:67-100): from g_raw [P,C] (C = 4 or 6: d loss / d [r,g,b,sigma,(sem0,sem1)]) and the activations

@@ -33,6 +33,7 @@ SIGNATURES = {
     "nsos_mlp_forward_rays_save_all": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_wgrad_workspace_bytes": (_sz, []),
     "nsos_wgrad": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _sz, _fp]),
+    "nsos_wgrad_x3": (_i32, [_fp, _i32, _fp, _i32, _i64, _fp, _i32, _fp, _fp, _sz, _fp]),
     "nsos_relu_mask": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _fp]),
     "nsos_sem_head_backward": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_sem_head_wgrad_workspace_bytes": (_sz, []),

@@ -128,7 +128,7 @@ def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor,
     ops.wgrad(G(ACTS_VIEWS, 128), col(ACTS_D, 32), dWv[:, W:])
     out["views_linears.0.weight"], out["views_linears.0.bias"] = dWv[:, :W + 27] * inv, db * inv
     dWf, dbf = torch.empty((W, W), **f32), torch.empty((W,), **f32)
-    ops.wgrad(G(ACTS_FEAT, W), h(7), dWf, dbf)
+    ops.wgrad(G(ACTS_FEAT, W), h(7), dWf, dbf, split_fp16=True)
     out["feature_linear.weight"], out["feature_linear.bias"] = dWf * inv, dbf * inv
     if sem_mode != SEM_NONE:
         dWs, dbs = torch.empty((128, W + 64), **f32), torch.empty((128,), **f32)
@@ -150,12 +150,12 @@ def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor,
             dW5 = torch.empty((W, 63 + W), **f32)
             ops.wgrad(g, col(ACTS_X, 64), tmp_x, dbl)
             dWh = torch.empty((W, W), **f32)
-            ops.wgrad(g, h(4), dWh)
+            ops.wgrad(g, h(4), dWh, split_fp16=True)
             dW5[:, :63], dW5[:, 63:] = tmp_x[:, :63], dWh
             out[wname] = dW5 * inv
         else:
             dWl = torch.empty((W, W), **f32)
-            ops.wgrad(g, h(l - 1), dWl, dbl)
+            ops.wgrad(g, h(l - 1), dWl, dbl, split_fp16=True)
             out[wname] = dWl * inv
         out[bname] = dbl * inv
     return out

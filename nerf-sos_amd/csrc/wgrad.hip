@@ -176,6 +176,182 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, i
     *reinterpret_cast<f32x4*>(g + p * ldg + c) = gv;
 }
 
+// ---- split-fp16 variant for the 256 x 256 layers (K7-X3) -------------------------------------------------------------
+// Same reduction on the 16-bit matrix pipe: both operands are split on the fly into hi = fp16(v), lo = fp16(v - hi) and
+// every 16-point k-step runs hi.hi + lo.hi + hi.lo (v_mfma_f32_32x32x16_f16, fp32 accumulate): 3 x 32 cycles per 16 points
+// per 32x32 tile instead of 8 x 64.  With K = points an MFMA operand is 8 CONSECUTIVE POINTS of one column per lane, i.e. a
+// strided gather; so the workgroup gathers each k-step ONCE (1024 operand slots = 16 column tiles x 64 lanes, 4 per
+// thread: 8 coalesced dword loads, 4 split2, two ds_write_b128), stages it in LDS in MFMA operand order (double buffered,
+// one barrier per k-step) and all 4 waves read their A (2 row tiles) and B (8 column tiles) operands from there.
+// Operand loads run two k-steps ahead in registers.  G is expected in fp16 range (the fused input-gradient kernel's
+// power-of-two scale takes care of that); db is accumulated from the fp32 values.  Output: the same partial layout as
+// wgrad_kernel (KW = 1), reduced by wgrad_reduce_kernel.
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void wg_split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+    float t0 = v0, t1 = v1;
+    asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                 "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_cvt_pk_f16_f32 %1, %2, %3"
+                 : "=&v"(hi), "=&v"(lo), "+v"(t0), "+v"(t1));
+}
+__device__ __forceinline__ f32x16 wg_mfma16(wg_u32x4 a, wg_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, a), __builtin_bit_cast(wg_f16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                          long long n_pts, float* __restrict__ partial) {
+    constexpr int M = 256, N = 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 16 * 2 * 1024];   // [buffer][tile 0..15][hi, lo][64 lanes x 16 B]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kg = lane >> 5;
+    // this workgroup's k-steps (16 points each): a contiguous range; the last step of the whole problem may be ragged
+    const long long n_steps = (n_pts + 15) / 16;
+    const long long per = (n_steps + gridDim.x - 1) / gridDim.x;
+    const long long s0 = (long long)blockIdx.x * per, s1 = s0 + per < n_steps ? s0 + per : n_steps;
+    const long long n_full_all = n_pts / 16;
+    const long long f1 = s1 < n_full_all ? s1 : n_full_all;            // full steps are [s0, f1)
+    const bool ragged = s1 > f1 && s1 > s0;                              // ... and possibly one ragged step, index f1
+    f32x16 acc[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.0f;
+    float bsum[2] = {0.0f, 0.0f};
+
+    // slot j of this thread: column tile T = 4j + wave of [G | X] (T < 8: G), lane position (i, kg): points 8kg .. 8kg+7 of the step.
+    // Addressing as in wgrad_kernel: wave-uniform row pointers (scalar unit) + one constant 32-bit lane offset per slot.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const float* src[4];
+    int ld[4];
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int T = 4 * j + wave_s;
+        src[j] = (T < 8 ? G : X) + 32 * (T & 7);
+        ld[j] = T < 8 ? ldg : ldx;
+        voff[j] = (unsigned)(8 * kg * ld[j] + i) * 4u;   // bytes
+    }
+    auto fetch = [&](long long step, float (&raw)[4][8]) {               // every point of the step is in range
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long rb = (unsigned long long)(src[j] + step * 16 * ld[j]);   // wave-uniform; tell hipcc so
+            typedef const __attribute__((address_space(1))) float* gptr;
+            const gptr row = (gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rb >> 32)) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)rb));   // (the builtin returns int)
+            unsigned vo = voff[j];
+            asm volatile("" : "+v"(vo));   // ... and keep LICM from hoisting zext(lane offset) out of the loop, which loses the saddr form
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {   // scalar base + zero-extended 32-bit lane offset: global_load_dword v, v_off, s[base]
+                unsigned long long re = (unsigned long long)(row + (long long)e * ld[j]);
+                asm("" : "+s"(re));         // keep the row pointer a scalar of its own (hipcc otherwise folds e * ld into the lane offset)
+                raw[j][e] = *reinterpret_cast<gptr>(reinterpret_cast<const __attribute__((address_space(1))) char*>(re) + vo);
+            }
+        }
+    };
+    auto fetch_masked = [&](long long step, float (&raw)[4][8]) {
+        const long long p0 = step * 16 + 8 * kg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long long p = p0 + e;
+                const float v = src[j][(p < n_pts ? p : n_pts - 1) * ld[j] + i];
+                raw[j][e] = p < n_pts ? v : 0.0f;
+            }
+    };
+    // split one slot and put it into LDS in operand order; w = 1 if the step is a real one (0: a re-fetched step past the end)
+    auto stage_slot = [&](int j, const float (&raw)[4][8], int buf, float w) {
+        wg_u32x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b;
+            wg_split2(raw[j][2 * q], raw[j][2 * q + 1], a, b);
+            h[q] = a; l[q] = b;
+        }
+        if (j < 2) bsum[j] += w * (((raw[j][0] + raw[j][1]) + (raw[j][2] + raw[j][3])) + ((raw[j][4] + raw[j][5]) + (raw[j][6] + raw[j][7])));
+        unsigned char* dst = lds + ((buf * 16 + 4 * j + wave_s) * 2) * 1024 + lane * 16;
+        *reinterpret_cast<wg_u32x4*>(dst) = h;
+        *reinterpret_cast<wg_u32x4*>(dst + 1024) = l;
+    };
+    auto operand = [&](int buf, int T, int part) {
+        return *reinterpret_cast<const wg_u32x4*>(lds + ((buf * 16 + T) * 2 + part) * 1024 + lane * 16);
+    };
+    // the 48 MFMAs of one k-step in 4 quarters (column-tile pairs); `between(q)` runs after quarter q
+    auto compute = [&](int buf, auto&& between) {
+        wg_u32x4 ah[2], al[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { ah[r] = operand(buf, wave_s + 4 * r, 0); al[r] = operand(buf, wave_s + 4 * r, 1); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wg_u32x4 bh[2], bl[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { bh[c] = operand(buf, 8 + 2 * q + c, 0); bl[c] = operand(buf, 8 + 2 * q + c, 1); }
+            // product-major: the same accumulator comes back every 4th MFMA (free from distance 4, mfma_chain.hip)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = wg_mfma16(ah[r], bh[c], acc[r][2 * q + c]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = wg_mfma16(al[r], bh[c], acc[r][2 * q + c]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = wg_mfma16(ah[r], bl[c], acc[r][2 * q + c]);
+            between(q);
+        }
+    };
+
+    const long long nf = f1 > s0 ? f1 - s0 : 0;                           // full steps of this workgroup
+    if (nf > 0) {
+        float R0[4][8], R1[4][8];
+        const long long s0u = __builtin_amdgcn_readfirstlane((int)s0);   // < 2^31 steps
+        auto clampf = [&](long long j) { return s0u + (j < nf ? j : nf - 1); };   // past the end: re-fetch the last full step
+        fetch(clampf(0), R0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_slot(j, R0, 0, 1.0f);
+        fetch(clampf(1), R1);
+        fetch(clampf(2), R0);
+        __syncthreads();
+        // pairs of steps (2p, 2p+1), no branch inside: at the top buffer 0 holds step 2p, R1 step 2p+1, R0 step 2p+2
+        for (long long pp = 0; pp < nf / 2; ++pp) {
+            compute(0, [&](int q) { stage_slot(q, R1, 1, 1.0f); });
+            fetch(clampf(2 * pp + 3), R1);
+            __syncthreads();
+            const float w0 = 2 * pp + 2 < nf ? 1.0f : 0.0f;       // past the end this stages a re-fetched step that is never computed
+            compute(1, [&](int q) { stage_slot(q, R0, 0, w0); });
+            fetch(clampf(2 * pp + 4), R0);
+            __syncthreads();
+        }
+        if (nf & 1) compute(0, [&](int) {});                      // the odd last full step is already staged in buffer 0
+    }
+    if (ragged) {
+        float R[4][8];
+        fetch_masked(f1, R);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_slot(j, R, 1, 1.0f);    // buffer 1 is free: its last readers passed a barrier
+        __syncthreads();
+        compute(1, [&](int) {});
+    }
+    float* out = partial + (size_t)blockIdx.x * ((size_t)M * N + M);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int mt = wave + 4 * r;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)   // accumulator element e of lane (i, kg): row (e&3) + 8(e>>2) + 4kg, column i
+                out[(size_t)(32 * mt + (e & 3) + 8 * (e >> 2) + 4 * kg) * N + 32 * t + i] = acc[r][t][e];
+        const float sb = bsum[r] + __shfl_xor(bsum[r], 32, NSOS_WAVE);   // slot j = r is column tile 4r + wave = mt of G
+        if (kg == 0) out[(size_t)M * N + 32 * mt + i] = sb;
+    }
+}
+
 template <int RT, int NT>
 void launch_wgrad(int blocks, hipStream_t st, const float* G, int ldg, const float* X, int ldx, long long n_pts, int M, int N, float* ws) {
     hipLaunchKernelGGL((wgrad_kernel<RT, NT>), dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, n_pts, M, N, ws);
@@ -218,5 +394,24 @@ extern "C" int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t
     NSOS_REQUIRE((tot + 255) / 256 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, h, ldh,
                        (long long)n_pts, n_cols);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw,
+                                 float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    constexpr int M = 256, N = 256;
+    NSOS_REQUIRE(dW && workspace, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts >= 0, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_pts == 0 || (G && X), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(ldg >= M && ldx >= N && ldw >= N, NSOS_ERR_BAD_SHAPE);
+    int blocks = kWgradMaxBlocks;
+    const long long steps = (n_pts + 15) / 16;
+    if (steps < blocks) blocks = (int)(steps > 0 ? steps : 1);
+    NSOS_REQUIRE(workspace_bytes >= (size_t)blocks * ((size_t)M * N + M) * sizeof(float), NSOS_ERR_BUFFER_TOO_SMALL);
+    const hipStream_t st = (hipStream_t)stream;
+    float* ws = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, (long long)n_pts, ws);
+    const int tot = M * N + M;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, ws, blocks, M, N, dW, ldw, db);
     return nsos_launch_status();
 }

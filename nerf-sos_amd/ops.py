@@ -450,9 +450,11 @@ def _rows(t: torch.Tensor, name: str):
     return t, t.stride(0)
 
 
-def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor] = None) -> None:
+def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor] = None, split_fp16: bool = False) -> None:
     """dW [M,N] = G^T X, db [M] = column sums of G (nsos_wgrad); G [P,M], X [P,N] may be column slices of wider
-    buffers, dW a column slice of a weight-gradient matrix.  M, N in {32,64,128,256}."""
+    buffers, dW a column slice of a weight-gradient matrix.  M, N in {32,64,128,256}.
+    split_fp16: for M = N = 256 run on the 16-bit matrix pipe with split operands (nsos_wgrad_x3); the caller guarantees
+    |G|, |X| < 65504 (the fused input-gradient kernel's output is scaled into that range)."""
     G, ldg = _rows(G, "G")
     X, ldx = _rows(X, "X")
     dW, ldw = _rows(dW, "dW")
@@ -464,6 +466,10 @@ def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch
     if dev not in _WG_WS:
         _WG_WS[dev] = torch.empty(_lib.lib().nsos_wgrad_workspace_bytes() // 4, device=dev, dtype=torch.float32)
     ws = _WG_WS[dev]
+    if split_fp16 and M == 256 and N == 256:
+        _lib.check(_lib.lib().nsos_wgrad_x3(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, dW.data_ptr(), ldw, _p(db), _p(ws),
+                                            ws.numel() * 4, _stream()), "nsos_wgrad_x3")
+        return
     _lib.check(_lib.lib().nsos_wgrad(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, M, N, dW.data_ptr(), ldw, _p(db), _p(ws),
                                      ws.numel() * 4, _stream()), "nsos_wgrad")
 

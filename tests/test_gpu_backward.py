@@ -222,3 +222,25 @@ def test_fused_input_gradient_chain_vs_gemms(name, n_pts_rays):
             assert float((got[:, a:a + n] - want).abs().max()) <= 2e-6 * sc, (a, float((got[:, a:a + n] - want).abs().max()) / sc)
         assert float((outs[0][:, a:a + n] - outs[1][:, a:a + n]).abs().max()) <= 1e-6 * sc
     assert (guard == 777.0).all()
+
+
+@pytest.mark.parametrize("P", [5, 16, 37, 4096 + 16, 256 * 16 * 5 + 3, 200003])
+def test_wgrad_split_fp16_vs_fp64(P):
+    """nsos_wgrad_x3 (operands split into fp16 hi + lo on the fly, three MFMAs per product) against an fp64 reduction, next
+    to the exact-fp32 kernel: same accuracy class; ragged point counts, strided operands, deterministic."""
+    g = torch.Generator(DEV).manual_seed(P)
+    Gw = torch.randn(P, 300, device=DEV, generator=g) * torch.rand(P, 1, device=DEV, generator=g) * 40.0
+    Xw = torch.relu(torch.randn(P, 2656, device=DEV, generator=g))
+    G, X = Gw[:, 7:263], Xw[:, 256:512]                       # column slices of wider buffers, as in the backward
+    want = (G.double().T @ X.double())
+    want_b = G.double().sum(0)
+    outs = {}
+    for split in (False, True):
+        dW, db = torch.empty(256, 256, device=DEV), torch.empty(256, device=DEV)
+        ops.wgrad(G, X, dW, db, split_fp16=split)
+        dW2, db2 = torch.empty(256, 256, device=DEV), torch.empty(256, device=DEV)
+        ops.wgrad(G, X, dW2, db2, split_fp16=split)
+        assert torch.equal(dW, dW2) and torch.equal(db, db2), "not deterministic"
+        outs[split] = (float((dW.double() - want).abs().max() / want.abs().max()), float((db.double() - want_b).abs().max() / want_b.abs().max()))
+    assert outs[True][0] <= max(2e-6, 4 * outs[False][0]), outs
+    assert outs[True][1] <= max(2e-6, 4 * outs[False][1]), outs
