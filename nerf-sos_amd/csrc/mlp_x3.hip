@@ -253,9 +253,11 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<f32x2*>(row + 32 * t + 2 * (q & 1) + 8 * (2 * u + (q >> 1)) + 4 * kg) =
-                            f32x2{join<0>(Hh[2 * t + u][q], Hl[2 * t + u][q]), join<1>(Hh[2 * t + u][q], Hl[2 * t + u][q])};
+                    for (int q = 0; q < 4; q += 2) {   // words q, q+1 = accumulator elements 8u+2q .. +3 = 4 consecutive features
+                        const u32x4 hh = Hh[2 * t + u], hl = Hl[2 * t + u];
+                        *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                            f32x4{join<0>(hh[q], hl[q]), join<1>(hh[q], hl[q]), join<0>(hh[q + 1], hl[q + 1]), join<1>(hh[q + 1], hl[q + 1])};
+                    }
         };
         auto store_slices = [&](float* row, auto ns_c, const u32x4* sh, const u32x4* sl_) __attribute__((always_inline)) {   // encoded slices: features 16s + 8kg + 2q, +1
 #pragma unroll

@@ -22,6 +22,12 @@ constexpr int kBAuxSem2W = 384;   // 2 x 128
 constexpr int kBAuxAlphaW = 640;  // 256: [kg][t 0..7][r 0..15] -> alpha_linear.weight[0][acc_feature(t, r, kg)]
 constexpr int kBAuxWords = 1024;
 
+#ifndef NSOS_X3B_RING
+#define NSOS_X3B_RING 16
+#endif
+constexpr int kMaskRing = NSOS_X3B_RING;   // ReLU-mask quads (16 B per lane) in flight ahead of the pass that uses them
+static_assert(kMaskRing >= 4 && kMaskRing <= 16 && kDmaPieces + 32 <= 63, "vmcnt is a 6-bit counter");
+
 __host__ __device__ constexpr int x3_bwd_chunks(int sem) { return 4 + 8 + (sem ? 4 : 0) + 56; }   // 16 items (32 A operands) each
 
 struct X3BwdParams {
@@ -61,6 +67,14 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kDmaPieces) : "memory");   // counted: the newest chunk's pieces may still fly
         __builtin_amdgcn_s_barrier();
     };
+    // The first two chunks after a pass: the mask loads of that pass's ring refill and the kMaskRing preloads of the next pass
+    // were issued AFTER the pieces this barrier needs, and loads retire in order, so that many more operations may stay in
+    // flight (stores are NOT counted: nothing here relies on their order relative to loads).  The loads are unconditional
+    // (lanes past the end redo the last point), so the count is exact.
+    auto mid_extra = [&](auto n_c) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kDmaPieces + decltype(n_c)::value) : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     auto tail = [&]() {
         const unsigned tc = c0, td = d0;
         c0 = c1; c1 = c2; c2 = c3; c3 = tc;
@@ -88,9 +102,11 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
 #define IC(n) std::integral_constant<int, (n)> {}
     // One chunk = 16 items of a product with 8 output tiles; item I0 + i = (K-slice s = a / 8, tile t = a % 8).  32 A operands in
     // the skewed order hi_0, [hi_k, lo_{k-1}], lo_15 (mlp_x3.hip).  ZF: slice 0 starts the accumulation (C = 0).
-    auto run_chunk = [&](auto i0_c, auto zf_c, auto& Zm, auto& Zx, auto&& bh, auto&& bl) __attribute__((always_inline)) {
+    auto run_chunk = [&](auto i0_c, auto zf_c, auto relaxed_c, auto& Zm, auto& Zx, auto&& bh, auto&& bl) __attribute__((always_inline)) {
         constexpr int NI = 16, NG = 32, I0 = decltype(i0_c)::value;
         constexpr bool ZF = decltype(zf_c)::value != 0;
+        constexpr int EXTRA = decltype(relaxed_c)::value;   // loads known to have been issued after the pieces this chunk's barrier needs
+        auto mid_sel = [&]() { if constexpr (EXTRA > 0) mid_extra(std::integral_constant<int, EXTRA>{}); else mid(); };
         a_pipeline<NG, kRing, kPre, kMid>(ring, ctx(), [&](auto ic, const f32x4& a32) {
             constexpr int g = decltype(ic)::value;
             constexpr bool IS_HI = g == 0 || (g != NG - 1 && (g & 1));
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
                 Zx[t] = mfma16(aop, bh(IC(s)), FIRST ? zero : Zx[t]);
             }
             dma_slot<g - kMid, kDmaPieces>(side);
-        }, mid, tail);
+        }, mid_sel, tail);
 #pragma unroll
         for (int t = 0; t < 8; ++t) asm volatile("" : "+a"(Zm[t]), "+a"(Zx[t]));   // see mlp_x3.hip: keeps LLVM from sinking the MFMAs
     };
@@ -151,15 +167,16 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
                 Hh[2 * t + (q >> 1)][2 * (q & 1) + 1] = h1; Hl[2 * t + (q >> 1)][2 * (q & 1) + 1] = l1;
             }
         };
+        // ReLU masks of the NEXT pass: the first kMaskRing quads are requested before that layer's MFMA chunks start
+        f32x4 mk[kMaskRing];
+        auto preload = [&](const float* act) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < kMaskRing; ++i) mk[i] = *reinterpret_cast<const f32x4*>(act + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
+        };
         // accumulators -> gbuf and the next product's split B operands: z = Zm + 2^-11 Zx [+ w_alpha g_sigma], [* (act > 0)]
         auto pass = [&](auto mask_c, auto alpha_c, const float* act, float* out) __attribute__((always_inline)) {
             constexpr bool MASK = decltype(mask_c)::value != 0, ALPHA = decltype(alpha_c)::value != 0;
-            constexpr int RING = 8;
-            f32x4 mk[RING];
-            if constexpr (MASK) {
-#pragma unroll
-                for (int i = 0; i < RING; ++i) mk[i] = *reinterpret_cast<const f32x4*>(act + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
-            }
+            constexpr int RING = kMaskRing;
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (the reads are inside asm)
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
@@ -189,19 +206,21 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
 
         // view branch: g_v (VALU) -> g_feat = g_v @ W_views[:, :256]   (K = 128: 64 items)
         head_grad(IC(3), arow + NSOS_ACTS_VIEWS, grow + NSOS_ACTS_VIEWS, aux_l + kBAuxRgbW + kg * 64, gr);
-        static_for<0, 4>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), Zm, Zx, h_h, h_l); });
+        static_for<0, 4>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(0), Zm, Zx, h_h, h_l); });
         pass(IC(0), IC(0), arow, grow + NSOS_ACTS_FEAT);
         // d/d h7 = g_feat @ W_feature (+ g_hs @ W_sem0[:, :256]) (+ g_sigma w_alpha, in the pass)
-        static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), Zm, Zx, h_h, h_l); });
+        preload(arow + 256 * 7);
+        static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(decltype(cc)::value < 2 ? kMaskRing : 0), Zm, Zx, h_h, h_l); });   // pass(feat) loads nothing
         if constexpr (SEM != 0) {
             head_grad(IC(2), arow + NSOS_ACTS_SEM, grow + NSOS_ACTS_SEM, aux_l + kBAuxSem2W + kg * 64, gr + 4);
-            static_for<0, 4>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(0), Zm, Zx, h_h, h_l); });
+            static_for<0, 4>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(0), IC(0), Zm, Zx, h_h, h_l); });
         }
         pass(IC(1), IC(1), arow + 256 * 7, grow + 256 * 7);
         // trunk: g_z(l-1) = (g_z(l) @ W_l[:, h part]) * (h(l-1) > 0)
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
-            static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), Zm, Zx, h_h, h_l); });
+            preload(arow + 256 * (l - 1));
+            static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(decltype(cc)::value < 2 ? 32 : 0), Zm, Zx, h_h, h_l); });   // 32 - ring refills + ring preloads
             pass(IC(1), IC(0), arow + 256 * (l - 1), grow + 256 * (l - 1));
         }
     }
