@@ -168,6 +168,13 @@ size_t nsos_sem_head_wgrad_workspace_bytes(void);
 int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
                             const float* sem_in, int64_t n_rays, int32_t n_samples, float* gw1_aug, float* gw2,
                             float* gb2, void* workspace, size_t workspace_bytes, void* stream);
+/* The same on the 16-bit matrix pipe with split-fp16 operands (three MFMAs per product, fp32 accumulate): HBM-bound
+ * instead of MFMA-bound.  `scale` (device scalar, a power of two) brings g_hid = (g_logits @ W_sem2) * mask into fp16
+ * range: gw1_aug comes out multiplied by it (divide afterwards); gw2 / gb2 are plain fp32 sums as above.
+ * n_samples >= 8, n_rays * n_samples < 2^31. */
+int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+                               const float* sem_in, int64_t n_rays, int32_t n_samples, const float* scale, float* gw1_aug,
+                               float* gw2, float* gb2, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2-LP: the same fused network with 16-bit MFMA inputs and fp32 accumulation (reduced-precision configs) ----
  * For BASELINE configs C3 (bf16) and C5 (fp16, eval-only).  NOT bit/1e-4-comparable with the reference's fp32

@@ -12,6 +12,7 @@
 //   dW2 = g_logits^T hid,  db2 = g_logits^T 1,  [dW1 | db1] = g_hid^T [h7, x63, 1].
 // This kernel is the element-wise part: HBM-bound, reads 512 B + writes 520 B per point.
 #include "common.h"
+#include "x3_common.h"   // split2 / mfma16 of the split-fp16 kernels (sem_head_wgrad_x3_kernel)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -144,6 +145,157 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_kernel(const float* __r
     }
 }
 
+// The same reduction on the 16-bit matrix pipe with split operands (hi = fp16(v), lo = fp16(v - hi); hi.hi + lo.hi + hi.lo,
+// fp32 accumulate): 3 x 32 cycles per 16 points per 32x32 tile instead of 8 x 64 -- the kernel becomes HBM-bound (1.8 KB per
+// point).  Structure of wgrad_x3_kernel (wgrad.hip): per 16-point k-step the workgroup forms / gathers every operand ONCE
+// (14 column tiles x 64 lanes = 896 slots: wave w forms g_hid tile w from sem_hid, the compositing weight and dL/dsemantics,
+// and gathers sem_in tiles w, 4+w and -- waves 0, 1 -- 8+w), splits it and stages it in LDS in MFMA operand order (double
+// buffered, one barrier per k-step); wave w then runs its 30 MFMAs (A = g_hid tile w, B = the 10 sem_in tiles).  g_hid has
+// no natural scale: the caller passes a power of two (device scalar) that brings it into fp16 range and divides gw1 by it;
+// gw2 / gb2 stay plain fp32 sums exactly as in sem_head_wgrad_kernel.  n_samples >= 8, n_pts < 2^31.
+__global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* __restrict__ weights, const float* __restrict__ g_sem,
+                                                                   const float* __restrict__ w2, const float* __restrict__ hid,
+                                                                   const float* __restrict__ sem_in, const float* __restrict__ scale_p,
+                                                                   long long n_pts, int S, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 14 * 2 * 1024];   // [buffer][tile 0..13][hi, lo][64 lanes x 16 B]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kg = lane >> 5;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const long long n_steps = (n_pts + 15) / 16;
+    const long long per = (n_steps + gridDim.x - 1) / gridDim.x;
+    const long long s0 = (long long)blockIdx.x * per, s1 = s0 + per < n_steps ? s0 + per : n_steps;
+    const long long n_full_all = n_pts / 16;
+    const long long f1 = s1 < n_full_all ? s1 : n_full_all;            // full steps are [s0, f1), then possibly one ragged step f1
+    const bool ragged = s1 > f1 && s1 > s0;
+    const float scale = *scale_p;
+    const float w2a = w2[32 * wave + i], w2b = w2[128 + 32 * wave + i];
+    f32x16 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float gw2[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f};
+    const int n_x = wave_s < 2 ? 3 : 2;                                 // sem_in tiles staged by this wave: w, 4+w (, 8+w)
+
+    struct Raw { float h[8], wt[8], g0[8], g1[8], x[3][8]; };
+    // MASKED: the (single) ragged step -- rows clamped, out-of-range points get weight 0 (their g_hid is then 0)
+    auto fetch = [&](long long step, Raw& R, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value != 0;
+        const unsigned p0 = (unsigned)(step * 16) + 8u * (unsigned)kg;
+        const unsigned q0 = p0 / (unsigned)S, rem0 = p0 - q0 * (unsigned)S;     // ray of the first point; S >= 8: at most one crossing below
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned p = p0 + e;
+            bool ok = true;
+            if constexpr (MASKED) { ok = p < (unsigned)n_pts; p = ok ? p : (unsigned)n_pts - 1u; }
+            unsigned r = q0 + ((rem0 + e) >= (unsigned)S ? 1u : 0u);
+            if constexpr (MASKED) r = p / (unsigned)S;
+            const float w = weights[p];
+            R.wt[e] = ok ? w : 0.0f;
+            R.g0[e] = g_sem[2ull * r];
+            R.g1[e] = g_sem[2ull * r + 1];
+            R.h[e] = hid[(unsigned long long)p * 128 + 32 * wave + i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < n_x) R.x[j][e] = sem_in[(unsigned long long)p * 320 + 32 * (4 * j + wave) + i];
+        }
+    };
+    auto put = [&](int buf, int T, const float (&v)[8]) {               // split 8 points of one column and store the operand pair
+        u32x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b;
+            split2(v[2 * q], v[2 * q + 1], a, b);
+            h[q] = a; l[q] = b;
+        }
+        unsigned char* dst = lds + ((buf * 14 + T) * 2) * 1024 + lane * 16;
+        *reinterpret_cast<u32x4*>(dst) = h;
+        *reinterpret_cast<u32x4*>(dst + 1024) = l;
+    };
+    // part 0: this wave's g_hid tile (and the plain fp32 sums); parts 1..3: its sem_in tiles.  w = 0 for a re-fetched step
+    auto stage_part = [&](int part, const Raw& R, int buf, float w) {
+        if (part == 0) {
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gl0 = R.wt[e] * R.g0[e], gl1 = R.wt[e] * R.g1[e];       // g_logits (models/renderer.py:64-66)
+                const float gh = R.h[e] > 0.0f ? gl0 * w2a + gl1 * w2b : 0.0f;       // g_hid (models/nerf_mlp.py:61)
+                a[e] = gh * scale;
+                gw2[0] += w * (gl0 * R.h[e]);                                        // hid is stored after its ReLU
+                gw2[1] += w * (gl1 * R.h[e]);
+                gb2[0] += w * gl0;
+                gb2[1] += w * gl1;
+            }
+            put(buf, wave_s, a);
+        } else if (part - 1 < n_x) {
+            put(buf, 4 + 4 * (part - 1) + wave_s, R.x[part - 1]);
+        }
+    };
+    auto operand = [&](int buf, int T, int part) {
+        return *reinterpret_cast<const u32x4*>(lds + ((buf * 14 + T) * 2 + part) * 1024 + lane * 16);
+    };
+    // 30 MFMAs of one k-step: two groups of 5 column tiles, product-major inside a group (an accumulator returns every 5th MFMA)
+    auto compute = [&](int buf, auto&& between) {
+        const u32x4 ah = operand(buf, wave_s, 0), al = operand(buf, wave_s, 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            u32x4 bh[5], bl[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { bh[c] = operand(buf, 4 + 5 * g + c, 0); bl[c] = operand(buf, 4 + 5 * g + c, 1); }
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[5 * g + c] = mfma16(ah, bh[c], acc[5 * g + c]);
+            between(2 * g);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[5 * g + c] = mfma16(al, bh[c], acc[5 * g + c]);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[5 * g + c] = mfma16(ah, bl[c], acc[5 * g + c]);
+            between(2 * g + 1);
+        }
+    };
+    const long long nf = f1 > s0 ? f1 - s0 : 0;
+    if (nf > 0) {
+        Raw R0, R1;
+        auto clampf = [&](long long j) { return s0 + (j < nf ? j : nf - 1); };   // past the end: re-fetch the last full step
+        fetch(clampf(0), R0, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int part = 0; part < 4; ++part) stage_part(part, R0, 0, 1.0f);
+        fetch(clampf(1), R1, std::integral_constant<int, 0>{});
+        fetch(clampf(2), R0, std::integral_constant<int, 0>{});
+        __syncthreads();
+        // pairs of steps (2p, 2p+1), no branch inside: at the top buffer 0 holds step 2p, R1 step 2p+1, R0 step 2p+2
+        for (long long pp = 0; pp < nf / 2; ++pp) {
+            compute(0, [&](int q) { stage_part(q, R1, 1, 1.0f); });
+            fetch(clampf(2 * pp + 3), R1, std::integral_constant<int, 0>{});
+            __syncthreads();
+            const float w0 = 2 * pp + 2 < nf ? 1.0f : 0.0f;              // past the end: staged, never computed, not summed
+            compute(1, [&](int q) { stage_part(q, R0, 0, w0); });
+            fetch(clampf(2 * pp + 4), R0, std::integral_constant<int, 0>{});
+            __syncthreads();
+        }
+        if (nf & 1) compute(0, [&](int) {});
+    }
+    if (ragged) {
+        Raw R;
+        fetch(f1, R, std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int part = 0; part < 4; ++part) stage_part(part, R, 1, 1.0f);
+        __syncthreads();
+        compute(1, [&](int) {});
+    }
+    float* out = partial + (size_t)blockIdx.x * kWgradOut;
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)   // accumulator element r of lane (i, kg): row (r&3) + 8(r>>2) + 4kg, column i
+            out[(size_t)(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg) * 320 + 32 * t + i] = acc[t][r];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const float s = gw2[o] + __shfl_xor(gw2[o], 32, NSOS_WAVE);
+        if (kg == 0) out[128 * 320 + o * 128 + 32 * wave + i] = s;
+        const float sb = gb2[o] + __shfl_xor(gb2[o], 32, NSOS_WAVE);
+        if (wave == 0 && lane == 0) out[128 * 320 + 256 + o] = sb;
+    }
+}
+
 __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks,
                                                                     float* __restrict__ gw1, float* __restrict__ gw2,
                                                                     float* __restrict__ gb2) {
@@ -188,6 +340,28 @@ extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_sema
     const hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sem_head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in,
                        n_pts, (int)n_samples, static_cast<float*>(workspace));
+    hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 255) / 256), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w,
+                                          const float* sem_hid, const float* sem_in, int64_t n_rays, int32_t n_samples,
+                                          const float* scale, float* gw1_aug, float* gw2, float* gb2, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    NSOS_REQUIRE(gw1_aug && gw2 && gb2, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_rays == 0 || (weights && g_semantics && sem2_w && sem_hid && sem_in && scale && workspace), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(workspace_bytes >= nsos_sem_head_wgrad_workspace_bytes(), NSOS_ERR_BUFFER_TOO_SMALL);
+    const long long n_pts = (long long)n_rays * n_samples;
+    NSOS_REQUIRE(n_samples >= 8 && n_pts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    int blocks = wgrad_blocks();
+    if (blocks > 1024) blocks = 1024;
+    const long long steps = (n_pts + 15) / 16;
+    if (steps < blocks) blocks = (int)(steps > 0 ? steps : 1);
+    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sem_head_wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in,
+                       scale, n_pts, (int)n_samples, static_cast<float*>(workspace));
     hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 255) / 256), dim3(256), 0, st,
                        static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
     return nsos_launch_status();

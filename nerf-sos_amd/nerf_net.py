@@ -160,7 +160,8 @@ class _FrozenBackboneRender(torch.autograd.Function):
                 continue
             w2 = mlp.mlp.semantic_linear[2].weight.detach()
             gw1_aug, gw2, gb2 = ops.sem_head_wgrad(sv["weights"], gs.reshape(-1, 2).contiguous(), w2, sv["sem_hid"],
-                                                   sv["sem_in"])           # [128,320] = [dW1 | (pad) | db1]
+                                                   sv["sem_in"],           # [128,320] = [dW1 | (pad) | db1]
+                                                   split_fp16=net.mlp_precision != "fp32")   # exact MFMA only on the exact path
             in_dim = mlp.mlp.semantic_linear[0].weight.shape[1]
             grads += [gw1_aug[:, :in_dim].contiguous(), gw1_aug[:, 319].contiguous(), gw2, gb2]
         ctx.saved = None   # release the saved operands now: the node itself lives as long as the caller keeps the loss

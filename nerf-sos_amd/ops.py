@@ -254,9 +254,11 @@ _WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
 
 
 def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: torch.Tensor, sem_hid: torch.Tensor,
-                   sem_in: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                   sem_in: torch.Tensor, split_fp16: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Backward of the semantic head in one pass (nsos_sem_head_wgrad): returns
-    (gw1_aug [128,320] = [dW1 | . | db1 in column 319], dW2 [2,128], db2 [2])."""
+    (gw1_aug [128,320] = [dW1 | . | db1 in column 319], dW2 [2,128], db2 [2]).
+    split_fp16: the big reduction on the 16-bit matrix pipe with split operands (nsos_sem_head_wgrad_x3; needs S >= 8 and
+    fewer than 2^31 points, else the exact kernel runs); a power-of-two scale derived on the device keeps g_hid in range."""
     weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
     sem2_w, sem_hid, sem_in = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid"), _dev(sem_in, "sem_in")
     R, S = weights.shape
@@ -270,6 +272,14 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     gw1 = torch.empty((128, 320), device=dev, dtype=torch.float32)
     gw2 = torch.empty((2, 128), device=dev, dtype=torch.float32)
     gb2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    if split_fp16 and S >= 8 and R * S < 2 ** 31:
+        # |g_hid| <= max|g_sem| * max_m (|W2[0,m]| + |W2[1,m]|) (compositing weights are <= 1): bring that bound to 2^8
+        bound = (g_semantics.abs().max() * sem2_w.abs().sum(0).max()).clamp_min(1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(256.0 / bound))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
+        _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,
+                                                     _p(scale), _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4, _stream()),
+                   "nsos_sem_head_wgrad_x3")
+        return gw1 * (1.0 / scale), gw2, gb2
     _lib.check(_lib.lib().nsos_sem_head_wgrad(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,
                                               _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4, _stream()),
                "nsos_sem_head_wgrad")

@@ -244,3 +244,28 @@ def test_wgrad_split_fp16_vs_fp64(P):
         outs[split] = (float((dW.double() - want).abs().max() / want.abs().max()), float((db.double() - want_b).abs().max() / want_b.abs().max()))
     assert outs[True][0] <= max(2e-6, 4 * outs[False][0]), outs
     assert outs[True][1] <= max(2e-6, 4 * outs[False][1]), outs
+
+
+@pytest.mark.parametrize("R,S", [(37, 64), (5, 192), (3, 9), (700, 64), (1, 8)])
+def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
+    """nsos_sem_head_wgrad_x3 (split-fp16 operands staged through LDS) against the exact-fp32 kernel and an fp64 reduction of
+    the same formulas (models/renderer.py:64-66, models/nerf_mlp.py:61,80): tiny gradients (1e-6), ragged point counts."""
+    g = torch.Generator(DEV).manual_seed(R * 1000 + S)
+    P = R * S
+    weights = torch.rand(R, S, device=DEV, generator=g) ** 4
+    g_sem = torch.randn(R, 2, device=DEV, generator=g) * 1e-6
+    w2 = torch.randn(2, 128, device=DEV, generator=g) * 0.1
+    hid = torch.relu(torch.randn(P, 128, device=DEV, generator=g))
+    sem_in = torch.randn(P, 320, device=DEV, generator=g)
+    sem_in[:, 319] = 1.0
+    gl = (weights.reshape(P, 1) * g_sem.repeat_interleave(S, 0)).double()
+    gh = (gl @ w2.double()) * (hid > 0)
+    want1, want2, wantb = gh.T @ sem_in.double(), gl.T @ hid.double(), gl.sum(0)
+    res = {}
+    for split in (False, True):
+        a = ops.sem_head_wgrad(weights, g_sem, w2, hid, sem_in, split_fp16=split)
+        b = ops.sem_head_wgrad(weights, g_sem, w2, hid, sem_in, split_fp16=split)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), "not deterministic"
+        res[split] = [float((x.double() - w).abs().max() / (w.abs().max() + 1e-300)) for x, w in zip(a, (want1, want2, wantb))]
+    for k in range(3):
+        assert res[True][k] <= max(3e-6, 4 * res[False][k]), (k, res)
