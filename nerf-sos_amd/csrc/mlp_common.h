@@ -47,17 +47,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // rotation, DMA source pointer) in the MFMA shadow after group NG-3, after the last use of the current values.
 template <int OFF_BYTES>
 __device__ __forceinline__ void lds_read_a(f32x4& dst, unsigned lds_addr) {
-#ifdef NSOS_EXP_NOLDS  // timing experiment only (garbage results)
-    asm volatile("" : "+v"(dst));
-    return;
-#endif
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF_BYTES) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {
-#ifdef NSOS_EXP_NOWAIT  // timing experiment only (racy)
-    return;
-#endif
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
 }
 

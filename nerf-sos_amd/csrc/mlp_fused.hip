@@ -214,16 +214,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpParams P) {
         const unsigned dst = dst_wave + (unsigned)i * 4096u;   // uniform
         dma_1k(src, dst, voff);
     };
-#ifdef NSOS_EXP_NODMA  // timing experiment only (results are garbage): how much does the DMA issue cost?
-    auto side = [&](int) {};
-#else
     auto side = [&](int i) { dma_piece(src2, d2, i); };
-#endif
     auto mid = [&]() {
-#ifndef NSOS_EXP_NOBARRIER  // timing experiment only (racy): how much does the per-chunk barrier cost?
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#endif
     };
     auto tail = [&]() {  // chunk cur -> cur+1
         const unsigned tc = c0, td = d0;

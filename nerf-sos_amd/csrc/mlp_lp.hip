@@ -232,11 +232,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
         // all DMA pieces except the newest kDmaPieces (chunk cur+2, issued one chunk ago) must have landed:
         // that is chunk cur+1, which the end of this chunk starts to read.  (Extra outstanding VM operations
         // of the compiler only make this counted wait stricter.)
-#ifdef NSOS_EXP_VM0
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kDmaPieces) : "memory");
-#endif
         __builtin_amdgcn_s_barrier();
     };
     auto tail = [&]() {
@@ -292,15 +288,6 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                     }
                 }
                 dma_slot<(g - kMid) * 2 + c, kDmaPieces>(side);
-#ifdef NSOS_LPX_RIDE   // timing experiment only: what does an activation-like word behind every MFMA cost in THIS stream?
-                if constexpr (NT == 8 && a >= NB && g < NWORK) {
-                    constexpr int t2 = ((a - NB) % NT + 4) & 7;
-                    unsigned r_, t_;
-                    asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_cvt_pk_f16_f32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, 0"
-                                 : "=&v"(r_), "=&v"(t_) : "a"(acc[c][t2][(g * 2) & 15]), "a"(acc[c][t2][(g * 2 + 1) & 15]));
-                    asm volatile("" :: "v"(r_));
-                }
-#endif
             });
         }, mid, tail);
     };
