@@ -392,17 +392,17 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #pragma unroll
                                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                                        for (int q = 0; q < 4; ++q) {   // word = accumulator elements 8u+2q, +1 of tile t
-                                            const unsigned w = H[c][2 * t + u][q];
-                                            *reinterpret_cast<f32x2*>(row + 32 * t + 2 * (q & 1) + 8 * (2 * u + (q >> 1)) + 4 * kg) =
-                                                f32x2{T::lo(w), T::hi(w)};
+                                        for (int q = 0; q < 4; q += 2) {   // words q, q+1 = accumulator elements 8u+2q .. +3 of tile t: 4 consecutive features
+                                            const unsigned w0 = H[c][2 * t + u][q], w1 = H[c][2 * t + u][q + 1];
+                                            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                                                f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
                                         }
 #pragma unroll
                                 for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) {       // slice word = features 16s + 8kg + 2q, +1; 63 is the 1.0 pad
-                                        const unsigned w = ex[c][sl][q];
-                                        *reinterpret_cast<f32x2*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x2{T::lo(w), T::hi(w)};
+                                    for (int q = 0; q < 4; q += 2) {    // slice words q, q+1 = features 16s + 8kg + 2q .. +3; 63 is the 1.0 pad
+                                        const unsigned w0 = ex[c][sl][q], w1 = ex[c][sl][q + 1];
+                                        *reinterpret_cast<f32x4*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
                                     }
 #pragma unroll
                                 for (int t = 0; t < 4; ++t)

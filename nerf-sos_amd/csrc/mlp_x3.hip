@@ -263,8 +263,9 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
 #pragma unroll
             for (int sl = 0; sl < decltype(ns_c)::value; ++sl)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x2*>(row + 16 * sl + 8 * kg + 2 * q) = f32x2{join<0>(sh[sl][q], sl_[sl][q]), join<1>(sh[sl][q], sl_[sl][q])};
+                for (int q = 0; q < 4; q += 2)
+                    *reinterpret_cast<f32x4*>(row + 16 * sl + 8 * kg + 2 * q) =
+                        f32x4{join<0>(sh[sl][q], sl_[sl][q]), join<1>(sh[sl][q], sl_[sl][q]), join<0>(sh[sl][q + 1], sl_[sl][q + 1]), join<1>(sh[sl][q + 1], sl_[sl][q + 1])};
         };
         auto store_hidden128 = [&](float* hrow, const f32x16 (&am)[4], const f32x16 (&ax)[4]) __attribute__((always_inline)) {   // relu(Zm + 2^-11 Zx) of a 128-wide layer
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
