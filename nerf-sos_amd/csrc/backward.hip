@@ -174,29 +174,62 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float gw2[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f};
-    const int n_x = wave_s < 2 ? 3 : 2;                                 // sem_in tiles staged by this wave: w, 4+w (, 8+w)
+    // sem_in tiles staged by this wave: w, 4+w and 8 + (w & 1): waves 2, 3 duplicate tiles 8, 9 (identical values into the same LDS
+    // slot) rather than branch around a third of their loads
+    const int xt2 = 8 + (wave_s & 1);
 
     struct Raw { float h[8], wt[8], g0[8], g1[8], x[3][8]; };
-    // MASKED: the (single) ragged step -- rows clamped, out-of-range points get weight 0 (their g_hid is then 0)
-    auto fetch = [&](long long step, Raw& R, auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value != 0;
+    // Addressing of the full steps as in wgrad_x3_kernel: wave-uniform row pointers (scalar unit) + constant 32-bit lane offsets
+    // (the half-wave's 8-point shift is part of the lane offset), so the loads are `global_load_dword v, v_off, s[row]`.
+    typedef const __attribute__((address_space(1))) float* gptr;
+    typedef const __attribute__((address_space(1))) char* gbytes;
+    auto uniform = [](const float* p) {                                   // tell hipcc the pointer is wave-uniform
+        const unsigned long long b = (unsigned long long)p;
+        return (gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b));
+    };
+    auto at = [](gptr row, unsigned byte_off) {
+        unsigned long long r = (unsigned long long)row;
+        asm("" : "+s"(r));                                                // keep the row pointer a scalar of its own
+        return *reinterpret_cast<gptr>(reinterpret_cast<gbytes>(r) + byte_off);
+    };
+    const unsigned off_w = 8u * kg * 4u, off_h = (8u * kg * 128u + i) * 4u, off_x = (8u * kg * 320u + i) * 4u;
+    auto fetch_full = [&](long long step, Raw& R) {
         const unsigned p0 = (unsigned)(step * 16) + 8u * (unsigned)kg;
         const unsigned q0 = p0 / (unsigned)S, rem0 = p0 - q0 * (unsigned)S;     // ray of the first point; S >= 8: at most one crossing below
+        unsigned ow = off_w, oh = off_h, ox = off_x;
+        asm volatile("" : "+v"(ow), "+v"(oh), "+v"(ox));                  // ... and keep LICM from hoisting their zero-extension
+        const gptr wrow = uniform(weights + step * 16), hrow = uniform(hid + step * 16 * 128 + 32 * wave_s);
+        gptr xrow[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xrow[j] = uniform(sem_in + step * 16 * 320 + 32 * (j < 2 ? 4 * j + wave_s : xt2));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned r = q0 + ((rem0 + e) >= (unsigned)S ? 1u : 0u);
+            R.wt[e] = at(wrow + e, ow);
+            R.g0[e] = g_sem[2ull * r];
+            R.g1[e] = g_sem[2ull * r + 1];
+            R.h[e] = at(hrow + e * 128, oh);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) R.x[j][e] = at(xrow[j] + e * 320, ox);
+        }
+    };
+    // the (single) ragged step -- rows clamped, out-of-range points get weight 0 (their g_hid is then 0)
+    auto fetch_masked = [&](long long step, Raw& R) {
+        const unsigned p0 = (unsigned)(step * 16) + 8u * (unsigned)kg;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             unsigned p = p0 + e;
-            bool ok = true;
-            if constexpr (MASKED) { ok = p < (unsigned)n_pts; p = ok ? p : (unsigned)n_pts - 1u; }
-            unsigned r = q0 + ((rem0 + e) >= (unsigned)S ? 1u : 0u);
-            if constexpr (MASKED) r = p / (unsigned)S;
+            const bool ok = p < (unsigned)n_pts;
+            p = ok ? p : (unsigned)n_pts - 1u;
+            const unsigned r = p / (unsigned)S;
             const float w = weights[p];
             R.wt[e] = ok ? w : 0.0f;
             R.g0[e] = g_sem[2ull * r];
             R.g1[e] = g_sem[2ull * r + 1];
             R.h[e] = hid[(unsigned long long)p * 128 + 32 * wave + i];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (j < n_x) R.x[j][e] = sem_in[(unsigned long long)p * 320 + 32 * (4 * j + wave) + i];
+            for (int j = 0; j < 3; ++j) R.x[j][e] = sem_in[(unsigned long long)p * 320 + 32 * (j < 2 ? 4 * j + wave : xt2) + i];
         }
     };
     auto put = [&](int buf, int T, const float (&v)[8]) {               // split 8 points of one column and store the operand pair
@@ -226,8 +259,8 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
                 gb2[1] += w * gl1;
             }
             put(buf, wave_s, a);
-        } else if (part - 1 < n_x) {
-            put(buf, 4 + 4 * (part - 1) + wave_s, R.x[part - 1]);
+        } else {
+            put(buf, 4 + (part < 3 ? 4 * (part - 1) + wave_s : xt2), R.x[part - 1]);
         }
     };
     auto operand = [&](int buf, int T, int part) {
@@ -254,28 +287,29 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
     const long long nf = f1 > s0 ? f1 - s0 : 0;
     if (nf > 0) {
         Raw R0, R1;
-        auto clampf = [&](long long j) { return s0 + (j < nf ? j : nf - 1); };   // past the end: re-fetch the last full step
-        fetch(clampf(0), R0, std::integral_constant<int, 0>{});
+        const long long s0u = __builtin_amdgcn_readfirstlane((int)s0);
+        auto clampf = [&](long long j) { return s0u + (j < nf ? j : nf - 1); };   // past the end: re-fetch the last full step
+        fetch_full(clampf(0), R0);
 #pragma unroll
         for (int part = 0; part < 4; ++part) stage_part(part, R0, 0, 1.0f);
-        fetch(clampf(1), R1, std::integral_constant<int, 0>{});
-        fetch(clampf(2), R0, std::integral_constant<int, 0>{});
+        fetch_full(clampf(1), R1);
+        fetch_full(clampf(2), R0);
         __syncthreads();
         // pairs of steps (2p, 2p+1), no branch inside: at the top buffer 0 holds step 2p, R1 step 2p+1, R0 step 2p+2
         for (long long pp = 0; pp < nf / 2; ++pp) {
             compute(0, [&](int q) { stage_part(q, R1, 1, 1.0f); });
-            fetch(clampf(2 * pp + 3), R1, std::integral_constant<int, 0>{});
+            fetch_full(clampf(2 * pp + 3), R1);
             __syncthreads();
             const float w0 = 2 * pp + 2 < nf ? 1.0f : 0.0f;              // past the end: staged, never computed, not summed
             compute(1, [&](int q) { stage_part(q, R0, 0, w0); });
-            fetch(clampf(2 * pp + 4), R0, std::integral_constant<int, 0>{});
+            fetch_full(clampf(2 * pp + 4), R0);
             __syncthreads();
         }
         if (nf & 1) compute(0, [&](int) {});
     }
     if (ragged) {
         Raw R;
-        fetch(f1, R, std::integral_constant<int, 1>{});
+        fetch_masked(f1, R);
 #pragma unroll
         for (int part = 0; part < 4; ++part) stage_part(part, R, 1, 1.0f);
         __syncthreads();
