@@ -11,6 +11,7 @@
 // coalesced 128 B rows.  Per-(workgroup, k-subset) partials are summed in a fixed order in fp64: deterministic.
 // MFMA-bound for M = N = 256 (65 536 MAC per point per layer).
 #include "common.h"
+#include "x3_common.h"   // split2 / mfma16 of the split-fp16 kernels (wgrad_x3_kernel)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -186,21 +187,6 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, i
 // Operand loads run two k-steps ahead in registers.  G is expected in fp16 range (the fused input-gradient kernel's
 // power-of-two scale takes care of that); db is accumulated from the fp32 values.  Output: the same partial layout as
 // wgrad_kernel (KW = 1), reduced by wgrad_reduce_kernel.
-typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void wg_split2(float v0, float v1, unsigned& hi, unsigned& lo) {
-    float t0 = v0, t1 = v1;
-    asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
-                 "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-                 "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                 "v_cvt_pk_f16_f32 %1, %2, %3"
-                 : "=&v"(hi), "=&v"(lo), "+v"(t0), "+v"(t1));
-}
-__device__ __forceinline__ f32x16 wg_mfma16(wg_u32x4 a, wg_u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wg_f16x8, a), __builtin_bit_cast(wg_f16x8, b), c, 0, 0, 0);
-}
-
 __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
                                                           long long n_pts, float* __restrict__ partial) {
     constexpr int M = 256, N = 256;
@@ -265,44 +251,44 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
     };
     // split one slot and put it into LDS in operand order; w = 1 if the step is a real one (0: a re-fetched step past the end)
     auto stage_slot = [&](int j, const float (&raw)[4][8], int buf, float w) {
-        wg_u32x4 h, l;
+        u32x4 h, l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned a, b;
-            wg_split2(raw[j][2 * q], raw[j][2 * q + 1], a, b);
+            split2(raw[j][2 * q], raw[j][2 * q + 1], a, b);
             h[q] = a; l[q] = b;
         }
         if (j < 2) bsum[j] += w * (((raw[j][0] + raw[j][1]) + (raw[j][2] + raw[j][3])) + ((raw[j][4] + raw[j][5]) + (raw[j][6] + raw[j][7])));
         unsigned char* dst = lds + ((buf * 16 + 4 * j + wave_s) * 2) * 1024 + lane * 16;
-        *reinterpret_cast<wg_u32x4*>(dst) = h;
-        *reinterpret_cast<wg_u32x4*>(dst + 1024) = l;
+        *reinterpret_cast<u32x4*>(dst) = h;
+        *reinterpret_cast<u32x4*>(dst + 1024) = l;
     };
     auto operand = [&](int buf, int T, int part) {
-        return *reinterpret_cast<const wg_u32x4*>(lds + ((buf * 16 + T) * 2 + part) * 1024 + lane * 16);
+        return *reinterpret_cast<const u32x4*>(lds + ((buf * 16 + T) * 2 + part) * 1024 + lane * 16);
     };
     // the 48 MFMAs of one k-step in 4 quarters (column-tile pairs); `between(q)` runs after quarter q
     auto compute = [&](int buf, auto&& between) {
-        wg_u32x4 ah[2], al[2];
+        u32x4 ah[2], al[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) { ah[r] = operand(buf, wave_s + 4 * r, 0); al[r] = operand(buf, wave_s + 4 * r, 1); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            wg_u32x4 bh[2], bl[2];
+            u32x4 bh[2], bl[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) { bh[c] = operand(buf, 8 + 2 * q + c, 0); bl[c] = operand(buf, 8 + 2 * q + c, 1); }
             // product-major: the same accumulator comes back every 4th MFMA (free from distance 4, mfma_chain.hip)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = wg_mfma16(ah[r], bh[c], acc[r][2 * q + c]);
+                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = mfma16(ah[r], bh[c], acc[r][2 * q + c]);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = wg_mfma16(al[r], bh[c], acc[r][2 * q + c]);
+                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = mfma16(al[r], bh[c], acc[r][2 * q + c]);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = wg_mfma16(ah[r], bl[c], acc[r][2 * q + c]);
+                for (int r = 0; r < 2; ++r) acc[r][2 * q + c] = mfma16(ah[r], bl[c], acc[r][2 * q + c]);
             between(q);
         }
     };
