@@ -171,10 +171,12 @@ int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, cons
 /* The same on the 16-bit matrix pipe with split-fp16 operands (three MFMAs per product, fp32 accumulate): HBM-bound
  * instead of MFMA-bound.  `scale` (device scalar, a power of two) brings g_hid = (g_logits @ W_sem2) * mask into fp16
  * range: gw1_aug comes out multiplied by it (divide afterwards); gw2 / gb2 are plain fp32 sums as above.
- * n_samples >= 8, n_rays * n_samples < 2^31. */
+ * sem_in_dtype: NSOS_DTYPE_F32 for the fp32 matrix, NSOS_DTYPE_F16 / NSOS_DTYPE_BF16 for the compact 16-bit matrix of
+ * nsos_mlp_forward_rays_save16_lp (half the operand traffic).  n_samples >= 8, n_rays * n_samples < 2^31. */
 int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
-                               const float* sem_in, int64_t n_rays, int32_t n_samples, const float* scale, float* gw1_aug,
-                               float* gw2, float* gb2, void* workspace, size_t workspace_bytes, void* stream);
+                               const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
+                               const float* scale, float* gw1_aug, float* gw2, float* gb2, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---- K2-LP: the same fused network with 16-bit MFMA inputs and fp32 accumulation (reduced-precision configs) ----
  * For BASELINE configs C3 (bf16) and C5 (fp16, eval-only).  NOT bit/1e-4-comparable with the reference's fp32
@@ -193,6 +195,11 @@ int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t d
 int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                       const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                       int32_t n_samples, float* raw, float* sem_in, float* sem_hid, void* stream);
+/* The same with sem_in kept in its 16-bit format (`dtype`): sem_in16 [P,320] halves (640 B per point instead of 1280);
+ * consumer: nsos_sem_head_wgrad_x3 with the matching sem_in_dtype. */
+int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                        const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
+                                        int32_t n_samples, float* raw, void* sem_in16, float* sem_hid, void* stream);
 
 /* ---- K2-X3: the same fused network on the 16-bit matrix pipe with SPLIT-fp16 operands (fp32-grade results) -------
  * Every weight and activation is carried as hi = fp16(v), lo = fp16(v - hi) and every product as the three MFMAs

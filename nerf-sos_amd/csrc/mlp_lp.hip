@@ -22,6 +22,7 @@
 using namespace nsos;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -137,6 +138,7 @@ struct LpParams {
     int n_tiles;
     unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays_lp): per-wave shader-clock stamps, or NULL
     float* sem_in;   // SAVE: [P,320] = [relu(h7) | x63 | 1.0] as the 16-bit values the semantic head consumed, widened to fp32
+    unsigned* sem_in16;   // ... or (if not NULL) the same matrix kept in its 16-bit format T: [P,320] halves = 160 words per point
     float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
 };
 constexpr int kProfSlots = 64;
@@ -384,9 +386,24 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const long long gp = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
+                            if (gp < P.n_pts && P.sem_in16) {   // compact: the packed words as they are (a word = 2 consecutive features)
+                                unsigned* row16 = P.sem_in16 + gp * 160;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                        for (int q = 0; q < 4; q += 2)   // words q, q+1 = features 32t + 8(2u + q/2) + 4kg + {0..3}
+                                            *reinterpret_cast<u32x2*>(row16 + (32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) / 2) =
+                                                u32x2{H[c][2 * t + u][q], H[c][2 * t + u][q + 1]};
+#pragma unroll
+                                for (int sl = 0; sl < 4; ++sl)          // slice words = features 16s + 8kg + {0..7}; 63 is the 1.0 pad
+                                    *reinterpret_cast<u32x4*>(row16 + 128 + 8 * sl + 4 * kg) = ex[c][sl];
+                            }
                             if (gp < P.n_pts) {
                                 float* row = P.sem_in + gp * 320;
                                 float* hrow = P.sem_hid + gp * 128;
+                                if (!P.sem_in16) {
 #pragma unroll
                                 for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                                         const unsigned w0 = ex[c][sl][q], w1 = ex[c][sl][q + 1];
                                         *reinterpret_cast<f32x4*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
                                     }
+                                }
 #pragma unroll
                                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -649,7 +667,7 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
 static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                int32_t n_samples, float* raw, unsigned long long* prof, float* sem_in, float* sem_hid,
-                               void* stream) {
+                               void* stream, unsigned* sem_in16 = nullptr) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
@@ -666,9 +684,10 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
     p.prof = prof;
     p.sem_in = sem_in;
+    p.sem_in16 = sem_in16;
     p.sem_hid = sem_hid;
     const hipStream_t st = (hipStream_t)stream;
-    if (sem_in) {
+    if (sem_in || sem_in16) {
         NSOS_REQUIRE(sem_hid && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
         if (dtype == NSOS_DTYPE_F16) return sem_mode == 1 ? launch_lp<F16, 1, true>(p, st) : launch_lp<F16, 2, true>(p, st);
         return sem_mode == 1 ? launch_lp<BF16, 1, true>(p, st) : launch_lp<BF16, 2, true>(p, st);
@@ -703,6 +722,17 @@ extern "C" int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem
     NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
     return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, sem_in,
                            sem_hid, stream);
+}
+
+extern "C" int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
+                                                   const float* rays_d, const float* viewdirs, const float* z_vals,
+                                                   int64_t n_rays, int32_t n_samples, float* raw, void* sem_in16,
+                                                   float* sem_hid, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(sem_in16 && sem_hid, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(((uintptr_t)sem_in16 & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
+    return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr,
+                           sem_hid, stream, static_cast<unsigned*>(sem_in16));
 }
 
 extern "C" int32_t nsos_mlp_profile_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,

@@ -303,7 +303,7 @@ class NeRFNet(nn.Module):
                 saved[tag] = dict(acts=acts, raw=raw, z=z)
                 return raw
             raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,
-                                                             rays_d, viewdirs, z, self.mlp_precision)
+                                                             rays_d, viewdirs, z, self.mlp_precision, compact=True)
             saved[tag] = dict(sem_in=sem_in, sem_hid=sem_hid)
             return raw
 

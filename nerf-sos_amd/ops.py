@@ -206,10 +206,11 @@ def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, ray
 
 
 def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
-                          viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32"):
+                          viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32", compact: bool = False):
     """Training-mode K2 (frozen backbone): raw [R,S,6] plus the semantic head's saved inputs
     sem_in [R*S,320] = [relu(h7) | x63 | 1] and sem_hid [R*S,128] (see nsos_mlp_forward_rays_save[_lp]).
-    `packed` must have been packed for the same `precision`."""
+    `packed` must have been packed for the same `precision`.  compact (16-bit precisions only): sem_in comes back in its
+    own 16-bit dtype (the values are 16-bit anyway), half the bytes to store and to read back in sem_head_wgrad."""
     if sem_mode == SEM_NONE:
         raise ValueError("mlp_forward_rays_save needs a semantic head")
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
@@ -217,7 +218,9 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     R, S = z_vals.shape
     dev = z_vals.device
     raw = torch.empty((R, S, 6), device=dev, dtype=torch.float32)
-    sem_in = torch.empty((R * S, 320), device=dev, dtype=torch.float32)
+    compact = compact and precision in ("fp16", "bf16")
+    sem_in = torch.empty((R * S, 320), device=dev,
+                         dtype=(torch.float16 if precision == "fp16" else torch.bfloat16) if compact else torch.float32)
     sem_hid = torch.empty((R * S, 128), device=dev, dtype=torch.float32)
     if precision == "fp32":
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
@@ -227,6 +230,11 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
                                                             _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
                    "nsos_mlp_forward_rays_save_x3")
+    elif compact:
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_save16_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o),
+                                                              _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
+                                                              _p(sem_in), _p(sem_hid), _stream()),
+                   "nsos_mlp_forward_rays_save16_lp")
     else:
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o),
                                                             _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
@@ -260,7 +268,11 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     split_fp16: the big reduction on the 16-bit matrix pipe with split operands (nsos_sem_head_wgrad_x3; needs S >= 8 and
     fewer than 2^31 points, else the exact kernel runs); a power-of-two scale derived on the device keeps g_hid in range."""
     weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
-    sem2_w, sem_hid, sem_in = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid"), _dev(sem_in, "sem_in")
+    sem2_w, sem_hid = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid")
+    x_dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}.get(sem_in.dtype)
+    if x_dtype is None or not sem_in.is_cuda:
+        raise TypeError(f"sem_in must be a float32 / float16 / bfloat16 GPU tensor, got {sem_in.dtype} on {sem_in.device}")
+    sem_in = sem_in.contiguous()
     R, S = weights.shape
     if (tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (R * S, 128) or tuple(sem2_w.shape) != (2, 128)
             or tuple(sem_in.shape) != (R * S, 320)):
@@ -272,12 +284,16 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     gw1 = torch.empty((128, 320), device=dev, dtype=torch.float32)
     gw2 = torch.empty((2, 128), device=dev, dtype=torch.float32)
     gb2 = torch.empty((2,), device=dev, dtype=torch.float32)
-    if split_fp16 and S >= 8 and R * S < 2 ** 31:
+    use_split = split_fp16 and S >= 8 and R * S < 2 ** 31
+    if not use_split and x_dtype != 0:
+        sem_in, x_dtype = sem_in.float(), 0          # the exact kernel reads fp32
+    if use_split:
         # |g_hid| <= max|g_sem| * max_m (|W2[0,m]| + |W2[1,m]|) (compositing weights are <= 1): bring that bound to 2^8
         bound = (g_semantics.abs().max() * sem2_w.abs().sum(0).max()).clamp_min(1e-30)
         scale = torch.exp2(torch.floor(torch.log2(256.0 / bound))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
-        _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,
-                                                     _p(scale), _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4, _stream()),
+        _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), x_dtype,
+                                                     R, S, _p(scale), _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
+                                                     _stream()),
                    "nsos_sem_head_wgrad_x3")
         return gw1 * (1.0 / scale), gw2, gb2
     _lib.check(_lib.lib().nsos_sem_head_wgrad(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,

@@ -269,3 +269,10 @@ def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
         res[split] = [float((x.double() - w).abs().max() / (w.abs().max() + 1e-300)) for x, w in zip(a, (want1, want2, wantb))]
     for k in range(3):
         assert res[True][k] <= max(3e-6, 4 * res[False][k]), (k, res)
+    # the compact 16-bit sem_in of the reduced-precision training path: same numbers when the values are 16-bit to begin with
+    for dt in (torch.float16, torch.bfloat16):
+        x16 = sem_in.to(dt)
+        a = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16, split_fp16=True)
+        b = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16.float(), split_fp16=True)
+        for x, y in zip(a, b):
+            assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max() + 1e-30), dt

@@ -602,6 +602,9 @@ def test_lp_training_variant(golden, manifest, precision, tol):
     assert torch.equal(raw, raw_inf)
     dt = torch.float16 if precision == "fp16" else torch.bfloat16
     assert torch.equal(sem_in, sem_in.to(dt).float()) and (sem_in[:, 319] == 1).all() and (sem_in[:, :256] >= 0).all()
+    raw_c, sem_in_c, sem_hid_c = ops.mlp_forward_rays_save(net.nerf.packed_weights(precision), mode, rays[0].contiguous(),
+                                                            rays[1].contiguous(), v, z, precision, compact=True)
+    assert sem_in_c.dtype == dt and torch.equal(sem_in_c.float(), sem_in) and torch.equal(raw_c, raw) and torch.equal(sem_hid_c, sem_hid)
     W1 = mlp.semantic_linear[0].weight.detach().to(dt).double()
     b1 = mlp.semantic_linear[0].bias.detach().to(dt).double()
     hid = torch.relu(sem_in[:, :W1.shape[1]].double() @ W1.T + b1).float()
