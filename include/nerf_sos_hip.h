@@ -256,6 +256,10 @@ int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float*
                               float* raw, uint64_t* stamps, void* stream);
 /* Same for the reduced-precision kernel; it stamps the SECOND tile of workgroups 0..3 (steady state), so give it
  * more than 2 x 256 x (CU count) points.  Slot meaning: scripts/phase_profile_lp.py. */
+/* ... and for the split-fp16 kernel (128-point tiles: more than 2 x 128 x (CU count) points).  scripts/phase_profile_x3.py. */
+int32_t nsos_mlp_profile_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                 const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                 float* raw, uint64_t* stamps, void* stream);
 int32_t nsos_mlp_profile_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                  const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                  int32_t n_samples, float* raw, uint64_t* stamps, void* stream);

@@ -60,7 +60,9 @@ struct X3Params {
     float* sem_in;   // SAVE: [P,320] = [relu(h7) | x63 | 1.0], the fp32 values hi + lo the semantic head consumed
     float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
     float* acts;     // SAVE == 2 (full backward): [P, NSOS_ACTS_DIM] every layer's activations, see nerf_sos_hip.h
+    unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays_x3): per-wave shader-clock stamps, or NULL
 };
+constexpr int kProfSlots = 64;
 
 // encoded feature idx lives in half-wave (idx >> 3) & 1: a K-slice of 16 consecutive features, lane half kg
 // supplying k-slots 8kg .. 8kg+7
@@ -219,6 +221,15 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
 
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         // ---- this lane's point: tile*128 + wave*32 + pj (both half-waves of a column hold the same point)
+        int stamp_k = 0;
+        auto stamp = [&]() {  // diagnostics only: one s_memtime per phase of the second tile of blocks 0..3 (steady state)
+            if (P.prof && tile == (int)(blockIdx.x + gridDim.x) && blockIdx.x < 4) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                if (lane == 0 && stamp_k < kProfSlots) P.prof[(blockIdx.x * 4 + wave) * kProfSlots + stamp_k] = t;
+            }
+            ++stamp_k;
+        };
+        stamp();  // 0: tile start
         const long long gp = (long long)tile * kTilePts + wave * 32 + pj;
         const long long gc = gp < P.n_pts ? gp : P.n_pts - 1;
         const int ray = (int)(gc / P.n_samples);
@@ -290,9 +301,12 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         }
 
         // pts_linears.0: 4 encoded slices x 8 tiles = 32 items in 2 chunks; slice 0 starts from C = 0
+        stamp();  // 1: inputs + xyz encoding
         run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(1), Zm, Zx, ex_h, ex_l);
         run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(1), Zm, Zx, ex_h, ex_l);
+        stamp();  // 2: L0 MFMAs
         activate<8, true>(Hh, Hl, Zm, Zx);
+        stamp();  // 3: L0 activation
         if constexpr (SAVE == 2) {
             if (valid) store_H(arow);
         }
@@ -304,7 +318,9 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(0), Zm, Zx, ex_h, ex_l);
                 run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(0), Zm, Zx, ex_h, ex_l);
             }
+            stamp();  // 2 + 2l: MFMAs of layer l
             if (l < 8) activate<8, true>(Hh, Hl, Zm, Zx); else activate<8, false>(Hh, Hl, Zm, Zx);
+            stamp();  // 3 + 2l: activation pass
             if constexpr (SAVE == 2) {
                 if (valid) store_H(arow + 256 * l);   // l == 8: the (linear) feature vector at NSOS_ACTS_FEAT
             }
@@ -355,11 +371,13 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
 #pragma unroll
                     for (int o = 0; o < 2; ++o) sem_out[o] = both_halves(ps[o]);
                 }
+                stamp();  // 18 (l == 7 only; the later slots shift by one): sigma + semantic heads
             }
         }
         // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
         f32x16 vm[4], vx[4];
         static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), vm, vx, h_h, h_l); });
+        stamp();  // 21: view-branch MFMAs on the feature
         u32x4 edh[2], edl[2];   // the direction encoding is evaluated only now: its registers would not fit beside the trunk
         {
             float dv[3];
@@ -371,8 +389,10 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
             enc_slice<NSOS_DIR_FREQS, 0, false>(e, dv, kg, edh[0], edl[0]);
             enc_slice<NSOS_DIR_FREQS, 1, false>(e, dv, kg, edh[1], edl[1]);
         }
+        stamp();  // 22: direction encoding
         run_chunk(IC(8), IC(4), IC(0), IC(0), IC(8), IC(0), vm, vx, [&](auto sc) { return edh[decltype(sc)::value & 1]; },
                   [&](auto sc) { return edl[decltype(sc)::value & 1]; });   // 2 slices x 4 tiles = 8 items (16 groups)
+        stamp();  // 23: direction MFMAs
         if constexpr (SAVE == 2) {
             if (valid) {
                 store_slices(arow + NSOS_ACTS_D, IC(2), edh, edl);   // 27 features, zero pad
@@ -402,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 }
             }
         }
+        stamp();  // 24: rgb head + stores
     }
 #undef IC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -572,7 +593,7 @@ extern "C" int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_mode
 namespace {
 int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d, const float* viewdirs,
                    const float* z_vals, int64_t n_rays, int32_t n_samples, float* raw, float* sem_in, float* sem_hid,
-                   float* acts, int save, void* stream) {
+                   float* acts, int save, void* stream, unsigned long long* prof = nullptr) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
@@ -596,7 +617,7 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
-    p.sem_in = sem_in; p.sem_hid = sem_hid; p.acts = acts;
+    p.sem_in = sem_in; p.sem_hid = sem_hid; p.acts = acts; p.prof = prof;
     const hipStream_t st = (hipStream_t)stream;
     if (save == 1) return sem_mode == 1 ? launch_x3<1, 1>(p, st) : launch_x3<2, 1>(p, st);
     if (save == 2) return sem_mode == 0 ? launch_x3<0, 2>(p, st) : (sem_mode == 1 ? launch_x3<1, 2>(p, st) : launch_x3<2, 2>(p, st));
@@ -624,4 +645,13 @@ extern "C" int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t
                                                      const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                                      float* raw, float* acts, void* stream) {
     return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, acts, 2, stream);
+}
+
+extern "C" int32_t nsos_mlp_profile_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                            float* raw, uint64_t* stamps, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(stamps, NSOS_ERR_NULL_POINTER);
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, nullptr, 0, stream,
+                      reinterpret_cast<unsigned long long*>(stamps));
 }
