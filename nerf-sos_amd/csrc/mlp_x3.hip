@@ -183,8 +183,9 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
     // the part: a < NB the bias of tile a, else K-slice (a - NB) / NT of tile (a - NB) % NT.  2 NI groups (A operands) in
     // the skewed order  hi_0, [hi_k, lo_{k-1}] k = 1..NI-1, lo_{NI-1}.   ZF: the part starts the accumulation with its
     // slice 0 (C = 0) instead of with bias items.  NWORK: items that carry work (the rest is padding).
-    auto run_chunk = [&](auto ni_c, auto nt_c, auto nb_c, auto i0_c, auto nwork_c, auto zf_c, auto& Zm, auto& Zx, auto&& bh, auto&& bl)
-                         __attribute__((always_inline)) {
+    // ride(g): extra work placed in the MFMA shadows after group g (the SAVE == 2 activation stores)
+    auto run_chunk = [&](auto ni_c, auto nt_c, auto nb_c, auto i0_c, auto nwork_c, auto zf_c, auto& Zm, auto& Zx, auto&& bh, auto&& bl,
+                         auto&& ride) __attribute__((always_inline)) {
         constexpr int NI = decltype(ni_c)::value, NT = decltype(nt_c)::value, NB = decltype(nb_c)::value;
         constexpr int I0 = decltype(i0_c)::value, NWORK = decltype(nwork_c)::value, NG = 2 * NI;
         constexpr bool ZF = decltype(zf_c)::value != 0;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 }
             }
             dma_slot<g - kMid, kDmaPieces>(side);
+            ride(ic);
         }, mid, tail);
         // the accumulators are complete HERE: without a use at this point LLVM sinks whole chunks of MFMAs below later
         // branches (the encodings' range checks), keeping every A operand of the chunk alive in spill slots
@@ -296,34 +298,47 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         };
         const bool valid = gp < P.n_pts;
         float* const arow = SAVE == 2 ? P.acts + gc * NSOS_ACTS_DIM : nullptr;
+        auto no_ride = [](auto) {};
+        // store number CC * PER + j (of 32 per layer: tile t, register half u, word pair) after group 12 + j * (20 / PER) of chunk CC
+        auto ride_store = [&](auto gc_, auto cc_, auto per_, float* row) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc_)::value, CC = decltype(cc_)::value, PER = decltype(per_)::value, STRIDE = 20 / PER;
+            if constexpr (SAVE == 2 && g >= 12 && (g - 12) % STRIDE == 0 && (g - 12) / STRIDE < PER) {
+                constexpr int k = CC * PER + (g - 12) / STRIDE, t = k >> 2, u = (k >> 1) & 1, q = 2 * (k & 1);
+                const u32x4 hh = Hh[2 * t + u], hl = Hl[2 * t + u];
+                if (valid)
+                    *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                        f32x4{join<0>(hh[q], hl[q]), join<1>(hh[q], hl[q]), join<0>(hh[q + 1], hl[q + 1]), join<1>(hh[q + 1], hl[q + 1])};
+            }
+        };
         if constexpr (SAVE == 2) {
             if (valid) store_slices(arow + NSOS_ACTS_X, IC(4), exh, exl);   // slot 63 is the 1.0 pad
         }
 
         // pts_linears.0: 4 encoded slices x 8 tiles = 32 items in 2 chunks; slice 0 starts from C = 0
         stamp();  // 1: inputs + xyz encoding
-        run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(1), Zm, Zx, ex_h, ex_l);
-        run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(1), Zm, Zx, ex_h, ex_l);
+        run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(1), Zm, Zx, ex_h, ex_l, no_ride);
+        run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(1), Zm, Zx, ex_h, ex_l, no_ride);
         stamp();  // 2: L0 MFMAs
         activate<8, true>(Hh, Hl, Zm, Zx);
         stamp();  // 3: L0 activation
-        if constexpr (SAVE == 2) {
-            if (valid) store_H(arow);
-        }
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8): 8 bias + 128 slice items = 8 chunks of 17
 #pragma unroll 1
         for (int l = 1; l <= 8; ++l) {
-            static_for<0, 8>([&](auto cc) { run_chunk(IC(17), IC(8), IC(8), IC(17 * decltype(cc)::value), IC(17), IC(0), Zm, Zx, h_h, h_l); });
+            // SAVE == 2: the activations this layer consumes (H of layer l-1) are written to acts from inside its own MFMA stream,
+            // 4 x 16 B per lane per chunk: stores issued in a burst after the activation pass made the next chunk's barrier
+            // (a counted vmcnt) wait for HBM to take them
+            float* const prow = SAVE == 2 ? arow + 256 * (l - 1) : nullptr;
+            static_for<0, 8>([&](auto cc) {
+                run_chunk(IC(17), IC(8), IC(8), IC(17 * decltype(cc)::value), IC(17), IC(0), Zm, Zx, h_h, h_l,
+                          [&](auto gc) { ride_store(gc, cc, IC(4), prow); });
+            });
             if (l == 5) {   // skip connection: + W_x x63
-                run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(0), Zm, Zx, ex_h, ex_l);
-                run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(0), Zm, Zx, ex_h, ex_l);
+                run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(0), Zm, Zx, ex_h, ex_l, no_ride);
+                run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(0), Zm, Zx, ex_h, ex_l, no_ride);
             }
             stamp();  // 2 + 2l: MFMAs of layer l
             if (l < 8) activate<8, true>(Hh, Hl, Zm, Zx); else activate<8, false>(Hh, Hl, Zm, Zx);
             stamp();  // 3 + 2l: activation pass
-            if constexpr (SAVE == 2) {
-                if (valid) store_H(arow + 256 * l);   // l == 8: the (linear) feature vector at NSOS_ACTS_FEAT
-            }
             if (l == 7) {
                 // sigma head (models/nerf_mlp.py:77): three dot products of the split activations and split weights
                 const unsigned* awh = aux_l + kAuxAlphaHi + kg * 64;
@@ -351,8 +366,8 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 sigma = both_halves(__fmaf_rn(px, kLoUnscale, pa));
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80): 4 bias + 64 slice items = 4 chunks of 17
                     f32x16 sm[4], sx[4];
-                    static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), sm, sx, h_h, h_l); });
-                    if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sm, sx, ex_h, ex_l);
+                    static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), sm, sx, h_h, h_l, no_ride); });
+                    if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sm, sx, ex_h, ex_l, no_ride);
                     if constexpr (SAVE == 1) {
                         if (valid) {
                             float* row = P.sem_in + gp * 320;
@@ -376,7 +391,10 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         }
         // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
         f32x16 vm[4], vx[4];
-        static_for<0, 4>([&](auto cc) { run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), vm, vx, h_h, h_l); });
+        static_for<0, 4>([&](auto cc) {
+            run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), vm, vx, h_h, h_l,
+                      [&](auto gc) { ride_store(gc, cc, IC(8), SAVE == 2 ? arow + NSOS_ACTS_FEAT : nullptr); });   // H = the feature vector
+        });
         stamp();  // 21: view-branch MFMAs on the feature
         u32x4 edh[2], edl[2];   // the direction encoding is evaluated only now: its registers would not fit beside the trunk
         {
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         }
         stamp();  // 22: direction encoding
         run_chunk(IC(8), IC(4), IC(0), IC(0), IC(8), IC(0), vm, vx, [&](auto sc) { return edh[decltype(sc)::value & 1]; },
-                  [&](auto sc) { return edl[decltype(sc)::value & 1]; });   // 2 slices x 4 tiles = 8 items (16 groups)
+                  [&](auto sc) { return edl[decltype(sc)::value & 1]; }, no_ride);   // 2 slices x 4 tiles = 8 items (16 groups)
         stamp();  // 23: direction MFMAs
         if constexpr (SAVE == 2) {
             if (valid) {
