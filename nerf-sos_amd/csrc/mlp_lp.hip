@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
     // one chunk: NG groups, group g = A operand `a0 + g` of a part with NT output tiles and NB leading bias
     // A operands; the K-slice of A operand a >= NB is (a - NB) / NT, its tile (a - NB) % NT.
     // zf_c != 0: the part starts the accumulation (slice 0 uses C = 0 instead of the old accumulator contents).
-    auto run_chunk = [&](auto ng_c, auto nt_c, auto nb_c, auto a0_c, auto nwork_c, auto zf_c, auto& acc, auto&& bsel) {
+    // ride(g): extra work placed in the MFMA shadows after group g (the compact SAVE stores of the semantic head's input)
+    auto run_chunk = [&](auto ng_c, auto nt_c, auto nb_c, auto a0_c, auto nwork_c, auto zf_c, auto& acc, auto&& bsel, auto&& ride) {
         constexpr int NG = decltype(ng_c)::value, NT = decltype(nt_c)::value, NB = decltype(nb_c)::value;
         constexpr int A0 = decltype(a0_c)::value, NWORK = decltype(nwork_c)::value;
         constexpr bool ZF = decltype(zf_c)::value != 0;
@@ -291,8 +292,10 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                 }
                 dma_slot<(g - kMid) * 2 + c, kDmaPieces>(side);
             });
+            ride(ic);
         }, mid, tail);
     };
+    auto no_ride = [](auto) {};
 #define IC(n) std::integral_constant<int, (n)> {}
 
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
@@ -307,6 +310,8 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
         stamp();  // 0: tile start
         // ---- this lane's two points (column tile c: point tile*256 + wave*64 + c*32 + pj)
         int ray_of[2];  // n_rays <= n_pts < 2^31 * 256, rays themselves < 2^31 (checked at the entry point)
+        bool save_ok[2] = {false, false};       // SAVE, compact: this lane's point is in range and the 16-bit matrix is wanted
+        unsigned* save_row[2] = {nullptr, nullptr};
         u32x4 ex[2][4];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -316,6 +321,10 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
             const float z = P.z_vals[gc];
             float x[3];
             ray_of[c] = (int)ray;
+            if constexpr (SAVE) {
+                save_ok[c] = gp < P.n_pts && P.sem_in16 != nullptr;
+                save_row[c] = P.sem_in16 + gc * 160;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float m = P.rays_d[3 * ray + k] * z;  // models/sampler.py:70,166 (mul, then add)
@@ -339,18 +348,18 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 
         // pts_linears.0: 4 encoded slices x 8 tiles; the first slice of every tile starts from C = 0
         stamp();  // 1: inputs + xyz encoding
-        run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), Z, from_ex);
+        run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), Z, from_ex, no_ride);
         stamp();  // 2: L0 MFMAs
         activate<T, 8, true>(H, Z);
         stamp();  // 3: L0 activation
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8)
 #pragma unroll 1
         for (int l = 1; l <= 8; ++l) {
-            run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), Z, from_H);
-            run_chunk(IC(34), IC(8), IC(8), IC(34), IC(34), IC(0), Z, from_H);
-            run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), Z, from_H);
-            run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), Z, from_H);
-            if (l == 5) run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), Z, from_ex);  // skip connection
+            run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), Z, from_H, no_ride);
+            run_chunk(IC(34), IC(8), IC(8), IC(34), IC(34), IC(0), Z, from_H, no_ride);
+            run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), Z, from_H, no_ride);
+            run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), Z, from_H, no_ride);
+            if (l == 5) run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), Z, from_ex, no_ride);  // skip connection
             stamp();  // 2 + 2l: MFMAs of layer l
             if (l < 8) activate<T, 8, true>(H, Z); else activate<T, 8, false>(H, Z);
             stamp();  // 3 + 2l: activation pass
@@ -373,9 +382,28 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                 sigma[1] = both_halves(pa[1]);
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
                     f32x16 sacc[2][4];
-                    run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), sacc, from_H);
-                    run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), sacc, from_H);
-                    if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sacc, from_ex);
+                    // SAVE, compact sem_in: the 72 stores of [relu(h7) | x63 | 1] (packed words as they are) ride in these two chunks'
+                    // MFMA shadows, two per group from group 11 on -- as a burst they made the next barrier wait for HBM
+                    auto ride_sem = [&](auto gc_, auto ch_c) {
+                        constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
+                        if constexpr (SAVE && g >= 11) {
+                            static_for<0, 2>([&](auto jc) {
+                                constexpr int k = CH * 46 + (g - 11) * 2 + decltype(jc)::value;
+                                if constexpr (k < 64) {          // word pair (q, q+1) of slice 2t+u of column c = features 32t + 8(2u + q/2) + 4kg + {0..3}
+                                    constexpr int c = k >> 5, t = (k >> 2) & 7, u = (k >> 1) & 1, q = 2 * (k & 1);
+                                    if (save_ok[c])
+                                        *reinterpret_cast<u32x2*>(save_row[c] + (32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) / 2) =
+                                            u32x2{H[c][2 * t + u][q], H[c][2 * t + u][q + 1]};
+                                } else if constexpr (k < 72) {   // slice words = features 16s + 8kg + {0..7}; 63 is the 1.0 pad
+                                    constexpr int c = (k - 64) >> 2, sl = (k - 64) & 3;
+                                    if (save_ok[c]) *reinterpret_cast<u32x4*>(save_row[c] + 128 + 8 * sl + 4 * kg) = ex[c][sl];
+                                }
+                            });
+                        }
+                    };
+                    run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), sacc, from_H, [&](auto gc_) { ride_sem(gc_, IC(0)); });
+                    run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), sacc, from_H, [&](auto gc_) { ride_sem(gc_, IC(1)); });
+                    if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), sacc, from_ex, no_ride);
                     if constexpr (SAVE) {
                         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
                         auto relu_acc = [](float a) {   // AGPR read inside asm: see pack8_acc
@@ -386,20 +414,6 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const long long gp = (long long)tile * kTilePts + wave * 64 + c * 32 + pj;
-                            if (gp < P.n_pts && P.sem_in16) {   // compact: the packed words as they are (a word = 2 consecutive features)
-                                unsigned* row16 = P.sem_in16 + gp * 160;
-#pragma unroll
-                                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                        for (int q = 0; q < 4; q += 2)   // words q, q+1 = features 32t + 8(2u + q/2) + 4kg + {0..3}
-                                            *reinterpret_cast<u32x2*>(row16 + (32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) / 2) =
-                                                u32x2{H[c][2 * t + u][q], H[c][2 * t + u][q + 1]};
-#pragma unroll
-                                for (int sl = 0; sl < 4; ++sl)          // slice words = features 16s + 8kg + {0..7}; 63 is the 1.0 pad
-                                    *reinterpret_cast<u32x4*>(row16 + 128 + 8 * sl + 4 * kg) = ex[c][sl];
-                            }
                             if (gp < P.n_pts) {
                                 float* row = P.sem_in + gp * 320;
                                 float* hrow = P.sem_hid + gp * 128;
@@ -447,8 +461,8 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
         }
         // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
         f32x16 vacc[2][4];
-        run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), vacc, from_H);
-        run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), vacc, from_H);
+        run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), vacc, from_H, no_ride);
+        run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), vacc, from_H, no_ride);
         stamp();  // 21: view-branch MFMAs on the feature
         // the direction encoding is evaluated only now (12 sincos per column): keeping its 16 VGPRs alive through
         // the trunk pushes the kernel into spilling, and a spilled "pending" ring register is a race
@@ -465,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
         }
         auto from_ed = [&](auto cc, auto sc) { return ed[decltype(cc)::value][decltype(sc)::value]; };
         stamp();  // 22: direction encoding
-        run_chunk(IC(16), IC(4), IC(0), IC(0), IC(8), IC(0), vacc, from_ed);  // 2 slices x 4 tiles; groups 8..15 are padding
+        run_chunk(IC(16), IC(4), IC(0), IC(0), IC(8), IC(0), vacc, from_ed, no_ride);  // 2 slices x 4 tiles; groups 8..15 are padding
         stamp();  // 23: direction MFMAs
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
