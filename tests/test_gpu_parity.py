@@ -698,3 +698,38 @@ def test_per_call_kwargs_follow_the_reference(manifest):
     assert not torch.equal(noisy["rgb"], full["rgb"]) and noisy["weights"].shape == (20, 192)
     with pytest.raises(AssertionError):
         net((rays[0], rays[1][:10]), (tp.NEAR, tp.FAR))
+
+
+@pytest.mark.parametrize("which", ["fp32", "fp16", "fp16x3"])
+def test_phase_profile_entries_stamp_monotonically_and_leave_results_alone(manifest, which):
+    """The diagnostics entry points (nsos_mlp_profile_rays[_lp|_x3]: shader-clock stamps per kernel phase, the source of the
+    phase tables under profiles/) must not change the kernel's output, and their stamps must increase along a tile."""
+    import ctypes as C
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128).to(DEV).eval()
+    R, S = 700, 192                                  # > 2 tiles per workgroup on 256 CUs: the stamped (second) tile exists
+    rays = tp.synthetic_rays(R, seed=0).to(DEV)
+    near, far = torch.full((R,), tp.NEAR, device=DEV), torch.full((R,), tp.FAR, device=DEV)
+    z, v = ops.ray_setup(rays[1], near, far, S, None)
+    o, d = rays[0].contiguous(), rays[1].contiguous()
+    P_ = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    packed = net.nerf_fine.packed_weights(which)
+    raw = torch.empty(R, S, 4, device=DEV)
+    stamps = torch.zeros(16 * 64, dtype=torch.int64, device=DEV)
+    lib = _lib.lib()
+    if which == "fp32":
+        rc = lib.nsos_mlp_profile_rays(P_(packed), 0, P_(o), P_(d), P_(v), P_(z), R, S, P_(raw), P_(stamps), None)
+        want = ops.mlp_forward_rays(packed, 0, o, d, v, z)
+    elif which == "fp16":
+        rc = lib.nsos_mlp_profile_rays_lp(P_(packed), 0, 1, P_(o), P_(d), P_(v), P_(z), R, S, P_(raw), P_(stamps), None)
+        want = ops.mlp_forward_rays_lp(packed, 0, "fp16", o, d, v, z)
+    else:
+        rc = lib.nsos_mlp_profile_rays_x3(P_(packed), 0, P_(o), P_(d), P_(v), P_(z), R, S, P_(raw), P_(stamps), None)
+        want = ops.mlp_forward_rays_lp(packed, 0, "fp16x3", o, d, v, z)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(raw, want)
+    st = stamps.cpu().view(16, 64)
+    used = st[0] > 0
+    assert int(used.sum()) >= 8, "no stamps were taken"
+    seq = st[0][used]
+    assert (seq[1:] >= seq[:-1]).all()
