@@ -140,7 +140,9 @@ def main():
             "kernel_ms": round(f_alt_ms, 4),
             "algorithmic_tflops": round(2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE) / (f_alt_ms * 1e-3) / 1e12, 1),
             "issued_frac_of_f16_peak": round(3 * 2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE) / (f_alt_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-            "max_abs_rgb0_vs_exact_fp32": float((ref_c - exact_c).abs().max())}}
+            "max_abs_rgb0_vs_exact_fp32": float((ref_c - exact_c).abs().max()),
+            "parity": "same tests and bars as the exact kernel (2e-5 vs the reference goldens; error vs an fp64 evaluation equal "
+                      "to fp32 arithmetic's own: profiles/r01/k_accuracy_x3.json)"}}
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
