@@ -238,7 +238,7 @@ int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, 
  * acts [P,NSOS_ACTS_DIM] saved by nsos_mlp_forward_rays_save_all[_x3] it writes gbuf [P,NSOS_GBUF_DIM], the gradients
  * with respect to every layer's pre-activation in the column map of acts (256 l: pts_linears.l, NSOS_ACTS_FEAT:
  * feature_linear output, NSOS_ACTS_VIEWS: views_linears.0, NSOS_ACTS_SEM: semantic_linear.0), each the GEMM input of
- * nsos_wgrad.  `scale` (device scalar, a power of two bringing max |g_raw| to ~2^8) is applied to g_raw on load: all of
+ * nsos_wgrad.  `scale` (device scalar, a power of two bringing max |g_raw| to ~2^4) is applied to g_raw on load: all of
  * gbuf is scaled by it and the weight gradients must be divided by it.  Weights are packed (transposed, split fp16) by
  * nsos_mlp_bwd_pack_x3 into nsos_mlp_bwd_packed_bytes_x3 bytes. */
 #define NSOS_GBUF_DIM 2560

@@ -103,9 +103,11 @@ def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor,
     f32 = dict(device=dev, dtype=torch.float32)
     col = lambda a, n: acts[:, a:a + n]  # noqa: E731
     h = lambda l: col(W * l, W)          # noqa: E731
-    # fp16 has 5 exponent bits: bring the gradients to ~2^8 with an exact power of two (no host sync), undo on the results
+    # fp16 has 5 exponent bits: bring max |g_raw| to ~2^4 with an exact power of two (no host sync), undo on the results.
+    # 2^4 leaves a factor 2^12 of growth along the chain before fp16 overflows and 2^-18 of shrinkage before the hi parts
+    # go subnormal (layer gains of trained NeRFs are O(1)).
     amax = g_raw.abs().max().clamp_min(1e-30)
-    scale = torch.exp2(torch.floor(torch.log2(256.0 / amax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
+    scale = torch.exp2(torch.floor(torch.log2(16.0 / amax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
     inv = 1.0 / scale
     gbuf = ops.mlp_input_grads_x3(packed_bwd, sem_mode, g_raw, acts, scale)
     G = lambda a, n: gbuf[:, a:a + n]    # noqa: E731

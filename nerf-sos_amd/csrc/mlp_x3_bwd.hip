@@ -10,7 +10,7 @@
 // no bias items) and written to gbuf [P, NSOS_GBUF_DIM] in the column map of the saved activations, ready for the weight-
 // gradient kernel (nsos_wgrad).  Masks come from the activations nsos_mlp_forward_rays_save_all[_x3] stored.
 // Gradients have no natural scale, fp16 has 5 exponent bits: the caller passes a power-of-two `scale` (device scalar) that
-// brings max |g_raw| to ~2^8; everything in gbuf is scaled by it (the chain is linear), weight gradients are unscaled after
+// brings max |g_raw| to ~2^4; everything in gbuf is scaled by it (the chain is linear), weight gradients are unscaled after
 // nsos_wgrad.  Products: g_hi.W_hi + g_lo.W_hi + g_hi.(2^11 W_lo), fp32 accumulation, as in the forward kernel.
 #include "x3_common.h"
 
