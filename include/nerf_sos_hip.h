@@ -221,10 +221,13 @@ int32_t nsos_mlp_forward_rays_save_x3(const void* packed, int32_t sem_mode, cons
                                       const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                       float* raw, float* sem_in, float* sem_hid, void* stream);
 /* Full training (every parameter trainable) on the split-fp16 kernel: as nsos_mlp_forward_rays_save_all, acts holding
- * the fp32 values hi + lo each layer handed to the next; the backward (K7) is the fp32 path's. */
+ * the fp32 values hi + lo each layer handed to the next.  relu_masks (nsos_mlp_relu_masks_bytes_x3(n_pts) bytes, 16-byte
+ * aligned) receives the ReLU patterns of the 8 trunk layers as bits in the kernel's own lane order (32 B per point per
+ * layer instead of 1 KB of fp32 reads): the input of nsos_mlp_input_grads_x3. */
+size_t nsos_mlp_relu_masks_bytes_x3(int64_t n_pts);
 int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                           const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
-                                          float* raw, float* acts, void* stream);
+                                          float* raw, float* acts, void* relu_masks, void* stream);
 
 /* nsos_wgrad for M = N = 256 on the 16-bit matrix pipe: both operands split on the fly into fp16 hi + lo, three MFMAs per
  * product, fp32 accumulation (K7-X3).  |G| and |X| must be within fp16 range (G from nsos_mlp_input_grads_x3 is, by its
@@ -239,14 +242,16 @@ int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, 
  * with respect to every layer's pre-activation in the column map of acts (256 l: pts_linears.l, NSOS_ACTS_FEAT:
  * feature_linear output, NSOS_ACTS_VIEWS: views_linears.0, NSOS_ACTS_SEM: semantic_linear.0), each the GEMM input of
  * nsos_wgrad.  `scale` (device scalar, a power of two bringing max |g_raw| to ~2^4) is applied to g_raw on load: all of
- * gbuf is scaled by it and the weight gradients must be divided by it.  Weights are packed (transposed, split fp16) by
+ * gbuf is scaled by it and the weight gradients must be divided by it.  relu_masks: the bit masks written by
+ * nsos_mlp_forward_rays_save_all_x3 for the same points, or NULL to derive the trunk masks from acts (fp32 reads).
+ * Weights are packed (transposed, split fp16) by
  * nsos_mlp_bwd_pack_x3 into nsos_mlp_bwd_packed_bytes_x3 bytes. */
 #define NSOS_GBUF_DIM 2560
 size_t nsos_mlp_bwd_packed_bytes_x3(int32_t sem_mode);
 int32_t nsos_mlp_bwd_pack_x3(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
                              void* stream);
 int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode, const float* g_raw, const float* acts,
-                                int64_t n_pts, const float* scale, float* gbuf, void* stream);
+                                const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream);
 
 /* Diagnostics: nsos_mlp_forward_rays plus per-phase shader-clock stamps (s_memtime) of the first tile of
  * workgroups 0..3: stamps out uint64 [16 waves][64 slots] (slot meaning: scripts/phase_profile.py).

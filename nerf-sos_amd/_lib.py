@@ -49,10 +49,11 @@ SIGNATURES = {
     "nsos_mlp_pack_x3": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
     "nsos_mlp_forward_rays_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays_save_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
-    "nsos_mlp_forward_rays_save_all_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
+    "nsos_mlp_forward_rays_save_all_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
+    "nsos_mlp_relu_masks_bytes_x3": (_sz, [_i64]),
     "nsos_mlp_bwd_packed_bytes_x3": (_sz, [_i32]),
     "nsos_mlp_bwd_pack_x3": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
-    "nsos_mlp_input_grads_x3": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp, _fp]),
+    "nsos_mlp_input_grads_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _i64, _fp, _fp, _fp]),
     "nsos_mlp_profile_rays_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_profile_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),

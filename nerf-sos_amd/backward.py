@@ -94,7 +94,8 @@ def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor) ->
     return out
 
 
-def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor) -> Dict[str, torch.Tensor]:
+def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor,
+                    masks=None) -> Dict[str, torch.Tensor]:
     """Same result as mlp_backward with the input-gradient chain (nine GEMMs + ReLU masks) replaced by ONE fused
     split-fp16 kernel (nsos_mlp_input_grads_x3, csrc/mlp_x3_bwd.hip); the weight-gradient reductions are the same
     nsos_wgrad calls, fed from its output matrix.  `packed_bwd` = the net's packed_weights("fp16x3_bwd")."""
@@ -109,7 +110,7 @@ def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor,
     amax = g_raw.abs().max().clamp_min(1e-30)
     scale = torch.exp2(torch.floor(torch.log2(16.0 / amax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
     inv = 1.0 / scale
-    gbuf = ops.mlp_input_grads_x3(packed_bwd, sem_mode, g_raw, acts, scale)
+    gbuf = ops.mlp_input_grads_x3(packed_bwd, sem_mode, g_raw, acts, scale, masks)   # masks: ReLU bit masks of the forward, or None
     G = lambda a, n: gbuf[:, a:a + n]    # noqa: E731
     out: Dict[str, torch.Tensor] = {}
 

@@ -61,6 +61,7 @@ struct X3Params {
     float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
     float* acts;     // SAVE == 2 (full backward): [P, NSOS_ACTS_DIM] every layer's activations, see nerf_sos_hip.h
     unsigned long long* prof;  // diagnostics (nsos_mlp_profile_rays_x3): per-wave shader-clock stamps, or NULL
+    unsigned* masks;  // SAVE == 2: ReLU bit masks of the 8 trunk layers, [tile][layer][256 threads][4 words] (activate_bits)
 };
 constexpr int kProfSlots = 64;
 
@@ -85,6 +86,26 @@ __device__ __forceinline__ void enc_slice(const Enc<L, SliceHalf>& e, const floa
 }
 
 // Hh/Hl[2t+u] = split(relu?(Zm[t] + Zx[t])[8u .. 8u+7])   -- one batched VALU pass per layer
+// ... and the same pass for the full-training variant: additionally collects the layer's ReLU pattern as a per-lane bit mask,
+// bit 31 - ((t & 1) * 16 + r) of word t / 2 for accumulator element r of tile t (what mlp_x3_bwd.hip applies to the gradient)
+template <int NT>
+__device__ __forceinline__ void activate_bits(u32x4 (&Hh)[2 * NT], u32x4 (&Hl)[2 * NT], const f32x16 (&Zm)[NT], const f32x16 (&Zx)[NT],
+                                              u32x4& mask) {
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h, l, m = mask[t >> 1];
+                split2_acc_bits(Zm[t][8 * u + 2 * q], Zx[t][8 * u + 2 * q], Zm[t][8 * u + 2 * q + 1], Zx[t][8 * u + 2 * q + 1], h, l, m);
+                mask[t >> 1] = m;
+                Hh[2 * t + u][q] = h;
+                Hl[2 * t + u][q] = l;
+            }
+}
+
 template <int NT, bool RELU>
 __device__ __forceinline__ void activate(u32x4 (&Hh)[2 * NT], u32x4 (&Hl)[2 * NT], const f32x16 (&Zm)[NT], const f32x16 (&Zx)[NT]) {
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (the reads are inside asm)
@@ -319,7 +340,11 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         run_chunk(IC(16), IC(8), IC(0), IC(0), IC(16), IC(1), Zm, Zx, ex_h, ex_l, no_ride);
         run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(1), Zm, Zx, ex_h, ex_l, no_ride);
         stamp();  // 2: L0 MFMAs
-        activate<8, true>(Hh, Hl, Zm, Zx);
+        // SAVE == 2: the trunk layers' ReLU patterns go to P.masks as bits (16 B per lane per layer, one coalesced store)
+        u32x4 relu_bits = {0u, 0u, 0u, 0u};
+        u32x4* const mrow = SAVE == 2 ? reinterpret_cast<u32x4*>(P.masks) + (size_t)tile * 8 * 256 + threadIdx.x : nullptr;
+        if constexpr (SAVE == 2) { activate_bits<8>(Hh, Hl, Zm, Zx, relu_bits); mrow[0] = relu_bits; }
+        else activate<8, true>(Hh, Hl, Zm, Zx);
         stamp();  // 3: L0 activation
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8): 8 bias + 128 slice items = 8 chunks of 17
 #pragma unroll 1
@@ -337,7 +362,12 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                 run_chunk(IC(16), IC(8), IC(0), IC(16), IC(16), IC(0), Zm, Zx, ex_h, ex_l, no_ride);
             }
             stamp();  // 2 + 2l: MFMAs of layer l
-            if (l < 8) activate<8, true>(Hh, Hl, Zm, Zx); else activate<8, false>(Hh, Hl, Zm, Zx);
+            if (l < 8) {
+                if constexpr (SAVE == 2) { activate_bits<8>(Hh, Hl, Zm, Zx, relu_bits); mrow[256 * l] = relu_bits; }
+                else activate<8, true>(Hh, Hl, Zm, Zx);
+            } else {
+                activate<8, false>(Hh, Hl, Zm, Zx);
+            }
             stamp();  // 3 + 2l: activation pass
             if (l == 7) {
                 // sigma head (models/nerf_mlp.py:77): three dot products of the split activations and split weights
@@ -611,7 +641,7 @@ extern "C" int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_mode
 namespace {
 int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d, const float* viewdirs,
                    const float* z_vals, int64_t n_rays, int32_t n_samples, float* raw, float* sem_in, float* sem_hid,
-                   float* acts, int save, void* stream, unsigned long long* prof = nullptr) {
+                   float* acts, int save, void* stream, unsigned long long* prof = nullptr, unsigned* masks = nullptr) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
@@ -624,8 +654,8 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
         NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
     }
     if (save == 2) {
-        NSOS_REQUIRE(acts, NSOS_ERR_NULL_POINTER);
-        NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
+        NSOS_REQUIRE(acts && masks, NSOS_ERR_NULL_POINTER);
+        NSOS_REQUIRE(((uintptr_t)acts & 15) == 0 && ((uintptr_t)masks & 15) == 0, NSOS_ERR_MISALIGNED);
     }
     const long long n_pts = (long long)n_rays * n_samples;
     NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
@@ -635,7 +665,7 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
-    p.sem_in = sem_in; p.sem_hid = sem_hid; p.acts = acts; p.prof = prof;
+    p.sem_in = sem_in; p.sem_hid = sem_hid; p.acts = acts; p.prof = prof; p.masks = masks;
     const hipStream_t st = (hipStream_t)stream;
     if (save == 1) return sem_mode == 1 ? launch_x3<1, 1>(p, st) : launch_x3<2, 1>(p, st);
     if (save == 2) return sem_mode == 0 ? launch_x3<0, 2>(p, st) : (sem_mode == 1 ? launch_x3<1, 2>(p, st) : launch_x3<2, 2>(p, st));
@@ -661,8 +691,13 @@ extern "C" int32_t nsos_mlp_forward_rays_save_x3(const void* packed, int32_t sem
 
 extern "C" int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                                      const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
-                                                     float* raw, float* acts, void* stream) {
-    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, acts, 2, stream);
+                                                     float* raw, float* acts, void* relu_masks, void* stream) {
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, acts, 2, stream,
+                      nullptr, static_cast<unsigned*>(relu_masks));
+}
+
+extern "C" size_t nsos_mlp_relu_masks_bytes_x3(int64_t n_pts) {   // 8 trunk layers x 256 threads x 16 B per 128-point tile
+    return n_pts <= 0 ? 0 : (size_t)((n_pts + kTilePts - 1) / kTilePts) * 8 * 256 * 16;
 }
 
 extern "C" int32_t nsos_mlp_profile_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,

@@ -37,11 +37,13 @@ struct X3BwdParams {
     const float* acts;     // [P, NSOS_ACTS_DIM]
     float* gbuf;           // [P, NSOS_GBUF_DIM]
     const float* scale;    // device scalar, power of two
+    const unsigned* masks; // BITS: ReLU bit masks of the trunk layers from nsos_mlp_forward_rays_save_all_x3, [tile][layer][256][4]
     long long n_pts;
     int n_tiles;
 };
 
-template <int SEM>
+// BITS: the trunk layers' ReLU masks come as bits (one 16-byte load per lane per layer) instead of as the fp32 activations
+template <int SEM, bool BITS>
 __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -168,10 +170,16 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
             }
         };
         // ReLU masks of the NEXT pass: the first kMaskRing quads are requested before that layer's MFMA chunks start
-        f32x4 mk[kMaskRing];
-        auto preload = [&](const float* act) __attribute__((always_inline)) {
+        f32x4 mk[BITS ? 1 : kMaskRing];
+        u32x4 bits = {0u, 0u, 0u, 0u};
+        const u32x4* const mrow = BITS ? reinterpret_cast<const u32x4*>(P.masks) + (size_t)tile * 8 * 256 + threadIdx.x : nullptr;
+        auto preload = [&](const float* act, int layer) __attribute__((always_inline)) {
+            if constexpr (BITS) {
+                bits = mrow[256 * layer];
+            } else {
 #pragma unroll
-            for (int i = 0; i < kMaskRing; ++i) mk[i] = *reinterpret_cast<const f32x4*>(act + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
+                for (int i = 0; i < kMaskRing; ++i) mk[i] = *reinterpret_cast<const f32x4*>(act + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
+            }
         };
         // accumulators -> gbuf and the next product's split B operands: z = Zm + 2^-11 Zx [+ w_alpha g_sigma], [* (act > 0)]
         auto pass = [&](auto mask_c, auto alpha_c, const float* act, float* out) __attribute__((always_inline)) {
@@ -188,10 +196,11 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
                     asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_fmac_f32 %0, 0x3a000000, %1"
                                  : "=&v"(r), "=&v"(y) : "a"(Zm[t][4 * q + j]), "a"(Zx[t][4 * q + j]));
                     if constexpr (ALPHA) r = __fmaf_rn(aux_l[kBAuxAlphaW + kg * 128 + t * 16 + 4 * q + j], gr[3], r);
-                    if constexpr (MASK) r = mk[i % RING][j] > 0.0f ? r : 0.0f;
+                    if constexpr (MASK && BITS) r = (bits[t >> 1] >> (31 - ((t & 1) * 16 + 4 * q + j))) & 1u ? r : 0.0f;   // activate_bits' order
+                    if constexpr (MASK && !BITS) r = mk[i % RING][j] > 0.0f ? r : 0.0f;
                     z[j] = r;
                 }
-                if constexpr (MASK) {
+                if constexpr (MASK && !BITS) {
                     if (i + RING < 32)
                         mk[i % RING] = *reinterpret_cast<const f32x4*>(act + 32 * ((i + RING) >> 2) + 8 * ((i + RING) & 3) + 4 * kg);
                 }
@@ -209,8 +218,8 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
         static_for<0, 4>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(0), Zm, Zx, h_h, h_l); });
         pass(IC(0), IC(0), arow, grow + NSOS_ACTS_FEAT);
         // d/d h7 = g_feat @ W_feature (+ g_hs @ W_sem0[:, :256]) (+ g_sigma w_alpha, in the pass)
-        preload(arow + 256 * 7);
-        static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(decltype(cc)::value < 2 ? kMaskRing : 0), Zm, Zx, h_h, h_l); });   // pass(feat) loads nothing
+        preload(arow + 256 * 7, 7);
+        static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(decltype(cc)::value < 2 && !BITS ? kMaskRing : 0), Zm, Zx, h_h, h_l); });   // pass(feat) loads nothing
         if constexpr (SEM != 0) {
             head_grad(IC(2), arow + NSOS_ACTS_SEM, grow + NSOS_ACTS_SEM, aux_l + kBAuxSem2W + kg * 64, gr + 4);
             static_for<0, 4>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(0), IC(0), Zm, Zx, h_h, h_l); });
@@ -219,8 +228,8 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
         // trunk: g_z(l-1) = (g_z(l) @ W_l[:, h part]) * (h(l-1) > 0)
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
-            preload(arow + 256 * (l - 1));
-            static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(decltype(cc)::value < 2 ? 32 : 0), Zm, Zx, h_h, h_l); });   // 32 - ring refills + ring preloads
+            preload(arow + 256 * (l - 1), l - 1);
+            static_for<0, 8>([&](auto cc) { run_chunk(IC(16 * decltype(cc)::value), IC(1), IC(decltype(cc)::value < 2 && !BITS ? 32 : 0), Zm, Zx, h_h, h_l); });   // 32 - ring refills + ring preloads
             pass(IC(1), IC(0), arow + 256 * (l - 1), grow + 256 * (l - 1));
         }
     }
@@ -283,18 +292,18 @@ int x3_bwd_num_cus() {
 
 constexpr int kLdsBytes = kSlots * kSlotBytes + kBAuxWords * 4;
 
-template <int SEM>
+template <int SEM, bool BITS>
 int32_t launch_x3_bwd(const X3BwdParams& p, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_bwd_kernel<SEM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_bwd_kernel<SEM, BITS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
     static const int cus = x3_bwd_num_cus();
     const int grid = p.n_tiles < cus ? p.n_tiles : cus;
-    hipLaunchKernelGGL((mlp_x3_bwd_kernel<SEM>), dim3(grid), dim3(256), kLdsBytes, stream, p);
+    hipLaunchKernelGGL((mlp_x3_bwd_kernel<SEM, BITS>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();
 }
 
@@ -336,7 +345,7 @@ extern "C" int32_t nsos_mlp_bwd_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_
 }
 
 extern "C" int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode, const float* g_raw, const float* acts,
-                                           int64_t n_pts, const float* scale, float* gbuf, void* stream) {
+                                           const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream) {
     if (n_pts == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && g_raw && acts && scale && gbuf, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_pts > 0, NSOS_ERR_BAD_SHAPE);
@@ -346,9 +355,11 @@ extern "C" int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode,
     X3BwdParams p = {};
     p.aux = static_cast<const unsigned*>(packed);
     p.chunks = reinterpret_cast<const unsigned char*>(p.aux + kBAuxWords);
-    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.scale = scale;
+    NSOS_REQUIRE(((uintptr_t)relu_masks & 15) == 0, NSOS_ERR_MISALIGNED);
+    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.scale = scale; p.masks = static_cast<const unsigned*>(relu_masks);
     p.n_pts = n_pts;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
     const hipStream_t st = (hipStream_t)stream;
-    return sem_mode == 0 ? launch_x3_bwd<0>(p, st) : launch_x3_bwd<1>(p, st);
+    if (relu_masks) return sem_mode == 0 ? launch_x3_bwd<0, true>(p, st) : launch_x3_bwd<1, true>(p, st);
+    return sem_mode == 0 ? launch_x3_bwd<0, false>(p, st) : launch_x3_bwd<1, false>(p, st);
 }

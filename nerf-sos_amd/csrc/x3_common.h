@@ -59,6 +59,22 @@ __device__ __forceinline__ void split2_acc(const float& m0, const float& x0, con
                      "v_cvt_pk_f16_f32 %1, %2, %3"
                      : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1), "=&v"(t2) : "a"(m0), "a"(x0), "a"(m1), "a"(x1));
 }
+// ReLU variant that also shifts the two "z > 0" bits into a per-lane bit mask (first element first): v_sub_co 0 - bits(z) borrows
+// exactly when the clamped z is not +0, v_addc M + M + borrow appends the bit.  The masks replace fp32 reads in the backward.
+__device__ __forceinline__ void split2_acc_bits(const float& m0, const float& x0, const float& m1, const float& x1, unsigned& hi,
+                                                unsigned& lo, unsigned& mask) {
+    unsigned t0, t1, t2;
+    asm volatile("v_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %4, %7\n\tv_accvgpr_read_b32 %3, %8\n\t"
+                 "v_fmac_f32 %2, 0x3a000000, %4\n\tv_accvgpr_read_b32 %4, %9\n\tv_max_f32 %2, 0, %2\n\tv_fmac_f32 %3, 0x3a000000, %4\n\t"
+                 "v_max_f32 %3, 0, %3\n\t"
+                 "v_sub_co_u32 %4, vcc, 0, %2\n\tv_addc_co_u32 %5, vcc, %5, %5, vcc\n\t"
+                 "v_sub_co_u32 %4, vcc, 0, %3\n\tv_addc_co_u32 %5, vcc, %5, %5, vcc\n\t"
+                 "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                 "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_cvt_pk_f16_f32 %1, %2, %3"
+                 : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1), "=&v"(t2), "+v"(mask) : "a"(m0), "a"(x0), "a"(m1), "a"(x1) : "vcc");
+}
 __device__ __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
     asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
     return acc;

@@ -214,7 +214,7 @@ class _FullRender(torch.autograd.Function):
                 g_raw = g_raw + get("raw").reshape(g_raw.shape)
             if net.mlp_precision == "fp16x3":   # fused split-fp16 input-gradient chain (K7-X3) instead of GEMMs + mask passes
                 by_name = mlp_backward_x3(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
-                                          mlp.packed_weights("fp16x3_bwd"))
+                                          mlp.packed_weights("fp16x3_bwd"), sv["masks"])
             else:
                 by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]))
             grads += [by_name.get(n) for n in names]
@@ -298,9 +298,9 @@ class NeRFNet(nn.Module):
                                                    self.mlp_precision, rays_o, rays_d, viewdirs, z)
                 return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
             if save == "all":   # full backward (K7): every layer's activations (exact-fp32 or split-fp16 kernel)
-                raw, acts = ops.mlp_forward_rays_save_all(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o, rays_d,
-                                                          viewdirs, z, self.mlp_precision)
-                saved[tag] = dict(acts=acts, raw=raw, z=z)
+                raw, acts, masks = ops.mlp_forward_rays_save_all(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,
+                                                                 rays_d, viewdirs, z, self.mlp_precision)
+                saved[tag] = dict(acts=acts, raw=raw, z=z, masks=masks)
                 return raw
             raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,
                                                              rays_d, viewdirs, z, self.mlp_precision, compact=True)

@@ -431,7 +431,7 @@ ACTS_FEAT, ACTS_VIEWS, ACTS_SEM, ACTS_X, ACTS_D, ACTS_DIM = 2048, 2304, 2432, 25
 
 def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
                               viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32"):
-    """Training-mode K2 with every layer's activations stored: (raw [R,S,C], acts [R*S, ACTS_DIM]).
+    """Training-mode K2 with every layer's activations stored: (raw [R,S,C], acts [R*S, ACTS_DIM], relu bit masks or None).
     precision "fp32" (exact kernel) or "fp16x3" (split-fp16 kernel, fp32-accurate); `packed` must match."""
     if precision not in ("fp32", "fp16x3"):
         raise NotImplementedError("the full backward needs fp32-accurate activations: precision 'fp32' or 'fp16x3'")
@@ -441,28 +441,36 @@ def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch
     dev = z_vals.device
     raw = torch.empty((R, S, 4 if sem_mode == SEM_NONE else 6), device=dev, dtype=torch.float32)
     acts = torch.empty((R * S, ACTS_DIM), device=dev, dtype=torch.float32)
-    fn = "nsos_mlp_forward_rays_save_all" + ("_x3" if precision == "fp16x3" else "")
-    _lib.check(getattr(_lib.lib(), fn)(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
-                                       R, S, _p(raw), _p(acts), _stream()), fn)
-    return raw, acts
+    if precision == "fp16x3":   # also returns the trunk layers' ReLU patterns as bit masks (input of mlp_input_grads_x3)
+        masks = torch.empty(int(_lib.lib().nsos_mlp_relu_masks_bytes_x3(R * S)) // 4, device=dev, dtype=torch.int32)
+        _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
+                                                                _p(z_vals), R, S, _p(raw), _p(acts), _p(masks), _stream()),
+                   "nsos_mlp_forward_rays_save_all_x3")
+        return raw, acts, masks
+    _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
+                                                         R, S, _p(raw), _p(acts), _stream()), "nsos_mlp_forward_rays_save_all")
+    return raw, acts, None
 
 
 GBUF_DIM = 2560
 
 
 def mlp_input_grads_x3(packed_bwd: torch.Tensor, sem_mode: int, g_raw: torch.Tensor, acts: torch.Tensor,
-                       scale: torch.Tensor) -> torch.Tensor:
+                       scale: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused split-fp16 input-gradient chain of the full backward (K7-X3): gbuf [P, GBUF_DIM] = scale * (d loss / d every
     layer's pre-activation), columns as in `acts` (256 l | ACTS_FEAT | ACTS_VIEWS | ACTS_SEM).  `packed_bwd` comes from
-    pack_mlp(..., precision="fp16x3_bwd"); `scale` is a 1-element device tensor holding a power of two."""
+    pack_mlp(..., precision="fp16x3_bwd"); `scale` is a 1-element device tensor holding a power of two; `masks` = the bit
+    masks mlp_forward_rays_save_all(..., "fp16x3") returned for the same points (None: trunk masks are read from `acts`)."""
     g_raw, acts = _dev(g_raw, "g_raw"), _dev(acts, "acts")
     P_, C_ = g_raw.shape
     if C_ != (4 if sem_mode == SEM_NONE else 6) or acts.shape != (P_, ACTS_DIM) or not acts.is_contiguous():
         raise ValueError(f"mlp_input_grads_x3: g_raw {tuple(g_raw.shape)} / acts {tuple(acts.shape)} do not fit sem_mode {sem_mode}")
     scale = _dev(scale.reshape(1), "scale")
     gbuf = torch.empty((P_, GBUF_DIM), device=acts.device, dtype=torch.float32)
-    _lib.check(_lib.lib().nsos_mlp_input_grads_x3(_p(packed_bwd), sem_mode, _p(g_raw), _p(acts), P_, _p(scale), _p(gbuf),
-                                                  _stream()), "nsos_mlp_input_grads_x3")
+    if masks is not None and (not masks.is_cuda or masks.numel() * 4 < int(_lib.lib().nsos_mlp_relu_masks_bytes_x3(P_))):
+        raise ValueError("mlp_input_grads_x3: `masks` does not belong to these points")
+    _lib.check(_lib.lib().nsos_mlp_input_grads_x3(_p(packed_bwd), sem_mode, _p(g_raw), _p(acts), _p(masks), P_, _p(scale),
+                                                  _p(gbuf), _stream()), "nsos_mlp_input_grads_x3")
     return gbuf
 
 

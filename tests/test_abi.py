@@ -137,9 +137,11 @@ def test_split_fp16_entry_points_validate_without_a_gpu():
     assert lib.nsos_mlp_forward_rays_x3(p, 0, p, p, None, p, 4, 64, p, None) == -1             # NULL
     assert lib.nsos_mlp_forward_rays_x3(p, 3, p, p, p, p, 4, 64, p, None) == -3                # unknown semantic mode
     assert lib.nsos_mlp_forward_rays_save_x3(p, 0, p, p, p, p, 4, 64, p, p, p, None) == -3     # needs a semantic head
-    assert lib.nsos_mlp_forward_rays_save_all_x3(p, 0, p, p, p, p, 4, 64, p, None, None) == -1
-    assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, 0, p, p, None) == 0
-    assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, 5, None, p, None) == -1
+    assert lib.nsos_mlp_forward_rays_save_all_x3(p, 0, p, p, p, p, 4, 64, p, None, p, None) == -1
+    assert lib.nsos_mlp_forward_rays_save_all_x3(p, 0, p, p, p, p, 4, 64, p, p, None, None) == -1   # the bit masks are not optional
+    assert lib.nsos_mlp_relu_masks_bytes_x3(129) == 2 * 8 * 256 * 16 and lib.nsos_mlp_relu_masks_bytes_x3(0) == 0
+    assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, None, 0, p, p, None) == 0
+    assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, None, 5, None, p, None) == -1
     assert lib.nsos_mlp_bwd_pack_x3(None, 0, p, 1 << 30, None) == -1
     assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 0, 4, 4, p, p, p, p, p, 1 << 30, None) == -3     # fewer than 8 samples per ray
     assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 0, 4, 64, None, p, p, p, p, 1 << 30, None) == -1   # scale NULL

@@ -188,7 +188,9 @@ def test_fused_input_gradient_chain_vs_gemms(name, n_pts_rays):
     vd = rays[1] / rays[1].norm(dim=-1, keepdim=True)
     prm = {k[len("nerf_fine") + 5:]: t.to(DEV) for k, t in sd.items() if k.startswith("nerf_fine.mlp.")}
     args = [t.to(DEV).contiguous() for t in (rays[0], rays[1], vd, z)]
-    raw, acts = ops.mlp_forward_rays_save_all(ops.pack_mlp(prm, mode), mode, *args)
+    raw, acts, _ = ops.mlp_forward_rays_save_all(ops.pack_mlp(prm, mode), mode, *args)
+    # the split-fp16 forward also hands over the trunk layers' ReLU patterns as bit masks: its own activations, its own masks
+    raw3, acts3, masks3 = ops.mlp_forward_rays_save_all(ops.pack_mlp(prm, mode, precision="fp16x3"), mode, *args, precision="fp16x3")
     P, C = R * S, raw.shape[-1]
     g_raw = torch.randn(P, C, device=DEV, generator=torch.Generator(DEV).manual_seed(1)) * 3e-4
     col = lambda a, n: acts[:, a:a + n]  # noqa: E731
@@ -221,6 +223,13 @@ def test_fused_input_gradient_chain_vs_gemms(name, n_pts_rays):
         for got in outs:
             assert float((got[:, a:a + n] - want).abs().max()) <= 2e-6 * sc, (a, float((got[:, a:a + n] - want).abs().max()) / sc)
         assert float((outs[0][:, a:a + n] - outs[1][:, a:a + n]).abs().max()) <= 1e-6 * sc
+    # bit masks instead of fp32 mask reads: identical output on the split forward's own activations
+    scale = torch.exp2(torch.floor(torch.log2(16.0 / g_raw.abs().max()))).reshape(1)
+    with_bits = ops.mlp_input_grads_x3(packed, mode, g_raw, acts3, scale, masks3)
+    from_acts = ops.mlp_input_grads_x3(packed, mode, g_raw, acts3, scale, None)
+    assert torch.equal(with_bits[:, :ACTS_SEM], from_acts[:, :ACTS_SEM])
+    if mode:
+        assert torch.equal(with_bits[:, ACTS_SEM:], from_acts[:, ACTS_SEM:])
     assert (guard == 777.0).all()
 
 
