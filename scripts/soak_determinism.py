@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GPU box: race detector for the hand-synchronised kernels.  Every kernel on the path is deterministic by construction
+(block-ordered reductions, no atomics), so two identical training runs must end with BIT-IDENTICAL parameters; a counted
+`s_waitcnt`, an LDS ring slot or a relaxed chunk barrier that is wrong only sometimes shows up here as a mismatch.
+Runs N optimiser steps twice per mode and compares every parameter.   usage: soak_determinism.py [steps] [rays]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import nerf_sos_amd
+from oracle import torch_port as tp
+
+dev = torch.device("cuda:0")
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+
+
+def run(mode: str, precision: str):
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True, perturb=1.0,
+                               raw_noise_std=1.0).to(dev).train()
+    if mode == "frozen":                                  # run_nerf.py:307-318 (--fix_backbone)
+        for n_, p_ in net.named_parameters():
+            p_.requires_grad = "semantic_linear" in n_
+    net.mlp_precision = precision
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
+    rays = tp.synthetic_rays(R, seed=1).to(dev)
+    gen = torch.Generator(dev).manual_seed(7)
+    gt, gt_sem = torch.rand(R, 3, device=dev, generator=gen), torch.rand(R, 2, device=dev, generator=gen)
+    torch.manual_seed(123)                                # the render's own draws (jitter, sigma noise)
+    losses = []
+    for _ in range(STEPS):
+        opt.zero_grad()
+        ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+        loss = ((ret["semantics"] - gt_sem) ** 2).mean() + ((ret["semantics0"] - gt_sem) ** 2).mean()
+        if mode == "full":
+            loss = loss + ((ret["rgb"] - gt) ** 2).mean() + ((ret["rgb0"] - gt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    return {n: p.detach().clone() for n, p in net.named_parameters()}, losses
+
+
+out = {}
+ok_all = True
+for mode, precision in (("full", "fp32"), ("full", "fp16x3"), ("frozen", "fp32"), ("frozen", "fp16x3"), ("frozen", "bf16"), ("frozen", "fp16")):
+    a, la = run(mode, precision)
+    b, lb = run(mode, precision)
+    bad = [n for n in a if not torch.equal(a[n], b[n])]
+    finite = all(torch.isfinite(v).all() for v in a.values())
+    ok = not bad and la == lb and finite
+    ok_all &= ok
+    out[f"{mode}_{precision}"] = {"steps": STEPS, "rays": R, "bit_identical": not bad, "losses_identical": la == lb, "finite": finite,
+                                  "loss_first": la[0], "loss_last": la[-1], "mismatching": bad[:4]}
+    print(f"{mode:6s} {precision:7s}: {'OK' if ok else 'MISMATCH'}  loss {la[0]:.5f} -> {la[-1]:.5f}", flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/soak_determinism.json", "w"), indent=1)
+sys.exit(0 if ok_all else 1)
