@@ -1,53 +1,95 @@
 #!/usr/bin/env python3
 """rays/s of the NeRF-SOS render path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
 
-A step = one pass of the hot path (NeRFNet.forward: coarse 64 + fine 192 MLP evaluations per ray, both
-compositing passes, hierarchical resampling) over one synthetic batch already resident in HBM.
-Workload at any N: BASELINE.json configs[1] per GPU ("flower_full, 4096 rays x (64+128), fp32"): weak scaling,
-rays sharded across ranks, no data-path collective.  Prints ONE JSON line on rank 0.
+`--gpus N` with N > 1 launches its own N ranks (re-exec under `python -m torch.distributed.run --nproc-per-node N
+--master-addr 127.0.0.1`); it is equally happy to be started by torch.distributed.run itself (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment).  One process per GPU over RCCL; rank 0 prints ONE JSON line.
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM:
+  c2 (default, the headline): BASELINE configs[1] -- eval-mode NeRFNet.forward, 4096 rays/GPU x (64 coarse + 192 fine MLP
+      evaluations), exact-fp32 MFMA, no semantic head.  Weak scaling, rays sharded across ranks, NO data-path collective.
+  c3: configs[2] -- 4096 rays (one 64x64 patch), semantic head with coordinates, bf16: train-mode render + both
+      correlation losses + backward of the semantic heads (the shipped --fix_backbone recipe) + Adam.
+  c4: configs[3] -- 8192 rays/GPU (two 64x64 patches per GPU), the c3 step with the patch batch sharded over the GPUs:
+      ONE flat RCCL all-gather of the patch tensors the batch-wide losses read, ONE flat all-reduce of the gradients.
+  c5: configs[4] -- full-image eval 1008x756 in 65536-ray chunks, fp16 MFMA, rays generated on device, row blocks
+      sharded over the GPUs, on-device post-processing; a step = one image.
+The default run also measures c3 / c5 / c4 (and the split-fp16 kernel) briefly, OUTSIDE the timed region, and reports
+them under "variants", each with its own roofline.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-N_RAYS = 4096
 N_COARSE, N_IMPORTANCE = 64, 128
-MAC_PER_POINT = 593408            # matmul MACs of one MLP evaluation, no semantic head
-EVALS_PER_RAY = N_COARSE + (N_COARSE + N_IMPORTANCE)   # 64 coarse + 192 fine
-FLOP_PER_RAY = 2 * MAC_PER_POINT * EVALS_PER_RAY       # 303.82 MFLOP
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16, dense (the split-fp16 variant issues 3 of them per product)
+N_FINE = N_COARSE + N_IMPORTANCE
+MAC_NOSEM, MAC_SEMCOORD = 593408, 634496   # matmul MACs of one MLP evaluation
+EVALS_PER_RAY = N_COARSE + N_FINE           # 64 coarse + 192 fine
+PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0             # v_mfma_f32_32x32x16_{f16,bf16}, dense
+PATCH, PATCH_STRIDE = 64, 6                 # scripts/train_flower_node0.sh:4-6
 
 
-def cpu_baseline(n_rays_sample: int, budget_s: float = 25.0):
+def _self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: become the launcher."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    os.execv(sys.executable, cmd)
+
+
+def physical_cores() -> int:
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(n_rays: int, budget_s: float = 30.0):
     """The reference's CPU path = the pure-torch op-for-op port (bit-identical to the reference on CPU,
-    tests/golden/make_goldens.py), eval-mode forward, on a bounded sample of the workload.  torch's CPU
-    kernels do not scale to every logical CPU of the GPU box (measured: 256 threads are 35x SLOWER than 32 on
-    the 2x64-core EPYC host), so a few thread counts are tried inside the budget and the best is reported,
-    with the thread count actually used."""
-    from oracle import torch_port as tp
-    ncpu = os.cpu_count() or 1
+    tests/golden/make_goldens.py): eval-mode forward over the FULL 4096-ray batch of the headline workload.
+    torch's CPU kernels do not scale to every core of the GPU box (measured in round 1: 256 threads are 35x slower
+    than 32 on the 2x64-core host), so 32 threads first, then 64 if the budget allows; best run reported with the
+    thread count used."""
+    import torch
+    from oracle import torch_port as tp            # the checker, timed as the CPU baseline (never the product path)
+    ncpu, phys = os.cpu_count() or 1, physical_cores()
     cfg = tp.PortConfig(n_samples=N_COARSE, n_importance=N_IMPORTANCE, use_semantics=False, pts_chunk=1024 * 256)
     sd = tp.init_state_dict(cfg, seed=0)
-    rays = tp.synthetic_rays(n_rays_sample, seed=0)
+    rays = tp.synthetic_rays(n_rays, seed=0)
     best, best_threads, reps, t_all = float("inf"), 0, 0, time.perf_counter()
     with torch.no_grad():
-        for threads in sorted({min(ncpu, t) for t in (32, 16, 64)}, key=lambda t: abs(t - 32)):
-            if reps and (time.perf_counter() - t_all) > budget_s * 0.6:
+        for threads in (32, 64):
+            threads = min(threads, ncpu)
+            if reps and (time.perf_counter() - t_all) > budget_s * 0.45:
                 break
             torch.set_num_threads(threads)
-            tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)  # warm-up
-            for _ in range(3):
+            tp.render(sd, cfg, rays[:, :512], (tp.NEAR, tp.FAR), retraw=True)     # warm-up (thread pool, allocator)
+            for _ in range(2):
                 t0 = time.perf_counter()
                 tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
                 dt = time.perf_counter() - t0
@@ -56,144 +98,360 @@ def cpu_baseline(n_rays_sample: int, budget_s: float = 25.0):
                     best, best_threads = dt, threads
                 if (time.perf_counter() - t_all) > budget_s:
                     break
-    return {"value": round(n_rays_sample / best, 1), "unit": "rays/s", "cores": best_threads, "kind": "port",
-            "sample": f"{n_rays_sample} of the {N_RAYS} rays of the same batch, eval-mode forward, best of {reps} runs over "
-                      f"thread counts <= 64 (host has {ncpu} logical CPUs), torch {torch.__version__} CPU ops"}
+    return {"value": round(n_rays / best, 1), "unit": "rays/s", "cores": best_threads, "kind": "port",
+            "physical_cores": phys, "logical_cpus": ncpu,
+            "sample": f"the full {n_rays}-ray batch of the headline workload, eval-mode forward, best of {reps} runs "
+                      f"(thread counts 32 then 64; host has {phys} physical cores / {ncpu} logical CPUs), "
+                      f"torch {torch.__version__} CPU ops"}
 
 
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for f in ("mlp_fused.hip", "mlp_common.h"):
+        h.update(open(os.path.join(ROOT, "nerf-sos_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class Ctx:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        one_gpu = os.environ.get("NSOS_BENCH_SHARE_GPU") == "1"       # CI only: all ranks on cuda:0 over gloo
+        n_dev = torch.cuda.device_count()
+        if not one_gpu and n_dev < self.world:
+            raise SystemExit(f"bench.py: --gpus {self.world} but only {n_dev} GPU(s) visible")
+        self.dev = torch.device("cuda", 0 if one_gpu else self.local_rank)
+        torch.cuda.set_device(self.dev)
+        self.backend = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.backend = "gloo" if one_gpu else "nccl"
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def ranks_seen(self) -> int:
+        """Number of ranks the collective library really connected: an all-reduce of ones on the GPU."""
+        t = self.torch.ones(1, device=self.dev)
+        if self.world > 1:
+            self.dist.all_reduce(t)
+        return int(t.item())
+
+    def gather_times(self, dt: float):
+        t = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
+        if self.world == 1:
+            return [dt]
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+
+
+def timed(ctx, step, warmup: int, steps: int):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides.  Returns
+    (max-over-ranks seconds, per-rank seconds, MLP kernel events recorded inside the timed region)."""
+    from nerf_sos_amd import ops
+    for i in range(warmup):
+        step(i)
+    ctx.barrier()
+    ops.KERNEL_EVENTS = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    ctx.torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    per_rank = ctx.gather_times(dt_own)
+    return max([dt] + per_rank) if ctx.world > 1 else dt, per_rank, events
+
+
+def kernel_roofline(events, n_points: int, mac_per_point: int, peak: float, kernel: str, extra=None):
+    """Dominant kernel = the fine-pass fused MLP launch: algorithmic FLOPs / mean HIP-event duration of those launches."""
+    ms = [a.elapsed_time(b) for (n_pts, a, b) in events if n_pts == n_points]
+    if not ms:
+        return None
+    mean_ms = sum(ms) / len(ms)
+    achieved = 2.0 * mac_per_point * n_points / (mean_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(achieved / peak, 4), "traffic": None, "kernel": kernel, "kernel_ms": round(mean_ms, 4),
+         "launches_timed": len(ms)}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def speed_fields(ctx, rays_per_rank_step: int, steps: int, dt: float, per_rank):
+    rates = [rays_per_rank_step * steps / t for t in per_rank]
+    return {"value": round(ctx.world * rays_per_rank_step * steps / dt, 1), "unit": "rays/s",
+            "ms_per_step": round(1e3 * dt / steps, 4),
+            "per_rank_rays_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1)}}
+
+
+# ------------------------------------------------------------------------------------------------------------------ c2
+def run_c2(ctx, args, precision="fp32", steps=None, warmup=None):
+    import nerf_sos_amd
+    from nerf_sos_amd import synthetic as syn
+    torch = ctx.torch
+    n_rays = 4096
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=False,
+                               perturb=1.0, raw_noise_std=1.0).to(ctx.dev).eval()
+    net.mlp_precision = precision
+    rays = syn.synthetic_rays(n_rays, seed=ctx.rank, device=ctx.dev)       # resident in HBM before the timed region
+    out = {}
+
+    def step(i):
+        with torch.no_grad():
+            out["ret"] = net(rays, (syn.NEAR, syn.FAR))
+
+    dt, per_rank, events = timed(ctx, step, args.warmup if warmup is None else warmup, args.steps if steps is None else steps)
+    assert out["ret"]["rgb"].shape == (n_rays, 3)
+    k = steps or args.steps
+    res = speed_fields(ctx, n_rays, k, dt, per_rank)
+    flop_per_ray = 2 * MAC_NOSEM * EVALS_PER_RAY
+    if precision == "fp32":
+        roof = kernel_roofline(events, n_rays * N_FINE, MAC_NOSEM, PEAK_FP32_MFMA_TFLOPS,
+                               "mlp_fused_kernel<0,true> (fine pass, 786432 points)")
+        peak = PEAK_FP32_MFMA_TFLOPS
+    else:
+        roof = kernel_roofline(events, n_rays * N_FINE, MAC_NOSEM, PEAK_16BIT_MFMA_TFLOPS,
+                               "mlp_x3_kernel<0> (fine pass, 786432 points)")
+        roof["issued_frac"] = round(3 * roof["frac"], 4)   # three 16-bit MFMAs per product
+        peak = PEAK_16BIT_MFMA_TFLOPS
+    roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
+    res.update(roofline=roof, flop_per_ray=flop_per_ray, rays_per_gpu=n_rays, out=out["ret"], net=net, rays=rays)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------- c3 / c4
+def _loss_args():
+    import types
+    # scripts/train_fortress_node0.sh: --use_correlation --use_geoCorr, app/geo parameters of the shipped recipe
+    return types.SimpleNamespace(rand_neg=False, self_corr_w=0, use_sim_matrix=True, patch_stride=PATCH_STRIDE,
+                                 app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
+
+
+def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: int, warmup: int):
+    """c3 (1 patch, 1 GPU) and c4 (2 patches per GPU, sharded): frozen-backbone training step on 64x64 patches."""
+    import nerf_sos_amd
+    from nerf_sos_amd import sharding, synthetic as syn
+    torch = ctx.torch
+    B = patches_per_gpu * ctx.world
+    own = sharding.local_patches(B, ctx.rank, ctx.world)
+    torch.manual_seed(0)                                          # same weights on every rank (one checkpoint in a real run)
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True,
+                               perturb=1.0, raw_noise_std=1.0, ray_chunk=1 << 20).to(ctx.dev)
+    for n_, p_ in net.named_parameters():                         # run_nerf.py:307-318 (--fix_backbone)
+        p_.requires_grad = "semantic_linear" in n_
+    net.train()
+    net.mlp_precision = precision
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
+    corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+    all_rays = syn.synthetic_patches(B, PATCH, PATCH_STRIDE, seed=0, device=ctx.dev)
+    rays = all_rays[:, own].contiguous()
+    # DINO features / class tokens of the rank's OWN ground-truth crops (DINO itself is outside the path): random, seeded by
+    # the global patch id, so that every world size sees the same batch
+    feat = torch.stack([torch.randn(384, 14, 14, generator=torch.Generator().manual_seed(1000 + b)) for b in own]).to(ctx.dev)
+    cls_ = torch.stack([torch.randn(384, generator=torch.Generator().manual_seed(2000 + b)) for b in own]).to(ctx.dev)
+    timings, state = {}, {}
+
+    def step(i):
+        opt.zero_grad(set_to_none=False)
+        state["loss"] = sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo,
+                                                    correlation_w=1.0, geo_w=0.01, step=i, seed=0,
+                                                    timings=timings if state.get("timed") else None)
+        opt.step()
+
+    for i in range(warmup):
+        step(i)
+    state["timed"] = True
+    dt, per_rank, events = timed(ctx, step, 0, steps)
+    n_rays = len(own) * PATCH * PATCH
+    res = speed_fields(ctx, n_rays, steps, dt, per_rank)
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+    kname = {"fp32": "mlp_fused_kernel<2,true,1>", "fp16x3": "mlp_x3_kernel<2,1>"}.get(precision, f"mlp_lp_kernel<{precision},2,SAVE>")
+    roof = kernel_roofline(events, n_rays * N_FINE, MAC_SEMCOORD, peak, f"{kname} (fine pass of the rank's {n_rays} rays, {n_rays * N_FINE} points)")
+    flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
+    if roof:
+        roof["whole_step_frac_forward_flops_only"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
+
+    def mean_ms(pairs):
+        v = [a.elapsed_time(b) for a, b in pairs]
+        return round(sum(v) / max(1, len(v)), 4)
+
+    st = timings.get("stats", {})
+    res.update(roofline=roof, rays_per_gpu=n_rays, patches=B, loss=round(float(state["loss"]), 6), precision=precision,
+               collectives={"backend": ctx.backend, "all_gather_ms": mean_ms(timings.get("gather", [])),
+                            "all_reduce_ms": mean_ms(timings.get("allreduce", [])),
+                            "gathered_bytes_per_patch": st.get("bytes_per_patch"),
+                            "gathered_keys": list(sharding.PATCH_KEYS), "all_gathers_per_step": st.get("collectives", 0 if ctx.world == 1 else None),
+                            "all_reduce_floats": sum(p.numel() for p in net.parameters() if p.requires_grad)})
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------ c5
+def run_c5(ctx, args, precision: str, steps: int, warmup: int):
+    """Full-image eval: every rank renders its contiguous block of the 762 048 rays in 65 536-ray chunks (rays generated
+    on device from the pose, `raw` never materialised) and post-processes its rows on device."""
+    import nerf_sos_amd
+    from nerf_sos_amd import ops, sharding, synthetic as syn
+    torch = ctx.torch
+    chunk = 65536
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True,
+                               perturb=1.0, raw_noise_std=1.0, ray_chunk=chunk).to(ctx.dev).eval()
+    net.mlp_precision = precision
+    s, e = sharding.shard_bounds(syn.H * syn.W, ctx.rank, ctx.world)
+    state = {}
+
+    def step(i):
+        with torch.no_grad():
+            rays = syn.image_rays(ctx.dev, (s, e))
+            ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+            state["post"] = ops.eval_postprocess(semantics=ret["semantics"])
+            state["rgb"] = ret["rgb"]
+
+    dt, per_rank, events = timed(ctx, step, warmup, steps)
+    n_rays = e - s
+    res = speed_fields(ctx, n_rays, steps, dt, per_rank)
+    # the total over ranks is the image, not world x the first rank's block
+    res["value"] = round(syn.H * syn.W * steps / dt, 1)
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+    full_chunk = min(chunk, n_rays)
+    roof = kernel_roofline(events, full_chunk * N_FINE, MAC_SEMCOORD, peak,
+                           f"mlp_lp_kernel<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)")
+    flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
+    if roof:
+        roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
+    res.update(roofline=roof, rays_per_gpu=n_rays, precision=precision, image=f"{syn.W}x{syn.H}", chunk=chunk,
+               finite=bool(torch.isfinite(state["rgb"]).all().item()))
+    return res
+
+
+def _strip(res):
+    return {k: v for k, v in res.items() if k not in ("out", "net", "rays")}
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2",
+                    help="BASELINE.json configs[1..4]; c2 is the headline the metric is quoted on")
+    ap.add_argument("--precision", choices=("fp32", "fp16x3", "bf16", "fp16"), default=None,
+                    help="MLP arithmetic; default: fp32 for c2 (the reference's), bf16 for c3/c4, fp16 for c5 (BASELINE's dtypes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=("fp32", "fp16x3"), default="fp32",
-                    help="fp32: exact-fp32 MFMA kernel (the headline).  fp16x3: split-fp16 kernel, fp32-grade results "
-                         "(DESIGN.md 4.6b); without this flag it is measured as a side note under \"variants\"")
+    ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
+    _self_launch(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctx = Ctx(args)
+    torch = ctx.torch
+    seen = ctx.ranks_seen()
+    prec = args.precision or {"c2": "fp32", "c3": "bf16", "c4": "bf16", "c5": "fp16"}[args.config]
+    dist_info = {"backend": ctx.backend, "ranks_seen_by_collective": seen}
 
-    import nerf_sos_amd
-    from nerf_sos_amd import ops
-    from oracle import torch_port as tp  # synthetic ray generator only (inputs, not arithmetic)
+    line = {"metric": "rays/sec (coarse+fine, 64+128 samples)", "unit": "rays/s", "n_gpus": ctx.world, "steps": args.steps,
+            "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    variants = {}
 
-    torch.manual_seed(0)
-    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=False,
-                               perturb=1.0, raw_noise_std=1.0).to(dev).eval()
-    net.mlp_precision = args.precision
-    rays = tp.synthetic_rays(N_RAYS, seed=rank).to(dev)     # resident in HBM before the timed region
+    if args.config == "c2":
+        if prec not in ("fp32", "fp16x3"):
+            raise SystemExit("bench.py: c2 is the fp32 configuration: --precision fp32 (exact) or fp16x3 (split-fp16, fp32-grade)")
+        res = run_c2(ctx, args, prec)
+        roof = res["roofline"]
+        if prec == "fp32":
+            tj = os.path.join(ROOT, "profiles", "r02", "traffic.json")       # PMC passes of this same command (separate runs)
+            if os.path.exists(tj):
+                t = json.load(open(tj))
+                if t.get("kernel_source_sha16") == kernel_source_hash():
+                    roof["traffic"] = t.get("hbm_bytes_per_launch")
+                    roof["traffic_note"] = t.get("note")
+                else:
+                    roof["traffic_note"] = "profiles/r02/traffic.json was measured on a different build of the kernel: not reported"
+        line.update({k: res[k] for k in ("value", "ms_per_step", "per_rank_rays_per_s")})
+        line["dtype"] = "f32" if prec == "fp32" else "f16x3 (split-fp16 operands, fp32 accumulate, fp32-grade results)"
+        line["config"] = {"workload": "BASELINE configs[1]: LLFF flower_full shape, 4096 rays/GPU x (64 coarse + 192 fine MLP "
+                                      "evaluations), eval-mode NeRFNet.forward, " +
+                                      ("fp32 exact-MFMA" if prec == "fp32" else "split-fp16 MFMA (fp32-grade)") +
+                                      ", no semantic head, random-init weights (seed 0), pinhole rays 1008x756 f=850",
+                          "rays_per_gpu": res["rays_per_gpu"], "parallelism": f"ray-sharded x{ctx.world}, no collective in the path",
+                          "flop_per_ray": res["flop_per_ray"]}
+        line["roofline"] = roof
+        if not args.no_variants:
+            vsteps = max(3, min(args.steps, 10))
+            if ctx.world == 1 and prec == "fp32":
+                exact_c = res["out"]["rgb0"]
+                alt = run_c2(ctx, args, "fp16x3", steps=vsteps, warmup=2)
+                v = _strip(alt)
+                v["what"] = "the c2 step with the MLP on the 16-bit matrix pipe, split-fp16 operands (3 MFMAs per product, fp32 accumulate)"
+                v["max_abs_rgb0_vs_exact_fp32"] = float((alt["out"]["rgb0"] - exact_c).abs().max())
+                v["parity"] = "same tests and bars as the exact kernel (2e-5 vs the reference goldens)"
+                variants["c2_fp16x3"] = v
+                v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 3))
+                v["what"] = "BASELINE configs[2]: one 64x64 patch = 4096 rays, sem+coord head, bf16 MFMA: train-mode render + appearance & geometric correlation losses + semantic-head backward + Adam"
+                variants["c3_bf16"] = v
+                v = _strip(run_c5(ctx, args, "fp16", 2, 1))
+                v["what"] = "BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device softmax/argmax; a step = one image"
+                variants["c5_fp16"] = v
+            v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 3))
+            v["what"] = ("BASELINE configs[3]: 8192 rays/GPU (2 patches of 64x64 per GPU), the c3 step sharded over the GPUs: one flat "
+                         "all-gather of semantics0/semantics/depth/feat/cls_/ray_o/ray_d, one flat gradient all-reduce")
+            variants["c4_bf16"] = v
+    elif args.config in ("c3", "c4"):
+        if args.config == "c3" and ctx.world != 1:
+            raise SystemExit("bench.py: c3 is the single-GPU configuration; the sharded one is c4")
+        res = _strip(run_patch_training(ctx, args, 1 if args.config == "c3" else 2, prec, args.steps, args.warmup))
+        line.update({k: res[k] for k in ("value", "ms_per_step", "per_rank_rays_per_s")})
+        line["dtype"] = {"fp32": "f32", "fp16x3": "f16x3"}.get(prec, prec)
+        line["config"] = {"workload": ("BASELINE configs[2]: 4096 rays = one 64x64 patch" if args.config == "c3" else
+                                       "BASELINE configs[3]: 8192 rays/GPU = two 64x64 patches per GPU, patch batch sharded over the GPUs "
+                                       "(RCCL all-gather of the patch tensors + gradient all-reduce)") +
+                                      f", (64+192) MLP evaluations/ray, sem+coord head, {prec} MLP, train mode, appearance + geometric "
+                                      "correlation losses, semantic-head backward (--fix_backbone recipe), Adam",
+                          "rays_per_gpu": res["rays_per_gpu"], "patches": res["patches"], "parallelism": f"patch-sharded x{ctx.world}",
+                          "flop_per_ray_forward": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
+        line["roofline"] = res["roofline"]
+        line["collectives"] = res["collectives"]
+        line["loss"] = res["loss"]
+    else:
+        res = _strip(run_c5(ctx, args, prec, args.steps, args.warmup))
+        line.update({k: res[k] for k in ("value", "ms_per_step", "per_rank_rays_per_s")})
+        line["scaling"] = "strong"
+        line["dtype"] = {"fp32": "f32", "fp16x3": "f16x3"}.get(prec, prec)
+        line["config"] = {"workload": f"BASELINE configs[4]: full-image render {res['image']} = 762048 rays in {res['chunk']}-ray chunks, "
+                                      f"eval mode, sem+coord head, {prec} MLP, rays generated on device, on-device post-processing; step = one image",
+                          "rays_per_gpu": res["rays_per_gpu"], "parallelism": f"row blocks sharded x{ctx.world}, no collective",
+                          "flop_per_ray": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
+        line["roofline"] = res["roofline"]
+        line["finite"] = res["finite"]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            net(rays, (tp.NEAR, tp.FAR))
-        barrier()
-        ops.KERNEL_EVENTS = []                               # live HIP-event timing of every MLP launch
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = net(rays, (tp.NEAR, tp.FAR))
-        barrier()
-        dt = time.perf_counter() - t0
-    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-    assert out["rgb"].shape == (N_RAYS, 3)
-
-    variants = None
-    if world == 1 and args.precision == "fp32":
-        # side note, outside the timed region: the same step on the split-fp16 kernel (fp32-grade results, see
-        # tests/test_gpu_parity.py::test_mlp_x3_is_fp32_grade) and how far its coarse pass is from the exact path's
-        net.mlp_precision = "fp16x3"
-        with torch.no_grad():
-            for _ in range(2):
-                alt = net(rays, (tp.NEAR, tp.FAR))
-            ref_c = alt["rgb0"]                            # eval mode: no perturbation, no noise
-            torch.cuda.synchronize()
-            ops.KERNEL_EVENTS = []
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                alt = net(rays, (tp.NEAR, tp.FAR))
-            torch.cuda.synchronize()
-            dt_alt = time.perf_counter() - t1
-            ev_alt, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-            net.mlp_precision = "fp32"
-            exact_c = out["rgb0"]
-        f_alt = [a.elapsed_time(b) for (n_pts, a, b) in ev_alt if n_pts == N_RAYS * (N_COARSE + N_IMPORTANCE)]
-        f_alt_ms = sum(f_alt) / max(1, len(f_alt))
-        variants = {"fp16x3": {
-            "what": "same step, MLP on the 16-bit matrix pipe with split-fp16 operands (3 MFMAs per product, fp32 accumulate)",
-            "value": round(N_RAYS * args.steps / dt_alt, 1), "unit": "rays/s", "ms_per_step": round(1e3 * dt_alt / args.steps, 4),
-            "kernel_ms": round(f_alt_ms, 4),
-            "algorithmic_tflops": round(2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE) / (f_alt_ms * 1e-3) / 1e12, 1),
-            "issued_frac_of_f16_peak": round(3 * 2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE) / (f_alt_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-            "max_abs_rgb0_vs_exact_fp32": float((ref_c - exact_c).abs().max()),
-            "parity": "same tests and bars as the exact kernel (2e-5 vs the reference goldens; error vs an fp64 evaluation equal "
-                      "to fp32 arithmetic's own: profiles/r01/k_accuracy_x3.json)"}}
-
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-
-    # dominant kernel = the fine-pass fused MLP launch (786 432 points): algorithmic FLOPs / mean duration
-    fine = [a.elapsed_time(b) for (n_pts, a, b) in events if n_pts == N_RAYS * (N_COARSE + N_IMPORTANCE)]
-    fine_ms = sum(fine) / max(1, len(fine))
-    fine_flop = 2.0 * MAC_PER_POINT * N_RAYS * (N_COARSE + N_IMPORTANCE)
-    achieved = fine_flop / (fine_ms * 1e-3) / 1e12 if fine else 0.0
-
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01", "traffic.json")   # PMC passes of this same command (separate runs)
-    if os.path.exists(tj):
-        traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-
-    if rank == 0:
-        value = world * N_RAYS * args.steps / dt
-        line = {
-            "metric": "rays/sec (coarse+fine, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: LLFF flower_full shape, 4096 rays/GPU x (64 coarse + 192 fine "
-                                   "MLP evaluations), eval-mode NeRFNet.forward, fp32 exact-MFMA, no semantic head, "
-                                   "random-init weights (seed 0), pinhole rays 1008x756 f=850",
-                       "rays_per_gpu": N_RAYS, "parallelism": f"ray-sharded x{world}, no collective in the path",
-                       "flop_per_ray": FLOP_PER_RAY},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per fine-pass launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01/traffic.json",
-                         "kernel": "mlp_fused_kernel<0,true> (fine pass, 786432 points)",
-                         "kernel_ms": round(fine_ms, 4), "launches_timed": len(fine),
-                         "whole_path_frac": round(value / world * FLOP_PER_RAY / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
-        }
-        if args.precision == "fp16x3":
-            issued = 3 * achieved
-            line["dtype"] = "f16x3 (split-fp16 operands, fp32 accumulate, fp32-grade results)"
-            line["config"]["workload"] = line["config"]["workload"].replace("fp32 exact-MFMA", "split-fp16 MFMA (fp32-grade)")
-            line["roofline"].update({"peak": PEAK_F16_MFMA_TFLOPS, "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                                     "issued_frac": round(issued / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
-                                     "kernel": "mlp_x3_kernel<0> (fine pass, 786432 points)",
-                                     "whole_path_frac": round(value / world * FLOP_PER_RAY / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)})
-        if variants:
-            line["variants"] = variants
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(1024)
+    line["distributed"] = dist_info
+    if variants:
+        line["variants"] = variants
+    if ctx.rank == 0:
+        if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c2":
+            line["cpu_baseline"] = cpu_baseline(4096)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -36,14 +36,15 @@ class GraphedRender:
         self._versions = self._param_versions()
 
     def _param_versions(self):
-        return tuple(p._version for p in self.net.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self.net.parameters())
 
     def __call__(self, ray_batch) -> Dict[str, torch.Tensor]:
         rays_o, rays_d = ray_batch
         if rays_o.numel() != self.n_rays * 3 or rays_d.numel() != self.n_rays * 3:
             raise ValueError(f"captured for {self.n_rays} rays")
         if self._param_versions() != self._versions:
-            raise RuntimeError("parameters changed since capture (the packed weight stream is baked into the graph): re-capture")
+            raise RuntimeError("parameters changed (or moved) since capture (the packed weight stream is baked into the graph): "
+                               "re-capture.  Edits through `.data` are invisible here: call net.invalidate_packed() and re-capture")
         self._rays[0].copy_(rays_o.reshape(self.n_rays, 3))
         self._rays[1].copy_(rays_d.reshape(self.n_rays, 3))
         self.graph.replay()

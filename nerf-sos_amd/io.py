@@ -97,4 +97,10 @@ class PreparedScene:
         ray-sharded rank renders).  Equal bit for bit to the stored `rays_<split>.npy` of a reference-prepared scene."""
         if self.poses is None:
             raise IOError("poses_<split>.npy is missing (prepare the scene with --w_pose, data/gen_dataset.py:223-230)")
+        mh, mw = self.meta_dict.get('H', self.height), self.meta_dict.get('W', self.width)
+        if (int(mh), int(mw)) != (self.height, self.width):
+            # `_x{subsample}` arrays: meta.json's focal / principal point describe the full-resolution camera, and the
+            # reference's sub-sampled ray files are not a pure rescaling of K -- refuse rather than return wrong rays
+            raise NotImplementedError(f"rays_on_device: the loaded arrays are {self.height}x{self.width} but meta.json "
+                                      f"describes a {mh}x{mw} camera (subsample != 0); use the stored rays of this split")
         return ops.generate_rays(self.height, self.width, self.K, self.poses[i][:3, :4], device, pix_range=pix_range)

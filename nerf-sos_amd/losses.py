@@ -53,13 +53,17 @@ class CorrelationLoss(nn.Module):
         self.rand_neg = bool(getattr(args, "rand_neg", False))
         self.self_corr_w = getattr(args, "self_corr_w", 1)
         self.use_sim_matrix = getattr(args, "use_sim_matrix", True)
+        # None = torch's global generator on the inputs' device, the reference's behaviour.  Sharded training sets a
+        # per-step generator seeded identically on every rank (sharding.loss_generator): all ranks must draw the same
+        # coordinates / permutations for the summed gradients to equal the single-process gradient.
+        self.generator: Optional[torch.Generator] = None
         raw = getattr(args, self._PARAM_ATTR, None) if args is not None else None
         self.self_shift, self.self_weight, self.neg_shift, self.neg_weight = _params_of(raw or [None] * 4, self._DEFAULTS)
 
     _PARAM_ATTR = "app_corr_params"
 
     def super_perm(self, size: int, device: torch.device):
-        perm = torch.randperm(size, device=device, dtype=torch.long)          # :306-309
+        perm = torch.randperm(size, device=device, dtype=torch.long, generator=self.generator)   # :306-309
         perm[perm == torch.arange(size, device=device)] += 1
         return perm % size
 
@@ -70,7 +74,7 @@ class CorrelationLoss(nn.Module):
             assert len(sim_matrix.shape) == 2
             neg = torch.min(sim_matrix, dim=0)[1]                              # :354
         if self.rand_neg:
-            neg = torch.randperm(sim_matrix.shape[0], device=device, dtype=torch.long)   # :357
+            neg = torch.randperm(sim_matrix.shape[0], device=device, dtype=torch.long, generator=self.generator)   # :357
         return neg.to(device=device, dtype=torch.int64).contiguous()
 
     def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor]):
@@ -81,8 +85,8 @@ class CorrelationLoss(nn.Module):
             raise ValueError(f"orig_feats has {B} patches, orig_code {Bc}")
         S = self.feature_samples
         dev = feats.device
-        rand1 = torch.rand([B, S, S, 2], device=dev)                           # :343 (the kernel applies *2-1)
-        rand2 = torch.rand([B, S, S, 2], device=dev)                           # :344
+        rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :343 (the kernel applies *2-1)
+        rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :344
         neg = self._neg_index(sim_matrix, B, dev)
         lib = _lib.lib()
         prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
@@ -121,8 +125,10 @@ class GeoCorrelationLoss(CorrelationLoss):
             raise ValueError("depth must be [B,1,P,P]")
         ray_o, ray_d = batch_rays[0], batch_rays[1]
         dev = depth.device
-        inplace = depth.is_contiguous() and depth.dtype == torch.float32
-        dbuf = depth if inplace else _dev(depth.detach().float().contiguous(), "depth")
+        # The kernel filters a PRIVATE copy of the depth (values above max_depth -> the largest value below it); the
+        # caller's tensor is then updated the way the reference does it, with an in-place masked assignment under
+        # autograd (utils/image.py:454): the version counter moves, and only the filtered elements lose their gradient.
+        dbuf = depth.detach().float().contiguous().clone()
         _dev(dbuf, "depth")
         ro = _dev(ray_o.detach().expand(B, 3, H, W), "ray_o")
         rd = _dev(ray_d.detach().expand(B, 3, H, W), "ray_d")
@@ -143,6 +149,7 @@ class GeoCorrelationLoss(CorrelationLoss):
             return loss, grad
 
         out = _CorrFn.apply(orig_code, launch)
-        if not inplace:   # a permuted view (engines/trainer.py:156): put the filtered values back through the view
-            depth.copy_(dbuf)
+        with torch.no_grad():
+            changed = dbuf != depth
+        depth.copy_(torch.where(changed, dbuf.to(depth.dtype), depth))   # masked assign without the host sync of a bool index
         return out

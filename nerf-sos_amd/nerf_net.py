@@ -93,6 +93,13 @@ class NeRFMLP(nn.Module):
             self._packed_key[precision] = key
         return self._packed[precision]
 
+    def invalidate_packed(self) -> None:
+        """Drop the cached weight streams.  The cache key is (data_ptr, _version) of every parameter, which optimizer
+        steps, `load_state_dict` and ordinary in-place ops change -- but edits made through ``p.data`` (``p.data.copy_()``,
+        ``p.data.mul_()``) bump neither: call this after such an edit, or the kernels keep the old weights."""
+        self._packed.clear()
+        self._packed_key.clear()
+
     def forward(self, inputs, viewdirs=None):
         if viewdirs is None:
             raise NotImplementedError("nerf_sos_amd.NeRFMLP: view directions are required (use_viewdirs=True)")
@@ -251,6 +258,12 @@ class NeRFNet(nn.Module):
         # "fp16" / "bf16" = 16-bit MFMA inputs with fp32 accumulation (BASELINE configs C5 / C3), inference only.
         self.mlp_precision = "fp32"
 
+    def invalidate_packed(self) -> None:
+        """Forget the packed weight streams of both networks (needed only after edits through ``param.data``, which
+        autograd's version counters do not see; see NeRFMLP.invalidate_packed)."""
+        self.nerf.invalidate_packed()
+        self.nerf_fine.invalidate_packed()
+
     # ---------------------------------------------------------------------------------------------
     def _sem_nets(self):
         """(tag, NeRFMLP) pairs whose semantic heads can receive gradients, in the order their parameters are
@@ -289,6 +302,10 @@ class NeRFNet(nn.Module):
         perturb = kwargs.get('perturb', self.perturb)
         n_samples = kwargs.get('N_samples', self.N_samples)
         R, dev = rays_d.shape[0], rays_d.device
+        # stage-wise pin (like `cdf_in` of the importance kernel): fine-pass sample positions handed in by the caller
+        # replace the importance sampler's -- the parity tests feed the REFERENCE's own z_fine to hold the fine
+        # network + compositing to the 1e-4 bar separately from last-ulp index flips of the sampler
+        z_fine_override = kwargs.get('z_fine_override')
         saved = {}
 
         def query(net, z, tag):
@@ -330,6 +347,8 @@ class NeRFNet(nn.Module):
             N = self.N_importance
             u = torch.rand((R, N), device=dev) if perturb != 0.0 else None                 # sampler.py:103,158
             z_fine, z_samples, z_std = ops.importance_sample(z_vals, ret0['weights'], N, u)
+            if z_fine_override is not None:
+                z_fine = z_fine_override.to(device=dev, dtype=torch.float32).reshape(R, n_samples + N).contiguous()
             raw = query(self.nerf_fine, z_fine, "fine")
             noise = torch.randn((R, n_samples + N), device=dev) if raw_noise_std > 0. else None
             ret = ops.composite(raw, z_fine, rays_d, noise, raw_noise_std, self.white_bkgd)
@@ -362,17 +381,34 @@ class NeRFNet(nn.Module):
         near = self._bound(near, rays_d)
         far = self._bound(far, rays_d)
 
+        zf = render_kwargs.pop('z_fine_override', None)
+        if zf is not None:
+            zf = zf.reshape(R, -1)
         all_ret: Dict[str, list] = {}
         for i in range(0, R, self.chunk):
             e = min(i + self.chunk, R)
+            if zf is not None:
+                render_kwargs['z_fine_override'] = zf[i:e]
             ret = self.render_rays(rays_o[i:e], rays_d[i:e], near[i:e], far[i:e], viewdirs=None, **render_kwargs)
             for k, v in ret.items():
                 all_ret.setdefault(k, []).append(v)
         out = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
         return {k: v.reshape(list(old_shape[:-1]) + list(v.shape[1:])) for k, v in out.items()}
 
+    _BOUNDS: Dict[tuple, torch.Tensor] = {}
+
     @staticmethod
     def _bound(b, rays_d) -> torch.Tensor:
+        """Scalar near / far -> one value per ray (models/nerf_net.py:168-173).  Constant fills are cached per
+        (device, ray count, value): the kernels only read them, and a fill launch per bound per call was a visible
+        share of the host-side floor at 16-bit rates."""
         if isinstance(b, (int, float)):
-            return torch.full((rays_d.shape[0],), float(b), device=rays_d.device, dtype=torch.float32)
+            key = (rays_d.device, rays_d.shape[0], float(b))
+            t = NeRFNet._BOUNDS.get(key)
+            if t is None:
+                if len(NeRFNet._BOUNDS) > 64:
+                    NeRFNet._BOUNDS.clear()
+                t = torch.full((rays_d.shape[0],), float(b), device=rays_d.device, dtype=torch.float32)
+                NeRFNet._BOUNDS[key] = t
+            return t
         return b.to(device=rays_d.device, dtype=torch.float32).reshape(-1).contiguous()

@@ -16,8 +16,11 @@ from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-# outputs the losses read across patches (engines/trainer.py:127-166)
-PATCH_KEYS = ("semantics", "semantics0", "depth")
+# What the batch-wide losses read from every patch of the global batch (engines/trainer.py:101-109,125-166):
+# rendered maps (`semantics`, `semantics0`, fine `depth`), the DINO tensors of the patch's ground-truth crop
+# (`feat` [384,14,14] -- the largest item, 294 KiB -- and the class token `cls_` [384] the similarity matrix is built
+# from) and the patch's rays (`ray_o`, `ray_d`: the geometric loss back-projects depth along them, utils/image.py:404-438).
+PATCH_KEYS = ("semantics", "semantics0", "depth", "feat", "cls_", "ray_o", "ray_d")
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -84,22 +87,43 @@ def all_gather_rows(t: torch.Tensor, rows_per_rank: Sequence[int], group=None) -
 
 
 def all_gather_patches(local: Dict[str, torch.Tensor], n_patches: int, group=None,
-                       keys: Iterable[str] = PATCH_KEYS) -> Dict[str, torch.Tensor]:
-    """Training: ``local[k]`` is [n_local, P, P, C] for the patches this rank owns (in increasing global
-    index).  Returns [n_patches, P, P, C] per key in GLOBAL patch order on every rank.  The gathered
-    tensors carry no autograd history (the remote patches act as the losses' detached negatives)."""
+                       keys: Iterable[str] = PATCH_KEYS, stats: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """Training: ``local[k]`` is [n_local, ...] for the patches this rank owns (in increasing global index; any
+    trailing shape, e.g. [n_local,P,P,2] semantics, [n_local,384,14,14] features).  Returns [n_patches, ...] per key in
+    GLOBAL patch order on every rank.  All keys of one dtype travel in ONE flat buffer -> one collective per step
+    (fp32 everywhere in practice): the payload is ~0.5 MiB per patch, latency-bound over xGMI.  The gathered tensors
+    carry no autograd history (remote patches act as the losses' detached negatives; see `splice_local_patches`).
+    `stats`, if given, receives ``bytes_per_patch`` and ``collectives``."""
     rank, world = _world(group)
-    out = {}
+    present = [k for k in keys if k in local]
+    if world == 1:
+        return {k: local[k].detach() for k in present}
     counts = [len(local_patches(n_patches, r, world)) for r in range(world)]
     order = [b for r in range(world) for b in local_patches(n_patches, r, world)]  # rank-major -> global id
     inv = torch.empty(n_patches, dtype=torch.long)
     inv[torch.tensor(order, dtype=torch.long)] = torch.arange(n_patches)
-    for k in keys:
-        if k not in local:
-            continue
-        g = all_gather_rows(local[k].detach(), counts, group)
-        out[k] = g[inv.to(g.device)]
-    return out
+    n_local = counts[rank]
+    out: Dict[str, torch.Tensor] = {}
+    by_dtype: Dict[torch.dtype, List[str]] = {}
+    for k in present:
+        if local[k].shape[0] != n_local:
+            raise ValueError(f"all_gather_patches: `{k}` holds {local[k].shape[0]} patches, this rank owns {n_local}")
+        by_dtype.setdefault(local[k].dtype, []).append(k)
+    nbytes = 0
+    for dt, ks in by_dtype.items():
+        widths = [int(torch.Size(local[k].shape[1:]).numel()) for k in ks]
+        flat = torch.cat([local[k].detach().reshape(n_local, wd) for k, wd in zip(ks, widths)], 1)
+        nbytes += flat.shape[1] * flat.element_size()
+        g = all_gather_rows(flat, counts, group)
+        g = g[inv.to(g.device)]
+        off = 0
+        for k, wd in zip(ks, widths):
+            out[k] = g[:, off:off + wd].reshape((n_patches,) + tuple(local[k].shape[1:]))
+            off += wd
+    if stats is not None:
+        stats["bytes_per_patch"] = nbytes
+        stats["collectives"] = len(by_dtype)
+    return {k: out[k] for k in present}
 
 
 def splice_local_patches(gathered: Dict[str, torch.Tensor], local: Dict[str, torch.Tensor], n_patches: int,
@@ -121,7 +145,7 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     """ONE flat all-reduce (sum, or mean with average=True) of the gradients of `params`, in place.  82 436 floats for
     the frozen-backbone recipe, 1.27 M for the full model: latency-bound, so a single bucket."""
     ps = [p for p in params if p.requires_grad]
-    if not ps or not (dist.is_available() and dist.is_initialized()):
+    if not ps or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     for p in ps:
         if p.grad is None:
@@ -135,3 +159,89 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
         n = p.numel()
         p.grad.copy_(flat[off:off + n].view_as(p.grad))
         off += n
+
+
+def loss_generator(device, step: int, base_seed: int = 0) -> torch.Generator:
+    """The correlation losses draw sample coordinates and permutations (utils/image.py:306-309,343-344,357); in the
+    sharded step every rank evaluates the batch-wide losses, and the summed gradients equal the single-process
+    gradient only if all ranks draw the SAME values.  Give the loss modules a generator of their own
+    (``loss.generator = loss_generator(dev, step)``), seeded identically on every rank and advanced per step, instead
+    of re-seeding the global generator (which would also freeze the render's perturbation / noise draws)."""
+    g = torch.Generator(device=device)
+    g.manual_seed((int(base_seed) * 1_000_003 + int(step)) & 0x7FFFFFFFFFFFFFFF)
+    return g
+
+
+def similarity_matrix(cls_tokens: torch.Tensor) -> torch.Tensor:
+    """[B,B] cosine similarity of the patches' class tokens (utils/image.py:187-190, engines/trainer.py:125): the
+    correlation losses take each patch's negative as the argmin of its column.  B x 384 values: host-side glue."""
+    x = cls_tokens.reshape(cls_tokens.shape[0], -1)
+    return torch.nn.functional.cosine_similarity(x.unsqueeze(0), x.unsqueeze(1), dim=2)
+
+
+def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: torch.Tensor, cls_tokens: torch.Tensor,
+                       corr_loss=None, geo_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01, step: int = 0,
+                       seed: Optional[int] = 0, group=None, timings: Optional[dict] = None) -> torch.Tensor:
+    """One patch-mode training step of the path with the patch batch sharded over the ranks -- the loss section of
+    `train_one_step` (engines/trainer.py:101-166) re-stated for one process per GPU:
+
+      render this rank's patches (`rays` [2, n_local, P, P, 3], train mode)
+      -> ONE flat all-gather of what the batch-wide losses read from every patch: semantics0 / semantics / fine depth,
+         DINO `feat` [n_local,384,14,14] and `cls_tokens` [n_local,384] of the rank's own crops, ray_o / ray_d
+      -> similarity matrix of the class tokens -> negatives (utils/image.py:354)
+      -> the rank's own gradient-carrying patches are spliced back into the detached batch
+      -> appearance + geometric correlation losses on `semantics0` and `semantics` (engines/trainer.py:127-166)
+      -> backward through the rank's own patches -> ONE flat all-reduce (sum) of the parameter gradients.
+
+    Returns the (batch-wide) loss; `.grad` of the trainable parameters then holds the single-process gradient.
+    With no process group it is the plain single-GPU step over `n_patches` local patches.  The losses' random draws come
+    from `loss_generator(device, step, seed)` -- identical on every rank; seed=None uses torch's global generator like the
+    reference (single process only: ranks would draw different coordinates).
+    `timings`, if a dict, receives HIP event pairs under 'gather' and 'allreduce' (recorded on the current stream;
+    RCCL's own stream is joined by the non-async collectives before the second event) and the gather `stats`."""
+    rank, world = _world(group)
+    own = local_patches(n_patches, rank, world)
+    if rays.shape[1] != len(own):
+        raise ValueError(f"sharded_patch_step: rank {rank} owns {len(own)} of {n_patches} patches, got rays for {rays.shape[1]}")
+    dev = rays.device
+    ret = net(rays, bounds, retraw=False)
+    local = {"semantics": ret["semantics"], "semantics0": ret["semantics0"], "depth": ret["depth"],
+             "feat": feat, "cls_": cls_tokens, "ray_o": rays[0], "ray_d": rays[1]}
+    ev = None
+    if timings is not None and dev.type == "cuda":
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+    stats: dict = {}
+    full = all_gather_patches(local, n_patches, group, stats=stats)
+    if ev:
+        ev[1].record()
+    full = splice_local_patches(full, local, n_patches, group)
+    sim = similarity_matrix(full["cls_"])
+    s0 = full["semantics0"].permute(0, 3, 1, 2)
+    s1 = full["semantics"].permute(0, 3, 1, 2)
+    loss = None
+    gen = loss_generator(dev, step, seed) if seed is not None else None   # None: the global generator (single process only)
+    if corr_loss is not None:
+        if gen is not None:
+            corr_loss.generator = gen
+        f = full["feat"]
+        loss = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
+    if geo_loss is not None:
+        if gen is not None:
+            geo_loss.generator = gen
+        depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()       # the geo loss uses the FINE depth for both terms
+        ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
+        g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim) + geo_loss(depth, s1, [ro, rd, None], sim))
+        loss = g if loss is None else loss + g
+    if loss is None:
+        raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")
+    loss.backward()
+    if ev:
+        ev[2].record()
+    all_reduce_grads(net.parameters(), group)
+    if ev:
+        ev[3].record()
+        timings.setdefault("gather", []).append((ev[0], ev[1]))
+        timings.setdefault("allreduce", []).append((ev[2], ev[3]))
+        timings["stats"] = stats
+    return loss.detach()

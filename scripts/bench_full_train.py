@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import nerf_sos_amd
-from oracle import torch_port as tp
+from nerf_sos_amd import synthetic as syn
 
 dev = torch.device("cuda:0")
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -19,7 +19,7 @@ torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0).to(dev).train()
 net.mlp_precision = PREC
 opt = torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.9, 0.999))
-rays = tp.synthetic_rays(R, seed=0).to(dev)
+rays = syn.synthetic_rays(R, seed=0, device=dev)
 gt = torch.rand(R, 3, device=dev)
 
 
@@ -27,7 +27,7 @@ def step(timing=None):
     opt.zero_grad()
     if timing is not None:
         torch.cuda.synchronize(); t0 = time.perf_counter()
-    ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+    ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
     loss = ((ret["rgb"] - gt) ** 2).mean() + ((ret["rgb0"] - gt) ** 2).mean()
     if timing is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter()

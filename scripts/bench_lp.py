@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import nerf_sos_amd
 from nerf_sos_amd import ops
-from oracle import torch_port as tp
+from nerf_sos_amd import synthetic as syn
 
 dev = torch.device("cuda:0")
 out = {}
@@ -20,19 +20,19 @@ for sem in (False, True):
     torch.manual_seed(0)
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=sem, sem_with_coord=sem,
                                ray_chunk=65536).to(dev).eval()
-    net.load_state_dict(tp.make_peaky({k: v.cpu() for k, v in net.state_dict().items()}, gain=40.0, shift=1.0))
-    rays = tp.synthetic_rays(4096, seed=0).to(dev)
+    syn.spiky_density_(net, gain=40.0, shift=1.0)
+    rays = syn.synthetic_rays(4096, seed=0, device=dev)
     ref = None
     for prec in ("fp32", "fp16x3", "fp16", "bf16"):
         net.mlp_precision = prec
         with torch.no_grad():
             for _ in range(3):
-                o = net(rays, (tp.NEAR, tp.FAR))
+                o = net(rays, (syn.NEAR, syn.FAR))
             torch.cuda.synchronize()
             ops.KERNEL_EVENTS = []
             t0 = time.perf_counter()
             for _ in range(20):
-                o = net(rays, (tp.NEAR, tp.FAR))
+                o = net(rays, (syn.NEAR, syn.FAR))
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 20
             ev, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
@@ -43,7 +43,7 @@ for sem in (False, True):
         rec = {"rays_per_s": round(4096 / dt), "ms_per_step": round(dt * 1e3, 3), "fine_kernel_ms": round(fine_ms, 3),
                "fine_kernel_tflops": round(tf, 1)}
         # the same step replayed from a captured HIP graph (host launch path out of the way)
-        gr = nerf_sos_amd.GraphedRender(net, 4096, (tp.NEAR, tp.FAR))
+        gr = nerf_sos_amd.GraphedRender(net, 4096, (syn.NEAR, syn.FAR))
         for _ in range(3):
             gr(rays)
         torch.cuda.synchronize()

@@ -12,7 +12,7 @@ import types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import nerf_sos_amd
-from oracle import torch_port as tp
+from nerf_sos_amd import synthetic as syn
 
 dev = torch.device("cuda:0")
 args = types.SimpleNamespace(rand_neg=False, self_corr_w=0, use_sim_matrix=True, patch_stride=6,
@@ -25,21 +25,21 @@ for B, P in CFG:
         torch.manual_seed(0)
         net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True, perturb=1.0,
                                    raw_noise_std=1.0, ray_chunk=1 << 20).to(dev)
-        net.load_state_dict(tp.make_peaky({k: v.cpu() for k, v in net.state_dict().items()}, gain=40.0, shift=1.0))
+        syn.spiky_density_(net, gain=40.0, shift=1.0)
         for n_, p_ in net.named_parameters():                      # run_nerf.py:307-318 (--fix_backbone)
             p_.requires_grad = "semantic_linear" in n_
         net.train()
         net.mlp_precision = prec
         opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
         corr, geo = nerf_sos_amd.CorrelationLoss(args), nerf_sos_amd.GeoCorrelationLoss(args)
-        rays = tp.synthetic_rays(B * P * P, seed=0).to(dev).reshape(2, B, P, P, 3)
+        rays = syn.synthetic_rays(B * P * P, seed=0, device=dev).reshape(2, B, P, P, 3)
         feat = torch.randn(B, 384, 14, 14, device=dev)
         sim = torch.rand(B, B, device=dev)
         ro, rd = rays[0].permute(0, 3, 1, 2), rays[1].permute(0, 3, 1, 2)
 
         def step():
             opt.zero_grad()
-            ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+            ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
             s0, s1 = ret["semantics0"].permute(0, 3, 1, 2), ret["semantics"].permute(0, 3, 1, 2)
             depth = ret["depth"].permute(0, 3, 1, 2)
             loss = corr(feat, s0, sim) + corr(feat, s1, sim)

@@ -8,15 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import nerf_sos_amd
 from nerf_sos_amd import _lib, ops
-from oracle import torch_port as tp
+from nerf_sos_amd import synthetic as syn
 
 sem = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=sem > 0, sem_with_coord=sem == 2).to(dev).eval()
-rays = tp.synthetic_rays(4096, seed=0).to(dev)
-near = torch.full((4096,), tp.NEAR, device=dev)
-far = torch.full((4096,), tp.FAR, device=dev)
+rays = syn.synthetic_rays(4096, seed=0, device=dev)
+near = torch.full((4096,), syn.NEAR, device=dev)
+far = torch.full((4096,), syn.FAR, device=dev)
 z, v = ops.ray_setup(rays[1], near, far, 192, None)
 packed = net.nerf_fine.packed_weights()
 raw = torch.empty(4096, 192, 6 if sem else 4, device=dev)

@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import nerf_sos_amd
-from oracle import torch_port as tp
+from nerf_sos_amd import synthetic as syn
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
@@ -17,8 +17,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=sem, sem_with_coord=sem).to(dev).eval()
 net.mlp_precision = prec
-rays = tp.synthetic_rays(4096, seed=0).to(dev)
+rays = syn.synthetic_rays(4096, seed=0, device=dev)
 with torch.no_grad():
     for _ in range(steps):
-        net(rays, (tp.NEAR, tp.FAR))
+        net(rays, (syn.NEAR, syn.FAR))
 torch.cuda.synchronize()

@@ -10,7 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import nerf_sos_amd
-from oracle import torch_port as tp
+from nerf_sos_amd import synthetic as syn
 
 dev = torch.device("cuda:0")
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
@@ -26,14 +26,14 @@ def run(mode: str, precision: str):
             p_.requires_grad = "semantic_linear" in n_
     net.mlp_precision = precision
     opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
-    rays = tp.synthetic_rays(R, seed=1).to(dev)
+    rays = syn.synthetic_rays(R, seed=1, device=dev)
     gen = torch.Generator(dev).manual_seed(7)
     gt, gt_sem = torch.rand(R, 3, device=dev, generator=gen), torch.rand(R, 2, device=dev, generator=gen)
     torch.manual_seed(123)                                # the render's own draws (jitter, sigma noise)
     losses = []
     for _ in range(STEPS):
         opt.zero_grad()
-        ret = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+        ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
         loss = ((ret["semantics"] - gt_sem) ** 2).mean() + ((ret["semantics0"] - gt_sem) ** 2).mean()
         if mode == "full":
             loss = loss + ((ret["rgb"] - gt) ** 2).mean() + ((ret["rgb0"] - gt) ** 2).mean()

@@ -1,0 +1,130 @@
+"""GPU (-m gpu): every BASELINE.json config that was not exercised at its own size / dtype in round 1.
+
+  * C5: the full 1008x756 image in fp16 at 65 536-ray chunks -- finite, independent of the chunking, PSNR against the
+    fp32 render of the same image, and a ray-sharded rank's block identical to the same rows of the full render;
+  * C4: the per-GPU workload of the sharded training configuration (8192 rays = two 64x64 patches, train mode, semantic
+    head with coordinates, both correlation losses, backward) on one GPU, in fp32 against the CPU port of the
+    reference's losses evaluated on the rendered maps, and in bf16 against the fp32 step.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import nerf_sos_amd
+from nerf_sos_amd import ops, sharding, synthetic as syn
+from helpers import CFGS, ref_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _psnr(a, b):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 10.0 * np.log10(1.0 / max(mse, 1e-30))
+
+
+def test_c5_full_image_fp16(manifest):
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, ray_chunk=65536, **CFGS["semcoord"]).to(DEV).eval()
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    n = syn.H * syn.W
+    assert n == 762048
+    rays = syn.image_rays(DEV)
+    keys = ("rgb", "depth", "acc", "semantics", "rgb0")
+    with torch.no_grad():
+        net.mlp_precision = "fp16"
+        a = {k: v for k, v in net(rays, (syn.NEAR, syn.FAR), retraw=False).items() if k in keys}
+        net.chunk = 32768 + 4096 + 7                              # ragged chunking of the same image
+        b = {k: v for k, v in net(rays, (syn.NEAR, syn.FAR), retraw=False).items() if k in keys}
+        net.chunk = 65536
+        for k in keys:
+            assert a[k].shape[0] == n
+            assert torch.isfinite(a[k]).all() or k == "depth", f"{k} not finite"
+            assert torch.equal(a[k], b[k]), f"fp16 {k}: result depends on the ray chunking"
+        # a ray-sharded rank (rank 3 of 8) renders its block from pixel indices alone: identical rows
+        s, e = sharding.shard_bounds(n, 3, 8)
+        assert (s, e) == (3 * 95256, 4 * 95256)
+        blk = net(syn.image_rays(DEV, (s, e)), (syn.NEAR, syn.FAR), retraw=False)
+        for k in keys:
+            assert torch.equal(blk[k], a[k][s:e]), f"shard != full for {k}"
+        post = ops.eval_postprocess(semantics=a["semantics"])
+        assert post["sem"].shape == (n, 1) and int(post["sem"].min()) >= 0 and int(post["sem"].max()) <= 1
+        del b, blk
+        net.mlp_precision = "fp32"
+        ref = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+    p_rgb, p_rgb0 = _psnr(a["rgb"], ref["rgb"]), _psnr(a["rgb0"], ref["rgb0"])
+    print(f"C5 fp16 vs fp32 over the full image: PSNR rgb {p_rgb:.1f} dB, rgb0 {p_rgb0:.1f} dB")
+    assert p_rgb >= 55.0 and p_rgb0 >= 55.0
+    agree = float((ops.eval_postprocess(semantics=ref["semantics"])["sem"] == post["sem"]).float().mean())
+    assert agree > 0.995, f"fp16 and fp32 label maps agree on {agree:.4f} of the pixels"
+
+
+def _loss_args():
+    return types.SimpleNamespace(rand_neg=False, self_corr_w=0, use_sim_matrix=True, patch_stride=6,
+                                 app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
+
+
+def _c4_step(precision, manifest, seed_draws=7):
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0, ray_chunk=1 << 20,
+                               **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    for n_, p_ in net.named_parameters():
+        p_.requires_grad = "semantic_linear" in n_
+    net.train()
+    net.mlp_precision = precision
+    B = 2
+    rays = syn.synthetic_patches(B, 64, 6, seed=0, device=DEV)
+    assert rays.shape == (2, B, 64, 64, 3) and rays[0].numel() // 3 == 8192
+    feat = torch.randn(B, 384, 14, 14, generator=torch.Generator().manual_seed(1)).to(DEV)
+    cls_ = torch.randn(B, 384, generator=torch.Generator().manual_seed(2)).to(DEV)
+    corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+    torch.manual_seed(seed_draws)                                # the render's jitter / noise draws
+    loss = sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, step=3, seed=11)
+    grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+    return net, rays, feat, cls_, loss, grads
+
+
+def test_c4_per_gpu_workload_fp32_vs_port_losses(manifest):
+    """8192 rays in train mode through render -> losses -> backward on one GPU; the loss value is re-derived on the CPU
+    with the port of the reference's loss classes (oracle/losses_port.py, pinned to the real classes) from the maps the
+    HIP path rendered and the same generator draws."""
+    from oracle import losses_port as lp
+    net, rays, feat, cls_, loss, grads = _c4_step("fp32", manifest)
+    assert torch.isfinite(loss)
+    assert len(grads) == 8 and all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in grads.values())
+    # replay: same render draws -> same maps; then the port's losses on the CPU with the generator's draws
+    torch.manual_seed(7)
+    with torch.no_grad():
+        ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+    gen = sharding.loss_generator(torch.device(DEV), 3, 11)
+    S = 11
+    draws = [torch.rand([2, S, S, 2], device=DEV, generator=gen).cpu() for _ in range(4)]   # corr(s0): 2 draws, corr(s1): 2 draws
+    sim = sharding.similarity_matrix(cls_).cpu()
+    s0, s1 = ret["semantics0"].permute(0, 3, 1, 2).cpu(), ret["semantics"].permute(0, 3, 1, 2).cpu()
+    depth = ret["depth"].permute(0, 3, 1, 2).cpu().contiguous()
+    ro, rd = rays[0].permute(0, 3, 1, 2).cpu(), rays[1].permute(0, 3, 1, 2).cpu()
+    neg = lp.neg_index(sim)
+    pa = lp.CorrParams(self_shift=0.18, self_weight=1.0, neg_shift=0.46, neg_weight=1.0)
+    pg = lp.CorrParams(self_shift=0.5, self_weight=1.0, neg_shift=3.0, neg_weight=1.0)
+    c = [d_ * 2 - 1 for d_ in draws]                              # utils/image.py:343-344
+    with torch.no_grad():
+        want = (lp.correlation_loss(feat.cpu(), s0, neg, c[0], c[1], pa) + lp.correlation_loss(feat.cpu(), s1, neg, c[2], c[3], pa))
+        want = want + 0.01 * (lp.geo_correlation_loss(depth.clone(), s0, ro, rd, neg, pg) +
+                              lp.geo_correlation_loss(depth.clone(), s1, ro, rd, neg, pg))
+    assert abs(float(loss) - float(want)) <= 1e-4 * (1 + abs(float(want))), (float(loss), float(want))
+    # determinism of the whole step
+    _, _, _, _, loss2, grads2 = _c4_step("fp32", manifest)
+    assert float(loss2) == float(loss) and all(torch.equal(grads[k], grads2[k]) for k in grads)
+
+
+def test_c4_per_gpu_workload_bf16_vs_fp32(manifest):
+    _, _, _, _, loss32, g32 = _c4_step("fp32", manifest)
+    _, _, _, _, loss16, g16 = _c4_step("bf16", manifest)
+    assert torch.isfinite(loss16)
+    assert abs(float(loss16) - float(loss32)) <= 3e-2 * (1 + abs(float(loss32))), (float(loss16), float(loss32))
+    for k in g32:
+        a, b = g32[k].flatten().double(), g16[k].flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        assert cos > 0.98, f"{k}: bf16 gradient direction differs from fp32 (cos {cos:.4f})"

@@ -1,0 +1,153 @@
+"""GPU (-m gpu): the N > 1 path on the HIP kernels -- two processes, one per rank.
+
+On a box with >= 2 GPUs the ranks use RCCL ("nccl"), one GPU each.  The round-end test box has ONE GPU, and RCCL refuses
+two ranks on one device, so there the same code runs with both ranks on cuda:0 and "gloo" carrying the (GPU-resident)
+tensors: everything but the transport is the production path -- HIP render per rank, the flat patch all-gather, the
+splice, the batch-wide losses, backward through the rank's own patches, the flat gradient all-reduce, and bench.py's own
+multi-rank launch.
+"""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _loss_args():
+    return types.SimpleNamespace(rand_neg=False, self_corr_w=0, use_sim_matrix=True, patch_stride=6,
+                                 app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
+
+
+def _build(dev):
+    import nerf_sos_amd
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=0.0, raw_noise_std=0.0, ray_chunk=1 << 20,
+                               use_semantics=True, sem_with_coord=True).to(dev)
+    for n_, p_ in net.named_parameters():
+        p_.requires_grad = "semantic_linear" in n_
+    net.train()
+    return net
+
+
+def _batch(B, P, dev):
+    from nerf_sos_amd import synthetic as syn
+    rays = syn.synthetic_patches(B, P, 6, seed=5, device=dev)
+    feat = torch.stack([torch.randn(384, 14, 14, generator=torch.Generator().manual_seed(100 + b)) for b in range(B)]).to(dev)
+    cls_ = torch.stack([torch.randn(384, generator=torch.Generator().manual_seed(200 + b)) for b in range(B)]).to(dev)
+    return rays, feat, cls_
+
+
+def _worker(rank, world, port, backend, q):
+    import nerf_sos_amd
+    from nerf_sos_amd import sharding, synthetic as syn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok, why = True, []
+        B, P = 5, 16                                         # 5 patches over 2 ranks: ragged ownership (3 + 2)
+        net = _build(dev)
+        rays, feat, cls_ = _batch(B, P, dev)
+        own = sharding.local_patches(B, rank, world)
+        corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+        # --- single-process reference on this rank's GPU: the whole batch, no process group involved
+        ref_net = _build(dev)
+        solo = [dist.new_group([r]) for r in range(world)][rank]      # every rank creates every group, in the same order
+        ref_loss = sharding.sharded_patch_step(ref_net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, step=4, seed=9,
+                                               group=solo)
+        # --- sharded step
+        stats = {}
+        loss = sharding.sharded_patch_step(net, rays[:, own].contiguous(), (syn.NEAR, syn.FAR), B, feat[own], cls_[own],
+                                           corr, geo, step=4, seed=9, timings=stats)
+        if abs(float(loss) - float(ref_loss)) > 1e-6 * (1 + abs(float(ref_loss))):
+            ok = False
+            why.append(f"loss {float(loss)} vs single-process {float(ref_loss)}")
+        for (n_, p_), (_, r_) in zip(net.named_parameters(), ref_net.named_parameters()):
+            if not p_.requires_grad:
+                continue
+            scale = float(r_.grad.abs().max()) + 1e-30
+            err = float((p_.grad - r_.grad).abs().max()) / scale
+            if err > 2e-5:
+                ok = False
+                why.append(f"grad {n_}: {err:.2e} of scale")
+        if stats["stats"]["collectives"] != 1:
+            ok = False
+            why.append(f"{stats['stats']['collectives']} all-gathers per step (one flat buffer expected)")
+        want_bytes = 4 * (2 * P * P * 2 + P * P + 384 * 14 * 14 + 384 + 2 * P * P * 3)
+        if stats["stats"]["bytes_per_patch"] != want_bytes:
+            ok = False
+            why.append(f"gathered {stats['stats']['bytes_per_patch']} B/patch, expected {want_bytes}")
+        # --- eval: ray-sharded render of an image == the single-process render, bit for bit
+        net.eval()
+        img = syn.image_rays(dev, (1000, 1000 + 2001))       # 2001 rays: not divisible by the world size
+        with torch.no_grad():
+            full = net(img, (syn.NEAR, syn.FAR), retraw=False)
+            got = sharding.render_image_sharded(net, img[0], img[1], (syn.NEAR, syn.FAR), gather=True,
+                                                keys=("rgb", "depth", "semantics", "acc"), retraw=False)
+        for k in got:
+            if not torch.equal(got[k], full[k]):
+                ok = False
+                why.append(f"sharded render differs in {k}")
+        q.put((rank, ok, "; ".join(why)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (7 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_sharing_the_gpu_over_gloo():
+    _run("gloo")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has one")
+def test_two_ranks_over_rccl():
+    _run("nccl")
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (the driver's command shape) must start two ranks itself and print ONE JSON line whose
+    n_gpus is 2 and whose collective really saw two ranks; the C4 variant (patch all-gather + gradient all-reduce) rides
+    along.  On a one-GPU box both ranks share cuda:0 over gloo (NSOS_BENCH_SHARE_GPU=1): the numbers mean nothing there,
+    the code path is the point."""
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env["NSOS_BENCH_SHARE_GPU"] = "1"
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["distributed"]["ranks_seen_by_collective"] == 2
+    assert j["scaling"] == "weak" and j["config"]["rays_per_gpu"] == 4096 and j["value"] > 0
+    assert j["per_rank_rays_per_s"]["min"] > 0
+    c4 = j["variants"]["c4_bf16"]
+    assert c4["patches"] == 4 and c4["rays_per_gpu"] == 8192
+    assert c4["collectives"]["all_gathers_per_step"] == 1 and c4["collectives"]["gathered_bytes_per_patch"] > 400_000
+    assert c4["collectives"]["all_gather_ms"] > 0 and c4["collectives"]["all_reduce_floats"] == 2 * 41218

@@ -73,4 +73,32 @@ def test_bench_cpu_baseline_leg_runs_on_a_tiny_sample():
     finally:
         torch.set_num_threads(threads)
     assert rec["unit"] == "rays/s" and rec["value"] > 0 and rec["kind"] == "port" and 1 <= rec["cores"] <= 64
-    assert bench.FLOP_PER_RAY == 2 * 593408 * 256
+    assert rec["physical_cores"] >= 1
+    assert 2 * bench.MAC_NOSEM * bench.EVALS_PER_RAY == 2 * 593408 * 256
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` outside torch.distributed.run must become the launcher: one rank per GPU on
+    127.0.0.1 -- checked without starting anything."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(os, "execv", lambda exe, cmd: seen.update(exe=exe, cmd=cmd))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    bench._self_launch(types.SimpleNamespace(gpus=8))
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "8")                     # already under the launcher: nothing to do
+    bench._self_launch(types.SimpleNamespace(gpus=8))
+    bench._self_launch(types.SimpleNamespace(gpus=1))
+    assert not seen

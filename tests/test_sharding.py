@@ -45,11 +45,15 @@ def _worker(rank, world, port, q):
         ok = ok and torch.equal(mine["rgb"], full["rgb"][s:e]) and list(mine) == ["rgb"]
         # patches: B=5 patches of 4x4, owner = b mod world
         B, P = 5, 4
-        allp = {"semantics": torch.randn(B, P, P, 2), "depth": torch.randn(B, P, P, 1), "rgb": torch.randn(B, P, P, 3)}
+        allp = {"semantics": torch.randn(B, P, P, 2), "depth": torch.randn(B, P, P, 1), "rgb": torch.randn(B, P, P, 3),
+                "feat": torch.randn(B, 6, 3, 3), "cls_": torch.randn(B, 6)}
         own = sharding.local_patches(B, rank, world)
         local = {k: v[own].clone().requires_grad_(k == "semantics") for k, v in allp.items()}
-        g = sharding.all_gather_patches(local, B, keys=("semantics", "depth", "semantics0"))
-        ok = ok and set(g) == {"semantics", "depth"} and all(torch.equal(g[k], allp[k]) for k in g)
+        st = {}
+        g = sharding.all_gather_patches(local, B, keys=("semantics", "depth", "semantics0", "feat", "cls_"), stats=st)
+        ok = ok and set(g) == {"semantics", "depth", "feat", "cls_"} and all(torch.equal(g[k], allp[k]) for k in g)
+        # one flat buffer for all keys -> ONE collective; payload per patch = the sum of the per-patch tensors
+        ok = ok and st["collectives"] == 1 and st["bytes_per_patch"] == 4 * (P * P * 2 + P * P + 6 * 9 + 6)
         ok = ok and not g["semantics"].requires_grad
         # training: batch-wide loss on gathered patches, gradient through the rank's own patches, one grad all-reduce
         torch.manual_seed(1)
