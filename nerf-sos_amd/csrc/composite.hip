@@ -13,6 +13,14 @@
 // Compiled with -ffp-contract=off: element-wise fp32 expressions match the reference's op order.
 #include "common.h"
 
+// exp rounded correctly to fp32 (fp64 evaluation, one rounding).  alpha = 1 - exp(-sigma*delta) cancels: for a thin
+// sample the result lives on the 6e-8 grid of fl(exp) near 1, so an ulp of libm difference in exp moves a small alpha by
+// 1e-3 of itself -- and with it the coarse weights, the cdf and the importance samples (tests/test_gpu_pins.py::
+// test_free_running_render_at_c2_size).  The reference's CPU exp (SLEEF u10 / glibc) is correctly rounded in all but a
+// few per cent / per mille of the cases; ocml's expf is a different <= 1 ulp function.  This kernel is HBM-bound: the
+// fp64 exp costs nothing measurable.
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+
 template <int IPL>
 __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw,
                                                         const float* __restrict__ z_vals,
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
         float sigma = c[3];
         if (noise) sigma = sigma + noise[r * S + (live ? s : 0)] * noise_std;  // :46-50
         const float relu = sigma > 0.0f ? sigma : 0.0f;
-        const float a = live ? (1.0f - expf(-relu * dist)) : 0.0f;  // :52
+        const float a = live ? (1.0f - exp_cr(-relu * dist)) : 0.0f;  // :52
         alpha[i] = a;
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[i][k] = 1.0f / (1.0f + expf(-c[k]));  // sigmoid :41
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
         float sigma = c[3];
         if (noise) sigma = sigma + noise[r * S + (live ? s : 0)] * noise_std;
         const float relu = sigma > 0.0f ? sigma : 0.0f;
-        const float e = expf(-relu * dist);
+        const float e = exp_cr(-relu * dist);
         const float a = live ? (1.0f - e) : 0.0f;
         alpha[i] = a;
         dexp[i] = (live && sigma > 0.0f) ? dist * e : 0.0f;   // d alpha / d sigma

@@ -19,6 +19,20 @@ SEM_NONE, SEM_PLAIN, SEM_COORD = 0, 1, 2
 KERNEL_EVENTS = None
 
 
+def _ev_begin():
+    if KERNEL_EVENTS is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    return ev
+
+
+def _ev_end(ev, n_points: int):
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append((n_points, ev[0], ev[1]))
+
+
 def sem_mode_of(use_semantics: bool, sem_with_coord: bool) -> int:
     return SEM_NONE if not use_semantics else (SEM_COORD if sem_with_coord else SEM_PLAIN)
 
@@ -222,6 +236,7 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     sem_in = torch.empty((R * S, 320), device=dev,
                          dtype=(torch.float16 if precision == "fp16" else torch.bfloat16) if compact else torch.float32)
     sem_hid = torch.empty((R * S, 128), device=dev, dtype=torch.float32)
+    ev = _ev_begin()
     if precision == "fp32":
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
                                                          _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
@@ -240,6 +255,7 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
                                                             _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
                                                             _p(sem_in), _p(sem_hid), _stream()),
                    "nsos_mlp_forward_rays_save_lp")
+    _ev_end(ev, R * S)
     return raw, sem_in, sem_hid
 
 
@@ -441,14 +457,17 @@ def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch
     dev = z_vals.device
     raw = torch.empty((R, S, 4 if sem_mode == SEM_NONE else 6), device=dev, dtype=torch.float32)
     acts = torch.empty((R * S, ACTS_DIM), device=dev, dtype=torch.float32)
+    ev = _ev_begin()
     if precision == "fp16x3":   # also returns the trunk layers' ReLU patterns as bit masks (input of mlp_input_grads_x3)
         masks = torch.empty(int(_lib.lib().nsos_mlp_relu_masks_bytes_x3(R * S)) // 4, device=dev, dtype=torch.int32)
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
                                                                 _p(z_vals), R, S, _p(raw), _p(acts), _p(masks), _stream()),
                    "nsos_mlp_forward_rays_save_all_x3")
+        _ev_end(ev, R * S)
         return raw, acts, masks
     _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
                                                          R, S, _p(raw), _p(acts), _stream()), "nsos_mlp_forward_rays_save_all")
+    _ev_end(ev, R * S)
     return raw, acts, None
 
 
