@@ -261,6 +261,11 @@ int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float*
                               float* raw, uint64_t* stamps, void* stream);
 /* Same for the reduced-precision kernel; it stamps the SECOND tile of workgroups 0..3 (steady state), so give it
  * more than 2 x 256 x (CU count) points.  Slot meaning: scripts/phase_profile_lp.py. */
+/* Diagnostics: which kernel serves the 16-bit entry points above.  2 (default) = two 256-register waves per SIMD, 32 points
+ * each (mlp_lp8.hip); 1 = the round-1 kernel, one 512-register wave per SIMD with 64 points (mlp_lp.hip).  Same packed
+ * stream, bit-identical results; exists for A/B measurements (models/nerf_mlp.py:67-100 is what both replace). */
+int32_t nsos_mlp_lp_select_kernel(int32_t waves_per_simd);
+
 /* ... and for the split-fp16 kernel (128-point tiles: more than 2 x 128 x (CU count) points).  scripts/phase_profile_x3.py. */
 int32_t nsos_mlp_profile_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                  const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,

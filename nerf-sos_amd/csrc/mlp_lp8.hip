@@ -1,0 +1,445 @@
+// K2-LP8: the 16-bit fused positional-encoding + MLP kernel (mlp_lp.hip) re-shaped for TWO waves per SIMD.
+// Same network, same packed weight stream, same arithmetic and roundings as mlp_lp_kernel -- results are bit-identical
+// to it (tests/test_gpu_parity.py::test_lp8_equals_lp4) -- and the same replaced reference code
+// (models/embedder.py:34-48, models/nerf_mlp.py:67-100,179-215).
+//
+// Why.  mlp_lp_kernel runs one 512-register wave per SIMD with 64 points each.  Its phase table
+// (profiles/r01/phase_lp_*.txt) shows the matrix pipe busy only 58 % of the time: the nine activation passes
+// (v_accvgpr_read + v_cvt_pk + v_pk_max, ~5.8 cycles per instruction when ONE wave issues them), the positional
+// encodings and the vector-ALU heads all run with the matrix pipe idle, and nothing else is resident on the SIMD to
+// use it.  A single wave issues at most one instruction every ~4 cycles while the SIMD's vector ALU takes a wave64
+// instruction every 2: a second wave on the SIMD doubles the rate of every VALU phase and fills the first wave's
+// barrier / ring-restart bubbles in the MFMA phases.
+//
+// Shape.  Workgroup = 8 waves = 512 threads (two per SIMD, <= 256 registers each); wave = ONE 32-point column; tile =
+// 256 points, so the weight stream is still amortised over 256 points per CU (L2 traffic unchanged).  Per wave:
+// Z = 8 x 16 accumulators (128 registers), H = 16 packed K-slices (64), xyz encoding 16, A-operand ring 16 -- all VGPRs:
+// no AGPRs, so the activation pass needs no v_accvgpr_read (see activate1).
+//   * One ds_read_b128 per MFMA per wave = 128 B/clk/CU, half of the LDS's ds_read_b128 rate.
+//   * The A-operand ring is CONTINUOUS across chunks (no second "next chunk" register set, which does not fit in 256
+//     registers): slot of group g = (g + PHASE) % 4, and the reloads behind a chunk's last four groups already fetch
+//     the next chunk's first four operands; every group waits with lgkmcnt(3).  PHASE is static at every call site
+//     (chunks are 32, 34 or 16 groups; every part of the network is a multiple of 4 groups long).
+//   * DMA: 36 pieces per chunk over 8 waves = 5 per wave (the surplus four re-copy piece 35: same bytes, same place).
+#include "lp_common.h"
+
+using namespace nsos;
+using namespace nsos::lp;
+
+namespace {
+
+constexpr int kRing8 = 4, kMid8 = 2, kDma8 = 5;
+
+// continuous-ring A-operand pipeline (see the header comment).  ring[(g + PHASE) % RING] holds group g's operand.
+template <int NG, int RING, int PHASE, int MID, class M, class B, class TL>
+__device__ __forceinline__ void a_pipeline_c(f32x4 (&ring)[RING], const ChunkCtx ctx, M&& work, B&& mid, TL&& tail) {
+    static_assert(NG >= RING + MID + 2, "chunk too short: the next chunk's operands would be read before this chunk's barrier");
+    static_for<0, NG>([&](auto ic) {
+        constexpr int g = decltype(ic)::value, slot = (g + PHASE) % RING;
+        if constexpr (g == MID) {
+            NSOS_PIN();
+            mid();
+            NSOS_PIN();
+        }
+        lgkm_wait<RING - 1>();  // the RING-1 reads issued after group g's are the only ones that may still fly
+        NSOS_PIN();
+        work(ic, ring[slot]);
+        NSOS_PIN();
+        if constexpr (g + RING < NG) lds_read_a<(g + RING) * 1024>(ring[slot], ctx.wl_cur);
+        else lds_read_a<(g + RING - NG) * 1024>(ring[slot], ctx.wl_nxt);   // resident: proven by this chunk's barrier
+        if constexpr (g == NG - 3) {
+            NSOS_PIN();
+            tail();
+            NSOS_PIN();
+        }
+    });
+}
+
+template <int NT, class A>
+__device__ __forceinline__ void pin_accumulators(A& acc) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
+}
+
+// H[2t+u] = pack16(relu?(Z[t][8u .. 8u+7]))   -- one batched VALU pass per layer (one column).
+// The kernel contains NO inline asm with AGPR ("a") operands: with <= 256 registers per wave and no AGPR use hipcc selects
+// the VGPR form of the MFMAs and treats the whole budget as one file (with any "a" operand it splits 128 + 128, and
+// H + encoding + ring + temporaries do not fit in 128).  So the accumulators are ordinary VGPRs here, and the pass is
+// v_cvt_pk + v_pk_max_i16 per packed word: no v_accvgpr_read (the most expensive half of mlp_lp_kernel's pass).
+template <class T, int NT, bool RELU>
+__device__ __forceinline__ void activate1(u32x4 (&H)[2 * NT], const f32x16 (&Z)[NT]) {
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (the asm below hides the reads)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned r = T::pack2(Z[t][8 * u + 2 * q], Z[t][8 * u + 2 * q + 1]);
+                if constexpr (RELU) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(r));
+                w[q] = r;
+            }
+            H[2 * t + u] = w;
+        }
+}
+
+// fp32 vector-ALU heads on fp32 accumulators held in VGPRs (rgb: NO = 3, semantics: NO = 2): this half-wave's partial
+// chains part[o] = fma(w[o][f], relu(h[f]), part[o]) over the lane's NT*16 features, weights from the LDS copy of aux;
+// same order as lp_common.h's heads_partial_f32 (bit-identical results).
+template <int NT, int NO>
+__device__ __forceinline__ void heads_partial_v(const f32x16 (&h)[NT], const float* w_lane, float (&part)[NO]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 w[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) w[o] = *reinterpret_cast<const f32x4*>(w_lane + o * 128 + t * 16 + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = fmaxf(h[t][q * 4 + j], 0.0f);
+#pragma unroll
+                for (int o = 0; o < NO; ++o) part[o] = __fmaf_rn(w[o][j], x, part[o]);
+            }
+        }
+}
+
+template <class T, int SEM, bool SAVE = false>
+__global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pj = lane & 31, kg = lane >> 5;
+    constexpr int NCH = lp_chunks(SEM);
+    constexpr int C = SEM ? 6 : 4;
+
+    // ---- weight stream: slots rotate (c0 = chunk cur, c1 = cur+1, c2 = cur+2, c3 = being filled with cur+3)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)(lane * 16);
+    auto lane_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotBytes + lane * 16); };
+    auto slot_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotBytes); };
+    unsigned c0 = lane_addr(0), c1 = lane_addr(1), c2 = lane_addr(2), c3 = lane_addr(3);
+    unsigned d0 = slot_addr(0), d1 = slot_addr(1), d2 = slot_addr(2), d3 = slot_addr(3);
+    unsigned poff[kDma8];     // byte offset of this wave's i-th piece inside a chunk / slot (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < kDma8; ++i) {
+        const int p = wave_s + 8 * i;
+        poff[i] = (unsigned)((p < kSlotGroups ? p : kSlotGroups - 1) * 1024);
+    }
+    const unsigned char* const src_end = P.chunks + (size_t)NCH * kSlotBytes;
+    const unsigned char* src3 = P.chunks + (size_t)(3 % NCH) * kSlotBytes;
+    auto dma_piece = [&](const unsigned char* src_chunk, unsigned dst_slot, int i) {
+        dma_1k(src_chunk + poff[i], dst_slot + poff[i], voff);
+    };
+    auto side = [&](int i) { dma_piece(src3, d3, i); };
+    auto mid = [&]() {
+        // all DMA pieces except the newest kDma8 (chunk cur+2, issued one chunk ago) must have landed: that is chunk
+        // cur+1, which the end of this chunk starts to read
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kDma8) : "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    auto tail = [&]() {
+        const unsigned tc = c0, td = d0;
+        c0 = c1; c1 = c2; c2 = c3; c3 = tc;
+        d0 = d1; d1 = d2; d2 = d3; d3 = td;
+        src3 += kSlotBytes;
+        if (src3 == src_end) src3 = P.chunks;
+    };
+    auto ctx = [&]() { return ChunkCtx{c0, c1}; };
+
+    f32x4 ring[kRing8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < kDma8; ++i)
+            dma_piece(P.chunks + (size_t)(k % NCH) * kSlotBytes, k == 0 ? d0 : (k == 1 ? d1 : d2), i);
+    const unsigned* const aux_l = reinterpret_cast<const unsigned*>(lds + kSlots * kSlotBytes);
+    if (threadIdx.x < kAuxWords / 4)
+        *reinterpret_cast<u32x4*>(lds + kSlots * kSlotBytes + threadIdx.x * 16) = reinterpret_cast<const u32x4*>(P.aux)[threadIdx.x];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    static_for<0, kRing8>([&](auto ic) { lds_read_a<decltype(ic)::value * 1024>(ring[decltype(ic)::value], c0); });
+    NSOS_PIN();
+
+    // one chunk: NG groups = NG A operands `a0 + g` of a part with NT output tiles and NB leading bias operands; the
+    // K-slice of operand a >= NB is (a - NB) / NT, its tile (a - NB) % NT.  zf_c != 0: the part starts the accumulation.
+    auto run_chunk = [&](auto ng_c, auto nt_c, auto nb_c, auto a0_c, auto nwork_c, auto zf_c, auto ph_c, auto& acc, auto&& bsel, auto&& ride) {
+        constexpr int NG = decltype(ng_c)::value, NT = decltype(nt_c)::value, NB = decltype(nb_c)::value;
+        constexpr int A0 = decltype(a0_c)::value, NWORK = decltype(nwork_c)::value, PH = decltype(ph_c)::value;
+        constexpr bool ZF = decltype(zf_c)::value != 0;
+        a_pipeline_c<NG, kRing8, PH, kMid8>(ring, ctx(), [&](auto ic, const f32x4& a32) {
+            constexpr int g = decltype(ic)::value, a = A0 + g;
+            const u32x4 aop = __builtin_bit_cast(u32x4, a32);
+            if constexpr (g < NWORK) {
+                if constexpr (a < NB) {
+                    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    const u32x4 ones = {T::kOnes, T::kOnes, T::kOnes, T::kOnes};
+                    acc[a] = T::mfma(aop, ones, zero);
+                } else {
+                    constexpr int s = (a - NB) / NT, t = (a - NB) % NT;
+                    if constexpr (ZF && s == 0) {
+                        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        acc[t] = T::mfma(aop, bsel(std::integral_constant<int, s>{}), zero);
+                    } else {
+                        acc[t] = T::mfma(aop, bsel(std::integral_constant<int, s>{}), acc[t]);
+                    }
+                }
+            }
+            dma_slot<g - kMid8, kDma8>(side);
+            ride(ic);
+        }, mid, tail);
+        // pin the accumulators here: without a use at the chunk's end LLVM sinks whole chunks of MFMAs below later
+        // branches and keeps their A operands (pending ring registers!) alive in scratch
+        pin_accumulators<NT>(acc);
+    };
+    auto no_ride = [](auto) {};
+#define IC(n) std::integral_constant<int, (n)> {}
+
+    for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        int stamp_k = 0;
+        auto stamp = [&]() {  // diagnostics only: one s_memtime per phase of the second tile of blocks 0..3
+            if (P.prof && tile == (int)(blockIdx.x + gridDim.x) && blockIdx.x < 4) {
+                const unsigned long long t = __builtin_readcyclecounter();
+                if (lane == 0 && stamp_k < kProfSlots) P.prof[(blockIdx.x * 8 + wave) * kProfSlots + stamp_k] = t;
+            }
+            ++stamp_k;
+        };
+        stamp();  // 0: tile start
+        // ---- this lane's point: tile*256 + wave*32 + pj
+        const long long gp = (long long)tile * kTilePts + wave * 32 + pj;
+        const long long gc = gp < P.n_pts ? gp : P.n_pts - 1;
+        const int ray = (int)(gc / P.n_samples);
+        bool save_ok = false;
+        unsigned* save_row = nullptr;
+        if constexpr (SAVE) {
+            save_ok = gp < P.n_pts && P.sem_in16 != nullptr;
+            save_row = P.sem_in16 + gc * 160;
+        }
+        u32x4 ex[4];
+        {
+            const float z = P.z_vals[gc];
+            float x[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float m = P.rays_d[3ll * ray + k] * z;  // models/sampler.py:70,166 (mul, then add)
+                x[k] = P.rays_o[3ll * ray + k] + m;
+            }
+            Enc<NSOS_XYZ_FREQS, SliceHalf> e;
+            e.evaluate(x, kg);
+            ex[0] = enc_slice<T, NSOS_XYZ_FREQS, 0, true>(e, x, kg);
+            ex[1] = enc_slice<T, NSOS_XYZ_FREQS, 1, true>(e, x, kg);
+            ex[2] = enc_slice<T, NSOS_XYZ_FREQS, 2, true>(e, x, kg);
+            ex[3] = enc_slice<T, NSOS_XYZ_FREQS, 3, true>(e, x, kg);  // feature 63 (pad) = 1.0: layer-0 bias
+        }
+
+        f32x16 Z[8];
+        u32x4 H[16];
+        float sigma = 0.0f, sem_out[2] = {0.0f, 0.0f};
+        auto from_ex = [&](auto sc) { return ex[decltype(sc)::value]; };
+        auto from_H = [&](auto sc) { return H[decltype(sc)::value]; };
+
+        stamp();  // 1: inputs + xyz encoding
+        run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), IC(0), Z, from_ex, no_ride);
+        stamp();  // 2: L0 MFMAs
+        activate1<T, 8, true>(H, Z);
+        stamp();  // 3: L0 activation
+#pragma unroll 1
+        for (int l = 1; l <= 8; ++l) {
+            run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), IC(0), Z, from_H, no_ride);
+            run_chunk(IC(34), IC(8), IC(8), IC(34), IC(34), IC(0), IC(2), Z, from_H, no_ride);
+            run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), IC(0), Z, from_H, no_ride);
+            run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), IC(2), Z, from_H, no_ride);
+            if (l == 5) run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), IC(0), Z, from_ex, no_ride);  // skip connection
+            stamp();  // 2 + 2l: MFMAs of layer l
+            if (l < 8) activate1<T, 8, true>(H, Z); else activate1<T, 8, false>(H, Z);
+            stamp();  // 3 + 2l: activation pass
+            if (l == 7) {
+                // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
+                const unsigned* aw = aux_l + kAuxAlphaW + kg * 64;
+                float pa = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(aw + 4 * s);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pa = T::dot2(H[s][q], w[q], pa);
+                }
+                asm volatile("s_nop 3" ::: "memory");  // v_dot2c result -> non-dot VALU read: 3 wait states hipcc cannot see (asm)
+                sigma = both_halves(pa);
+                if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
+                    f32x16 sacc[4];
+                    // SAVE, compact sem_in: the 36 stores of [relu(h7) | x63 | 1] (packed words as they are) ride in these two
+                    // chunks' MFMA shadows, one per group from group 11 on
+                    auto ride_sem = [&](auto gc_, auto ch_c) {
+                        constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
+                        if constexpr (SAVE && g >= 11) {
+                            constexpr int k = CH * 23 + (g - 11);
+                            if constexpr (k < 32) {          // word pair (q, q+1) of slice 2t+u = features 32t + 8(2u + q/2) + 4kg + {0..3}
+                                constexpr int t = (k >> 2) & 7, u = (k >> 1) & 1, q = 2 * (k & 1);
+                                if (save_ok)
+                                    *reinterpret_cast<u32x2*>(save_row + (32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) / 2) =
+                                        u32x2{H[2 * t + u][q], H[2 * t + u][q + 1]};
+                            } else if constexpr (k < 36) {   // slice words = features 16s + 8kg + {0..7}; 63 is the 1.0 pad
+                                constexpr int sl = k - 32;
+                                if (save_ok) *reinterpret_cast<u32x4*>(save_row + 128 + 8 * sl + 4 * kg) = ex[sl];
+                            }
+                        }
+                    };
+                    run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), IC(0), sacc, from_H, [&](auto gc_) { ride_sem(gc_, IC(0)); });
+                    run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), IC(2), sacc, from_H, [&](auto gc_) { ride_sem(gc_, IC(1)); });
+                    if constexpr (SEM == 2) run_chunk(IC(16), IC(4), IC(0), IC(0), IC(16), IC(0), IC(0), sacc, from_ex, no_ride);
+                    if constexpr (SAVE) {
+                        auto relu_acc = [](float a) { return fmaxf(a, 0.0f); };
+                        if (gp < P.n_pts) {
+                            float* hrow = P.sem_hid + gp * 128;
+                            if (!P.sem_in16) {
+                                float* row = P.sem_in + gp * 320;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                        for (int q = 0; q < 4; q += 2) {   // words q, q+1 = accumulator elements 8u+2q .. +3 of tile t: 4 consecutive features
+                                            const unsigned w0 = H[2 * t + u][q], w1 = H[2 * t + u][q + 1];
+                                            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                                                f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
+                                        }
+#pragma unroll
+                                for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                                    for (int q = 0; q < 4; q += 2) {    // slice words q, q+1 = features 16s + 8kg + 2q .. +3; 63 is the 1.0 pad
+                                        const unsigned w0 = ex[sl][q], w1 = ex[sl][q + 1];
+                                        *reinterpret_cast<f32x4*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
+                                    }
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
+                                        f32x4{relu_acc(sacc[t][4 * q]), relu_acc(sacc[t][4 * q + 1]),
+                                              relu_acc(sacc[t][4 * q + 2]), relu_acc(sacc[t][4 * q + 3])};
+                        }
+                    }
+                    float ps[2];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) ps[o] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars + 4 + o]);
+                    heads_partial_v<4, 2>(sacc, reinterpret_cast<const float*>(aux_l) + kAuxSem2W + kg * 64, ps);
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) sem_out[o] = both_halves(ps[o]);
+                }
+                stamp();  // 18 (l == 7 only; the later slots shift by one): sigma + semantic heads
+            }
+        }
+        // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
+        f32x16 vacc[4];
+        run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), IC(0), vacc, from_H, no_ride);
+        run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), IC(2), vacc, from_H, no_ride);
+        stamp();  // 21: view-branch MFMAs on the feature
+        u32x4 ed[2];
+        {
+            float dv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3ll * ray + k];
+            Enc<NSOS_DIR_FREQS, SliceHalf> e;
+            e.evaluate(dv, kg);
+            ed[0] = enc_slice<T, NSOS_DIR_FREQS, 0, false>(e, dv, kg);
+            ed[1] = enc_slice<T, NSOS_DIR_FREQS, 1, false>(e, dv, kg);
+        }
+        auto from_ed = [&](auto sc) { return ed[decltype(sc)::value]; };
+        stamp();  // 22: direction encoding
+        run_chunk(IC(16), IC(4), IC(0), IC(0), IC(8), IC(0), IC(0), vacc, from_ed, no_ride);  // 2 slices x 4 tiles; groups 8..15 are padding
+        stamp();  // 23: direction MFMAs
+        {
+            float rgb[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) rgb[o] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars + 1 + o]);
+            heads_partial_v<4, 3>(vacc, reinterpret_cast<const float*>(aux_l) + kAuxRgbW + kg * 64, rgb);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) rgb[o] = both_halves(rgb[o]);
+            {   // NaN / Inf in the point's inputs must come out as NaN (the reference propagates them; the packed integer
+                // ReLU would launder them).  The inputs are re-read here (L2 hits) rather than kept alive across the tile.
+                const float z = P.z_vals[gc];
+                float chk = z - z;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float o = P.rays_o[3ll * ray + k], d = P.rays_d[3ll * ray + k], v = P.viewdirs[3ll * ray + k];
+                    chk += ((o - o) + (d - d)) + (v - v);
+                }
+                if (chk != chk) {
+                    const float qnan = __builtin_nanf("");
+                    rgb[0] = rgb[1] = rgb[2] = sigma = sem_out[0] = sem_out[1] = qnan;
+                }
+            }
+            if (gp < P.n_pts) {
+                float* out = P.raw + gp * C;
+                if constexpr (C == 4) {
+                    if (kg == 0) *reinterpret_cast<f32x4*>(out) = f32x4{rgb[0], rgb[1], rgb[2], sigma};
+                } else {
+                    if (kg == 0) {
+                        *reinterpret_cast<f32x2*>(out) = f32x2{rgb[0], rgb[1]};
+                        *reinterpret_cast<f32x2*>(out + 2) = f32x2{rgb[2], sigma};
+                    } else {
+                        *reinterpret_cast<f32x2*>(out + 4) = f32x2{sem_out[0], sem_out[1]};
+                    }
+                }
+            }
+        }
+        stamp();  // 24: rgb head + stores
+    }
+#undef IC
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+int lp8_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 256;
+}
+
+constexpr int kLdsBytes8 = kSlots * kSlotBytes + kAuxWords * 4;
+
+template <class T, int SEM, bool SAVE>
+int32_t launch8(const LpParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_lp8_kernel<T, SEM, SAVE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes8);
+        if (e != hipSuccess) return (int32_t)e;
+        configured = true;
+    }
+    static const int cus = lp8_num_cus();
+    const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+    hipLaunchKernelGGL((mlp_lp8_kernel<T, SEM, SAVE>), dim3(grid), dim3(512), kLdsBytes8, stream, p);
+    return nsos_launch_status();
+}
+
+}  // namespace
+
+namespace nsos {
+namespace lp {
+
+// dispatch used by forward_rays_lp (mlp_lp.hip); sem_mode and dtype were validated there
+int32_t launch_lp8(const LpParams& p, int32_t sem_mode, bool is_f16, bool save, hipStream_t st) {
+    if (save) {
+        if (is_f16) return sem_mode == 1 ? launch8<F16, 1, true>(p, st) : launch8<F16, 2, true>(p, st);
+        return sem_mode == 1 ? launch8<BF16, 1, true>(p, st) : launch8<BF16, 2, true>(p, st);
+    }
+    if (is_f16) {
+        switch (sem_mode) {
+            case 0: return launch8<F16, 0, false>(p, st);
+            case 1: return launch8<F16, 1, false>(p, st);
+            default: return launch8<F16, 2, false>(p, st);
+        }
+    }
+    switch (sem_mode) {
+        case 0: return launch8<BF16, 0, false>(p, st);
+        case 1: return launch8<BF16, 1, false>(p, st);
+        default: return launch8<BF16, 2, false>(p, st);
+    }
+}
+
+}  // namespace lp
+}  // namespace nsos

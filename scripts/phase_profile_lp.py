@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: per-phase cycle attribution of the reduced-precision MLP kernel (nsos_mlp_profile_rays_lp stamps).
-usage: phase_profile_lp.py [sem_mode 0|1|2] [fp16|bf16]"""
+usage: phase_profile_lp.py [sem_mode 0|1|2] [fp16|bf16] [waves_per_simd 2|1]"""
 import ctypes as C
 import os
 import sys
@@ -13,6 +13,8 @@ from nerf_sos_amd import synthetic as syn
 
 sem = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp16"
+wps = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # 2: mlp_lp8_kernel (8 waves x 32 points), 1: mlp_lp_kernel (4 x 64)
+NW, COLS = (8, 1) if wps == 2 else (4, 2)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=sem > 0, sem_with_coord=sem == 2).to(dev).eval()
@@ -23,30 +25,35 @@ far = torch.full((R,), syn.FAR, device=dev)
 z, v = ops.ray_setup(rays[1], near, far, 192, None)
 packed = net.nerf_fine.packed_weights(prec)
 raw = torch.empty(R, 192, 6 if sem else 4, device=dev)
-stamps = torch.zeros(16 * 64, dtype=torch.int64, device=dev)
+stamps = torch.zeros(4 * NW * 64, dtype=torch.int64, device=dev)
+_lib.check(_lib.lib().nsos_mlp_lp_select_kernel(wps), 'select')
 P = lambda t: C.c_void_p(t.data_ptr())
 dt = {"fp16": 1, "bf16": 2}[prec]
 for _ in range(3):
     _lib.check(_lib.lib().nsos_mlp_profile_rays_lp(P(packed), sem, dt, P(rays[0].contiguous()), P(rays[1].contiguous()),
                                                   P(v), P(z), R, 192, P(raw), P(stamps), None), "profile")
 torch.cuda.synchronize()
-st = stamps.cpu().view(16, 64).numpy()
+st = stamps.cpu().view(4 * NW, 64).numpy()
 M = 32  # cycles of one 32x32x16 MFMA
-names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * 2 * M}
+names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * COLS * M}
 for l in range(1, 9):
     names += [f"L{l} mfma", f"L{l} act"]
-    ideal[f"L{l} mfma"] = (136 + (32 if l == 5 else 0)) * 2 * M
+    ideal[f"L{l} mfma"] = (136 + (32 if l == 5 else 0)) * COLS * M
     if l == 7:
         names.append("sigma+sem heads")
-        ideal["sigma+sem heads"] = {0: 0, 1: 68, 2: 84}[sem] * 2 * M
+        ideal["sigma+sem heads"] = {0: 0, 1: 68, 2: 84}[sem] * COLS * M
 names += ["view mfma", "dir enc", "dir mfma", "rgb head + store"]
-ideal["view mfma"] = 68 * 2 * M
-ideal["dir mfma"] = 8 * 2 * M
-print(f"{'phase':18s}" + "".join(f" w{w:<8d}" for w in range(4)) + "   ideal_mfma")
-tot = [0] * 4
+ideal["view mfma"] = 68 * COLS * M
+ideal["dir mfma"] = 8 * COLS * M
+print(f"# {'mlp_lp8_kernel: 8 waves x 32 points (two per SIMD: waves w and w+4 share one matrix pipe)' if wps == 2 else 'mlp_lp_kernel: 4 waves x 64 points'}"
+      f", sem_mode {sem}, {prec}; cycles per phase of one 256-point tile, per wave; ideal = this wave's MFMAs x 32")
+print(f"{'phase':18s}" + "".join(f" w{w:<8d}" for w in range(NW)) + "   ideal_mfma")
+tot = [0] * NW
 for k in range(1, len(names)):
-    d = [int(st[w, k] - st[w, k - 1]) for w in range(4)]
-    for w in range(4):
+    d = [int(st[w, k] - st[w, k - 1]) for w in range(NW)]
+    for w in range(NW):
         tot[w] += d[w]
     print(f"{names[k]:18s}" + "".join(f" {x:<9d}" for x in d) + f"   {ideal.get(names[k], 0)}")
 print(f"{'total':18s}" + "".join(f" {x:<9d}" for x in tot) + f"   {sum(ideal.values())}")
+print(f"matrix-pipe time of the tile per SIMD (both waves' MFMAs): {sum(ideal.values()) * (2 if wps == 2 else 1)}; "
+      f"wall per tile (wave 0): {tot[0]}  -> pipe busy {sum(ideal.values()) * (2 if wps == 2 else 1) / tot[0]:.3f}")
