@@ -21,6 +21,16 @@
 //     the next chunk's first four operands; every group waits with lgkmcnt(3).  PHASE is static at every call site
 //     (chunks are 32, 34 or 16 groups; every part of the network is a multiple of 4 groups long).
 //   * DMA: 36 pieces per chunk over 8 waves = 5 per wave (the surplus four re-copy piece 35: same bytes, same place).
+//   * The two waves of a SIMD run in lock step (same chunk, one barrier per chunk for all eight waves).  A one-chunk lag
+//     between them was built and measured (NSOS_LP8_LAG below): no gain.
+//
+// What it buys and what it cannot.  Cycles per 256-point tile (sem+coord, bf16, profiles/r02/b_phase_*): 144.4 k -> 117.8 k,
+// matrix pipe busy 58 % -> 71 %: activation pass 2.9 k -> 1.24 k per layer, encodings and heads about halved, MFMA phases
+// 92 % -> 94 % of issue rate.  Wall clock improves by only 6-8 % (bf16 fine pass 1.30 -> 1.40 PFLOP/s), because the chip
+// is POWER-limited on this workload: a pure stream of the same MFMAs on random operands sustains 1.54-1.90 PFLOP/s on
+// the whole chip, not 2.5 (scripts/ubench/mfma_power.hip, profiles/r02/c_mfma_power.txt: the clock falls to 1.5-1.7 GHz),
+// and a busier pipe is answered with a lower clock (lp4 ~2.2 GHz, lp8 ~2.0 GHz).  This kernel runs at 74-81 % of what
+// the bare matrix pipe sustains on ReLU-like data.
 #include "lp_common.h"
 
 using namespace nsos;
@@ -127,24 +137,38 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         const int p = wave_s + 8 * i;
         poff[i] = (unsigned)((p < kSlotGroups ? p : kSlotGroups - 1) * 1024);
     }
+    // ---- Experimental (-DNSOS_LP8_LAG; NOT the shipped build): the two waves of a SIMD one chunk apart.  Waves 4..7
+    // ("lagging") start one barrier interval late, so that a wave's activation pass falls into an interval in which its
+    // SIMD partner runs MFMAs.  Slot protocol with a lag of one chunk: leaders at chunk c, laggers at c-1; resident: c-1,
+    // c, c+1; the fourth slot, which held c-2 (both groups done with it: proven by the barrier), is refilled with c+2 -- in
+    // each group's own numbering "cur+2 -> slot of cur+2" for leaders and "cur+3 -> slot of cur+3" for laggers: the same
+    // chunk, the same slot, issued in the same interval, 20 + 20 pieces; a chunk then has ONE interval to land, so the
+    // barrier waits for all of the wave's pieces (the lock-step build uses that scheme too: it is what the fp32 kernel does).
+    // Measured (profiles/r02/c_lp8_lag_vs_lockstep.txt): bit-identical results, no win -- without priorities the two waves'
+    // MFMAs interleave evenly and each activation pass is then exposed on its own (layer 11.5 k cycles vs 10.5 k in lock
+    // step); with s_setprio 3 around the pass's interval the layer comes back to 10.6 k, and the long VALU phases
+    // (encodings) serialise between the groups; wall clock 0.5-1.5 % behind lock step.
+#ifdef NSOS_LP8_LAG
+    const bool lagging = wave_s >= 4;
+#else
+    const bool lagging = false;   // shipped: both waves of a SIMD in the same chunk (every wave fills 'cur+2')
+#endif
     const unsigned char* const src_end = P.chunks + (size_t)NCH * kSlotBytes;
-    const unsigned char* src3 = P.chunks + (size_t)(3 % NCH) * kSlotBytes;
+    const unsigned char* srcf = P.chunks + (size_t)((lagging ? 3 : 2) % NCH) * kSlotBytes;
     auto dma_piece = [&](const unsigned char* src_chunk, unsigned dst_slot, int i) {
         dma_1k(src_chunk + poff[i], dst_slot + poff[i], voff);
     };
-    auto side = [&](int i) { dma_piece(src3, d3, i); };
+    auto side = [&](int i) { dma_piece(srcf, lagging ? d3 : d2, i); };
     auto mid = [&]() {
-        // all DMA pieces except the newest kDma8 (chunk cur+2, issued one chunk ago) must have landed: that is chunk
-        // cur+1, which the end of this chunk starts to read
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kDma8) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
     auto tail = [&]() {
         const unsigned tc = c0, td = d0;
         c0 = c1; c1 = c2; c2 = c3; c3 = tc;
         d0 = d1; d1 = d2; d2 = d3; d3 = td;
-        src3 += kSlotBytes;
-        if (src3 == src_end) src3 = P.chunks;
+        srcf += kSlotBytes;
+        if (srcf == src_end) srcf = P.chunks;
     };
     auto ctx = [&]() { return ChunkCtx{c0, c1}; };
 
@@ -160,6 +184,8 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     static_for<0, kRing8>([&](auto ic) { lds_read_a<decltype(ic)::value * 1024>(ring[decltype(ic)::value], c0); });
+    NSOS_PIN();
+    if (lagging) __builtin_amdgcn_s_barrier();   // the laggers' extra interval (pairs with the leaders' first chunk barrier)
     NSOS_PIN();
 
     // one chunk: NG groups = NG A operands `a0 + g` of a part with NT output tiles and NB leading bias operands; the
@@ -194,12 +220,22 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         pin_accumulators<NT>(acc);
     };
     auto no_ride = [](auto) {};
+#ifdef NSOS_LP8_LAG
+    auto hi_prio = [] { NSOS_PIN(); __builtin_amdgcn_s_setprio(3); NSOS_PIN(); };
+    auto lo_prio = [] { NSOS_PIN(); __builtin_amdgcn_s_setprio(0); NSOS_PIN(); };
+#else
+    auto hi_prio = [] {};
+    auto lo_prio = [] {};
+#endif
 #define IC(n) std::integral_constant<int, (n)> {}
 
+    if (P.prof && blockIdx.x < 2 && lane == 0) P.prof[(blockIdx.x * 8 + wave) * kProfSlots + kProfSlots - 2] = __builtin_readcyclecounter();
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         int stamp_k = 0;
-        auto stamp = [&]() {  // diagnostics only: one s_memtime per phase of the second tile of blocks 0..3
-            if (P.prof && tile == (int)(blockIdx.x + gridDim.x) && blockIdx.x < 4) {
+        auto stamp = [&]() {  // diagnostics only: one s_memtime per phase of the second tile of blocks 0..1 (16 rows of
+            // kProfSlots stamps, the buffer contract of nsos_mlp_profile_rays_lp; the last two slots of a row hold the
+            // wave's first and last cycle in the kernel)
+            if (P.prof && tile == (int)(blockIdx.x + gridDim.x) && blockIdx.x < 2) {
                 const unsigned long long t = __builtin_readcyclecounter();
                 if (lane == 0 && stamp_k < kProfSlots) P.prof[(blockIdx.x * 8 + wave) * kProfSlots + stamp_k] = t;
             }
@@ -240,19 +276,26 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         auto from_H = [&](auto sc) { return H[decltype(sc)::value]; };
 
         stamp();  // 1: inputs + xyz encoding
+        hi_prio();   // (lag build only) this wave issues its MFMAs first in the interval that ends with its activation pass
         run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), IC(0), Z, from_ex, no_ride);
         stamp();  // 2: L0 MFMAs
         activate1<T, 8, true>(H, Z);
+        lo_prio();
         stamp();  // 3: L0 activation
 #pragma unroll 1
         for (int l = 1; l <= 8; ++l) {
             run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), IC(0), Z, from_H, no_ride);
             run_chunk(IC(34), IC(8), IC(8), IC(34), IC(34), IC(0), IC(2), Z, from_H, no_ride);
             run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), IC(0), Z, from_H, no_ride);
+            if (l != 5) hi_prio();
             run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), IC(2), Z, from_H, no_ride);
-            if (l == 5) run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), IC(0), Z, from_ex, no_ride);  // skip connection
+            if (l == 5) {
+                hi_prio();
+                run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), IC(0), Z, from_ex, no_ride);  // skip connection
+            }
             stamp();  // 2 + 2l: MFMAs of layer l
             if (l < 8) activate1<T, 8, true>(H, Z); else activate1<T, 8, false>(H, Z);
+            lo_prio();
             stamp();  // 3 + 2l: activation pass
             if (l == 7) {
                 // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
@@ -388,6 +431,8 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         stamp();  // 24: rgb head + stores
     }
 #undef IC
+    if (P.prof && blockIdx.x < 2 && lane == 0) P.prof[(blockIdx.x * 8 + wave) * kProfSlots + kProfSlots - 1] = __builtin_readcyclecounter();
+    if (!lagging) __builtin_amdgcn_s_barrier();  // pairs with the laggers' last chunk barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 }

@@ -25,7 +25,7 @@ far = torch.full((R,), syn.FAR, device=dev)
 z, v = ops.ray_setup(rays[1], near, far, 192, None)
 packed = net.nerf_fine.packed_weights(prec)
 raw = torch.empty(R, 192, 6 if sem else 4, device=dev)
-stamps = torch.zeros(4 * NW * 64, dtype=torch.int64, device=dev)
+stamps = torch.zeros(16 * 64, dtype=torch.int64, device=dev)   # 16 rows: 4 blocks x 4 waves, or 2 blocks x 8 waves
 _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(wps), 'select')
 P = lambda t: C.c_void_p(t.data_ptr())
 dt = {"fp16": 1, "bf16": 2}[prec]
@@ -33,7 +33,15 @@ for _ in range(3):
     _lib.check(_lib.lib().nsos_mlp_profile_rays_lp(P(packed), sem, dt, P(rays[0].contiguous()), P(rays[1].contiguous()),
                                                   P(v), P(z), R, 192, P(raw), P(stamps), None), "profile")
 torch.cuda.synchronize()
-st = stamps.cpu().view(4 * NW, 64).numpy()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
+for _ in range(10):
+    _lib.check(_lib.lib().nsos_mlp_profile_rays_lp(P(packed), sem, dt, P(rays[0].contiguous()), P(rays[1].contiguous()),
+                                                  P(v), P(z), R, 192, P(raw), P(stamps), None), "profile")
+ev[1].record()
+torch.cuda.synchronize()
+launch_ms = ev[0].elapsed_time(ev[1]) / 10
+st = stamps.cpu().view(16, 64).numpy()
 M = 32  # cycles of one 32x32x16 MFMA
 names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * COLS * M}
 for l in range(1, 9):
@@ -57,3 +65,7 @@ for k in range(1, len(names)):
 print(f"{'total':18s}" + "".join(f" {x:<9d}" for x in tot) + f"   {sum(ideal.values())}")
 print(f"matrix-pipe time of the tile per SIMD (both waves' MFMAs): {sum(ideal.values()) * (2 if wps == 2 else 1)}; "
       f"wall per tile (wave 0): {tot[0]}  -> pipe busy {sum(ideal.values()) * (2 if wps == 2 else 1) / tot[0]:.3f}")
+if wps == 2:
+    whole = int(st[0, 63] - st[0, 62])
+    print(f"whole kernel, block 0 wave 0: {whole} shader cycles for {R * 192 // 256 // 256} tiles = {whole / (R * 192 / 256 / 256):.0f} per tile; launch {launch_ms:.4f} ms "
+          f"-> effective shader clock {whole / launch_ms / 1e6:.3f} GHz")

@@ -88,7 +88,7 @@ def test_lds_ring_protocol_holds_in_the_built_code():
     if not os.path.exists(chk.OBJDUMP):
         pytest.skip("llvm-objdump not found")
     kernels = {k: v for k, v in chk.disassemble(_lib.LIB_PATH).items() if "mlp_" in k and "pack" not in k}
-    assert len(kernels) >= 22, sorted(kernels)
+    assert len(kernels) >= 32, sorted(kernels)
     for name, ins in kernels.items():
         bad, n_reads, n_scratch = chk.check_kernel(ins)
         assert n_reads > 100, name
@@ -98,6 +98,8 @@ def test_lds_ring_protocol_holds_in_the_built_code():
         limit = 0
         if "mlp_lp_kernel" in name:   # ...ELi<SEM>ELb<SAVE>E...: the training (SAVE) variant unpacks 128 words for its stores
             limit = 160 if "ELb1EEE" in name else 16
+        if "mlp_lp8_kernel" in name:  # 256-register budget: a few pointers / per-tile scalars live in scratch OUTSIDE the
+            limit = 80 if "ELb1EEE" in name else 24   # MFMA chunks (never a ring register: `bad` above)
         if "mlp_x3_kernel" in name and "ELi0EEE" not in name:   # ...ELi<SEM>ELi<SAVE>E...: the training variants may park a
             limit = 64                                            # few row pointers / unpacked words in scratch around their stores
         assert n_scratch <= limit, (name, n_scratch)
