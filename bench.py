@@ -194,6 +194,21 @@ def kernel_roofline(events, n_points: int, mac_per_point: int, peak: float, kern
     return r
 
 
+# profiles/r02/c_mfma_power.txt (scripts/ubench/mfma_power.hip): what a PURE stream of these MFMAs sustains on the whole chip
+# with operands of which half are zero (what a ReLU network feeds the pipe) -- the chip clocks to its power budget, so the
+# nominal 2.5 PFLOP/s (2.4 GHz) is not reachable on real data.  Reported next to `frac` (which stays against the nominal peak).
+MEASURED_PIPE_CEILING_TFLOPS = {"fp16": 1881.0, "bf16": 1898.0}
+
+
+def add_power_note(roof, precision):
+    if roof and precision in MEASURED_PIPE_CEILING_TFLOPS:
+        c = MEASURED_PIPE_CEILING_TFLOPS[precision]
+        roof["measured_pipe_ceiling"] = {"tflops": c, "frac_of_it": round(roof["achieved"] / c, 4),
+                                         "what": "pure MFMA stream, two waves per SIMD, random operands with half of them zero, whole chip "
+                                                 "(power-limited clock); profiles/r02/c_mfma_power.txt"}
+    return roof
+
+
 def speed_fields(ctx, rays_per_rank_step: int, steps: int, dt: float, per_rank):
     rates = [rays_per_rank_step * steps / t for t in per_rank]
     return {"value": round(ctx.world * rays_per_rank_step * steps / dt, 1), "unit": "rays/s",
@@ -283,8 +298,8 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
     n_rays = len(own) * PATCH * PATCH
     res = speed_fields(ctx, n_rays, steps, dt, per_rank)
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
-    kname = {"fp32": "mlp_fused_kernel<2,true,1>", "fp16x3": "mlp_x3_kernel<2,1>"}.get(precision, f"mlp_lp_kernel<{precision},2,SAVE>")
-    roof = kernel_roofline(events, n_rays * N_FINE, MAC_SEMCOORD, peak, f"{kname} (fine pass of the rank's {n_rays} rays, {n_rays * N_FINE} points)")
+    kname = {"fp32": "mlp_fused_kernel<2,true,1>", "fp16x3": "mlp_x3_kernel<2,1>"}.get(precision, f"mlp_lp8_kernel<{precision},2,SAVE>")
+    roof = add_power_note(kernel_roofline(events, n_rays * N_FINE, MAC_SEMCOORD, peak, f"{kname} (fine pass of the rank's {n_rays} rays, {n_rays * N_FINE} points)"), precision)
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
         roof["whole_step_frac_forward_flops_only"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
@@ -332,8 +347,8 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int):
     res["value"] = round(syn.H * syn.W * steps / dt, 1)
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
     full_chunk = min(chunk, n_rays)
-    roof = kernel_roofline(events, full_chunk * N_FINE, MAC_SEMCOORD, peak,
-                           f"mlp_lp_kernel<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)")
+    roof = add_power_note(kernel_roofline(events, full_chunk * N_FINE, MAC_SEMCOORD, peak,
+                                          f"mlp_lp8_kernel<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)"), precision)
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
         roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
