@@ -317,6 +317,25 @@ int32_t nsos_eval_postprocess(const float* semantics, const float* rgb, const fl
                               int32_t sem_dim, float* sem_prob, int32_t* sem_pred, float* metrics, void* workspace,
                               void* stream);
 
+/* Row-partitioned GeoCorrelationLoss for the ray/patch-sharded multi-GPU step (utils/image.py:448-487; call site
+ * engines/trainer.py:159-160): every rank holds the WHOLE batch's depth / code / rays (sharding.all_gather_patches) but
+ * evaluates the O(P^4) pair sets only for ITS OWN row patches `rows[0..n_rows)` (device int32, global patch ids).  The patches
+ * are coupled through four global sums (mean(fd), mean(fd1) per pair set, utils/image.py:316-319) and through the gradient a
+ * patch receives as the NEGATIVE of another rank's patch, so the call is split into phases with a sum-all-reduce of workspace
+ * slots in between (offsets from nsos_corr_workspace_slots; the workspace is nsos_corr_workspace_bytes(1, ...)):
+ *   phase 0: prep + pass 1            -> all-reduce scal[0..1]   (2 doubles at scal_offset_bytes)
+ *   phase 1: pass 2                   -> all-reduce scal[2..3]
+ *   phase 2: passes 3, 4 + role sums  -> all-reduce scal[4..5] and gsum (gsum_floats fp32 at gsum_offset_bytes)
+ *   phase 3: loss (the batch-wide value, identical on every rank) and grad_code [B,C,H,W] for every patch.
+ * With rows = all patches and no reductions the four phases equal nsos_geo_correlation_loss up to summation order. */
+int32_t nsos_corr_workspace_slots(int32_t batch, int32_t n_points, int64_t* scal_offset_bytes, int64_t* gsum_offset_bytes,
+                                  int64_t* gsum_floats);
+int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float* code, const float* ray_o, const float* ray_d,
+                                       const int64_t* neg_indx, const int32_t* rows, int32_t n_rows, int32_t batch,
+                                       int32_t code_dim, int32_t height, int32_t width, float self_shift, float self_weight,
+                                       float neg_shift, float neg_weight, float max_depth, int32_t filter_in_place, float* loss,
+                                       float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- correlation losses on the rendered patches --------------------------------
  * CorrelationLoss.forward (utils/image.py:335-370) and GeoCorrelationLoss.forward (utils/image.py:448-487) for one
  * batch of B patches, with the random choices made by the caller:

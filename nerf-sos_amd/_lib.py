@@ -67,6 +67,9 @@ SIGNATURES = {
                                          _f32, _f32, _f32, _f32, _fp, _fp, _fp, _sz, _fp]),
     "nsos_geo_correlation_loss": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32,
                                          _i32, _fp, _fp, _fp, _sz, _fp]),
+    "nsos_corr_workspace_slots": (_i32, [_i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "nsos_geo_correlation_loss_rows": (_i32, [_i32, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32,
+                                              _f32, _i32, _fp, _fp, _fp, _sz, _fp]),
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 

@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int kMaxC = 4;        // semantic code channels supported (sem_dim; the shipped recipes use 2)
-constexpr int kRedBlocks = 1024;  // upper bound on partial sums per reduction
+constexpr int kRedBlocks = 8192;  // upper bound on partial sums per reduction (64 row blocks x 128 patches)
 
 struct CorrParams {
     float self_shift, self_weight, neg_shift, neg_weight;
@@ -44,6 +44,7 @@ struct Ws {
     float* gcol;       // [2][B][N][kMaxC] gradient w.r.t. normalised column codes
     float* fdmat;      // app only: [2][B][N][N]
     float* fn;         // app only: normalised sampled features [2][B][N][Cf]  (0: coords1 of n, 1: coords2 of neg[n])
+    float* gsum;       // geo only: [B][N][kMaxC] gradient w.r.t. the normalised codes, summed over roles (row-partitioned call)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -63,7 +64,8 @@ inline size_t ws_layout(Ws* w, void* base, int B, int N, int Cf, bool app) {
     float* gcol = (float*)take(sizeof(float) * 2 * B * N * kMaxC);
     float* fdmat = (float*)take(app ? sizeof(float) * 2 * B * N * N : 0);
     float* fn = (float*)take(app ? sizeof(float) * 2 * B * N * Cf : 0);
-    if (w) *w = Ws{rowsum, partial, scal, pts, cn, cn2, dinv, dinv2, grow, gcol, fdmat, fn};
+    float* gsum = (float*)take(app ? 0 : sizeof(float) * B * N * kMaxC);
+    if (w) *w = Ws{rowsum, partial, scal, pts, cn, cn2, dinv, dinv2, grow, gcol, fdmat, fn, gsum};
     return off;
 }
 
@@ -173,7 +175,11 @@ struct PairArgs {
     float* gcol;
     float max_depth;
     CorrParams prm;
+    const int* rows;       // row patches this call evaluates (blockIdx.y indexes it), or NULL = all B patches
+    int n_rows;
 };
+
+__device__ __forceinline__ int row_patch(const PairArgs& A) { return A.rows ? A.rows[blockIdx.y] : (int)blockIdx.y; }
 
 template <bool GEO>
 __device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, int n) {
@@ -182,11 +188,23 @@ __device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, in
 }
 
 // PASS 1: row sums.  PASS 2: sum fl32(fd - rowmean).  PASS 3: loss + row-code gradient.
+// GEO: a workgroup = 64 row points x kSlabs column slabs (wave w loops over columns [w N/4, (w+1) N/4)); the slabs' fp64
+// partials are folded in slab order through LDS.  With 256 rows per workgroup a call with few row patches (one or two per
+// GPU in the sharded step) put 32-64 workgroups on 256 CUs; this way it is 4x as many, each a quarter as long.
+template <bool GEO>
+struct PairShape {
+    static constexpr int kSlabs = GEO ? 4 : 1;
+    static constexpr int kThreads = GEO ? 256 : 128;
+    static constexpr int kRows = kThreads / kSlabs;
+};
+
 template <bool GEO, int C, int PASS>
-__global__ __launch_bounds__(256) void pair_rows_kernel(const PairArgs A) {
+__global__ __launch_bounds__(PairShape<GEO>::kThreads) void pair_rows_kernel(const PairArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // columns: GEO xyz [N][4] then codes [N][kMaxC]
     __shared__ double red[4];
-    const int set = blockIdx.z, n = blockIdx.y, N = A.N;
+    constexpr int kSlabs = PairShape<GEO>::kSlabs, kRows = PairShape<GEO>::kRows;
+    __shared__ double slab[kSlabs > 1 ? (kSlabs - 1) * kRows * (1 + kMaxC) : 1];
+    const int set = blockIdx.z, n = row_patch(A), N = A.N;
     const int m = set == 0 ? (int)A.neg[n] : n;
     float* lx = lds;
     float* lc = lds + (GEO ? (size_t)N * 4 : 0);
@@ -197,7 +215,8 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(const PairArgs A) {
         for (int i = threadIdx.x; i < N * kMaxC; i += blockDim.x) lc[i] = cc[i];
     }
     __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rl = threadIdx.x % kRows, sl = threadIdx.x / kRows;       // row within the block, column slab
+    const int p = blockIdx.x * kRows + rl;
     const bool live = p < N;
     const int pc = live ? p : N - 1;
     const size_t row = (size_t)n * N + pc;
@@ -214,12 +233,14 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(const PairArgs A) {
     const float gscale = -(set == 0 ? A.prm.neg_weight : A.prm.self_weight) / (float)cnt;
     // sums: fp32 over blocks of kBlk consecutive q (fixed order), blocks folded into fp64
     constexpr int kBlk = 32;
+    const int per = ((N + kSlabs * kBlk - 1) / (kSlabs * kBlk)) * kBlk;   // columns per slab, a multiple of kBlk
+    const int qb = sl * per, qend = qb + per < N ? qb + per : N;
     double acc = 0.0;
     double g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = 0.0;
-    for (int q0 = 0; q0 < N; q0 += kBlk) {
-        const int qe = q0 + kBlk < N ? q0 + kBlk : N;
+    for (int q0 = qb; q0 < qend; q0 += kBlk) {
+        const int qe = q0 + kBlk < qend ? q0 + kBlk : qend;
         float acc32 = 0.0f, g32[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) g32[c] = 0.0f;
@@ -256,28 +277,46 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(const PairArgs A) {
 #pragma unroll
         for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
     }
-    if (PASS == 1 && live) A.rowsum[((size_t)set * A.B + n) * N + p] = acc;
-    if (PASS == 3 && live)
+    if (kSlabs > 1) {   // fold the slabs in slab order: slab 0's lanes own the row
+        if (sl > 0) {
+            slab[((sl - 1) * kRows + rl) * (1 + kMaxC)] = acc;
+#pragma unroll
+            for (int c = 0; c < C; ++c) slab[((sl - 1) * kRows + rl) * (1 + kMaxC) + 1 + c] = g[c];
+        }
+        __syncthreads();
+        if (sl == 0)
+            for (int k = 1; k < kSlabs; ++k) {
+                acc += slab[((k - 1) * kRows + rl) * (1 + kMaxC)];
+#pragma unroll
+                for (int c = 0; c < C; ++c) g[c] += slab[((k - 1) * kRows + rl) * (1 + kMaxC) + 1 + c];
+            }
+    }
+    const bool owner = live && sl == 0;
+    if (PASS == 1 && owner) A.rowsum[((size_t)set * A.B + n) * N + p] = acc;
+    if (PASS == 3 && owner)
 #pragma unroll
         for (int c = 0; c < kMaxC; ++c) A.grow[(((size_t)set * A.B + n) * N + p) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
-    const double s = block_sum(live ? acc : 0.0, red);
+    const double s = block_sum(owner ? acc : 0.0, red);
     if (threadIdx.x == 0) A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
-// scal[slot + set] = sum of the block partials, fixed order
+// scal[slot + set] = sum of the block partials, fixed order (64 lanes, each a strided sub-sum, then a fixed tree)
 __global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, int slot) {
-    const int set = threadIdx.x;
-    if (set >= 2) return;
+    const int set = blockIdx.x, lane = threadIdx.x;
     double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += partial[(size_t)set * kRedBlocks + i];
-    scal[slot + set] = s;
+    for (int i = lane; i < nb; i += 64) s += partial[(size_t)set * kRedBlocks + i];
+    s = nsos_wave_sum(s);
+    if (lane == 0) scal[slot + set] = s;
 }
 
-// PASS 4: gradient w.r.t. the column codes: thread = column point q of pair (n -> m), loop over the row points p.
+// PASS 4: gradient w.r.t. the column codes: thread = column point q of pair (n -> m), loop over the row points p
+// (GEO: split into kSlabs row slabs per workgroup like the row passes, folded in slab order).
 template <bool GEO, int C>
-__global__ __launch_bounds__(256) void pair_cols_kernel(const PairArgs A) {
+__global__ __launch_bounds__(PairShape<GEO>::kThreads) void pair_cols_kernel(const PairArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // rows: xyz [N][4] (GEO), codes [N][kMaxC], rowmean [N]
-    const int set = blockIdx.z, n = blockIdx.y, N = A.N;
+    constexpr int kSlabs = PairShape<GEO>::kSlabs, kRows = PairShape<GEO>::kRows;
+    __shared__ double slab[kSlabs > 1 ? (kSlabs - 1) * kRows * kMaxC : 1];
+    const int set = blockIdx.z, n = row_patch(A), N = A.N;
     const int m = set == 0 ? (int)A.neg[n] : n;
     float* lx = lds;
     float* lc = lds + (GEO ? (size_t)N * 4 : 0);
@@ -287,24 +326,28 @@ __global__ __launch_bounds__(256) void pair_cols_kernel(const PairArgs A) {
     for (int i = threadIdx.x; i < N * kMaxC; i += blockDim.x) lc[i] = A.cn[(size_t)n * N * kMaxC + i];
     for (int i = threadIdx.x; i < N; i += blockDim.x) lr[i] = (float)(A.rowsum[((size_t)set * A.B + n) * N + i] / (double)N);
     __syncthreads();
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= N) return;
+    const int ql = threadIdx.x % kRows, sl = threadIdx.x / kRows;
+    const int q = blockIdx.x * kRows + ql;
+    const bool live = q < N;
+    const int qc = live ? q : N - 1;
     float y[3] = {0, 0, 0}, c2[C];
-    if (GEO) { const size_t col = (size_t)m * N + q; y[0] = A.pts[col * 4]; y[1] = A.pts[col * 4 + 1]; y[2] = A.pts[col * 4 + 2]; }
+    if (GEO) { const size_t col = (size_t)m * N + qc; y[0] = A.pts[col * 4]; y[1] = A.pts[col * 4 + 1]; y[2] = A.pts[col * 4 + 2]; }
     const float* cc = col_codes<GEO>(A, set, n);
 #pragma unroll
-    for (int c = 0; c < C; ++c) c2[c] = cc[(size_t)q * kMaxC + c];
+    for (int c = 0; c < C; ++c) c2[c] = cc[(size_t)qc * kMaxC + c];
     const double cnt = (double)A.B * N * N;
     const float old_mean = (float)(A.scal[set] / cnt), m1 = (float)(A.scal[2 + set] / cnt);
     const float shift = set == 0 ? A.prm.neg_shift : A.prm.self_shift;
     const float gscale = -(set == 0 ? A.prm.neg_weight : A.prm.self_weight) / (float)cnt;
-    const float* fdcol = GEO ? nullptr : A.fdmat + ((size_t)set * A.B + n) * N * N + q;
+    const float* fdcol = GEO ? nullptr : A.fdmat + ((size_t)set * A.B + n) * N * N + qc;
     constexpr int kBlk = 32;
+    const int per = ((N + kSlabs * kBlk - 1) / (kSlabs * kBlk)) * kBlk;
+    const int pb = sl * per, pend = pb + per < N ? pb + per : N;
     double g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = 0.0;
-    for (int p0 = 0; p0 < N; p0 += kBlk) {
-        const int pe = p0 + kBlk < N ? p0 + kBlk : N;
+    for (int p0 = pb; p0 < pend; p0 += kBlk) {
+        const int pe = p0 + kBlk < pend ? p0 + kBlk : pend;
         float g32[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) g32[c] = 0.0f;
@@ -341,8 +384,19 @@ __global__ __launch_bounds__(256) void pair_cols_kernel(const PairArgs A) {
 #pragma unroll
         for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
     }
+    if (kSlabs > 1) {
+        if (sl > 0)
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) A.gcol[(((size_t)set * A.B + n) * N + q) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
+            for (int c = 0; c < C; ++c) slab[((sl - 1) * kRows + ql) * kMaxC + c] = g[c];
+        __syncthreads();
+        if (sl == 0)
+            for (int k = 1; k < kSlabs; ++k)
+#pragma unroll
+                for (int c = 0; c < C; ++c) g[c] += slab[((k - 1) * kRows + ql) * kMaxC + c];
+    }
+    if (live && sl == 0)
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) A.gcol[(((size_t)set * A.B + n) * N + q) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
 }
 
 __global__ void loss_finish_kernel(const double* __restrict__ scal, double cnt, CorrParams prm, float* __restrict__ loss) {
@@ -544,16 +598,16 @@ __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, i
 
 // ------------------------------------------------------------------------------------------ host side
 template <bool GEO, int C>
-int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st) {
+int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases = 7) {
     const int N = A.N, B = A.B;
-    const int tb = GEO ? 256 : 128;
-    const dim3 grid((N + tb - 1) / tb, B, 2);
+    const int tb = PairShape<GEO>::kThreads, rows_per_block = PairShape<GEO>::kRows;
+    const dim3 grid((N + rows_per_block - 1) / rows_per_block, A.rows ? A.n_rows : B, 2);
     const int nb = (int)(grid.x * grid.y);
     if (nb > kRedBlocks) return NSOS_ERR_UNSUPPORTED;
     const size_t lds_rows12 = GEO ? (size_t)N * 4 * 4 : 0;
     const size_t lds_rows3 = lds_rows12 + (size_t)N * kMaxC * 4;
     const size_t lds_cols = lds_rows3 + (size_t)N * 4;
-    constexpr int kLdsCap = 150 * 1024;   // dynamic part; the kernels also hold a few bytes of static LDS (160 KiB per CU)
+    constexpr int kLdsCap = 148 * 1024;   // dynamic part; the kernels also hold up to 8 KiB of static LDS (slab folds; 160 KiB per CU)
     if (lds_cols > (size_t)kLdsCap) return NSOS_ERR_UNSUPPORTED;
     static bool configured = false;
     if (!configured) {
@@ -565,14 +619,23 @@ int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStrea
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
-    hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1>), grid, dim3(tb), lds_rows12, st, A);
-    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, 0);
-    hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 2>), grid, dim3(tb), lds_rows12, st, A);
-    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, 2);
-    hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3>), grid, dim3(tb), lds_rows3, st, A);
-    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, 4);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss);
-    if (want_grad) hipLaunchKernelGGL((pair_cols_kernel<GEO, C>), grid, dim3(tb), lds_cols, st, A);
+    // phases (bit mask): 1 = pass 1, 2 = pass 2, 4 = passes 3 (+4).  A single-process call runs all of them; the row-partitioned
+    // multi-GPU call runs them one at a time and all-reduces scal[0..1], scal[2..3] over the ranks in between (the global
+    // means of fd and fd1 couple every patch of the batch, utils/image.py:316-319).
+    if (phases & 1) {
+        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1>), grid, dim3(tb), lds_rows12, st, A);
+        hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
+    }
+    if (phases & 2) {
+        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 2>), grid, dim3(tb), lds_rows12, st, A);
+        hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 2);
+    }
+    if (phases & 4) {
+        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3>), grid, dim3(tb), lds_rows3, st, A);
+        hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
+        if (loss) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss);
+        if (want_grad) hipLaunchKernelGGL((pair_cols_kernel<GEO, C>), grid, dim3(tb), lds_cols, st, A);
+    }
     return nsos_launch_status();
 }
 
@@ -593,6 +656,91 @@ int32_t geo_impl(float* depth, const float* code, const float* ray_o, const floa
     if (grad_code)
         hipLaunchKernelGGL((geo_grad_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, neg, w.cn, w.dinv, w.grow,
                            w.gcol, grad_code);
+    return nsos_launch_status();
+}
+
+// ---- row-partitioned geometric loss (multi-GPU: each rank evaluates the pair sets of ITS OWN row patches) -----------
+// gsum[m] = sum over the roles patch m plays in the row patches `rows`:  rows(neg,m) + rows(self,m) + cols(self,m) if m is one
+// of them, + cols(neg,n) for every n in `rows` whose negative is m.  Summed over the ranks (all-reduce) it is the argument of
+// normalize_backward in geo_grad_kernel.
+template <int C>
+__global__ __launch_bounds__(256) void geo_gsum_kernel(int B, int N, const long long* __restrict__ neg, const int* __restrict__ rows,
+                                                       int n_rows, const float* __restrict__ grow, const float* __restrict__ gcol,
+                                                       float* __restrict__ gsum) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N) return;
+    const int m = (int)(i / N), p = (int)(i % N);
+    float gy[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gy[c] = 0.0f;
+    for (int r = 0; r < n_rows; ++r) {
+        const int n = rows[r];
+        if (n == m) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float s = grow[((size_t)(0 * B + m) * N + p) * kMaxC + c];
+                s += grow[((size_t)(1 * B + m) * N + p) * kMaxC + c];
+                s += gcol[((size_t)(1 * B + m) * N + p) * kMaxC + c];
+                gy[c] += s;
+            }
+        }
+        if ((int)neg[n] == m)
+#pragma unroll
+            for (int c = 0; c < C; ++c) gy[c] += gcol[((size_t)(0 * B + n) * N + p) * kMaxC + c];
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) gsum[i * kMaxC + c] = c < C ? gy[c] : 0.0f;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void geo_finish_kernel(int B, int N, const float* __restrict__ cn, const float* __restrict__ dinv,
+                                                         const float* __restrict__ gsum, float* __restrict__ grad_code) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * N) return;
+    const int m = (int)(i / N), p = (int)(i % N);
+    float gy[C], gv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gy[c] = gsum[i * kMaxC + c];
+    normalize_backward<C>(gy, cn + i * kMaxC, dinv[i * 2], dinv[i * 2 + 1], gv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) grad_code[((long long)m * C + c) * N + p] = gv[c];
+}
+
+// phase 0: depth filter + points + normalised codes of the WHOLE batch (cheap, every rank), pass 1 over own rows -> scal[0..1]
+// phase 1: (scal[0..1] all-reduced) pass 2 -> scal[2..3]
+// phase 2: (scal[2..3] all-reduced) passes 3 and 4 over own rows -> scal[4..5] (loss sums), gsum
+// phase 3: (scal[4..5], gsum all-reduced) loss value and d loss / d code for every patch of the batch
+template <int C>
+int32_t geo_rows_impl(int phase, float* depth, const float* code, const float* ray_o, const float* ray_d, const long long* neg,
+                      const int* rows, int n_rows, int B, int N, CorrParams prm, float max_depth, int write_back, float* loss,
+                      float* grad_code, void* workspace, hipStream_t st) {
+    Ws w;
+    ws_layout(&w, workspace, B, N, 0, false);
+    const long long tot = (long long)B * N;
+    const unsigned gb = (unsigned)((tot + 255) / 256);
+    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, rows, n_rows};
+    if (phase == 0) {
+        const int rb = (int)(gb < 256 ? gb : 256);
+        hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot, max_depth, w.partial);
+        hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
+        hipLaunchKernelGGL((geo_prep_kernel<C>), dim3(gb), dim3(256), 0, st, depth, code, ray_o, ray_d, B, N, max_depth, write_back,
+                           w.scal, w.pts, w.cn, w.dinv);
+    }
+    if (phase <= 2) {
+        const int slot = phase * 2;
+        if (n_rows == 0) {   // a rank without patches contributes zeros
+            hipError_t e = hipMemsetAsync(w.scal + slot, 0, 2 * sizeof(double), st);
+            if (e == hipSuccess && phase == 2) e = hipMemsetAsync(w.gsum, 0, sizeof(float) * tot * kMaxC, st);
+            return e == hipSuccess ? nsos_launch_status() : (int32_t)e;
+        }
+        const int32_t rc = run_pair_passes<true, C>(A, true, nullptr, st, 1 << phase);
+        if (rc != NSOS_OK) return rc;
+        if (phase == 2)
+            hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, w.gsum);
+        return nsos_launch_status();
+    }
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss);
+    if (grad_code) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, grad_code);
     return nsos_launch_status();
 }
 
@@ -652,6 +800,44 @@ extern "C" int32_t nsos_geo_correlation_loss(float* depth, const float* code, co
         case 2: return geo_impl<2>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
         case 3: return geo_impl<3>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
         default: return geo_impl<4>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+    }
+}
+
+extern "C" int32_t nsos_corr_workspace_slots(int32_t batch, int32_t n_points, int64_t* scal_offset_bytes,
+                                             int64_t* gsum_offset_bytes, int64_t* gsum_floats) {
+    NSOS_REQUIRE(batch > 0 && n_points > 0 && scal_offset_bytes && gsum_offset_bytes && gsum_floats, NSOS_ERR_BAD_SHAPE);
+    Ws w;
+    ws_layout(&w, reinterpret_cast<void*>((uintptr_t)4096), batch, n_points, 0, false);   // offsets relative to a fake base
+    *scal_offset_bytes = (int64_t)((uintptr_t)w.scal - 4096);
+    *gsum_offset_bytes = (int64_t)((uintptr_t)w.gsum - 4096);
+    *gsum_floats = (int64_t)batch * n_points * kMaxC;
+    return NSOS_OK;
+}
+
+extern "C" int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float* code, const float* ray_o,
+                                                  const float* ray_d, const int64_t* neg_indx, const int32_t* rows, int32_t n_rows,
+                                                  int32_t batch, int32_t code_dim, int32_t height, int32_t width,
+                                                  float self_shift, float self_weight, float neg_shift, float neg_weight,
+                                                  float max_depth, int32_t filter_in_place, float* loss, float* grad_code,
+                                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch == 0) return NSOS_OK;
+    NSOS_REQUIRE(phase >= 0 && phase <= 3, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(depth && code && ray_o && ray_d && neg_indx && workspace && (n_rows == 0 || rows), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(phase < 3 || loss, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(batch > 0 && height > 0 && width > 0 && n_rows >= 0 && n_rows <= batch, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
+    const long long N = (long long)height * width;
+    NSOS_REQUIRE(N <= 4096, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(((uintptr_t)workspace & 15) == 0, NSOS_ERR_MISALIGNED);
+    NSOS_REQUIRE(workspace_bytes >= nsos_corr_workspace_bytes(1, batch, (int32_t)N, 0), NSOS_ERR_BUFFER_TOO_SMALL);
+    const CorrParams prm = {self_shift, self_weight, neg_shift, neg_weight};
+    const long long* neg = reinterpret_cast<const long long*>(neg_indx);
+    const hipStream_t st = (hipStream_t)stream;
+    switch (code_dim) {
+        case 1: return geo_rows_impl<1>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        case 2: return geo_rows_impl<2>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        case 3: return geo_rows_impl<3>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        default: return geo_rows_impl<4>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
     }
 }
 

@@ -118,7 +118,13 @@ class GeoCorrelationLoss(CorrelationLoss):
         self.max_depth = 15
         self.ps = getattr(args, "patch_stride", 8)
 
-    def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, batch_rays, sim_matrix: Optional[torch.Tensor]):
+    def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, batch_rays, sim_matrix: Optional[torch.Tensor],
+                rows: Optional[Sequence[int]] = None, group=None):
+        """`rows` (not in the reference): the row patches THIS rank evaluates, for the patch-sharded multi-GPU step.  Every
+        rank passes the whole batch (depth, code and rays of all B patches, as gathered by sharding.all_gather_patches) and its
+        own patch ids; the O(P^4) pair sets are then evaluated once across the ranks instead of once per rank, and four tiny
+        sum-all-reduces over `group` (the global means of fd / fd1, the loss sums, and the [B,P*P,4] role sums of the gradient)
+        make the returned loss and d loss / d code of EVERY patch the batch-wide, single-process values."""
         depth = orig_feats
         B, one, H, W = depth.shape
         if one != 1:
@@ -143,9 +149,28 @@ class GeoCorrelationLoss(CorrelationLoss):
             ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
             loss = torch.empty((), device=dev, dtype=torch.float32)
             grad = torch.empty_like(code) if want_grad else None
-            _lib.check(lib.nsos_geo_correlation_loss(dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(), B, C, H, W, *prm,
-                                                     float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
-                                                     ws.numel() * 8, _stream()), "nsos_geo_correlation_loss")
+            if rows is None:
+                _lib.check(lib.nsos_geo_correlation_loss(dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(), B, C, H, W, *prm,
+                                                         float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
+                                                         ws.numel() * 8, _stream()), "nsos_geo_correlation_loss")
+                return loss, grad
+            import ctypes as C_
+            import torch.distributed as dist
+            so, go, gn = C_.c_int64(), C_.c_int64(), C_.c_int64()
+            _lib.check(lib.nsos_corr_workspace_slots(B, H * W, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
+            scal = ws[so.value // 8: so.value // 8 + 6]
+            gsum = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
+            rows_t = torch.tensor(list(rows), dtype=torch.int32, device=dev)
+            reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+            for phase in range(4):
+                _lib.check(lib.nsos_geo_correlation_loss_rows(phase, dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(),
+                                                              rows_t.data_ptr() if len(rows) else None, len(rows), B, C, H, W, *prm,
+                                                              float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
+                                                              ws.numel() * 8, _stream()), "nsos_geo_correlation_loss_rows")
+                if reduce and phase < 3:
+                    dist.all_reduce(scal[2 * phase: 2 * phase + 2], group=group)
+                    if phase == 2 and want_grad:
+                        dist.all_reduce(gsum, group=group)
             return loss, grad
 
         out = _CorrFn.apply(orig_code, launch)

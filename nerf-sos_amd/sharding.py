@@ -190,7 +190,8 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
          DINO `feat` [n_local,384,14,14] and `cls_tokens` [n_local,384] of the rank's own crops, ray_o / ray_d
       -> similarity matrix of the class tokens -> negatives (utils/image.py:354)
       -> the rank's own gradient-carrying patches are spliced back into the detached batch
-      -> appearance + geometric correlation losses on `semantics0` and `semantics` (engines/trainer.py:127-166)
+      -> appearance + geometric correlation losses on `semantics0` and `semantics` (engines/trainer.py:127-166); the
+         O(P^4) geometric one row-partitioned: each rank its own patches' pair sets, four tiny sum-all-reduces
       -> backward through the rank's own patches -> ONE flat all-reduce (sum) of the parameter gradients.
 
     Returns the (batch-wide) loss; `.grad` of the trainable parameters then holds the single-process gradient.
@@ -231,7 +232,9 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
             geo_loss.generator = gen
         depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()       # the geo loss uses the FINE depth for both terms
         ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
-        g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim) + geo_loss(depth, s1, [ro, rd, None], sim))
+        # the O(P^4) geometric loss is evaluated ONCE across the ranks: each rank its own row patches (losses.py)
+        g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim, rows=own, group=group) +
+                     geo_loss(depth, s1, [ro, rd, None], sim, rows=own, group=group))
         loss = g if loss is None else loss + g
     if loss is None:
         raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")

@@ -122,6 +122,68 @@ def test_geo_correlation_loss_golden(tag):
     assert np.array_equal(depth_cl.permute(0, 3, 1, 2).cpu().numpy(), GOLD[f"{tag}_depth_after"])
 
 
+@pytest.mark.parametrize("tag", ["geo_small", "geo_full"])
+def test_geo_correlation_loss_row_partitioned_equals_golden(tag):
+    """The phased, row-partitioned entry point (nsos_geo_correlation_loss_rows: what each rank of the patch-sharded step
+    calls for its own row patches) with rows = every patch and nothing to reduce is the same loss: golden value and
+    gradient within 1e-4; and the sum of the per-subset role sums over a 2-way split of the rows equals the whole --
+    emulated here in one process by running both halves' phases and adding the reduced slots by hand, the way the
+    all-reduce does across ranks (tests/test_gpu_sharded.py runs it over a real process group)."""
+    import ctypes as C
+    from nerf_sos_amd import _lib
+    mod = nerf_sos_amd.GeoCorrelationLoss(ref_args())
+    depth, sim = T(GOLD[f"{tag}_depth"]), T(GOLD[f"{tag}_sim"])
+    B, _, P, _ = depth.shape
+    ray_o = T(GOLD[f"{tag}_ray_o"])[:, :, None, None].expand(B, 3, P, P).contiguous()
+    ray_d = T(GOLD[f"{tag}_ray_d"])
+    code = T(GOLD[f"{tag}_code"]).requires_grad_(True)
+    loss = mod(depth.clone(), code, [ray_o, ray_d, None], sim, rows=list(range(B)))
+    want = GOLD[f"{tag}_loss"][0]
+    assert abs(loss.item() - want) < 1e-4 * (1 + abs(want)), (loss.item(), want)
+    loss.backward()
+    assert rel(code.grad, GOLD[f"{tag}_grad"]) < 1e-4
+    # two "ranks" in one process: phases interleaved, slots summed by hand
+    lib = _lib.lib()
+    neg = torch.min(sim, dim=0)[1].to(torch.int64).contiguous()
+    Cn = code.shape[1]
+    nbytes = lib.nsos_corr_workspace_bytes(1, B, P * P, 0)
+    so, go, gn = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(lib.nsos_corr_workspace_slots(B, P * P, C.byref(so), C.byref(go), C.byref(gn)), "slots")
+    halves = [list(range(0, B, 2)), list(range(1, B, 2))]
+    wss = [torch.zeros((nbytes + 15) // 16 * 2, device=DEV, dtype=torch.float64) for _ in halves]
+    rws = [torch.tensor(h, dtype=torch.int32, device=DEV) for h in halves]
+    dbs = [T(GOLD[f"{tag}_depth"]).contiguous() for _ in halves]
+    cd = code.detach().contiguous()
+    P_ = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    out_loss = [torch.empty((), device=DEV) for _ in halves]
+    out_grad = [torch.empty_like(cd) for _ in halves]
+    prm = (mod.self_shift, mod.self_weight, mod.neg_shift, mod.neg_weight)
+
+    def call(phase, k):
+        _lib.check(lib.nsos_geo_correlation_loss_rows(phase, P_(dbs[k]), P_(cd), P_(ray_o), P_(ray_d.contiguous()), P_(neg),
+                                                      P_(rws[k]) if halves[k] else None, len(halves[k]), B, Cn, P, P, *prm, 15.0, 1,
+                                                      P_(out_loss[k]), P_(out_grad[k]), P_(wss[k]), wss[k].numel() * 8, None), "rows")
+
+    for phase in range(4):
+        for k in range(2):
+            call(phase, k)
+        torch.cuda.synchronize()
+        if phase < 3:
+            sl = slice(so.value // 8 + 2 * phase, so.value // 8 + 2 * phase + 2)
+            tot = wss[0][sl] + wss[1][sl]
+            wss[0][sl] = tot
+            wss[1][sl] = tot
+            if phase == 2:
+                gl = slice(go.value // 4, go.value // 4 + gn.value)
+                g = wss[0].view(torch.float32)[gl] + wss[1].view(torch.float32)[gl]
+                wss[0].view(torch.float32)[gl] = g
+                wss[1].view(torch.float32)[gl] = g
+    for k in range(2):
+        assert abs(out_loss[k].item() - want) < 1e-4 * (1 + abs(want))
+        assert rel(out_grad[k], GOLD[f"{tag}_grad"]) < 1e-4
+    assert torch.equal(out_grad[0], out_grad[1]) and torch.equal(out_loss[0], out_loss[1])
+
+
 def test_losses_on_rendered_patches_train_the_semantic_head():
     """The training step right after the path (engines/trainer.py:127-166, 201-203): rendered semantics -> both
     correlation losses -> backward through the frozen-backbone render -> the semantic head's gradients."""
