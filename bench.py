@@ -274,6 +274,7 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
         p_.requires_grad = "semantic_linear" in n_
     net.train()
     net.mlp_precision = precision
+    net.rng, net.rng_seed = "philox", 1 + ctx.rank      # train-mode jitter / noise draws: one launch per chunk (ops.render_draws)
     opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
     corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
     all_rays = syn.synthetic_patches(B, PATCH, PATCH_STRIDE, seed=0, device=ctx.dev)
@@ -439,7 +440,7 @@ def main():
                                        "BASELINE configs[3]: 8192 rays/GPU = two 64x64 patches per GPU, patch batch sharded over the GPUs "
                                        "(RCCL all-gather of the patch tensors + gradient all-reduce)") +
                                       f", (64+192) MLP evaluations/ray, sem+coord head, {prec} MLP, train mode, appearance + geometric "
-                                      "correlation losses, semantic-head backward (--fix_backbone recipe), Adam",
+                                      "correlation losses, semantic-head backward (--fix_backbone recipe), Adam; train-mode draws from the package's one-launch Philox stream",
                           "rays_per_gpu": res["rays_per_gpu"], "patches": res["patches"], "parallelism": f"patch-sharded x{ctx.world}",
                           "flop_per_ray_forward": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
         line["roofline"] = res["roofline"]

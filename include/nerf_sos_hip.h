@@ -292,6 +292,15 @@ int32_t nsos_composite_backward(const float* raw, const float* z_vals, const flo
                                 const float* g_rgb, const float* g_sem, const float* g_depth, const float* g_acc,
                                 const float* g_disp, const float* g_weights, float* g_raw, void* stream);
 
+/* Train-mode random tensors of one ray chunk in ONE launch (optional; NeRFNet.rng = "philox").  The reference draws, in this
+ * order, rand[R,S] (stratified jitter, models/sampler.py:61), randn[R,S] (coarse sigma noise, models/renderer.py:47),
+ * rand[R,N] (importance u, models/sampler.py:103), randn[R,S+N] (fine sigma noise) from torch's global generator: four
+ * launches.  Here a counter-based Philox4x32-10 stream keyed by `seed`, advanced by `call` (one value per chunk / step),
+ * fills whichever of the four buffers is not NULL.  NOT torch's values: the default path keeps torch's generator so that
+ * the reference's captured draws can be injected (tests/golden/end_to_end.npz). */
+int32_t nsos_render_draws(uint64_t seed, uint64_t call, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
+                          float* t_rand, float* noise0, float* u, float* noise1, void* stream);
+
 /* ---- K4: hierarchical sampling ----------------------------------------------------------------
  * ImportanceSampler.forward / sample_pdf (models/sampler.py:91-167) + z_std (models/nerf_net.py:124):
  * pdf over the inner 62 coarse weights, cdf (fp64-accumulated), right-bisect search of u,

@@ -246,6 +246,63 @@ __global__ __launch_bounds__(256) void importance_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ train-mode draws
+// The reference draws four random tensors per ray chunk in train mode (rand[R,S] jitter, randn[R,S] coarse
+// sigma noise, rand[R,N] importance u, randn[R,S+N] fine sigma noise: models/sampler.py:61,103, models/renderer.py:47) --
+// four generator launches plus their bookkeeping on the host.  This kernel fills all four in ONE launch from a
+// counter-based generator (Philox4x32-10, the generator behind torch's own CUDA/HIP streams): element e of the
+// concatenated stream is word (e & 3) of block e >> 2 under key = seed, counter = (block, call).  Uniforms are 24-bit
+// (k + 0.5) 2^-24 in (0,1); normals are Box-Muller pairs.  Opt-in (NeRFNet.rng = "philox"): the values are NOT torch's, so
+// the parity tests (which inject the reference's captured draws) keep the default path.
+struct Philox {
+    unsigned key[2];
+    __device__ __forceinline__ static void round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+        c[0] = h1 ^ c[1] ^ k0; c[1] = l1; c[2] = h0 ^ c[3] ^ k1; c[3] = l0;
+    }
+    __device__ __forceinline__ void operator()(unsigned (&c)[4]) const {
+        unsigned k0 = key[0], k1 = key[1];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    }
+};
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f; }   // (0,1)
+
+__global__ __launch_bounds__(256) void render_draws_kernel(unsigned long long seed, unsigned long long call,
+                                                           long long n_uniform0, long long n_normal0, long long n_uniform1,
+                                                           long long n_normal1, float* __restrict__ t_rand,
+                                                           float* __restrict__ noise0, float* __restrict__ u,
+                                                           float* __restrict__ noise1) {
+    // one thread = one Philox block = 4 consecutive elements of one of the four tensors (each padded to a multiple of 4)
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long q0 = (n_uniform0 + 3) >> 2, q1 = (n_normal0 + 3) >> 2, q2 = (n_uniform1 + 3) >> 2, q3 = (n_normal1 + 3) >> 2;
+    if (b >= q0 + q1 + q2 + q3) return;
+    const Philox gen = {{(unsigned)seed, (unsigned)(seed >> 32)}};
+    unsigned c[4] = {(unsigned)b, (unsigned)(b >> 32), (unsigned)call, (unsigned)(call >> 32)};
+    gen(c);
+    float* dst; long long e, n; bool normal;
+    if (b < q0) { dst = t_rand; e = b * 4; n = n_uniform0; normal = false; }
+    else if (b < q0 + q1) { dst = noise0; e = (b - q0) * 4; n = n_normal0; normal = true; }
+    else if (b < q0 + q1 + q2) { dst = u; e = (b - q0 - q1) * 4; n = n_uniform1; normal = false; }
+    else { dst = noise1; e = (b - q0 - q1 - q2) * 4; n = n_normal1; normal = true; }
+    float v[4];
+    if (normal) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float r = sqrtf(-2.0f * __logf(u01(c[2 * k]))), th = 6.283185307179586f * u01(c[2 * k + 1]);
+            v[2 * k] = r * __cosf(th);
+            v[2 * k + 1] = r * __sinf(th);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = u01(c[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (e + k < n) dst[e + k] = v[k];
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy,
                                       const float* c2w_host, int64_t pix_begin, int64_t pix_end, float* rays_o,
@@ -304,5 +361,19 @@ extern "C" int32_t nsos_importance_sample(const float* z_vals, const float* weig
     hipLaunchKernelGGL(importance_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        z_vals, weights, u, cdf_in, n_rays, n_coarse, n_importance, z_fine, z_samples, z_std, cdf_out,
                        inds_out);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_render_draws(uint64_t seed, uint64_t call, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
+                                     float* t_rand, float* noise0, float* u, float* noise1, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(n_rays > 0 && n_coarse >= 1 && n_importance >= 0, NSOS_ERR_BAD_SHAPE);
+    const long long n0 = t_rand ? (long long)n_rays * n_coarse : 0, n1 = noise0 ? (long long)n_rays * n_coarse : 0;
+    const long long n2 = u ? (long long)n_rays * n_importance : 0, n3 = noise1 ? (long long)n_rays * (n_coarse + n_importance) : 0;
+    const long long blocks4 = ((n0 + 3) >> 2) + ((n1 + 3) >> 2) + ((n2 + 3) >> 2) + ((n3 + 3) >> 2);
+    if (blocks4 == 0) return NSOS_OK;
+    NSOS_REQUIRE((blocks4 + 255) / 256 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(render_draws_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)seed, (unsigned long long)call, n0, n1, n2, n3, t_rand, noise0, u, noise1);
     return nsos_launch_status();
 }

@@ -256,6 +256,12 @@ class NeRFNet(nn.Module):
         # Not in the reference (which is fp32 only): "fp32" = exact-fp32 MFMA (parity path, default);
         # "fp16" / "bf16" = 16-bit MFMA inputs with fp32 accumulation (BASELINE configs C5 / C3), inference only.
         self.mlp_precision = "fp32"
+        # Train-mode random draws.  "torch" (default): the reference's four torch.rand / torch.randn calls per ray chunk, in
+        # its order, from torch's global generator (what the parity tests inject into).  "philox": ONE launch of the
+        # package's counter-based generator per chunk (ops.render_draws), keyed by `rng_seed`, advanced per chunk.
+        self.rng = "torch"
+        self.rng_seed = 0
+        self._rng_calls = 0
 
     def invalidate_packed(self) -> None:
         """Forget the packed weight streams of both networks (needed only after edits through ``param.data``, which
@@ -323,12 +329,21 @@ class NeRFNet(nn.Module):
             saved[tag] = dict(sem_in=sem_in, sem_hid=sem_hid)
             return raw
 
-        t_rand = torch.rand((R, n_samples), device=dev) if perturb > 0. else None          # sampler.py:61
+        n_importance = kwargs.get('N_importance', self.N_importance)
+        fine = self.N_importance > 0 and n_importance > 0
+        pre = None
+        if self.rng == "philox" and (perturb != 0. or raw_noise_std > 0.) and R > 0:
+            self._rng_calls += 1
+            pre = ops.render_draws(self.rng_seed, self._rng_calls, R, n_samples, self.N_importance if fine else 0, dev,
+                                   jitter=perturb > 0., noise=raw_noise_std > 0., importance=perturb != 0.)
+        elif self.rng not in ("torch", "philox"):
+            raise ValueError(f"NeRFNet.rng must be 'torch' or 'philox', got {self.rng!r}")
+        t_rand = (pre[0] if pre else torch.rand((R, n_samples), device=dev)) if perturb > 0. else None   # sampler.py:61
         z_vals, unit_dirs = ops.ray_setup(rays_d, near, far, n_samples, t_rand)
         if viewdirs is None:
             viewdirs = unit_dirs
         raw = query(self.nerf, z_vals, "coarse")
-        noise = torch.randn((R, n_samples), device=dev) if raw_noise_std > 0. else None    # renderer.py:47
+        noise = (pre[1] if pre else torch.randn((R, n_samples), device=dev)) if raw_noise_std > 0. else None   # renderer.py:47
         ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
         if save:
             saved["coarse"]["weights"] = ret['weights']
@@ -339,17 +354,16 @@ class NeRFNet(nn.Module):
         if retpts:
             ret['pts'] = ops.ray_points(rays_o, rays_d, z_vals)
 
-        n_importance = kwargs.get('N_importance', self.N_importance)
-        if self.N_importance > 0 and n_importance > 0:
+        if fine:
             ret0 = ret
             # the sample count is the constructor's, not the per-call kwarg (sampler.py:100,103)
             N = self.N_importance
-            u = torch.rand((R, N), device=dev) if perturb != 0.0 else None                 # sampler.py:103,158
+            u = (pre[2] if pre else torch.rand((R, N), device=dev)) if perturb != 0.0 else None   # sampler.py:103,158
             z_fine, z_samples, z_std = ops.importance_sample(z_vals, ret0['weights'], N, u)
             if z_fine_override is not None:
                 z_fine = z_fine_override.to(device=dev, dtype=torch.float32).reshape(R, n_samples + N).contiguous()
             raw = query(self.nerf_fine, z_fine, "fine")
-            noise = torch.randn((R, n_samples + N), device=dev) if raw_noise_std > 0. else None
+            noise = (pre[3] if pre else torch.randn((R, n_samples + N), device=dev)) if raw_noise_std > 0. else None
             ret = ops.composite(raw, z_fine, rays_d, noise, raw_noise_std, self.white_bkgd)
             if save:
                 saved["fine"]["weights"] = ret['weights']

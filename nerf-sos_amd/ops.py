@@ -331,6 +331,23 @@ def mlp_forward_points(packed: torch.Tensor, sem_mode: int, pts: torch.Tensor, d
     return raw
 
 
+# ------------------------------------------------------------------------------------------ train-mode draws
+def render_draws(seed: int, call: int, n_rays: int, n_coarse: int, n_importance: int, device, jitter: bool = True,
+                 noise: bool = True, importance: bool = True):
+    """The four random tensors of one train-mode ray chunk in one launch (nsos_render_draws): (t_rand [R,S] or None,
+    noise0 [R,S] or None, u [R,N] or None, noise1 [R,S+N] or None) from a Philox stream keyed by `seed`, block `call`."""
+    dev = torch.device(device)
+    f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+    fine = n_importance > 0
+    t = f(n_rays, n_coarse) if jitter else None
+    n0 = f(n_rays, n_coarse) if noise else None
+    u = f(n_rays, n_importance) if (importance and fine) else None
+    n1 = f(n_rays, n_coarse + n_importance) if (noise and fine) else None
+    _lib.check(_lib.lib().nsos_render_draws(int(seed) & (2 ** 64 - 1), int(call) & (2 ** 64 - 1), n_rays, n_coarse, n_importance,
+                                            _p(t), _p(n0), _p(u), _p(n1), _stream()), "nsos_render_draws")
+    return t, n0, u, n1
+
+
 # ------------------------------------------------------------------------------------------ K3
 def composite(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noise: Optional[torch.Tensor] = None,
               noise_std: float = 0.0, white_bkgd: bool = False) -> Dict[str, torch.Tensor]:

@@ -777,3 +777,43 @@ def test_lp8_equals_lp4_bitwise(manifest, name, precision):
     finally:
         _lib.check(lib.nsos_mlp_lp_select_kernel(2), "select")
     assert lib.nsos_mlp_lp_select_kernel(3) != 0
+
+
+# ------------------------------------------------------------------------------------------ train-mode draws in one launch
+def test_philox_render_draws():
+    """nsos_render_draws: the four train-mode random tensors of a ray chunk from one counter-based launch.  Checked:
+    ranges, moments (24-bit uniforms in (0,1); Box-Muller normals), independence of the four tensors and of consecutive
+    calls, reproducibility by (seed, call), odd sizes (tail blocks of 4), and the module option NeRFNet.rng = 'philox'."""
+    R, S, N = 4099, 64, 128
+    t, n0, u, n1 = ops.render_draws(1234, 1, R, S, N, DEV)
+    assert t.shape == (R, S) and n0.shape == (R, S) and u.shape == (R, N) and n1.shape == (R, S + N)
+    for x in (t, u):
+        assert float(x.min()) > 0.0 and float(x.max()) < 1.0
+        assert abs(float(x.mean()) - 0.5) < 2e-3 and abs(float(x.var()) - 1 / 12) < 1e-3
+    for x in (n0, n1):
+        assert torch.isfinite(x).all()
+        assert abs(float(x.mean())) < 5e-3 and abs(float(x.var()) - 1.0) < 1e-2
+        assert abs(float((x ** 4).mean()) - 3.0) < 0.1                       # kurtosis of a normal
+    assert abs(float(torch.corrcoef(torch.stack([t.flatten(), n0.flatten()]))[0, 1])) < 5e-3
+    assert abs(float(torch.corrcoef(torch.stack([n0.flatten()[:-1], n0.flatten()[1:]]))[0, 1])) < 5e-3   # Box-Muller pair halves
+    again = ops.render_draws(1234, 1, R, S, N, DEV)
+    assert all(torch.equal(a, b) for a, b in zip((t, n0, u, n1), again))
+    other = ops.render_draws(1234, 2, R, S, N, DEV)
+    assert not torch.equal(other[0], t) and abs(float(torch.corrcoef(torch.stack([other[0].flatten(), t.flatten()]))[0, 1])) < 5e-3
+    assert not torch.equal(ops.render_draws(1235, 1, R, S, N, DEV)[0], t)
+    only = ops.render_draws(7, 3, 5, 64, 0, DEV, jitter=True, noise=False)
+    assert only[1] is None and only[2] is None and only[3] is None and only[0].shape == (5, 64)
+    # module option: train-mode renders draw from the package's stream; reproducible by (seed, call counter)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0).to(DEV).train()
+    rays = tp.synthetic_rays(300, seed=2).to(DEV)
+    net.rng, net.rng_seed = "philox", 99
+    with torch.no_grad():
+        a = net(rays, (tp.NEAR, tp.FAR))
+        b = net(rays, (tp.NEAR, tp.FAR))
+        net._rng_calls = 0
+        c = net(rays, (tp.NEAR, tp.FAR))
+    assert torch.isfinite(a["rgb"]).all() and not torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["rgb"], c["rgb"])
+    state = torch.cuda.get_rng_state()
+    with torch.no_grad():
+        net(rays, (tp.NEAR, tp.FAR))
+    assert torch.equal(state, torch.cuda.get_rng_state()), "philox mode must not touch torch's generator"
