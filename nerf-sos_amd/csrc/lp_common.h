@@ -30,7 +30,8 @@ constexpr int kAuxSem2W = 512;    // 2 x 128 fp32
 constexpr int kAuxScalars = 768;  // alpha_b, rgb_b[3], sem2_b[2]
 constexpr int kAuxWords = 1024;
 
-enum ChunkKind { kHid8 = 0, kEnc8 = 1, kHid4 = 2, kEnc4 = 3, kDir4 = 4 };
+enum ChunkKind { kHid8 = 0, kEnc8 = 1, kHid4 = 2, kEnc4 = 3, kDir4 = 4,
+                 kPair8 = 5 };   // mlp_lp8's tile-pair-major hidden chunk: [bias t0, bias t1, (s0,t0), (s0,t1), (s1,t0), ...], t = 2c + {0,1}
 
 __host__ __device__ constexpr int lp_chunks(int sem) {
     // L0 enc(1) + 8 hidden layers x 4 + L5 enc(1) + [sem0 hid(2) (+enc 1)] + views hid(2) + dir(1)

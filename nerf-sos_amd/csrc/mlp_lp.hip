@@ -394,7 +394,14 @@ __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams P) {
     const int g = within >> 9, lane = (within >> 3) & 63, e = within & 7;  // 512 elements per A operand
     const int i = lane & 31, kgl = lane >> 5, m = 8 * kgl + e;
     float v = 0.0f;
-    if (g < ck.n_groups) {
+    if (g < ck.n_groups && ck.kind == kPair8) {   // a0 = tile pair c: operands [bias 2c, bias 2c+1, then slice-major over the two tiles]
+        const int t = 2 * ck.a0 + (g < 2 ? g : ((g - 2) & 1));
+        if (g < 2) v = (m == 0) ? ck.bias[32 * t + i] : 0.0f;
+        else {
+            const int s = (g - 2) >> 1;
+            v = ck.w[(long long)(32 * t + i) * ck.in_dim + ck.col_base + acc_feature(s >> 1, 8 * (s & 1) + e, kgl)];
+        }
+    } else if (g < ck.n_groups) {
         const int a = ck.a0 + g;
         const bool eight = ck.kind == kHid8 || ck.kind == kEnc8;
         const int nt = eight ? 8 : 4;
@@ -445,7 +452,8 @@ int32_t launch_lp(const LpParams& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode) {
     if (sem_mode < 0 || sem_mode > 2) return 0;
-    return (size_t)kAuxWords * 4 + (size_t)lp_chunks(sem_mode) * kSlotBytes;
+    // aux + the slice-major stream of mlp_lp_kernel + the stream of mlp_lp8_kernel (tile-pair-major hidden layers)
+    return (size_t)kAuxWords * 4 + 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes;
 }
 
 extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
@@ -459,44 +467,47 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
                      T_->rgb_w && T_->rgb_b, NSOS_ERR_NULL_POINTER);
     if (sem_mode) NSOS_REQUIRE(T_->sem0_w && T_->sem0_b && T_->sem2_w && T_->sem2_b, NSOS_ERR_NULL_POINTER);
 
-    LpPackParams P = {};
-    int n = 0;
-    auto add = [&](const float* w, const float* bias, int in_dim, int col, int kind, int a0, int ng) {
-        P.ch[n++] = LpChunk{w, bias, in_dim, col, kind, a0, ng};
-    };
-    auto hidden8 = [&](const float* w, const float* b, int in_dim, int col) {
-        for (int c = 0; c < 4; ++c) add(w, b, in_dim, col, kHid8, 34 * c, 34);
-    };
-    auto hidden4 = [&](const float* w, const float* b, int in_dim, int col) {
-        for (int c = 0; c < 2; ++c) add(w, b, in_dim, col, kHid4, 34 * c, 34);
-    };
     const int X = NSOS_XYZ_DIM, W = NSOS_NET_WIDTH;
-    add(T_->pts_w[0], T_->pts_b[0], X, 0, kEnc8, 0, 32);  // bias in the pad slot
-    for (int l = 1; l <= 4; ++l) hidden8(T_->pts_w[l], T_->pts_b[l], W, 0);
-    hidden8(T_->pts_w[5], T_->pts_b[5], X + W, X);         // skip layer: h part (with its bias slice) ...
-    add(T_->pts_w[5], nullptr, X + W, 0, kEnc8, 0, 32);    // ... then the x63 part
-    hidden8(T_->pts_w[6], T_->pts_b[6], W, 0);
-    hidden8(T_->pts_w[7], T_->pts_b[7], W, 0);
-    if (sem_mode) {
-        const int in_dim = sem_mode == NSOS_SEM_COORD ? W + X : W;
-        hidden4(T_->sem0_w, T_->sem0_b, in_dim, 0);
-        if (sem_mode == NSOS_SEM_COORD) add(T_->sem0_w, nullptr, in_dim, W, kEnc4, 0, 16);
+    for (int layout = 0; layout < 2; ++layout) {   // 0: slice-major hidden layers (mlp_lp_kernel), 1: tile-pair-major (mlp_lp8_kernel)
+        LpPackParams P = {};
+        int n = 0;
+        auto add = [&](const float* w, const float* bias, int in_dim, int col, int kind, int a0, int ng) {
+            P.ch[n++] = LpChunk{w, bias, in_dim, col, kind, a0, ng};
+        };
+        auto hidden8 = [&](const float* w, const float* b, int in_dim, int col, bool pairs) {
+            for (int c = 0; c < 4; ++c) pairs ? add(w, b, in_dim, col, kPair8, c, 34) : add(w, b, in_dim, col, kHid8, 34 * c, 34);
+        };
+        auto hidden4 = [&](const float* w, const float* b, int in_dim, int col) {
+            for (int c = 0; c < 2; ++c) add(w, b, in_dim, col, kHid4, 34 * c, 34);
+        };
+        const bool pm = layout == 1;
+        add(T_->pts_w[0], T_->pts_b[0], X, 0, kEnc8, 0, 32);  // bias in the pad slot
+        for (int l = 1; l <= 4; ++l) hidden8(T_->pts_w[l], T_->pts_b[l], W, 0, pm);
+        hidden8(T_->pts_w[5], T_->pts_b[5], X + W, X, false);  // skip layer: h part (with its bias slice), slice-major in both ...
+        add(T_->pts_w[5], nullptr, X + W, 0, kEnc8, 0, 32);    // ... then the x63 part
+        hidden8(T_->pts_w[6], T_->pts_b[6], W, 0, pm);
+        hidden8(T_->pts_w[7], T_->pts_b[7], W, 0, pm);
+        if (sem_mode) {
+            const int in_dim = sem_mode == NSOS_SEM_COORD ? W + X : W;
+            hidden4(T_->sem0_w, T_->sem0_b, in_dim, 0);
+            if (sem_mode == NSOS_SEM_COORD) add(T_->sem0_w, nullptr, in_dim, W, kEnc4, 0, 16);
+        }
+        hidden8(T_->feature_w, T_->feature_b, W, 0, pm);
+        hidden4(T_->views_w, T_->views_b, W + NSOS_DIR_DIM, 0);
+        add(T_->views_w, nullptr, W + NSOS_DIR_DIM, W, kDir4, 0, 8);
+        NSOS_REQUIRE(n == lp_chunks(sem_mode), NSOS_ERR_UNSUPPORTED);
+        P.n_chunks = n;
+        P.alpha_w = T_->alpha_w; P.alpha_b = T_->alpha_b;
+        P.rgb_w = T_->rgb_w; P.rgb_b = T_->rgb_b;
+        P.sem2_w = sem_mode ? T_->sem2_w : nullptr;
+        P.sem2_b = sem_mode ? T_->sem2_b : nullptr;
+        P.aux = static_cast<unsigned*>(packed);
+        P.chunks = reinterpret_cast<unsigned short*>(P.aux + kAuxWords) + (size_t)layout * n * (kSlotBytes / 2);
+        const long long total = (long long)n * (kSlotBytes / 2);
+        const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (dtype == NSOS_DTYPE_F16) hipLaunchKernelGGL(lp_pack_kernel<F16>, grid, block, 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL(lp_pack_kernel<BF16>, grid, block, 0, (hipStream_t)stream, P);
     }
-    hidden8(T_->feature_w, T_->feature_b, W, 0);
-    hidden4(T_->views_w, T_->views_b, W + NSOS_DIR_DIM, 0);
-    add(T_->views_w, nullptr, W + NSOS_DIR_DIM, W, kDir4, 0, 8);
-    NSOS_REQUIRE(n == lp_chunks(sem_mode), NSOS_ERR_UNSUPPORTED);
-    P.n_chunks = n;
-    P.alpha_w = T_->alpha_w; P.alpha_b = T_->alpha_b;
-    P.rgb_w = T_->rgb_w; P.rgb_b = T_->rgb_b;
-    P.sem2_w = sem_mode ? T_->sem2_w : nullptr;
-    P.sem2_b = sem_mode ? T_->sem2_b : nullptr;
-    P.aux = static_cast<unsigned*>(packed);
-    P.chunks = reinterpret_cast<unsigned short*>(P.aux + kAuxWords);
-    const long long total = (long long)n * (kSlotBytes / 2);
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (dtype == NSOS_DTYPE_F16) hipLaunchKernelGGL(lp_pack_kernel<F16>, grid, block, 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(lp_pack_kernel<BF16>, grid, block, 0, (hipStream_t)stream, P);
     return nsos_launch_status();
 }
 
@@ -544,6 +555,7 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     // NSOS_LP_WAVES=4 selects the one-wave-per-SIMD kernel of round 1 (A/B measurements); default: two waves per SIMD
     if (lp_waves_per_simd() == 2) {
         if (sem_in || sem_in16) NSOS_REQUIRE(sem_hid && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
+        p.chunks += (size_t)lp_chunks(sem_mode) * kSlotBytes;   // the second stream: tile-pair-major hidden layers
         return launch_lp8(p, sem_mode, dtype == NSOS_DTYPE_F16, sem_in || sem_in16, st);
     }
     if (sem_in || sem_in16) {

@@ -41,9 +41,22 @@ namespace {
 constexpr int kRing8 = 4, kMid8 = 2, kDma8 = 5;
 
 // continuous-ring A-operand pipeline (see the header comment).  ring[(g + PHASE) % RING] holds group g's operand.
-template <int NG, int RING, int PHASE, int MID, class M, class B, class TL>
+// Groups NWORK..NG-1 of a padded chunk carry no MFMA: their operands are NOT read (a read whose result nobody consumes
+// leaves its destination "dead" for hipcc, which then reuses the register while the read is still in flight -- the
+// checker found exactly that); the counted waits follow the reads that were really issued.
+template <int NG, int NWORK, int RING, int g>
+constexpr bool issues_read_after() {   // does the slot freed by group g get reloaded?
+    return g + RING < NG ? (g + RING < NWORK) : true;          // own chunk: only consumed groups; next chunk: always
+}
+template <int NG, int NWORK, int RING, int g, int h = (g - RING + 1 > 0 ? g - RING + 1 : 0)>
+constexpr int younger_reads_c() {       // reads issued after group g's own and before its work (within this chunk)
+    if constexpr (h >= g) return (g - RING + 1 < 0) ? -(g - RING + 1) : 0;   // groups of the previous chunk always reload: count them
+    else return (issues_read_after<NG, NWORK, RING, h>() ? 1 : 0) + younger_reads_c<NG, NWORK, RING, g, h + 1>();
+}
+template <int NG, int RING, int PHASE, int MID, int NWORK = NG, class M, class B, class TL>
 __device__ __forceinline__ void a_pipeline_c(f32x4 (&ring)[RING], const ChunkCtx ctx, M&& work, B&& mid, TL&& tail) {
     static_assert(NG >= RING + MID + 2, "chunk too short: the next chunk's operands would be read before this chunk's barrier");
+    static_assert(NWORK >= RING && NWORK <= NG, "the first RING groups were read by the previous chunk");
     static_for<0, NG>([&](auto ic) {
         constexpr int g = decltype(ic)::value, slot = (g + PHASE) % RING;
         if constexpr (g == MID) {
@@ -51,12 +64,15 @@ __device__ __forceinline__ void a_pipeline_c(f32x4 (&ring)[RING], const ChunkCtx
             mid();
             NSOS_PIN();
         }
-        lgkm_wait<RING - 1>();  // the RING-1 reads issued after group g's are the only ones that may still fly
+        if constexpr (g < NWORK) lgkm_wait<younger_reads_c<NG, NWORK, RING, g>()>();
         NSOS_PIN();
         work(ic, ring[slot]);
         NSOS_PIN();
-        if constexpr (g + RING < NG) lds_read_a<(g + RING) * 1024>(ring[slot], ctx.wl_cur);
-        else lds_read_a<(g + RING - NG) * 1024>(ring[slot], ctx.wl_nxt);   // resident: proven by this chunk's barrier
+        if constexpr (g + RING < NG) {
+            if constexpr (g + RING < NWORK) lds_read_a<(g + RING) * 1024>(ring[slot], ctx.wl_cur);
+        } else {
+            lds_read_a<(g + RING - NG) * 1024>(ring[slot], ctx.wl_nxt);   // resident: proven by this chunk's barrier
+        }
         if constexpr (g == NG - 3) {
             NSOS_PIN();
             tail();
@@ -80,18 +96,25 @@ template <class T, int NT, bool RELU>
 __device__ __forceinline__ void activate1(u32x4 (&H)[2 * NT], const f32x16 (&Z)[NT]) {
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (the asm below hides the reads)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {                       // 8 conversions, then their 8 clamps: no instruction waits for the previous one
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            u32x4 w;
+        for (int k = 0; k < 8; ++k) H[2 * t + (k >> 2)][k & 3] = T::pack2(Z[t][2 * k], Z[t][2 * k + 1]);
+        if constexpr (RELU)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned r = T::pack2(Z[t][8 * u + 2 * q], Z[t][8 * u + 2 * q + 1]);
-                if constexpr (RELU) asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(r));
-                w[q] = r;
-            }
-            H[2 * t + u] = w;
-        }
+            for (int k = 0; k < 8; ++k) { unsigned w = H[2 * t + (k >> 2)][k & 3]; asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(w)); H[2 * t + (k >> 2)][k & 3] = w; }
+    }
+}
+
+// one packed activation word = max_i16(pack16(z0, z1), floor): floor = 0 is the ReLU of both halves, 0x80008000 (two int16
+// minima) passes everything (feature_linear has no activation).  2 VALU instructions; they ride behind the MFMAs of the next
+// tile pair (see the layer body).
+// The two instructions of a word are issued one MFMA gap apart (or in batches when exposed): v_pk_max right behind its
+// v_cvt_pk stalls the in-order wave -- and the MFMAs queued behind it -- for the conversion's latency (measured: 480 cycles
+// for 32 such instructions back to back).
+#define NSOS_RELU_WORD(W, FLOOR) do { unsigned w_ = (W); asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(w_) : "s"(FLOOR)); (W) = w_; } while (0)   // (vector elements bind neither to references nor to asm operands)
+__device__ __forceinline__ void mov_slice(u32x4& dst, const u32x4& src) {   // explicit copies at a chosen point of the stream
+    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                 : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]));
 }
 
 // fp32 vector-ALU heads on fp32 accumulators held in VGPRs (rgb: NO = 3, semantics: NO = 2): this half-wave's partial
@@ -131,12 +154,10 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
     auto slot_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotBytes); };
     unsigned c0 = lane_addr(0), c1 = lane_addr(1), c2 = lane_addr(2), c3 = lane_addr(3);
     unsigned d0 = slot_addr(0), d1 = slot_addr(1), d2 = slot_addr(2), d3 = slot_addr(3);
-    unsigned poff[kDma8];     // byte offset of this wave's i-th piece inside a chunk / slot (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < kDma8; ++i) {
-        const int p = wave_s + 8 * i;
-        poff[i] = (unsigned)((p < kSlotGroups ? p : kSlotGroups - 1) * 1024);
-    }
+    // byte offset of this wave's i-th piece inside a chunk / slot: piece wave + 8 i (the surplus ones re-copy piece 35)
+    const unsigned woff = (unsigned)wave_s * 1024u;
+    const unsigned wlast = wave_s + 32 < kSlotGroups ? woff + 32768u : (unsigned)(kSlotGroups - 1) * 1024u;
+    auto poff = [&](int i) { return i < 4 ? woff + 8192u * (unsigned)i : wlast; };
     // ---- Experimental (-DNSOS_LP8_LAG; NOT the shipped build): the two waves of a SIMD one chunk apart.  Waves 4..7
     // ("lagging") start one barrier interval late, so that a wave's activation pass falls into an interval in which its
     // SIMD partner runs MFMAs.  Slot protocol with a lag of one chunk: leaders at chunk c, laggers at c-1; resident: c-1,
@@ -156,7 +177,12 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
     const unsigned char* const src_end = P.chunks + (size_t)NCH * kSlotBytes;
     const unsigned char* srcf = P.chunks + (size_t)((lagging ? 3 : 2) % NCH) * kSlotBytes;
     auto dma_piece = [&](const unsigned char* src_chunk, unsigned dst_slot, int i) {
-        dma_1k(src_chunk + poff[i], dst_slot + poff[i], voff);
+        // the operands are wave-uniform by construction, but under SGPR pressure hipcc keeps some of the stream bookkeeping in
+        // VGPRs and then hands a VGPR to the asm's "s" operands: make the uniformity explicit where it is consumed
+        const unsigned long long sp = (unsigned long long)(src_chunk + poff(i));
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sp), hi = __builtin_amdgcn_readfirstlane((unsigned)(sp >> 32));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_slot + poff(i));
+        dma_1k(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo), dst, voff);
     };
     auto side = [&](int i) { dma_piece(srcf, lagging ? d3 : d2, i); };
     auto mid = [&]() {
@@ -194,7 +220,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         constexpr int NG = decltype(ng_c)::value, NT = decltype(nt_c)::value, NB = decltype(nb_c)::value;
         constexpr int A0 = decltype(a0_c)::value, NWORK = decltype(nwork_c)::value, PH = decltype(ph_c)::value;
         constexpr bool ZF = decltype(zf_c)::value != 0;
-        a_pipeline_c<NG, kRing8, PH, kMid8>(ring, ctx(), [&](auto ic, const f32x4& a32) {
+        a_pipeline_c<NG, kRing8, PH, kMid8, NWORK>(ring, ctx(), [&](auto ic, const f32x4& a32) {
             constexpr int g = decltype(ic)::value, a = A0 + g;
             const u32x4 aop = __builtin_bit_cast(u32x4, a32);
             if constexpr (g < NWORK) {
@@ -220,6 +246,26 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         pin_accumulators<NT>(acc);
     };
     auto no_ride = [](auto) {};
+    // one tile-pair chunk of a hidden layer (stream layout kPair8): operands [bias t0, bias t1, (s0,t0), (s0,t1), (s1,t0), ...];
+    // accumulators zp[0..1]; the B operand of slice s is hsel(s)
+    auto run_pair = [&](auto ph_c, auto& zp, auto&& hsel, auto&& ride) {
+        constexpr int PH = decltype(ph_c)::value;
+        a_pipeline_c<34, kRing8, PH, kMid8>(ring, ctx(), [&](auto ic, const f32x4& a32) {
+            constexpr int g = decltype(ic)::value;
+            const u32x4 aop = __builtin_bit_cast(u32x4, a32);
+            if constexpr (g < 2) {
+                const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const u32x4 ones = {T::kOnes, T::kOnes, T::kOnes, T::kOnes};
+                zp[g] = T::mfma(aop, ones, zero);
+            } else {
+                constexpr int s = (g - 2) >> 1, t = (g - 2) & 1;
+                zp[t] = T::mfma(aop, hsel(std::integral_constant<int, s>{}), zp[t]);
+            }
+            dma_slot<g - kMid8, kDma8>(side);
+            ride(ic);
+        }, mid, tail);
+        pin_accumulators<2>(zp);
+    };
 #ifdef NSOS_LP8_LAG
     auto hi_prio = [] { NSOS_PIN(); __builtin_amdgcn_s_setprio(3); NSOS_PIN(); };
     auto lo_prio = [] { NSOS_PIN(); __builtin_amdgcn_s_setprio(0); NSOS_PIN(); };
@@ -282,21 +328,84 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         activate1<T, 8, true>(H, Z);
         lo_prio();
         stamp();  // 3: L0 activation
+        // Layers 1..4 and 6..8 are tile-pair-major with a riding activation; the skip layer 5 (its x63 part follows the h part in
+        // every accumulator) stays slice-major with one exposed pass.  Two runtime loops with ONE uniform body each (a single
+        // loop with both bodies made hipcc reconcile their register assignments with 160 v_mov per layer at the back edge).
+        auto pair_layer = [&](const int l) {
+            // Tile-pair-major: chunk c accumulates output tiles 2c, 2c+1 over all 16 input slices into Zp[c & 1]; the
+            // activation of the PREVIOUS pair rides behind this chunk's MFMAs (2 VALU per packed word, one word per MFMA
+            // gap: the accumulators are VGPRs, nothing to read back).  The layer's input H stays live until its last
+            // chunk, so finished slices wait in Ho[0..7] (tiles 0..3) and move into H behind the last chunk's MFMAs, each
+            // right after its final use there; tiles 4,5 are activated straight into H[8..11] once those are dead
+            // (group 26 on); only tiles 6,7 (16 words) remain for after the chunk.  Per accumulator the MFMA order is
+            // the round-1 kernel's (bias, slices 0..15): results stay bit-identical.
+            const unsigned floor = l < 8 ? 0u : 0x80008000u;     // feature_linear (l == 8) has no activation
+            f32x16 Zp[2][2];
+            u32x4 Ho[8];
+            auto ride_act = [&](auto gc_, auto src_c, auto base_c) {   // 16 words of pair buffer src -> Ho[base .. base+3]: convert in groups 4..19, clamp one group later
+                constexpr int g = decltype(gc_)::value, SRC = decltype(src_c)::value, BASE = decltype(base_c)::value;
+                if constexpr (g >= 5 && g < 21) {
+                    constexpr int k = g - 5, tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                    NSOS_RELU_WORD(Ho[BASE + 2 * tt + u][q], floor);
+                }
+                if constexpr (g >= 4 && g < 20) {
+                    constexpr int k = g - 4, tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                    Ho[BASE + 2 * tt + u][q] = T::pack2(Zp[SRC][tt][8 * u + 2 * q], Zp[SRC][tt][8 * u + 2 * q + 1]);
+                }
+            };
+            run_pair(IC(0), Zp[0], from_H, no_ride);
+            run_pair(IC(2), Zp[1], from_H, [&](auto gc_) { ride_act(gc_, IC(0), IC(0)); });
+            run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_act(gc_, IC(1), IC(4)); });
+            run_pair(IC(2), Zp[1], from_H, [&](auto gc_) {
+                constexpr int g = decltype(gc_)::value;
+                if constexpr (g >= 4 && g <= 18 && (g & 1) == 0) {       // slice s = (g - 4) / 2 was last used by groups 2+2s, 3+2s
+                    constexpr int sl = (g - 4) >> 1;
+                    mov_slice(H[sl], Ho[sl]);
+                }
+                if constexpr (g >= 27) {                                 // clamp the two words converted one group earlier
+                    static_for<0, 2>([&](auto jc) {
+                        constexpr int k = (g - 27) * 2 + decltype(jc)::value, tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                        NSOS_RELU_WORD(H[8 + 2 * tt + u][q], floor);
+                    });
+                }
+                if constexpr (g >= 26) {                                 // H[8..11] are dead: tiles 4,5 (Zp[0]) go there directly
+                    static_for<0, 2>([&](auto jc) {
+                        constexpr int k = (g - 26) * 2 + decltype(jc)::value, tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                        H[8 + 2 * tt + u][q] = T::pack2(Zp[0][tt][8 * u + 2 * q], Zp[0][tt][8 * u + 2 * q + 1]);
+                    });
+                }
+            });
+            stamp();  // 2 + 2l: MFMAs of layer l (with the riding activation of tiles 0..5)
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (asm hides the reads)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {                       // tiles 6,7: 16 conversions, then 16 clamps (+ the last two of tiles 4,5)
+                const int tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                H[12 + 2 * tt + u][q] = T::pack2(Zp[1][tt][8 * u + 2 * q], Zp[1][tt][8 * u + 2 * q + 1]);
+            }
+            NSOS_RELU_WORD(H[11][2], floor);
+            NSOS_RELU_WORD(H[11][3], floor);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) NSOS_RELU_WORD(H[12 + (k >> 2)][k & 3], floor);
+            stamp();  // 3 + 2l: the exposed rest of the activation (tiles 6,7)
+        };
 #pragma unroll 1
-        for (int l = 1; l <= 8; ++l) {
+        for (int l = 1; l <= 4; ++l) pair_layer(l);
+        {
+            constexpr int l = 5;
+            // skip layer: slice-major over all 8 tiles (its x63 part follows the h part in every accumulator), one
+            // exposed activation pass
             run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), IC(0), Z, from_H, no_ride);
             run_chunk(IC(34), IC(8), IC(8), IC(34), IC(34), IC(0), IC(2), Z, from_H, no_ride);
             run_chunk(IC(34), IC(8), IC(8), IC(68), IC(34), IC(0), IC(0), Z, from_H, no_ride);
-            if (l != 5) hi_prio();
             run_chunk(IC(34), IC(8), IC(8), IC(102), IC(34), IC(0), IC(2), Z, from_H, no_ride);
-            if (l == 5) {
-                hi_prio();
-                run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), IC(0), Z, from_ex, no_ride);  // skip connection
-            }
+            run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(0), IC(0), Z, from_ex, no_ride);  // skip connection
             stamp();  // 2 + 2l: MFMAs of layer l
-            if (l < 8) activate1<T, 8, true>(H, Z); else activate1<T, 8, false>(H, Z);
-            lo_prio();
+            activate1<T, 8, true>(H, Z);
             stamp();  // 3 + 2l: activation pass
+        }
+#pragma unroll 1
+        for (int l = 6; l <= 8; ++l) {
+            pair_layer(l);
             if (l == 7) {
                 // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
                 const unsigned* aw = aux_l + kAuxAlphaW + kg * 64;
