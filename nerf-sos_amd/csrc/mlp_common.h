@@ -159,11 +159,8 @@ __host__ __device__ constexpr EncSlot enc_slot(int idx, int L) {
 // [-pi/4, pi/4] (~1 ulp).  ocml's sincosf takes its Payne-Hanek branch for arguments this large, which made the
 // encoding 10k cycles per tile AND desynchronised the four waves (the next barrier waits for the slowest).
 // Arguments >= 2^15 (never produced by a scene-normalised NeRF) fall back to ocml.
-__device__ __forceinline__ void sincos_pe(float a, float& sn, float& cs) {
-    if (__builtin_expect(!(fabsf(a) < 32768.0f), 0)) {
-        sincosf(a, &sn, &cs);
-        return;
-    }
+__device__ __forceinline__ bool sincos_in_range(float a) { return fabsf(a) < 32768.0f; }
+__device__ __forceinline__ void sincos_fast(float a, float& sn, float& cs) {      // branch-free; valid for |a| < 2^15
     const float q = __builtin_rintf(a * 0.636619772367581343f);          // 2/pi
     float r = __fmaf_rn(q, -1.57079637050628662109375f, a);              // pi/2 split into three fp32 terms
     r = __fmaf_rn(q, 4.37113900018624283e-8f, r);
@@ -179,6 +176,13 @@ __device__ __forceinline__ void sincos_pe(float a, float& sn, float& cs) {
     const float s0 = (n & 1) ? pc : ps, c0 = (n & 1) ? ps : pc;
     sn = (n & 2) ? -s0 : s0;
     cs = ((n + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ void sincos_pe(float a, float& sn, float& cs) {
+    if (__builtin_expect(!sincos_in_range(a), 0)) {
+        sincosf(a, &sn, &cs);
+        return;
+    }
+    sincos_fast(a, sn, cs);
 }
 
 // Encoding of a 3-vector with L octaves for an MFMA B-operand layout in which encoded feature idx lives in
@@ -196,11 +200,29 @@ struct Enc {
     float own_sn[kJobs], own_cs[kJobs], recv_sn[kJobs], recv_cs[kJobs];
 
     __device__ __forceinline__ void evaluate(const float (&x)[3], int hi) {
+        // 1. every job on the branch-free fast path (independent chains: the compiler interleaves them)
+        bool big = false;
         static_for<0, kJobs>([&](auto tc) {
             constexpr int t = decltype(tc)::value, pl = 2 * t, ph = 2 * t + 1;  // pair of the lo / hi half
             const float al = x[pl % 3] * (float)(1 << (pl / 3)), ah = x[ph % 3] * (float)(1 << (ph / 3));
-            sincos_pe(hi ? ah : al, own_sn[t], own_cs[t]);
-            // exchange what the OTHER half needs: hi needs lo's pair pl, lo needs hi's pair ph
+            const float a = hi ? ah : al;
+            big |= !sincos_in_range(a);
+            sincos_fast(a, own_sn[t], own_cs[t]);
+        });
+        // 2. ONE cold block for arguments >= 2^15 (ocml's Payne-Hanek path; never taken by a scene-normalised NeRF).  With the
+        //    range check inside every job the fifteen inlined slow paths sat in the middle of the hot code: 3 000 instructions
+        //    and 36 branches to skip per tile.
+        if (__builtin_expect(big, 0)) {
+            static_for<0, kJobs>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, pl = 2 * t, ph = 2 * t + 1;
+                const float al = x[pl % 3] * (float)(1 << (pl / 3)), ah = x[ph % 3] * (float)(1 << (ph / 3));
+                const float a = hi ? ah : al;
+                if (!sincos_in_range(a)) sincosf(a, &own_sn[t], &own_cs[t]);
+            });
+        }
+        // 3. exchange what the OTHER half needs (hi needs lo's pair pl, lo needs hi's pair ph): all shuffles back to back
+        static_for<0, kJobs>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, pl = 2 * t, ph = 2 * t + 1;
             if constexpr (HALF::of(sin_idx(pl)) == 1 || HALF::of(sin_idx(ph)) == 0)
                 recv_sn[t] = __shfl_xor(own_sn[t], 32, NSOS_WAVE);
             if constexpr (HALF::of(cos_idx(pl)) == 1 || HALF::of(cos_idx(ph)) == 0)
