@@ -423,9 +423,10 @@ def main():
                 v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 3))
                 v["what"] = "BASELINE configs[2]: one 64x64 patch = 4096 rays, sem+coord head, bf16 MFMA: train-mode render + appearance & geometric correlation losses + semantic-head backward + Adam"
                 variants["c3_bf16"] = v
-                v = _strip(run_c5(ctx, args, "fp16", 2, 1))
-                v["what"] = "BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device softmax/argmax; a step = one image"
-                variants["c5_fp16"] = v
+            v = _strip(run_c5(ctx, args, "fp16", 2 if ctx.world == 1 else 4, 1))
+            v["what"] = ("BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device "
+                         "softmax/argmax; row blocks sharded over the GPUs (strong scaling, no collective); a step = one image")
+            variants["c5_fp16"] = v
             v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 3))
             v["what"] = ("BASELINE configs[3]: 8192 rays/GPU (2 patches of 64x64 per GPU), the c3 step sharded over the GPUs: one flat "
                          "all-gather of semantics0/semantics/depth/feat/cls_/ray_o/ray_d, one flat gradient all-reduce")

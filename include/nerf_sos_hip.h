@@ -292,6 +292,14 @@ int32_t nsos_composite_backward(const float* raw, const float* z_vals, const flo
                                 const float* g_rgb, const float* g_sem, const float* g_depth, const float* g_acc,
                                 const float* g_disp, const float* g_weights, float* g_raw, void* stream);
 
+/* nsos_composite on the coarse samples followed by nsos_importance_sample on its weights, in ONE launch (models/nerf_net.py:98-113:
+ * renderer -> importance_sampler): same device code, bit-identical outputs, one launch and one round trip of the weights
+ * less per step.  n_coarse in [2, 64]. */
+int32_t nsos_composite_importance(const float* raw, const float* z_vals, const float* rays_d, const float* noise, float noise_std,
+                                  int64_t n_rays, int32_t n_coarse, int32_t n_ch, int32_t white_bkgd, float* weights, float* rgb,
+                                  float* sem, float* depth, float* acc, float* disp, const float* u, int32_t n_importance,
+                                  float* z_fine, float* z_samples, float* z_std, void* stream);
+
 /* Train-mode random tensors of one ray chunk in ONE launch (optional; NeRFNet.rng = "philox").  The reference draws, in this
  * order, rand[R,S] (stratified jitter, models/sampler.py:61), randn[R,S] (coarse sigma noise, models/renderer.py:47),
  * rand[R,N] (importance u, models/sampler.py:103), randn[R,S+N] (fine sigma noise) from torch's global generator: four

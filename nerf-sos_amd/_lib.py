@@ -59,6 +59,8 @@ SIGNATURES = {
     "nsos_mlp_profile_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),
     "nsos_composite": (_i32, [_fp, _fp, _fp, _fp, _f32, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "nsos_composite_importance": (_i32, [_fp, _fp, _fp, _fp, _f32, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32,
+                                         _fp, _fp, _fp, _fp]),
     "nsos_composite_backward": (_i32, [_fp, _fp, _fp, _fp, _f32, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "nsos_eval_workspace_bytes": (C.c_size_t, []),
     "nsos_eval_postprocess": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp, _fp]),

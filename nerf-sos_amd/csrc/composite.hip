@@ -12,6 +12,7 @@
 // its wave, so all fetched cache lines are fully used.
 // Compiled with -ffp-contract=off: element-wise fp32 expressions match the reference's op order.
 #include "common.h"
+#include "importance_device.h"
 
 // exp rounded correctly to fp32 (fp64 evaluation, one rounding).  alpha = 1 - exp(-sigma*delta) cancels: for a thin
 // sample the result lives on the 6e-8 grid of fl(exp) near 1, so an ulp of libm difference in exp moves a small alpha by
@@ -21,19 +22,16 @@
 // fp64 exp costs nothing measurable.
 __device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
 
+// One ray per wave: VolumetricRenderer.forward for ray r (models/renderer.py:35-85).  Returns the weight of the lane's FIRST
+// sample (for IPL == 1 -- S <= 64 -- that is lane j's sample j: what the hierarchical sampler consumes next).
 template <int IPL>
-__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw,
-                                                        const float* __restrict__ z_vals,
-                                                        const float* __restrict__ rays_d,
-                                                        const float* __restrict__ noise, float noise_std,
-                                                        int64_t n_rays, int S, int C, int white_bkgd,
-                                                        float* __restrict__ weights, float* __restrict__ rgb,
-                                                        float* __restrict__ sem, float* __restrict__ depth,
-                                                        float* __restrict__ acc, float* __restrict__ disp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
-
+__device__ __forceinline__ float composite_ray(const int64_t r, const int lane, const float* __restrict__ raw,
+                                               const float* __restrict__ z_vals, const float* __restrict__ rays_d,
+                                               const float* __restrict__ noise, float noise_std, int S, int C, int white_bkgd,
+                                               float* __restrict__ weights, float* __restrict__ rgb, float* __restrict__ sem,
+                                               float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ disp,
+                                               float* z_first) {
+    float w_first = 0.0f;
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
     const float norm = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);  // :38
 
@@ -84,6 +82,7 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
             const float T = (float)(excl * tloc[i]);  // :58 (fp64 running product, rounded per element)
             const float w = alpha[i] * T;             // :61
             weights[r * S + s] = w;
+            if (i == 0) w_first = w;
 #pragma unroll
             for (int k = 0; k < 3; ++k) s_rgb[k] += (double)(w * col[i][k]);  // :62
             s_sem[0] += (double)(w * smv[i][0]);                              // :64-66
@@ -117,6 +116,45 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
             if (C > 5) sem[(C - 4) * r + 1] = (float)s_sem[1] + bg;
         }
     }
+    if (z_first) *z_first = z[0];
+    return w_first;
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) void composite_kernel(const float* __restrict__ raw,
+                                                        const float* __restrict__ z_vals,
+                                                        const float* __restrict__ rays_d,
+                                                        const float* __restrict__ noise, float noise_std,
+                                                        int64_t n_rays, int S, int C, int white_bkgd,
+                                                        float* __restrict__ weights, float* __restrict__ rgb,
+                                                        float* __restrict__ sem, float* __restrict__ depth,
+                                                        float* __restrict__ acc, float* __restrict__ disp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    composite_ray<IPL>(r, lane, raw, z_vals, rays_d, noise, noise_std, S, C, white_bkgd, weights, rgb, sem, depth, acc, disp, nullptr);
+}
+
+// Coarse compositing + hierarchical resampling of the same ray in ONE launch (models/nerf_net.py:98-113: renderer, then
+// importance_sampler on ret['weights']): the coarse weights go from the compositing registers straight into the pdf -- one
+// launch and one round trip of the weights less per step.  Same device code as the two separate kernels: bit-identical outputs.
+__global__ __launch_bounds__(256) void composite_importance_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                                   const float* __restrict__ rays_d, const float* __restrict__ noise,
+                                                                   float noise_std, int64_t n_rays, int S, int C, int white_bkgd,
+                                                                   float* __restrict__ weights, float* __restrict__ rgb,
+                                                                   float* __restrict__ sem, float* __restrict__ depth,
+                                                                   float* __restrict__ acc, float* __restrict__ disp,
+                                                                   const float* __restrict__ u_in, int N, float* __restrict__ z_fine,
+                                                                   float* __restrict__ z_samples, float* __restrict__ z_std) {
+    __shared__ ImportanceLds lds_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= n_rays) return;  // whole wave exits together; no block-level barrier below
+    float z = 0.0f;
+    const float w = composite_ray<1>(r, lane, raw, z_vals, rays_d, noise, noise_std, S, C, white_bkgd, weights, rgb, sem, depth, acc,
+                                     disp, &z);
+    importance_ray(lds_all[wave], r, lane, lane < S ? z : 0.0f, lane < S ? w : 0.0f, u_in, nullptr, S, N, z_fine, z_samples, z_std,
+                   nullptr, nullptr);
 }
 
 extern "C" int32_t nsos_composite(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
@@ -303,5 +341,23 @@ extern "C" int32_t nsos_composite_backward(const float* raw, const float* z_vals
         default: NSOS_LAUNCH_CB(8); break;
     }
 #undef NSOS_LAUNCH_CB
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_composite_importance(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
+                                             float noise_std, int64_t n_rays, int32_t n_coarse, int32_t n_ch, int32_t white_bkgd,
+                                             float* weights, float* rgb, float* sem, float* depth, float* acc, float* disp,
+                                             const float* u, int32_t n_importance, float* z_fine, float* z_samples, float* z_std,
+                                             void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(raw && z_vals && rays_d && weights && rgb && depth && acc && disp && z_fine && z_samples && z_std, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_ch == 4 || n_ch == 5 || n_ch == 6, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(n_ch == 4 || sem, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_importance >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_coarse >= 2 && n_coarse <= 64 && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE((n_rays + 3) / 4 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(composite_importance_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z_vals,
+                       rays_d, noise, noise_std, n_rays, n_coarse, n_ch, white_bkgd, weights, rgb, sem, depth, acc, disp, u,
+                       n_importance, z_fine, z_samples, z_std);
     return nsos_launch_status();
 }

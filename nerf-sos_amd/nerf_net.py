@@ -344,7 +344,14 @@ class NeRFNet(nn.Module):
             viewdirs = unit_dirs
         raw = query(self.nerf, z_vals, "coarse")
         noise = (pre[1] if pre else torch.randn((R, n_samples), device=dev)) if raw_noise_std > 0. else None   # renderer.py:47
-        ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
+        sampled = None
+        if fine and 2 <= n_samples <= 64 and R > 0:
+            # coarse compositing and hierarchical resampling in ONE launch (the draws keep the reference's order:
+            # sigma noise of the coarse pass, then the importance u -- renderer.py:47, sampler.py:103)
+            u = (pre[2] if pre else torch.rand((R, self.N_importance), device=dev)) if perturb != 0.0 else None
+            ret, *sampled = ops.composite_importance(raw, z_vals, rays_d, self.N_importance, noise, raw_noise_std, self.white_bkgd, u)
+        else:
+            ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
         if save:
             saved["coarse"]["weights"] = ret['weights']
             saved["coarse"]["noise"] = noise
@@ -358,8 +365,11 @@ class NeRFNet(nn.Module):
             ret0 = ret
             # the sample count is the constructor's, not the per-call kwarg (sampler.py:100,103)
             N = self.N_importance
-            u = (pre[2] if pre else torch.rand((R, N), device=dev)) if perturb != 0.0 else None   # sampler.py:103,158
-            z_fine, z_samples, z_std = ops.importance_sample(z_vals, ret0['weights'], N, u)
+            if sampled is not None:
+                z_fine, z_samples, z_std = sampled
+            else:
+                u = (pre[2] if pre else torch.rand((R, N), device=dev)) if perturb != 0.0 else None   # sampler.py:103,158
+                z_fine, z_samples, z_std = ops.importance_sample(z_vals, ret0['weights'], N, u)
             if z_fine_override is not None:
                 z_fine = z_fine_override.to(device=dev, dtype=torch.float32).reshape(R, n_samples + N).contiguous()
             raw = query(self.nerf_fine, z_fine, "fine")

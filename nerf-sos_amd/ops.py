@@ -371,6 +371,37 @@ def composite(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noi
     return ret
 
 
+def composite_importance(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, n_importance: int,
+                         noise: Optional[torch.Tensor] = None, noise_std: float = 0.0, white_bkgd: bool = False,
+                         u: Optional[torch.Tensor] = None):
+    """composite(...) of the coarse pass + importance_sample(...) on its weights in one launch (nsos_composite_importance).
+    Returns (the composite dict, z_fine [R,S+N], z_samples [R,N], z_std [R]); bit-identical to the two separate calls."""
+    raw, z_vals, rays_d = _dev(raw, "raw"), _dev(z_vals, "z_vals"), _dev(rays_d, "rays_d")
+    R, S, Cn = raw.shape
+    N = int(n_importance)
+    if noise is not None:
+        noise = _dev(noise, "noise")
+        if tuple(noise.shape) != (R, S):
+            raise ValueError(f"noise must be [{R},{S}]")
+    if u is not None:
+        u = _dev(u, "u")
+        if tuple(u.shape) != (R, N):
+            raise ValueError(f"u must be [{R},{N}]")
+    dev = raw.device
+    f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
+    weights, rgb, depth, acc, disp = f(R, S), f(R, 3), f(R, 1), f(R, 1), f(R, 1)
+    sem = f(R, Cn - 4) if Cn > 4 else None
+    z_fine, z_samples, z_std = f(R, S + N), f(R, N), f(R)
+    _lib.check(_lib.lib().nsos_composite_importance(_p(raw), _p(z_vals), _p(rays_d), _p(noise), float(noise_std), R, S, Cn,
+                                                    int(bool(white_bkgd)), _p(weights), _p(rgb), _p(sem), _p(depth), _p(acc),
+                                                    _p(disp), _p(u), N, _p(z_fine), _p(z_samples), _p(z_std), _stream()),
+               "nsos_composite_importance")
+    ret = dict(rgb=rgb, disp=disp, acc=acc, weights=weights, depth=depth)
+    if sem is not None:
+        ret["semantics"] = sem
+    return ret, z_fine, z_samples, z_std
+
+
 def composite_backward(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noise: Optional[torch.Tensor] = None,
                        noise_std: float = 0.0, white_bkgd: bool = False, g_rgb=None, g_sem=None, g_depth=None, g_acc=None,
                        g_disp=None, g_weights=None) -> torch.Tensor:

@@ -817,3 +817,24 @@ def test_philox_render_draws():
     with torch.no_grad():
         net(rays, (tp.NEAR, tp.FAR))
     assert torch.equal(state, torch.cuda.get_rng_state()), "philox mode must not touch torch's generator"
+
+
+def test_fused_composite_importance_equals_the_two_kernels(golden):
+    """nsos_composite_importance (coarse compositing + hierarchical resampling in one launch) is the same device code as
+    nsos_composite followed by nsos_importance_sample: every output bit-identical, deterministic and random u, noise,
+    semantics channels, white background, ragged coarse sample counts."""
+    g = torch.Generator().manual_seed(3)
+    for R, S, N, C, white, noisy, rand_u in ((257, 64, 128, 6, False, True, True), (5, 64, 128, 4, True, False, False),
+                                             (33, 17, 40, 6, False, False, True), (1, 2, 448, 4, False, True, False)):
+        raw = (torch.randn(R, S, C, generator=g) * 2).to(DEV)
+        z = (tp.NEAR + (tp.FAR - tp.NEAR) * torch.rand(R, S, generator=g)).sort(-1).values.to(DEV)
+        d = torch.randn(R, 3, generator=g).to(DEV)
+        noise = torch.randn(R, S, generator=g).to(DEV) if noisy else None
+        u = torch.rand(R, N, generator=g).to(DEV) if rand_u else None
+        a = ops.composite(raw, z, d, noise, 0.7 if noisy else 0.0, white)
+        zf, zs, zstd = ops.importance_sample(z, a["weights"], N, u)
+        b, zf2, zs2, zstd2 = ops.composite_importance(raw, z, d, N, noise, 0.7 if noisy else 0.0, white, u)
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, R, S)
+        assert torch.equal(zf, zf2) and torch.equal(zs, zs2) and torch.equal(zstd, zstd2)
