@@ -184,10 +184,23 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(dst_slot + poff(i));
         dma_1k(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo), dst, voff);
     };
-    auto side = [&](int i) { dma_piece(srcf, lagging ? d3 : d2, i); };
+    // per chunk: the fill source / destination and this wave's piece offset are made scalar ONCE (at the barrier, right
+    // before the five pieces that use them), the pieces add constants on the scalar ALU
+    unsigned fill_lo = 0, fill_hi = 0, fill_dst = 0, fill_w = 0, fill_wlast = 0;
+    auto side = [&](int i) {
+        const unsigned off = i < 4 ? fill_w + 8192u * (unsigned)i : fill_wlast;
+        const unsigned long long sp = (((unsigned long long)fill_hi << 32) | fill_lo) + off;
+        dma_1k(reinterpret_cast<const void*>(sp), fill_dst + off, voff);
+    };
     auto mid = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        const unsigned long long sp = (unsigned long long)srcf;
+        fill_lo = __builtin_amdgcn_readfirstlane((unsigned)sp);
+        fill_hi = __builtin_amdgcn_readfirstlane((unsigned)(sp >> 32));
+        fill_dst = __builtin_amdgcn_readfirstlane(lagging ? d3 : d2);
+        fill_w = __builtin_amdgcn_readfirstlane(woff);
+        fill_wlast = __builtin_amdgcn_readfirstlane(wlast);
     };
     auto tail = [&]() {
         const unsigned tc = c0, td = d0;
