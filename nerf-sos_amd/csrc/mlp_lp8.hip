@@ -403,8 +403,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         };
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) pair_layer(l);
-        {
-            constexpr int l = 5;
+        {   // l = 5
             // skip layer: slice-major over all 8 tiles (its x63 part follows the h part in every accumulator), one
             // exposed activation pass
             run_chunk(IC(34), IC(8), IC(8), IC(0), IC(34), IC(0), IC(0), Z, from_H, no_ride);
