@@ -261,6 +261,10 @@ int32_t nsos_mlp_profile_rays(const void* packed, int32_t sem_mode, const float*
                               float* raw, uint64_t* stamps, void* stream);
 /* Same for the reduced-precision kernel; it stamps the SECOND tile of workgroups 0..3 (steady state), so give it
  * more than 2 x 256 x (CU count) points.  Slot meaning: scripts/phase_profile_lp.py. */
+/* Diagnostics: stamp EVERY following 16-bit MLP launch (the training variants included) into `stamps` (layout of
+ * nsos_mlp_profile_rays_lp), or stop with NULL.  scripts/phase_profile_lp.py --save. */
+int32_t nsos_mlp_lp_set_stamp_buffer(uint64_t* stamps);
+
 /* Diagnostics: which kernel serves the 16-bit entry points above.  2 (default) = two 256-register waves per SIMD, 32 points
  * each (mlp_lp8.hip); 1 = the round-1 kernel, one 512-register wave per SIMD with 64 points (mlp_lp.hip).  Same packed
  * stream, bit-identical results; exists for A/B measurements (models/nerf_mlp.py:67-100 is what both replace). */

@@ -523,6 +523,14 @@ static int lp_waves_per_simd() {
     return g_lp_waves_per_simd;
 }
 
+// diagnostics: a stamp buffer for EVERY following 16-bit launch (inference and training variants alike), or NULL to stop;
+// layout as nsos_mlp_profile_rays_lp
+static unsigned long long* g_lp_stamps = nullptr;
+extern "C" int32_t nsos_mlp_lp_set_stamp_buffer(uint64_t* stamps) {
+    g_lp_stamps = reinterpret_cast<unsigned long long*>(stamps);
+    return NSOS_OK;
+}
+
 extern "C" int32_t nsos_mlp_lp_select_kernel(int32_t waves_per_simd) {
     NSOS_REQUIRE(waves_per_simd == 1 || waves_per_simd == 2, NSOS_ERR_UNSUPPORTED);
     g_lp_waves_per_simd = waves_per_simd;
@@ -547,7 +555,7 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
     p.raw = raw; p.n_pts = n_pts; p.n_samples = n_samples;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
-    p.prof = prof;
+    p.prof = prof ? prof : g_lp_stamps;
     p.sem_in = sem_in;
     p.sem_in16 = sem_in16;
     p.sem_hid = sem_hid;

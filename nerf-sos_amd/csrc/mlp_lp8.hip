@@ -433,11 +433,14 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
                     f32x16 sacc[4];
                     // SAVE, compact sem_in: the 36 stores of [relu(h7) | x63 | 1] (packed words as they are) ride in these two
-                    // chunks' MFMA shadows, one per group from group 11 on
+                    // chunks' MFMA shadows, one per group in groups 3..20 -- EARLY in the chunk: the next chunk's barrier waits
+                    // for every outstanding vector-memory operation (its DMA pieces share the counter with the stores), and a
+                    // store issued just ahead of it exposes its whole HBM latency (measured: this phase took 35 k cycles
+                    // instead of 10 k with the stores in groups 11..33)
                     auto ride_sem = [&](auto gc_, auto ch_c) {
                         constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
-                        if constexpr (SAVE && g >= 11) {
-                            constexpr int k = CH * 23 + (g - 11);
+                        if constexpr (SAVE && g >= 3 && g < 21) {
+                            constexpr int k = CH * 18 + (g - 3);
                             if constexpr (k < 32) {          // word pair (q, q+1) of slice 2t+u = features 32t + 8(2u + q/2) + 4kg + {0..3}
                                 constexpr int t = (k >> 2) & 7, u = (k >> 1) & 1, q = 2 * (k & 1);
                                 if (save_ok)

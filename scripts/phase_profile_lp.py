@@ -13,7 +13,7 @@ from nerf_sos_amd import synthetic as syn
 
 sem = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp16"
-wps = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # 2: mlp_lp8_kernel (8 waves x 32 points), 1: mlp_lp_kernel (4 x 64)
+wps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 2      # 2: mlp_lp8_kernel (8 waves x 32 points), 1: mlp_lp_kernel (4 x 64)
 NW, COLS = (8, 1) if wps == 2 else (4, 2)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -29,18 +29,27 @@ stamps = torch.zeros(16 * 64, dtype=torch.int64, device=dev)   # 16 rows: 4 bloc
 _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(wps), 'select')
 P = lambda t: C.c_void_p(t.data_ptr())
 dt = {"fp16": 1, "bf16": 2}[prec]
-for _ in range(3):
+SAVE = "--save" in sys.argv          # the training (SAVE) variant: stamps through nsos_mlp_lp_set_stamp_buffer
+if SAVE:
+    assert sem > 0
+    _lib.check(_lib.lib().nsos_mlp_lp_set_stamp_buffer(P(stamps)), "stamps")
+    o_, d_ = rays[0].contiguous(), rays[1].contiguous()
+    for _ in range(3):
+        keep = ops.mlp_forward_rays_save(packed, sem, o_, d_, v, z, prec, compact=True)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().nsos_mlp_lp_set_stamp_buffer(None), "stamps")
+for _ in range(0 if SAVE else 3):
     _lib.check(_lib.lib().nsos_mlp_profile_rays_lp(P(packed), sem, dt, P(rays[0].contiguous()), P(rays[1].contiguous()),
                                                   P(v), P(z), R, 192, P(raw), P(stamps), None), "profile")
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
-for _ in range(10):
+for _ in range(0 if SAVE else 10):
     _lib.check(_lib.lib().nsos_mlp_profile_rays_lp(P(packed), sem, dt, P(rays[0].contiguous()), P(rays[1].contiguous()),
                                                   P(v), P(z), R, 192, P(raw), P(stamps), None), "profile")
 ev[1].record()
 torch.cuda.synchronize()
-launch_ms = ev[0].elapsed_time(ev[1]) / 10
+launch_ms = ev[0].elapsed_time(ev[1]) / 10 if not SAVE else float('nan')
 st = stamps.cpu().view(16, 64).numpy()
 M = 32  # cycles of one 32x32x16 MFMA
 names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * COLS * M}
