@@ -353,13 +353,31 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
     }
 }
 
+// 64 outputs x 4 slabs of partials per workgroup, two independent fp64 chains per thread, slabs folded in order through LDS
+// (a single thread walking all the partials of its output was 256 dependent loads: 63 us per call)
 __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks,
                                                                     float* __restrict__ gw1, float* __restrict__ gw2,
                                                                     float* __restrict__ gb2) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kWgradOut) return;
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += (double)partial[(size_t)b * kWgradOut + e];
+    __shared__ double fold[3][64];
+    const int el = threadIdx.x & 63, slab = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int per = (n_blocks + 3) / 4, b0 = slab * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    double s0 = 0.0, s1 = 0.0;
+    if (e < kWgradOut) {
+        int b = b0;
+        for (; b + 1 < b1; b += 2) {
+            s0 += (double)partial[(size_t)b * kWgradOut + e];
+            s1 += (double)partial[(size_t)(b + 1) * kWgradOut + e];
+        }
+        if (b < b1) s0 += (double)partial[(size_t)b * kWgradOut + e];
+    }
+    double s = s0 + s1;
+    if (slab > 0) fold[slab - 1][el] = s;
+    __syncthreads();
+    if (slab != 0 || e >= kWgradOut) return;
+    s += fold[0][el];
+    s += fold[1][el];
+    s += fold[2][el];
     if (e < 128 * 320) gw1[e] = (float)s;
     else if (e < 128 * 320 + 256) gw2[e - 128 * 320] = (float)s;
     else gb2[e - 128 * 320 - 256] = (float)s;
@@ -397,7 +415,7 @@ extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_sema
     const hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sem_head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in,
                        n_pts, (int)n_samples, static_cast<float*>(workspace));
-    hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,
                        static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
     return nsos_launch_status();
 }
@@ -424,7 +442,7 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
         case 1: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel<1>, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in, scale, n_pts, (int)n_samples, ws); break;
         default: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel<2>, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in, scale, n_pts, (int)n_samples, ws); break;
     }
-    hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,
                        static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
     return nsos_launch_status();
 }
