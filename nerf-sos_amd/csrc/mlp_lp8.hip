@@ -437,17 +437,24 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                     // for every outstanding vector-memory operation (its DMA pieces share the counter with the stores), and a
                     // store issued just ahead of it exposes its whole HBM latency (measured: this phase took 35 k cycles
                     // instead of 10 k with the stores in groups 11..33)
+                    // Full-sector stores: a lane holds, per 32-feature tile, the 4-feature quads q0,q2,q4,q6 (lane half 0) or
+                    // q1,q3,q5,q7 (half 1) of its point -- written as they are, every store put 8 B per lane = two HALF 32-byte
+                    // sectors per point (and the training kernel was bound by write transactions: +33 k cycles per tile).  Two
+                    // v_permlane32_swap per word pair hand q2 <-> q1 and q6 <-> q5 across the halves, after which half 0 owns
+                    // features 0..7 / 16..23 and half 1 owns 8..15 / 24..31 of the tile: one dwordx4 per lane, 32 contiguous
+                    // bytes per point and instruction.
                     auto ride_sem = [&](auto gc_, auto ch_c) {
                         constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
                         if constexpr (SAVE && g >= 3 && g < 21) {
                             constexpr int k = CH * 18 + (g - 3);
-                            if constexpr (k < 32) {          // word pair (q, q+1) of slice 2t+u = features 32t + 8(2u + q/2) + 4kg + {0..3}
-                                constexpr int t = (k >> 2) & 7, u = (k >> 1) & 1, q = 2 * (k & 1);
-                                if (save_ok)
-                                    *reinterpret_cast<u32x2*>(save_row + (32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) / 2) =
-                                        u32x2{H[2 * t + u][q], H[2 * t + u][q + 1]};
-                            } else if constexpr (k < 36) {   // slice words = features 16s + 8kg + {0..7}; 63 is the 1.0 pad
-                                constexpr int sl = k - 32;
+                            if constexpr (k < 16) {          // tile t = k / 2, half-tile j = k & 1 (features 32t + 16j + {0..15})
+                                constexpr int t = k >> 1, j = k & 1;
+                                const auto s0 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][0], H[2 * t + j][2], false, false);
+                                const auto s1 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][1], H[2 * t + j][3], false, false);
+                                if (save_ok)   // halves: features 32t + 16j + 8kg + {0..7} = words 16t + 8j + 4kg + {0..3}
+                                    *reinterpret_cast<u32x4*>(save_row + 16 * t + 8 * j + 4 * kg) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                            } else if constexpr (k < 20) {   // slice words = features 16s + 8kg + {0..7}; 63 is the 1.0 pad
+                                constexpr int sl = k - 16;
                                 if (save_ok) *reinterpret_cast<u32x4*>(save_row + 128 + 8 * sl + 4 * kg) = ex[sl];
                             }
                         }
