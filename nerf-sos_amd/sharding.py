@@ -205,7 +205,12 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     if rays.shape[1] != len(own):
         raise ValueError(f"sharded_patch_step: rank {rank} owns {len(own)} of {n_patches} patches, got rays for {rays.shape[1]}")
     dev = rays.device
-    ret = net(rays, bounds, retraw=False)
+    if len(own):
+        ret = net(rays, bounds, retraw=False)
+    else:   # more ranks than patches: this rank renders nothing but still takes part in every collective
+        P_ = tuple(rays.shape[2:4])
+        ret = {"semantics": rays.new_zeros((0,) + P_ + (2,)), "semantics0": rays.new_zeros((0,) + P_ + (2,)),
+               "depth": rays.new_zeros((0,) + P_ + (1,))}
     local = {"semantics": ret["semantics"], "semantics0": ret["semantics0"], "depth": ret["depth"],
              "feat": feat, "cls_": cls_tokens, "ray_o": rays[0], "ray_d": rays[1]}
     ev = None
@@ -238,7 +243,8 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
         loss = g if loss is None else loss + g
     if loss is None:
         raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")
-    loss.backward()
+    if loss.requires_grad:
+        loss.backward()
     if ev:
         ev[2].record()
     all_reduce_grads(net.parameters(), group)
