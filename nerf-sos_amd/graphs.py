@@ -17,8 +17,9 @@ class GraphedRender:
     def __init__(self, net, n_rays: int, near_far: Tuple[float, float], warmup: int = 3, **render_kwargs):
         if net.training:
             raise ValueError("GraphedRender captures the deterministic eval-mode path: call net.eval() first")
-        if any(p.requires_grad for p in net.parameters()) and torch.is_grad_enabled():
-            pass  # captured under no_grad below
+        # Trainable nets re-pack their weight streams on every call (NeRFMLP.packed_weights), so the pack launches are part
+        # of the graph and a replay reads the parameters' CURRENT values; a frozen net's streams are packed once, outside.
+        self._packs_in_graph = all(any(p.requires_grad for p in m.parameters()) for m in (net.nerf, net.nerf_fine))
         self.net, self.n_rays, self.near_far, self.kw = net, int(n_rays), near_far, render_kwargs
         dev = next(net.parameters()).device
         self._rays = torch.zeros((2, self.n_rays, 3), device=dev, dtype=torch.float32)
@@ -36,6 +37,8 @@ class GraphedRender:
         self._versions = self._param_versions()
 
     def _param_versions(self):
+        if self._packs_in_graph:
+            return tuple(p.data_ptr() for p in self.net.parameters())
         return tuple((p.data_ptr(), p._version) for p in self.net.parameters())
 
     def __call__(self, ray_batch) -> Dict[str, torch.Tensor]:
@@ -43,8 +46,9 @@ class GraphedRender:
         if rays_o.numel() != self.n_rays * 3 or rays_d.numel() != self.n_rays * 3:
             raise ValueError(f"captured for {self.n_rays} rays")
         if self._param_versions() != self._versions:
-            raise RuntimeError("parameters changed (or moved) since capture (the packed weight stream is baked into the graph): "
-                               "re-capture.  Edits through `.data` are invisible here: call net.invalidate_packed() and re-capture")
+            raise RuntimeError("parameters moved (or, for a frozen net, changed) since capture -- the graph holds their "
+                               "addresses and a frozen net's packed weight stream: re-capture.  `.data` edits of a frozen "
+                               "net are invisible here: call net.invalidate_packed() and re-capture")
         self._rays[0].copy_(rays_o.reshape(self.n_rays, 3))
         self._rays[1].copy_(rays_d.reshape(self.n_rays, 3))
         self.graph.replay()

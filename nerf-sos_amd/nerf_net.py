@@ -78,27 +78,43 @@ class NeRFMLP(nn.Module):
                        sem_layer=sem_layer, sem_dim=sem_dim, sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
         self._packed = {}      # precision -> packed stream
         self._packed_key = {}  # precision -> (data_ptr, version) of every parameter when it was packed
+        self._plan = None      # ops.PackPlan of the current parameter storages
 
     @property
     def sem_mode(self) -> int:
         return self.mlp.sem_mode
 
     def packed_weights(self, precision: str = "fp32") -> torch.Tensor:
-        """The MFMA-order weight stream for `precision`, re-packed on device whenever a parameter changed
-        (optimizer steps and load_state_dict bump ``Tensor._version``)."""
-        params = dict(self.mlp.named_parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params.values())
-        if precision not in self._packed or key != self._packed_key.get(precision):
-            self._packed[precision] = ops.pack_mlp(params, self.sem_mode, self._packed.get(precision), precision)
+        """The MFMA-order weight stream for `precision`, packed on device from the parameters.
+
+        Trainable parameters (any ``requires_grad``) are re-packed on EVERY call -- one ~6 us launch per net.  Nothing
+        cheaper is safe: ``torch.optim.Adam(fused=True)`` (and every other fused/`.data`-style update) changes the values
+        without bumping ``Tensor._version``, so a version-keyed cache would keep rendering -- and differentiating -- the
+        initial weights while the optimizer moves the parameters.  A fully frozen net is packed once and re-packed when
+        (data_ptr, _version) of a parameter changes (``load_state_dict``, in-place ops); after a ``p.data`` edit of a
+        frozen net call invalidate_packed()."""
+        params = list(self.mlp.parameters())
+        ptrs = tuple(p.data_ptr() for p in params)
+        if self._plan is None or self._plan.ptrs != ptrs:
+            self._plan = ops.PackPlan(dict(self.mlp.named_parameters()), self.sem_mode)
+        trainable = any(p.requires_grad for p in params)
+        key = None if trainable else tuple((p.data_ptr(), p._version) for p in params)
+        if trainable or precision not in self._packed or key != self._packed_key.get(precision):
+            self._packed[precision] = self._plan.run(self._packed.get(precision), precision)
             self._packed_key[precision] = key
         return self._packed[precision]
 
+    def __getstate__(self):  # copy.deepcopy / pickling: the plan holds raw device pointers, the streams are derived data
+        state = self.__dict__.copy()
+        state["_plan"], state["_packed"], state["_packed_key"] = None, {}, {}
+        return state
+
     def invalidate_packed(self) -> None:
-        """Drop the cached weight streams.  The cache key is (data_ptr, _version) of every parameter, which optimizer
-        steps, `load_state_dict` and ordinary in-place ops change -- but edits made through ``p.data`` (``p.data.copy_()``,
-        ``p.data.mul_()``) bump neither: call this after such an edit, or the kernels keep the old weights."""
+        """Drop the cached weight streams of a frozen net (see packed_weights: edits made through ``p.data`` bump neither
+        data_ptr nor _version).  Trainable nets never need it."""
         self._packed.clear()
         self._packed_key.clear()
+        self._plan = None
 
     def forward(self, inputs, viewdirs=None):
         if viewdirs is None:

@@ -125,51 +125,68 @@ def packed_bytes(sem_mode: int, precision: str = "fp32") -> int:
     return int(_lib.lib().nsos_mlp_packed_bytes_lp(sem_mode))
 
 
+class PackPlan:
+    """The argument block of one net's pack launches: the validated parameter pointers (MlpTensors) plus the tensors that
+    own them.  Building it walks ~26 parameters; a training loop re-packs every step (NeRFMLP.packed_weights), so the
+    plan is built once per set of parameter storages and a re-pack is one C call."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], sem_mode: int):
+        keep = []
+
+        def g(name):
+            t = _dev(params[name].detach(), name)
+            keep.append(t)
+            return t.data_ptr()
+
+        T = _lib.MlpTensors()
+        for i in range(8):
+            T.pts_w[i] = g(f"pts_linears.{i}.weight")
+            T.pts_b[i] = g(f"pts_linears.{i}.bias")
+        for field, name in _MLP_FIELDS:
+            setattr(T, field + "_w", g(name + ".weight"))
+            setattr(T, field + "_b", g(name + ".bias"))
+        if sem_mode != SEM_NONE:
+            T.sem0_w, T.sem0_b = g("semantic_linear.0.weight"), g("semantic_linear.0.bias")
+            T.sem2_w, T.sem2_b = g("semantic_linear.2.weight"), g("semantic_linear.2.bias")
+        shapes = {"pts_linears.0.weight": (256, 63), "pts_linears.5.weight": (256, 319),
+                  "views_linears.0.weight": (128, 283), "rgb_linear.weight": (3, 128), "alpha_linear.weight": (1, 256)}
+        if sem_mode != SEM_NONE:
+            shapes["semantic_linear.0.weight"] = (128, 319 if sem_mode == SEM_COORD else 256)
+            shapes["semantic_linear.2.weight"] = (2, 128)
+        for k, shp in shapes.items():
+            if tuple(params[k].shape) != shp:
+                raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
+        self.tensors, self.keep, self.sem_mode, self.device = T, keep, sem_mode, keep[0].device
+        self.ptrs = tuple(t.data_ptr() for t in keep)
+        self.nbytes = {}
+
+    def run(self, out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
+        if precision not in DTYPES:
+            raise ValueError(f"precision must be one of {list(DTYPES)}, got {precision!r}")
+        nbytes = self.nbytes.get(precision)
+        if nbytes is None:
+            nbytes = self.nbytes[precision] = packed_bytes(self.sem_mode, precision)
+        if out is None or out.numel() * 4 < nbytes or out.device != self.device:
+            out = torch.empty(nbytes // 4, device=self.device, dtype=torch.float32)
+        T, L = C.byref(self.tensors), _lib.lib()
+        if precision == "fp32":
+            _lib.check(L.nsos_mlp_pack(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
+        elif precision == "fp16x3":
+            _lib.check(L.nsos_mlp_pack_x3(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack_x3")
+        elif precision == "fp16x3_bwd":
+            _lib.check(L.nsos_mlp_bwd_pack_x3(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_bwd_pack_x3")
+        else:
+            _lib.check(L.nsos_mlp_pack_lp(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp")
+        return out
+
+
 def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch.Tensor] = None,
              precision: str = "fp32") -> torch.Tensor:
     """Gather one net's state-dict tensors (keys relative to `<net>.mlp.`) into the MFMA-order stream
     (fp32 exact-MFMA layout, or the 16-bit layout of the reduced-precision kernel)."""
     if precision not in DTYPES:
         raise ValueError(f"precision must be one of {list(DTYPES)}, got {precision!r}")
-    keep = []
-
-    def g(name):
-        t = _dev(params[name].detach(), name)
-        keep.append(t)
-        return t.data_ptr()
-
-    T = _lib.MlpTensors()
-    for i in range(8):
-        T.pts_w[i] = g(f"pts_linears.{i}.weight")
-        T.pts_b[i] = g(f"pts_linears.{i}.bias")
-    for field, name in _MLP_FIELDS:
-        setattr(T, field + "_w", g(name + ".weight"))
-        setattr(T, field + "_b", g(name + ".bias"))
-    if sem_mode != SEM_NONE:
-        T.sem0_w, T.sem0_b = g("semantic_linear.0.weight"), g("semantic_linear.0.bias")
-        T.sem2_w, T.sem2_b = g("semantic_linear.2.weight"), g("semantic_linear.2.bias")
-    shapes = {"pts_linears.0.weight": (256, 63), "pts_linears.5.weight": (256, 319),
-              "views_linears.0.weight": (128, 283), "rgb_linear.weight": (3, 128), "alpha_linear.weight": (1, 256)}
-    if sem_mode != SEM_NONE:
-        shapes["semantic_linear.0.weight"] = (128, 319 if sem_mode == SEM_COORD else 256)
-        shapes["semantic_linear.2.weight"] = (2, 128)
-    for k, shp in shapes.items():
-        if tuple(params[k].shape) != shp:
-            raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
-    nbytes = packed_bytes(sem_mode, precision)
-    dev = keep[0].device
-    if out is None or out.numel() * 4 < nbytes or out.device != dev:
-        out = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-    if precision == "fp32":
-        _lib.check(_lib.lib().nsos_mlp_pack(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack")
-    elif precision == "fp16x3":
-        _lib.check(_lib.lib().nsos_mlp_pack_x3(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack_x3")
-    elif precision == "fp16x3_bwd":
-        _lib.check(_lib.lib().nsos_mlp_bwd_pack_x3(C.byref(T), sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_bwd_pack_x3")
-    else:
-        _lib.check(_lib.lib().nsos_mlp_pack_lp(C.byref(T), sem_mode, DTYPES[precision], _p(out), nbytes, _stream()),
-                   "nsos_mlp_pack_lp")
-    return out
+    return PackPlan(params, sem_mode).run(out, precision)
 
 
 def mlp_forward_rays(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,

@@ -288,3 +288,42 @@ def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
         b = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16.float(), split_fp16=True)
         for x, y in zip(a, b):
             assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max() + 1e-30), dt
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_optimizer_updates_reach_the_kernels(precision, fused):
+    """Three Adam steps on a full-render loss, then the trained module must render exactly what a FRESH module loaded
+    with its state_dict renders.  torch.optim.Adam(fused=True) updates parameters without bumping Tensor._version: with a
+    version-keyed weight-stream cache the kernels kept the initial weights (the loss never moved and nothing complained).
+    bf16 covers the head-only training path, the other two the full backward."""
+    import nerf_sos_amd
+    from nerf_sos_amd import synthetic as syn
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    kw = dict(N_samples=32, N_importance=32, use_semantics=True, sem_with_coord=True)
+    net = syn.spiky_density_(nerf_sos_amd.NeRFNet(**kw).to(dev).train(), 1.0, 0.5)   # fog: every sample carries weight
+    net.mlp_precision = precision
+    if precision == "bf16":
+        for n, p in net.named_parameters():
+            p.requires_grad_("semantic_linear" in n)
+    rays = syn.synthetic_rays(512, seed=1, device=dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-2, fused=fused)
+    losses = []
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        out = net(rays, (syn.NEAR, syn.FAR))
+        loss = (out["semantics"] ** 2).mean() + (0.0 if precision == "bf16" else (out["rgb"] ** 2).mean())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert len(set(losses)) == 3, losses                    # every update is seen by the next forward
+    fresh = nerf_sos_amd.NeRFNet(**kw).to(dev).eval()
+    fresh.mlp_precision = precision
+    fresh.load_state_dict(net.state_dict())
+    net.eval()
+    with torch.no_grad():
+        a, b = net(rays, (syn.NEAR, syn.FAR)), fresh(rays, (syn.NEAR, syn.FAR))
+    for k in ("rgb", "semantics", "depth"):
+        assert torch.equal(a[k], b[k]), k

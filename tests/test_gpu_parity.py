@@ -628,7 +628,16 @@ def test_graphed_render_equals_eager(manifest, precision):
         assert set(got) == set(want)
         for k in want:
             assert torch.equal(got[k], want[k]), k
-    with torch.no_grad():
+    with torch.no_grad():                       # trainable net: the pack launches are in the graph, a replay follows
+        net.nerf_fine.mlp.rgb_linear.bias.add_(0.1)   # in-place parameter updates (optimizer steps, fused or not)
+        want = net(rays, (tp.NEAR, tp.FAR), retraw=False)
+    got = g(rays)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    for p in net.parameters():
+        p.requires_grad_(False)
+    g = nerf_sos_amd.GraphedRender(net, 300, (tp.NEAR, tp.FAR), retraw=False)
+    with torch.no_grad():                       # frozen net: packed once outside the graph -> a change must be refused
         net.nerf.mlp.rgb_linear.bias.add_(0.1)
     with pytest.raises(RuntimeError, match="re-capture"):
         g(rays)

@@ -102,3 +102,59 @@ def test_bench_self_launch_command(monkeypatch):
     bench._self_launch(types.SimpleNamespace(gpus=8))
     bench._self_launch(types.SimpleNamespace(gpus=1))
     assert not seen
+
+
+class _FakePlan:
+    """Stands in for ops.PackPlan on a machine without a GPU: counts the pack launches it would issue."""
+    runs = 0
+
+    def __init__(self, params, sem_mode):
+        self.ptrs = tuple(p.data_ptr() for p in params.values())
+
+    def run(self, out, precision):
+        _FakePlan.runs += 1
+        return torch.zeros(1) if out is None else out
+
+
+def test_packed_weights_policy(monkeypatch):
+    """Trainable nets re-pack on every call (fused optimizers update parameters without bumping Tensor._version, which a
+    version-keyed cache would miss); frozen nets pack once and again only when (data_ptr, _version) changes."""
+    import copy
+    from nerf_sos_amd import ops
+    monkeypatch.setattr(ops, "PackPlan", _FakePlan)
+    _FakePlan.runs = 0
+    mlp = nerf_sos_amd.NeRFMLP()
+    mlp.packed_weights(); mlp.packed_weights()
+    assert _FakePlan.runs == 2                      # trainable: every call
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    mlp.packed_weights(); mlp.packed_weights(); mlp.packed_weights()
+    assert _FakePlan.runs == 3                      # frozen: once
+    with torch.no_grad():
+        next(mlp.parameters()).mul_(2.0)            # in-place op: _version changes
+    mlp.packed_weights()
+    assert _FakePlan.runs == 4
+    next(mlp.parameters()).data.mul_(2.0)           # .data edit: invisible -> documented invalidate_packed()
+    mlp.packed_weights()
+    assert _FakePlan.runs == 4
+    mlp.invalidate_packed()
+    mlp.packed_weights()
+    assert _FakePlan.runs == 5
+    clone = copy.deepcopy(mlp)                      # the plan (raw pointers) and the streams do not travel
+    assert clone._plan is None and clone._packed == {}
+    clone.packed_weights()
+    assert _FakePlan.runs == 6
+
+
+def test_fused_adam_does_not_bump_versions():
+    """The fact the packing policy rests on; if torch ever changes it the policy is merely conservative."""
+    p = torch.nn.Parameter(torch.ones(4))
+    try:
+        opt = torch.optim.Adam([p], lr=0.1, fused=True)
+    except RuntimeError:
+        pytest.skip("no fused Adam on this device")
+    p.grad = torch.ones(4)
+    v = p._version
+    opt.step()
+    assert not torch.equal(p.detach(), torch.ones(4))
+    assert p._version in (v, v + 1)
