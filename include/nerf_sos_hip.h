@@ -168,11 +168,13 @@ size_t nsos_sem_head_wgrad_workspace_bytes(void);
 int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
                             const float* sem_in, int64_t n_rays, int32_t n_samples, float* gw1_aug, float* gw2,
                             float* gb2, void* workspace, size_t workspace_bytes, void* stream);
-/* The same on the 16-bit matrix pipe with split-fp16 operands (three MFMAs per product, fp32 accumulate): HBM-bound
- * instead of MFMA-bound.  `scale` (device scalar, a power of two) brings g_hid = (g_logits @ W_sem2) * mask into fp16
- * range: gw1_aug comes out multiplied by it (divide afterwards); gw2 / gb2 are plain fp32 sums as above.
- * sem_in_dtype: NSOS_DTYPE_F32 for the fp32 matrix, NSOS_DTYPE_F16 / NSOS_DTYPE_BF16 for the compact 16-bit matrix of
- * nsos_mlp_forward_rays_save16_lp (half the operand traffic).  n_samples >= 8, n_rays * n_samples < 2^31. */
+/* The same on the 16-bit matrix pipe with split-fp16 operands (fp32 accumulate): HBM-bound instead of MFMA-bound.
+ * g_hid = (g_logits @ W_sem2) * mask is brought into fp16 range by a power of two and gw1_aug divided by it again on
+ * the way out: `scale` = that power of two as a device scalar, or NULL to have it derived on the device from
+ * max |g_semantics| * max_m (|W_sem2[0,m]| + |W_sem2[1,m]|) (one extra small launch).  gw2 / gb2 are plain fp32 sums.
+ * sem_in_dtype: NSOS_DTYPE_F32 for the fp32 matrix (three MFMAs per product), NSOS_DTYPE_F16 / NSOS_DTYPE_BF16 for the
+ * compact 16-bit matrix of nsos_mlp_forward_rays_save16_lp (half the operand traffic; a 16-bit operand has no lo part:
+ * two MFMAs per product; csrc/sem_wgrad16.hip).  n_samples >= 8, n_rays * n_samples < 2^31. */
 int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
                                const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
                                const float* scale, float* gw1_aug, float* gw2, float* gb2, void* workspace,

@@ -355,9 +355,10 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
 
 // 64 outputs x 4 slabs of partials per workgroup, two independent fp64 chains per thread, slabs folded in order through LDS
 // (a single thread walking all the partials of its output was 256 dependent loads: 63 us per call)
+// gw1 is divided by *scale_p (a power of two; nullptr: 1) on the way out
 __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks,
-                                                                    float* __restrict__ gw1, float* __restrict__ gw2,
-                                                                    float* __restrict__ gb2) {
+                                                                    const float* __restrict__ scale_p, float* __restrict__ gw1,
+                                                                    float* __restrict__ gw2, float* __restrict__ gb2) {
     __shared__ double fold[3][64];
     const int el = threadIdx.x & 63, slab = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float*
     s += fold[0][el];
     s += fold[1][el];
     s += fold[2][el];
-    if (e < 128 * 320) gw1[e] = (float)s;
+    if (e < 128 * 320) gw1[e] = (float)s * (scale_p ? 1.0f / *scale_p : 1.0f);
     else if (e < 128 * 320 + 256) gw2[e - 128 * 320] = (float)s;
     else gb2[e - 128 * 320 - 256] = (float)s;
 }
@@ -397,7 +398,8 @@ int wgrad_blocks() {
 }
 }  // namespace
 
-extern "C" size_t nsos_sem_head_wgrad_workspace_bytes(void) { return (size_t)1024 * kWgradOut * sizeof(float); }
+// 1024 blocks of partial sums, then one float: the scale nsos_sem_head_wgrad_x3 derives when the caller passes none
+extern "C" size_t nsos_sem_head_wgrad_workspace_bytes(void) { return (size_t)1024 * kWgradOut * sizeof(float) + 256; }
 
 extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w,
                                        const float* sem_hid, const float* sem_in, int64_t n_rays, int32_t n_samples,
@@ -416,9 +418,43 @@ extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_sema
     hipLaunchKernelGGL(sem_head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in,
                        n_pts, (int)n_samples, static_cast<float*>(workspace));
     hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,
-                       static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
+                       static_cast<const float*>(workspace), blocks, (const float*)nullptr, gw1_aug, gw2, gb2);
     return nsos_launch_status();
 }
+
+namespace nsos_detail {
+int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+                         const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples, const float* scale,
+                         float* partial, int blocks, hipStream_t st);   // sem_wgrad16.hip
+}
+
+namespace {
+// The power of two that brings g_hid into fp16 range: |g_hid| <= max|dL/dsemantics| * max_m (|W2[0,m]| + |W2[1,m]|) (compositing
+// weights are <= 1); that bound goes to 2^8.  One workgroup: 2 n_rays + 128 values.
+__global__ __launch_bounds__(1024) void sem_head_scale_kernel(const float* __restrict__ g_sem, long long n, const float* __restrict__ w2,
+                                                              float* __restrict__ scale_out) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (long long j = threadIdx.x; j < n; j += 1024) m = fmaxf(m, fabsf(g_sem[j]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, NSOS_WAVE));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    m = threadIdx.x < 16 ? red[threadIdx.x] : 0.0f;
+    float c = fmaxf(fabsf(w2[threadIdx.x]) + fabsf(w2[128 + threadIdx.x]), fabsf(w2[64 + threadIdx.x]) + fabsf(w2[192 + threadIdx.x]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off, NSOS_WAVE));
+        c = fmaxf(c, __shfl_xor(c, off, NSOS_WAVE));
+    }
+    if (threadIdx.x == 0) {
+        const float bound = fmaxf(m * c, 1e-30f);
+        const float e = fminf(fmaxf(floorf(log2f(256.0f / bound)), -60.0f), 60.0f);
+        *scale_out = exp2f(e);
+    }
+}
+}  // namespace
 
 extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w,
                                           const float* sem_hid, const void* sem_in, int32_t sem_in_dtype, int64_t n_rays,
@@ -427,7 +463,7 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
     NSOS_REQUIRE(sem_in_dtype >= 0 && sem_in_dtype <= 2, NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(gw1_aug && gw2 && gb2, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
-    NSOS_REQUIRE(n_rays == 0 || (weights && g_semantics && sem2_w && sem_hid && sem_in && scale && workspace), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays == 0 || (weights && g_semantics && sem2_w && sem_hid && sem_in && workspace), NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(workspace_bytes >= nsos_sem_head_wgrad_workspace_bytes(), NSOS_ERR_BUFFER_TOO_SMALL);
     const long long n_pts = (long long)n_rays * n_samples;
     NSOS_REQUIRE(n_samples >= 8 && n_pts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
@@ -437,12 +473,19 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
     if (steps < blocks) blocks = (int)(steps > 0 ? steps : 1);
     const hipStream_t st = (hipStream_t)stream;
     float* ws = static_cast<float*>(workspace);
+    if (!scale) {
+        float* derived = ws + (size_t)1024 * kWgradOut;
+        hipLaunchKernelGGL(sem_head_scale_kernel, dim3(1), dim3(1024), 0, st, g_semantics, 2ll * n_rays, sem2_w, derived);
+        scale = derived;
+    }
     switch (sem_in_dtype) {
         case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel<0>, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in, scale, n_pts, (int)n_samples, ws); break;
-        case 1: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel<1>, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in, scale, n_pts, (int)n_samples, ws); break;
-        default: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel<2>, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in, scale, n_pts, (int)n_samples, ws); break;
+        default: {
+            const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype, n_rays, n_samples, scale, ws, blocks, st);
+            if (rc != NSOS_OK) return rc;
+        }
     }
     hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,
-                       static_cast<const float*>(workspace), blocks, gw1_aug, gw2, gb2);
+                       static_cast<const float*>(workspace), blocks, scale, gw1_aug, gw2, gb2);
     return nsos_launch_status();
 }

@@ -299,7 +299,7 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     """Backward of the semantic head in one pass (nsos_sem_head_wgrad): returns
     (gw1_aug [128,320] = [dW1 | . | db1 in column 319], dW2 [2,128], db2 [2]).
     split_fp16: the big reduction on the 16-bit matrix pipe with split operands (nsos_sem_head_wgrad_x3; needs S >= 8 and
-    fewer than 2^31 points, else the exact kernel runs); a power-of-two scale derived on the device keeps g_hid in range."""
+    fewer than 2^31 points, else the exact kernel runs)."""
     weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
     sem2_w, sem_hid = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid")
     x_dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}.get(sem_in.dtype)
@@ -320,15 +320,12 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     use_split = split_fp16 and S >= 8 and R * S < 2 ** 31
     if not use_split and x_dtype != 0:
         sem_in, x_dtype = sem_in.float(), 0          # the exact kernel reads fp32
-    if use_split:
-        # |g_hid| <= max|g_sem| * max_m (|W2[0,m]| + |W2[1,m]|) (compositing weights are <= 1): bring that bound to 2^8
-        bound = (g_semantics.abs().max() * sem2_w.abs().sum(0).max()).clamp_min(1e-30)
-        scale = torch.exp2(torch.floor(torch.log2(256.0 / bound))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
+    if use_split:   # the power of two that keeps g_hid in fp16 range is derived (and divided out again) on the device
         _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), x_dtype,
-                                                     R, S, _p(scale), _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
+                                                     R, S, None, _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
                                                      _stream()),
                    "nsos_sem_head_wgrad_x3")
-        return gw1 * (1.0 / scale), gw2, gb2
+        return gw1, gw2, gb2
     _lib.check(_lib.lib().nsos_sem_head_wgrad(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,
                                               _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4, _stream()),
                "nsos_sem_head_wgrad")
