@@ -527,18 +527,30 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
     }
 }
 
-// fd[set][n][p][q] = <f1n[n][p], f2n[q]>, f2n = side 1 for the negative set, side 0 (the same patch) for the self set
+// fd[set][n][p][q] = <f1n[n][p], f2n[q]>, f2n = side 1 for the negative set, side 0 (the same patch) for the self set.
+// One workgroup per row point p; a wave takes four column points at a time, lanes across channels (coalesced), so four
+// independent row fetches are in flight per lane (one column per iteration was a chain of dependent L2 round trips: 63 us
+// for 14 MFLOP).  Products are rounded to fp32 and summed in fp64, as before.
 __global__ __launch_bounds__(256) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat) {
     const int set = blockIdx.z, n = blockIdx.y, p = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const float* a = fn + (((size_t)0 * B + n) * N + p) * Cf;
     const float* bb = fn + (((size_t)(set == 0 ? 1 : 0) * B + n) * N) * Cf;
-    for (int q = wave; q < N; q += nw) {   // one wave per column point, lanes across channels (coalesced)
-        const float* b = bb + (size_t)q * Cf;
-        double s = 0.0;
-        for (int c = lane; c < Cf; c += 64) s += (double)(a[c] * b[c]);
-        s = nsos_wave_sum(s);
-        if (lane == 0) fdmat[(((size_t)set * B + n) * N + p) * N + q] = (float)s;
+    for (int q = 4 * wave; q < N; q += 4 * nw) {
+        const float* b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = bb + (size_t)(q + u < N ? q + u : N - 1) * Cf;
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = lane; c < Cf; c += 64) {
+            const float av = a[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += (double)(av * b[u][c]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double t = nsos_wave_sum(s[u]);
+            if (lane == 0 && q + u < N) fdmat[(((size_t)set * B + n) * N + p) * N + q + u] = (float)t;
+        }
     }
 }
 
@@ -565,33 +577,57 @@ __global__ __launch_bounds__(128) void app_point_grad_kernel(int B, int N, const
 }
 
 // grid_sample backward as a gather (deterministic): thread = one pixel of patch m; it collects the bilinear weights
-// of the coords1 samples of m and of the coords2 samples of every n whose negative is m
+// of the coords1 samples of m and of the coords2 samples of every n whose negative is m.  The geometry of a sample set
+// (corner + four weights per sample) is worked out once per workgroup into LDS; every thread then walks the N samples with
+// broadcast reads (each thread re-deriving it, divisions and all, for all N samples: 70 us per call on 32 CUs).
 template <int C>
 __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, int Hc, int Wc, const long long* __restrict__ neg,
                                                           const float* __restrict__ rnd1, const float* __restrict__ rnd2,
                                                           const float* __restrict__ g1, const float* __restrict__ g2,
                                                           float* __restrict__ grad_code) {
+    constexpr int kMaxSamples = 1024;
+    __shared__ int corner[kMaxSamples];          // x0 | y0 << 16
+    __shared__ float weight[kMaxSamples][4];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)B * Hc * Wc) return;
-    const int m = (int)(i / (Hc * Wc)), y = (int)((i / Wc) % Hc), x = (int)(i % Wc);
+    const long long px = (long long)Hc * Wc;
+    // a workgroup's pixels may straddle two patches when Hc*Wc is not a multiple of 256: geometry is staged per patch below
+    const bool live = i < (long long)B * px;
+    const int m = live ? (int)(i / px) : -1, y = live ? (int)((i / Wc) % Hc) : 0, x = live ? (int)(i % Wc) : 0;
+    const int m_first = (int)(((long long)blockIdx.x * blockDim.x) / px);
+    const long long last_i = (long long)blockIdx.x * blockDim.x + blockDim.x - 1;
+    const int m_last = (int)((last_i < (long long)B * px ? last_i : (long long)B * px - 1) / px);
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
-    for (int side = 0; side < 2; ++side)
-        for (int n = 0; n < B; ++n) {
-            if (side == 0 ? n != m : (int)neg[n] != m) continue;
-            const float* gsrc = (side == 0 ? g1 : g2) + (size_t)n * N * kMaxC;
-            for (int p = 0; p < N; ++p) {
-                float gx, gy;
-                sample_coord(side == 0 ? rnd1 : rnd2, n, p, S, gx, gy);
-                const Bilinear b = bilinear_of(gx, gy, Wc, Hc);
-                const int dx = x - b.x0, dy = y - b.y0;
-                if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
-                const float w = b.w[dy * 2 + dx];
+    for (int mm = m_first; mm <= m_last; ++mm)
+        for (int side = 0; side < 2; ++side)
+            for (int n = 0; n < B; ++n) {
+                if (side == 0 ? n != mm : (int)neg[n] != mm) continue;        // workgroup-uniform
+                const float* gsrc = (side == 0 ? g1 : g2) + (size_t)n * N * kMaxC;
+                for (int p0 = 0; p0 < N; p0 += kMaxSamples) {
+                    const int cnt = N - p0 < kMaxSamples ? N - p0 : kMaxSamples;
+                    __syncthreads();
+                    for (int p = threadIdx.x; p < cnt; p += blockDim.x) {
+                        float gx, gy;
+                        sample_coord(side == 0 ? rnd1 : rnd2, n, p0 + p, S, gx, gy);
+                        const Bilinear b = bilinear_of(gx, gy, Wc, Hc);
+                        corner[p] = b.x0 | (b.y0 << 16);
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] += gsrc[(size_t)p * kMaxC + c] * w;
+                        for (int k = 0; k < 4; ++k) weight[p][k] = b.w[k];
+                    }
+                    __syncthreads();
+                    if (m != mm) continue;
+                    for (int p = 0; p < cnt; ++p) {
+                        const int cr = corner[p];
+                        const int dx = x - (cr & 0xffff), dy = y - (cr >> 16);
+                        if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
+                        const float w = weight[p][dy * 2 + dx];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] += gsrc[(size_t)(p0 + p) * kMaxC + c] * w;
+                    }
+                }
             }
-        }
+    if (!live) return;
 #pragma unroll
     for (int c = 0; c < C; ++c) grad_code[((size_t)m * C + c) * Hc * Wc + (size_t)y * Wc + x] = acc[c];
 }

@@ -160,7 +160,8 @@ class GeoCorrelationLoss(CorrelationLoss):
             _lib.check(lib.nsos_corr_workspace_slots(B, H * W, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
             scal = ws[so.value // 8: so.value // 8 + 6]
             gsum = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
-            rows_t = torch.tensor(list(rows), dtype=torch.int32, device=dev)
+            from .sharding import device_index
+            rows_t = device_index(rows, torch.int32, dev)     # uploaded once (a fresh torch.tensor(..., device=) synchronises)
             reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
             for phase in range(4):
                 _lib.check(lib.nsos_geo_correlation_loss_rows(phase, dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(),

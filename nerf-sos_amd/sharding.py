@@ -100,8 +100,9 @@ def all_gather_patches(local: Dict[str, torch.Tensor], n_patches: int, group=Non
         return {k: local[k].detach() for k in present}
     counts = [len(local_patches(n_patches, r, world)) for r in range(world)]
     order = [b for r in range(world) for b in local_patches(n_patches, r, world)]  # rank-major -> global id
-    inv = torch.empty(n_patches, dtype=torch.long)
-    inv[torch.tensor(order, dtype=torch.long)] = torch.arange(n_patches)
+    inv = [0] * n_patches
+    for pos, b in enumerate(order):
+        inv[b] = pos
     n_local = counts[rank]
     out: Dict[str, torch.Tensor] = {}
     by_dtype: Dict[torch.dtype, List[str]] = {}
@@ -115,7 +116,7 @@ def all_gather_patches(local: Dict[str, torch.Tensor], n_patches: int, group=Non
         flat = torch.cat([local[k].detach().reshape(n_local, wd) for k, wd in zip(ks, widths)], 1)
         nbytes += flat.shape[1] * flat.element_size()
         g = all_gather_rows(flat, counts, group)
-        g = g[inv.to(g.device)]
+        g = g[device_index(inv, torch.long, g.device)]      # cached on the device: no per-step upload (= synchronisation)
         off = 0
         for k, wd in zip(ks, widths):
             out[k] = g[:, off:off + wd].reshape((n_patches,) + tuple(local[k].shape[1:]))
@@ -133,12 +134,28 @@ def splice_local_patches(gathered: Dict[str, torch.Tensor], local: Dict[str, tor
     rank rendered -- in both of their roles (as patch n and as the negative of other patches, utils/image.py:359-360).
     Summing the parameter gradients over the ranks (`all_reduce_grads`) gives the single-process gradient."""
     rank, world = _world(group)
-    own = torch.tensor(local_patches(n_patches, rank, world), dtype=torch.long)
+    own = local_patches(n_patches, rank, world)
     out = dict(gathered)
     for k, g in gathered.items():
         if k in local and local[k].requires_grad and len(own):
-            out[k] = g.index_put((own.to(g.device),), local[k])
+            # one process: the "gathered" batch IS the local one (no copy, no index kernel)
+            out[k] = local[k] if world == 1 else g.index_put((device_index(own, torch.long, g.device),), local[k])
     return out
+
+
+_INDEX_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def device_index(values, dtype, device) -> torch.Tensor:
+    """A small constant index list as a device tensor, uploaded once: `torch.tensor(list, device=gpu)` is a pageable
+    host-to-device copy, i.e. a full synchronisation of the stream -- per step, per call site."""
+    key = (tuple(int(v) for v in values), dtype, str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        if len(_INDEX_CACHE) > 256:
+            _INDEX_CACHE.clear()
+        t = _INDEX_CACHE[key] = torch.tensor(list(key[0]), dtype=dtype, device=device)
+    return t
 
 
 def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
