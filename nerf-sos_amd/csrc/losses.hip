@@ -188,22 +188,25 @@ __device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, in
 }
 
 // PASS 1: row sums.  PASS 2: sum fl32(fd - rowmean).  PASS 3: loss + row-code gradient.
-// GEO: a workgroup = 64 row points x kSlabs column slabs (wave w loops over columns [w N/4, (w+1) N/4)); the slabs' fp64
-// partials are folded in slab order through LDS.  With 256 rows per workgroup a call with few row patches (one or two per
-// GPU in the sharded step) put 32-64 workgroups on 256 CUs; this way it is 4x as many, each a quarter as long.
-template <bool GEO>
+// GEO: a workgroup = kRows row points x kSlabs column slabs, 1024 threads = four waves per SIMD (thread (row, slab) loops over
+// the slab's N / kSlabs columns); the slabs' fp64 partials are folded in slab order through LDS -- the dynamic region, reused
+// once every wave is done with the column image.  The column image (up to 144 KiB) allows ONE workgroup per CU, so the
+// threads of that workgroup are all the latency hiding there is: 256 threads (one wave per SIMD) ran the C4 step's pair
+// kernels in 0.80 ms, 1024 in 0.45 ms.  Rows per workgroup: 64, or 32 (NARROW) when 64 would leave CUs without a workgroup
+// (one or two row patches per GPU in the sharded step; each workgroup re-stages the image, so narrow only when needed).
+template <bool GEO, bool NARROW = false>
 struct PairShape {
-    static constexpr int kSlabs = GEO ? 4 : 1;
-    static constexpr int kThreads = GEO ? 256 : 128;
-    static constexpr int kRows = kThreads / kSlabs;
+    static constexpr int kThreads = GEO ? 1024 : 128;
+    static constexpr int kRows = GEO ? (NARROW ? 32 : 64) : 128;
+    static constexpr int kSlabs = kThreads / kRows;
 };
 
-template <bool GEO, int C, int PASS>
-__global__ __launch_bounds__(PairShape<GEO>::kThreads) void pair_rows_kernel(const PairArgs A) {
+template <bool GEO, int C, int PASS, bool NARROW = false>
+__global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_kernel(const PairArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // columns: GEO xyz [N][4] then codes [N][kMaxC]
     __shared__ double red[4];
-    constexpr int kSlabs = PairShape<GEO>::kSlabs, kRows = PairShape<GEO>::kRows;
-    __shared__ double slab[kSlabs > 1 ? (kSlabs - 1) * kRows * (1 + kMaxC) : 1];
+    constexpr int kSlabs = PairShape<GEO, NARROW>::kSlabs, kRows = PairShape<GEO, NARROW>::kRows;
+    double* const slab = reinterpret_cast<double*>(lds);   // the slab fold reuses the column image once every wave is done with it
     const int set = blockIdx.z, n = row_patch(A), N = A.N;
     const int m = set == 0 ? (int)A.neg[n] : n;
     float* lx = lds;
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(PairShape<GEO>::kThreads) void pair_rows_kernel(con
         for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
     }
     if (kSlabs > 1) {   // fold the slabs in slab order: slab 0's lanes own the row
+        __syncthreads();
         if (sl > 0) {
             slab[((sl - 1) * kRows + rl) * (1 + kMaxC)] = acc;
 #pragma unroll
@@ -311,11 +315,11 @@ __global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, d
 
 // PASS 4: gradient w.r.t. the column codes: thread = column point q of pair (n -> m), loop over the row points p
 // (GEO: split into kSlabs row slabs per workgroup like the row passes, folded in slab order).
-template <bool GEO, int C>
-__global__ __launch_bounds__(PairShape<GEO>::kThreads) void pair_cols_kernel(const PairArgs A) {
+template <bool GEO, int C, bool NARROW = false>
+__global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_cols_kernel(const PairArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // rows: xyz [N][4] (GEO), codes [N][kMaxC], rowmean [N]
-    constexpr int kSlabs = PairShape<GEO>::kSlabs, kRows = PairShape<GEO>::kRows;
-    __shared__ double slab[kSlabs > 1 ? (kSlabs - 1) * kRows * kMaxC : 1];
+    constexpr int kSlabs = PairShape<GEO, NARROW>::kSlabs, kRows = PairShape<GEO, NARROW>::kRows;
+    double* const slab = reinterpret_cast<double*>(lds);   // the slab fold reuses the row image once every wave is done with it
     const int set = blockIdx.z, n = row_patch(A), N = A.N;
     const int m = set == 0 ? (int)A.neg[n] : n;
     float* lx = lds;
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(PairShape<GEO>::kThreads) void pair_cols_kernel(con
         for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
     }
     if (kSlabs > 1) {
+        __syncthreads();
         if (sl > 0)
 #pragma unroll
             for (int c = 0; c < C; ++c) slab[((sl - 1) * kRows + ql) * kMaxC + c] = g[c];
@@ -633,46 +638,65 @@ __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, i
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <bool GEO, int C>
-int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases = 7) {
+template <bool GEO, int C, bool NARROW>
+int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases) {
     const int N = A.N, B = A.B;
-    const int tb = PairShape<GEO>::kThreads, rows_per_block = PairShape<GEO>::kRows;
+    const int tb = PairShape<GEO, NARROW>::kThreads, rows_per_block = PairShape<GEO, NARROW>::kRows;
     const dim3 grid((N + rows_per_block - 1) / rows_per_block, A.rows ? A.n_rows : B, 2);
     const int nb = (int)(grid.x * grid.y);
     if (nb > kRedBlocks) return NSOS_ERR_UNSUPPORTED;
-    const size_t lds_rows12 = GEO ? (size_t)N * 4 * 4 : 0;
-    const size_t lds_rows3 = lds_rows12 + (size_t)N * kMaxC * 4;
-    const size_t lds_cols = lds_rows3 + (size_t)N * 4;
-    constexpr int kLdsCap = 148 * 1024;   // dynamic part; the kernels also hold up to 8 KiB of static LDS (slab folds; 160 KiB per CU)
-    if (lds_cols > (size_t)kLdsCap) return NSOS_ERR_UNSUPPORTED;
-    static bool configured = false;
-    if (!configured) {
-        const int cap = kLdsCap;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_cols_kernel<GEO, C>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    const size_t lds_rows12_ = GEO ? (size_t)N * 4 * 4 : 0;
+    const size_t lds_rows3_ = lds_rows12_ + (size_t)N * kMaxC * 4;
+    const size_t lds_cols_ = lds_rows3_ + (size_t)N * 4;
+    // the slab folds reuse the dynamic region after the pair loops: it must hold them even when N is small
+    constexpr size_t kLdsTotal = 160 * 1024 - 256, kFold = (size_t)(PairShape<GEO, NARROW>::kSlabs - 1) * PairShape<GEO, NARROW>::kRows * (1 + kMaxC) * 8;
+    const size_t lds_rows12 = lds_rows12_ > kFold ? lds_rows12_ : kFold, lds_rows3 = lds_rows3_ > kFold ? lds_rows3_ : kFold,
+                 lds_cols = lds_cols_ > kFold ? lds_cols_ : kFold;
+    if (lds_rows3 > kLdsTotal || lds_cols > kLdsTotal) return NSOS_ERR_UNSUPPORTED;
+    static size_t configured_rows = 0, configured_cols = 0;      // the largest dynamic size each kernel has been allowed so far
+    if (lds_rows3 > configured_rows || lds_cols > configured_cols) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 1, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 2, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_cols_kernel<GEO, C, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols);
         if (e != hipSuccess) return (int32_t)e;
-        configured = true;
+        configured_rows = lds_rows3;
+        configured_cols = lds_cols;
     }
     // phases (bit mask): 1 = pass 1, 2 = pass 2, 4 = passes 3 (+4).  A single-process call runs all of them; the row-partitioned
     // multi-GPU call runs them one at a time and all-reduces scal[0..1], scal[2..3] over the ranks in between (the global
     // means of fd and fd1 couple every patch of the batch, utils/image.py:316-319).
     if (phases & 1) {
-        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1>), grid, dim3(tb), lds_rows12, st, A);
+        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1, NARROW>), grid, dim3(tb), lds_rows12, st, A);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
     }
     if (phases & 2) {
-        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 2>), grid, dim3(tb), lds_rows12, st, A);
+        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 2, NARROW>), grid, dim3(tb), lds_rows12, st, A);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 2);
     }
     if (phases & 4) {
-        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3>), grid, dim3(tb), lds_rows3, st, A);
+        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
         if (loss) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss);
-        if (want_grad) hipLaunchKernelGGL((pair_cols_kernel<GEO, C>), grid, dim3(tb), lds_cols, st, A);
+        if (want_grad) hipLaunchKernelGGL((pair_cols_kernel<GEO, C, NARROW>), grid, dim3(tb), lds_cols, st, A);
     }
     return nsos_launch_status();
+}
+
+template <bool GEO, int C>
+int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases = 7) {
+    if constexpr (GEO) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const long long wide = (long long)((A.N + 63) / 64) * (A.rows ? A.n_rows : A.B) * 2;   // workgroups at 64 rows each
+        if (wide < cus) return run_pair_passes_shape<true, C, true>(A, want_grad, loss, st, phases);
+    }
+    return run_pair_passes_shape<GEO, C, false>(A, want_grad, loss, st, phases);
 }
 
 template <int C>
