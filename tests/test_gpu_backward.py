@@ -258,7 +258,7 @@ def test_wgrad_split_fp16_vs_fp64(P):
     assert outs[True][1] <= max(2e-6, 4 * outs[False][1]), outs
 
 
-@pytest.mark.parametrize("R,S", [(37, 64), (5, 192), (3, 9), (700, 64), (1, 8)])
+@pytest.mark.parametrize("R,S", [(37, 64), (5, 192), (3, 9), (700, 64), (1, 8), (1536, 8), (2048, 8), (4099, 24)])
 def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
     """nsos_sem_head_wgrad_x3 (split-fp16 operands staged through LDS) against the exact-fp32 kernel and an fp64 reduction of
     the same formulas (models/renderer.py:64-66, models/nerf_mlp.py:61,80): tiny gradients (1e-6), ragged point counts."""
