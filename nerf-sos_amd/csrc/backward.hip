@@ -153,11 +153,11 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_kernel(const float* __r
 // buffered, one barrier per k-step); wave w then runs its 30 MFMAs (A = g_hid tile w, B = the 10 sem_in tiles).  g_hid has
 // no natural scale: the caller passes a power of two (device scalar) that brings it into fp16 range and divides gw1 by it;
 // gw2 / gb2 stay plain fp32 sums exactly as in sem_head_wgrad_kernel.  n_samples >= 8, n_pts < 2^31.
-// XFMT: storage format of sem_in -- 0: fp32, 1: fp16, 2: bf16 (the compact matrix of nsos_mlp_forward_rays_save16_lp; widened on load)
-template <int XFMT>
+// sem_in here is the fp32 matrix (mlp_precision = "fp16x3"); the compact 16-bit matrix of the bf16 / fp16 paths has a kernel of
+// its own (sem_wgrad16.hip).
 __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* __restrict__ weights, const float* __restrict__ g_sem,
                                                                    const float* __restrict__ w2, const float* __restrict__ hid,
-                                                                   const void* __restrict__ sem_in_v, const float* __restrict__ scale_p,
+                                                                   const float* __restrict__ sem_in, const float* __restrict__ scale_p,
                                                                    long long n_pts, int S, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 14 * 2 * 1024];   // [buffer][tile 0..13][hi, lo][64 lanes x 16 B]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, kg = lane >> 5;
@@ -185,12 +185,6 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
     // (the half-wave's 8-point shift is part of the lane offset), so the loads are `global_load_dword v, v_off, s[row]`.
     typedef const __attribute__((address_space(1))) float* gptr;
     typedef const __attribute__((address_space(1))) char* gbytes;
-    const float* const sem_in = static_cast<const float*>(sem_in_v);                       // XFMT == 0
-    const unsigned short* const sem_in16 = static_cast<const unsigned short*>(sem_in_v);  // XFMT != 0
-    auto widen = [](unsigned short b) {
-        if constexpr (XFMT == 1) return (float)__builtin_bit_cast(_Float16, b);
-        else return __builtin_bit_cast(float, (unsigned)b << 16);
-    };
     auto uniform = [](const float* p) {                                   // tell hipcc the pointer is wave-uniform
         const unsigned long long b = (unsigned long long)p;
         return (gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
@@ -201,12 +195,7 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
         asm("" : "+s"(r));                                                // keep the row pointer a scalar of its own
         return *reinterpret_cast<gptr>(reinterpret_cast<gbytes>(r) + byte_off);
     };
-    auto at16 = [](gptr row, unsigned byte_off) {
-        unsigned long long r = (unsigned long long)row;
-        asm("" : "+s"(r));
-        return *reinterpret_cast<const __attribute__((address_space(1))) unsigned short*>(reinterpret_cast<gbytes>(r) + byte_off);
-    };
-    const unsigned off_w = 8u * kg * 4u, off_h = (8u * kg * 128u + i) * 4u, off_x = (8u * kg * 320u + i) * (XFMT ? 2u : 4u);
+    const unsigned off_w = 8u * kg * 4u, off_h = (8u * kg * 128u + i) * 4u, off_x = (8u * kg * 320u + i) * 4u;
     auto fetch_full = [&](long long step, Raw& R) {
         const unsigned p0 = (unsigned)(step * 16) + 8u * (unsigned)kg;
         const unsigned q0 = p0 / (unsigned)S, rem0 = p0 - q0 * (unsigned)S;     // ray of the first point; S >= 8: at most one crossing below
@@ -215,9 +204,9 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
         const gptr wrow = uniform(weights + step * 16), hrow = uniform(hid + step * 16 * 128 + 32 * wave_s);
         gptr xrow[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {   // (a row pointer in floats; for the 16-bit matrix it advances 160 floats = 320 halves per point)
+        for (int j = 0; j < 3; ++j) {
             const int T = j < 2 ? 4 * j + wave_s : xt2;
-            xrow[j] = XFMT ? uniform(reinterpret_cast<const float*>(sem_in16 + step * 16 * 320 + 32 * T)) : uniform(sem_in + step * 16 * 320 + 32 * T);
+            xrow[j] = uniform(sem_in + step * 16 * 320 + 32 * T);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -227,10 +216,7 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
             R.g1[e] = g_sem[2ull * r + 1];
             R.h[e] = at(hrow + e * 128, oh);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if constexpr (XFMT == 0) R.x[j][e] = at(xrow[j] + e * 320, ox);
-                else R.x[j][e] = widen(at16(xrow[j] + e * 160, ox));
-            }
+            for (int j = 0; j < 3; ++j) R.x[j][e] = at(xrow[j] + e * 320, ox);
         }
     };
     // the (single) ragged step -- rows clamped, out-of-range points get weight 0 (their g_hid is then 0)
@@ -248,11 +234,7 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
             R.g1[e] = g_sem[2ull * r + 1];
             R.h[e] = hid[(unsigned long long)p * 128 + 32 * wave + i];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const unsigned long long at_ = (unsigned long long)p * 320 + 32 * (j < 2 ? 4 * j + wave : xt2) + i;
-                if constexpr (XFMT == 0) R.x[j][e] = sem_in[at_];
-                else R.x[j][e] = widen(sem_in16[at_]);
-            }
+            for (int j = 0; j < 3; ++j) R.x[j][e] = sem_in[(unsigned long long)p * 320 + 32 * (j < 2 ? 4 * j + wave : xt2) + i];
         }
     };
     auto put = [&](int buf, int T, const float (&v)[8]) {               // split 8 points of one column and store the operand pair
@@ -479,7 +461,7 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
         scale = derived;
     }
     switch (sem_in_dtype) {
-        case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel<0>, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in, scale, n_pts, (int)n_samples, ws); break;
+        case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, static_cast<const float*>(sem_in), scale, n_pts, (int)n_samples, ws); break;
         default: {
             const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype, n_rays, n_samples, scale, ws, blocks, st);
             if (rc != NSOS_OK) return rc;
