@@ -319,7 +319,7 @@ int32_t nsos_render_draws(uint64_t seed, uint64_t call, int64_t n_rays, int32_t 
  * ImportanceSampler.forward / sample_pdf (models/sampler.py:91-167) + z_std (models/nerf_net.py:124):
  * pdf over the inner 62 coarse weights, cdf (fp64-accumulated), right-bisect search of u,
  * lerp inside the bin, merge-sort with the coarse depths, population std of the new samples.
- *   z_vals, weights [R,S] (2 <= S <= 64: one coarse sample per lane; every shipped config uses 64); u [R,N] or NULL (= det: linspace(0,1,N), perturb == 0);
+ *   z_vals, weights [R,S] (2 <= S <= 512; S <= 64 -- every shipped config uses 64 -- is the tuned one-sample-per-lane kernel); u [R,N] or NULL (= det: linspace(0,1,N), perturb == 0);
  *   cdf_in [R,S-1] or NULL: if given it REPLACES the computed cdf (stage-wise index pinning);
  *   outputs: z_fine [R,S+N] ascending; z_samples [R,N]; z_std [R];
  *   optional outputs (NULL to skip): cdf_out [R,S-1], inds_out int64 [R,N] (the searchsorted result). */

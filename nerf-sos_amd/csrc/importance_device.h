@@ -11,51 +11,22 @@ __device__ __forceinline__ bool nan_last_gt(float a, float b) { return (a > b) |
 // n_coarse is fixed at 64 (= one sample per lane); n_importance <= NSOS_MAX_IMPORTANCE.
 #define NSOS_MAX_IMPORTANCE 448  // 64 + 448 = 512 merged samples per ray at most
 
-struct ImportanceLds {
-    float cdf[64];    // 63 used
-    float bins[64];   // 63 used
-    float vals[512];  // coarse z (64) followed by the new samples (N)
+template <int CAP_S, int CAP_M>
+struct ImportanceLdsT {
+    float cdf[CAP_S];    // S - 1 used
+    float bins[CAP_S];   // S - 1 used
+    float vals[CAP_M];   // coarse z (S) followed by the new samples (N)
 };
+typedef ImportanceLdsT<64, 512> ImportanceLds;            // the shipped shape: one coarse sample per lane
+#define NSOS_MAX_COARSE_WIDE 512
+typedef ImportanceLdsT<NSOS_MAX_COARSE_WIDE, NSOS_MAX_COARSE_WIDE + NSOS_MAX_IMPORTANCE + 64> ImportanceLdsWide;   // per-call N_samples > 64
 
-// One ray per wave: everything after the coarse compositing.  `wlane` is lane j's coarse weight w[j] (from memory in the
-// stand-alone kernel, straight from the compositing registers in the fused one), `z` lane j's coarse depth.
-__device__ __forceinline__ void importance_ray(ImportanceLds& L, const int64_t r, const int lane, const float z, const float wlane,
-                                               const float* __restrict__ u_in, const float* __restrict__ cdf_in, int S, int N,
-                                               float* __restrict__ z_fine, float* __restrict__ z_samples,
-                                               float* __restrict__ z_std, float* __restrict__ cdf_out,
-                                               int64_t* __restrict__ inds_out) {
-    const int NB = S - 1;   // 2 <= S <= 64 coarse samples: one per lane, one cdf entry per lane
-
-    // bins = mid-points (models/sampler.py:155): lane j holds .5*(z[j+1]+z[j]), j < 63
-    const float z_next = __shfl_down(z, 1, NSOS_WAVE);
-    if (lane < S) L.vals[lane] = z;
-    if (lane < NB) L.bins[lane] = 0.5f * (z_next + z);
-
-    // cdf (models/sampler.py:93-97): entry k lives in lane k; entry 0 = 0, entry k>=1 = inclusive
-    // fp64 prefix sum of pdf over the inner weights w[1..k]
-    float cdf;
-    if (cdf_in) {
-        cdf = (lane < NB) ? cdf_in[r * NB + lane] : 0.0f;
-    } else {
-        const bool inner = (lane >= 1 && lane <= NB - 1);
-        const float w = inner ? (wlane + 1e-5f) : 0.0f;
-        const float fsum = (float)nsos_wave_sum((double)w);
-        const float pdf = inner ? (w / fsum) : 0.0f;
-        double run = (double)pdf;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(run, off, NSOS_WAVE);
-            if (lane >= off) run += o;
-        }
-        cdf = (float)run;  // lane 0: pdf 0 -> 0
-    }
-    if (lane < NB) {
-        L.cdf[lane] = cdf;
-        if (cdf_out) cdf_out[r * NB + lane] = cdf;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
+// Everything after the cdf: L.cdf[0..S-1), L.bins[0..S-1) and L.vals[0..S) (the coarse depths) are in LDS.
+template <typename LDS>
+__device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const int lane, const float* __restrict__ u_in, int S, int N,
+                                                float* __restrict__ z_fine, float* __restrict__ z_samples,
+                                                float* __restrict__ z_std, int64_t* __restrict__ inds_out) {
+    const int NB = S - 1;
     // invert the cdf (models/sampler.py:116-132): each lane owns samples i = lane, lane+64, ...
     double s1 = 0.0;
     for (int i = lane; i < N; i += 64) {
@@ -146,13 +117,14 @@ __device__ __forceinline__ void importance_ray(ImportanceLds& L, const int64_t r
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (lane < S) {                                  // coarse z_i: count of samples strictly below it
+    for (int j = lane; j < S; j += 64) {             // coarse z_j: count of samples strictly below it
+        const float z = L.vals[j];
         int lo = 0, hi = N;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (nan_last_gt(z, smp[mid])) lo = mid + 1; else hi = mid;
         }
-        z_fine[r * M + lane + lo] = z;
+        z_fine[r * M + j + lo] = z;
     }
     for (int i = lane; i < N; i += 64) {             // sample s_k: count of coarse z <= s_k
         const float sv = smp[i];
@@ -164,3 +136,92 @@ __device__ __forceinline__ void importance_ray(ImportanceLds& L, const int64_t r
         z_fine[r * M + i + lo] = sv;
     }
 }
+
+// One ray per wave: everything after the coarse compositing.  `wlane` is lane j's coarse weight w[j] (from memory in the
+// stand-alone kernel, straight from the compositing registers in the fused one), `z` lane j's coarse depth.
+__device__ __forceinline__ void importance_ray(ImportanceLds& L, const int64_t r, const int lane, const float z, const float wlane,
+                                               const float* __restrict__ u_in, const float* __restrict__ cdf_in, int S, int N,
+                                               float* __restrict__ z_fine, float* __restrict__ z_samples,
+                                               float* __restrict__ z_std, float* __restrict__ cdf_out,
+                                               int64_t* __restrict__ inds_out) {
+    const int NB = S - 1;   // 2 <= S <= 64 coarse samples: one per lane, one cdf entry per lane
+
+    // bins = mid-points (models/sampler.py:155): lane j holds .5*(z[j+1]+z[j]), j < 63
+    const float z_next = __shfl_down(z, 1, NSOS_WAVE);
+    if (lane < S) L.vals[lane] = z;
+    if (lane < NB) L.bins[lane] = 0.5f * (z_next + z);
+
+    // cdf (models/sampler.py:93-97): entry k lives in lane k; entry 0 = 0, entry k>=1 = inclusive
+    // fp64 prefix sum of pdf over the inner weights w[1..k]
+    float cdf;
+    if (cdf_in) {
+        cdf = (lane < NB) ? cdf_in[r * NB + lane] : 0.0f;
+    } else {
+        const bool inner = (lane >= 1 && lane <= NB - 1);
+        const float w = inner ? (wlane + 1e-5f) : 0.0f;
+        const float fsum = (float)nsos_wave_sum((double)w);
+        const float pdf = inner ? (w / fsum) : 0.0f;
+        double run = (double)pdf;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(run, off, NSOS_WAVE);
+            if (lane >= off) run += o;
+        }
+        cdf = (float)run;  // lane 0: pdf 0 -> 0
+    }
+    if (lane < NB) {
+        L.cdf[lane] = cdf;
+        if (cdf_out) cdf_out[r * NB + lane] = cdf;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    importance_tail(L, r, lane, u_in, S, N, z_fine, z_samples, z_std, inds_out);
+}
+
+// The same for 64 < S <= NSOS_MAX_COARSE_WIDE coarse samples (a per-call N_samples override, models/sampler.py:41; no shipped
+// config): lane l owns the contiguous entries [l K, (l+1) K), K = ceil(S / 64); the prefix sum is a local fp64 run plus a
+// wave scan of the lanes' totals.  A correctness path, not a tuned one.
+__device__ __forceinline__ void importance_ray_wide(ImportanceLdsWide& L, const int64_t r, const int lane,
+                                                    const float* __restrict__ z_row, const float* __restrict__ w_row,
+                                                    const float* __restrict__ u_in, const float* __restrict__ cdf_in, int S, int N,
+                                                    float* __restrict__ z_fine, float* __restrict__ z_samples,
+                                                    float* __restrict__ z_std, float* __restrict__ cdf_out,
+                                                    int64_t* __restrict__ inds_out) {
+    const int NB = S - 1;
+    for (int j = lane; j < S; j += 64) L.vals[j] = z_row[j];
+    for (int j = lane; j < NB; j += 64) L.bins[j] = 0.5f * (z_row[j + 1] + z_row[j]);
+    if (cdf_in) {
+        for (int j = lane; j < NB; j += 64) L.cdf[j] = cdf_in[r * NB + j];
+    } else {
+        const int K = (S + 63) >> 6, j0 = lane * K;
+        double part = 0.0;
+        for (int t = 0; t < K; ++t) {
+            const int j = j0 + t;
+            if (j >= 1 && j <= NB - 1) part += (double)(w_row[j] + 1e-5f);
+        }
+        const float fsum = (float)nsos_wave_sum(part);
+        double local = 0.0;                                   // this lane's pdf total, then the exclusive scan over the lanes
+        for (int t = 0; t < K; ++t) {
+            const int j = j0 + t;
+            if (j >= 1 && j <= NB - 1) local += (double)((w_row[j] + 1e-5f) / fsum);
+        }
+        double run = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(run, off, NSOS_WAVE);
+            if (lane >= off) run += o;
+        }
+        run -= local;
+        for (int t = 0; t < K; ++t) {
+            const int j = j0 + t;
+            if (j >= 1 && j <= NB - 1) run += (double)((w_row[j] + 1e-5f) / fsum);
+            if (j < NB) L.cdf[j] = (float)run;                // entry 0 = 0; entry j = inclusive sum over the inner weights w[1..j]
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (cdf_out)
+        for (int j = lane; j < NB; j += 64) cdf_out[r * NB + j] = L.cdf[j];
+    importance_tail(L, r, lane, u_in, S, N, z_fine, z_samples, z_std, inds_out);
+}
+

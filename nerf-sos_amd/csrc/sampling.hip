@@ -96,6 +96,20 @@ __global__ __launch_bounds__(256) void importance_kernel(const float* __restrict
     importance_ray(lds_all[wave], r, lane, z, w, u_in, cdf_in, S, N, z_fine, z_samples, z_std, cdf_out, inds_out);
 }
 
+// 64 < S <= NSOS_MAX_COARSE_WIDE coarse samples per ray (a per-call N_samples override): one wave per ray, two rays per block
+__global__ __launch_bounds__(128) void importance_wide_kernel(const float* __restrict__ z_vals, const float* __restrict__ weights,
+                                                              const float* __restrict__ u_in, const float* __restrict__ cdf_in,
+                                                              int64_t n_rays, int S, int N, float* __restrict__ z_fine,
+                                                              float* __restrict__ z_samples, float* __restrict__ z_std,
+                                                              float* __restrict__ cdf_out, int64_t* __restrict__ inds_out) {
+    __shared__ ImportanceLdsWide lds_all[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 2 + wave;
+    if (r >= n_rays) return;
+    importance_ray_wide(lds_all[wave], r, lane, z_vals + r * S, weights ? weights + r * S : nullptr, u_in, cdf_in, S, N, z_fine,
+                        z_samples, z_std, cdf_out, inds_out);
+}
+
 // ------------------------------------------------------------------------------------------ train-mode draws
 // The reference draws four random tensors per ray chunk in train mode (rand[R,S] jitter, randn[R,S] coarse
 // sigma noise, rand[R,N] importance u, randn[R,S+N] fine sigma noise: models/sampler.py:61,103, models/renderer.py:47) --
@@ -205,9 +219,13 @@ extern "C" int32_t nsos_importance_sample(const float* z_vals, const float* weig
     if (n_rays == 0) return NSOS_OK;  // empty batch: nothing to launch (empty tensors have NULL data pointers)
     NSOS_REQUIRE(z_vals && (weights || cdf_in) && z_fine && z_samples && z_std, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_importance >= 1, NSOS_ERR_BAD_SHAPE);
-    NSOS_REQUIRE(n_coarse >= 2 && n_coarse <= 64 && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);
-    if (n_rays == 0) return NSOS_OK;
-    NSOS_REQUIRE((n_rays + 3) / 4 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(n_coarse >= 2 && n_coarse <= NSOS_MAX_COARSE_WIDE && n_importance <= NSOS_MAX_IMPORTANCE, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE((n_rays + 1) / 2 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
+    if (n_coarse > 64) {   // more than one coarse sample per lane: the general (untuned) kernel
+        hipLaunchKernelGGL(importance_wide_kernel, dim3((unsigned)((n_rays + 1) / 2)), dim3(128), 0, (hipStream_t)stream,
+                           z_vals, weights, u, cdf_in, n_rays, n_coarse, n_importance, z_fine, z_samples, z_std, cdf_out, inds_out);
+        return nsos_launch_status();
+    }
     hipLaunchKernelGGL(importance_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        z_vals, weights, u, cdf_in, n_rays, n_coarse, n_importance, z_fine, z_samples, z_std, cdf_out,
                        inds_out);

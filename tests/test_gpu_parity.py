@@ -137,8 +137,23 @@ def test_importance_other_counts():
             ref = co.importance(z[:, :S], w[:, :S], uu, 128)
             assert np.array_equal(N(cdf), ref["cdf"]) and np.array_equal(N(inds), ref["inds"]), S
             assert np.array_equal(N(zf), ref["z_fine"]) and np.array_equal(N(zs), ref["z_samples"]), S
-    with pytest.raises(RuntimeError, match="specialised"):
-        ops.importance_sample(T(np.repeat(z, 2, 1)[:, :65]), T(np.repeat(w, 2, 1)[:, :65]), 128)
+    # more than 64 coarse samples (per-call N_samples > 64): the general kernel, several entries per lane
+    for S in (65, 96, 128, 200, 512):
+        zz = np.sort(1.2 + 13 * rng.random((R, S), dtype=np.float32), -1)
+        ww = rng.random((R, S), dtype=np.float32) ** 6
+        for n_imp in (64, 128, 448):
+            u = rng.random((R, n_imp), dtype=np.float32)
+            for uu in (None, u):
+                zf, zs, zstd, cdf, inds = ops.importance_sample(T(zz), T(ww), n_imp, None if uu is None else T(uu), debug=True)
+                ref = co.importance(zz, ww, uu, n_imp)
+                close(N(cdf), ref["cdf"], atol=2e-7, rtol=0, what=f"cdf S={S}")
+                # the same cdf handed in (stage-wise pin): indices and samples are then exact
+                zf, zs, zstd, _, inds = ops.importance_sample(T(zz), T(ww), n_imp, None if uu is None else T(uu), cdf_in=T(ref["cdf"]), debug=True)
+                assert np.array_equal(N(inds), ref["inds"]) and np.array_equal(N(zf), ref["z_fine"]), (S, n_imp)
+                assert np.array_equal(N(zs), ref["z_samples"]), (S, n_imp)
+                close(N(zstd), ref["z_std"], atol=1e-6, rtol=1e-6, what="z_std")
+    with pytest.raises(RuntimeError, match="nsos_importance_sample"):
+        ops.importance_sample(T(np.zeros((2, 513), np.float32)), T(np.zeros((2, 513), np.float32)), 128)
 
 
 # ------------------------------------------------------------------------------------------ K2
@@ -666,23 +681,30 @@ def test_nan_and_inf_inputs_stay_in_their_ray(manifest, precision):
         assert torch.equal(bad[k][keep], good[k][keep]), k
 
 
-def test_per_call_sample_count_override(manifest):
+@pytest.mark.parametrize("n_coarse", [32, 96, 130])
+def test_per_call_sample_count_override(manifest, n_coarse):
     """`N_samples` is a per-call kwarg in the reference (models/sampler.py:41); the fine pass still draws the
-    constructor's N_importance samples (models/sampler.py:100,103).  32 coarse + 128 new = 160 fine samples."""
+    constructor's N_importance samples (models/sampler.py:100,103).  32 coarse + 128 new = 160 fine samples; more than 64
+    coarse samples take the general importance kernel (several coarse samples per lane) and the unfused compositing."""
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS["semcoord"]).to(DEV).eval()
     sd = ref_state("semcoord", manifest)
     net.load_state_dict(sd)
     rays = tp.synthetic_rays(40, seed=12)
     with torch.no_grad():
-        out = net(rays.to(DEV), (tp.NEAR, tp.FAR), N_samples=32)
-    cfg = tp.PortConfig(n_samples=32, n_importance=128, **CFGS["semcoord"])
+        out = net(rays.to(DEV), (tp.NEAR, tp.FAR), N_samples=n_coarse)
+    cfg = tp.PortConfig(n_samples=n_coarse, n_importance=128, **CFGS["semcoord"])
     ref = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR))
-    assert out["weights"].shape == (40, 160) and out["weights0"].shape == (40, 32) and out["raw"].shape == (40, 160, 6)
+    M = n_coarse + 128
+    assert out["weights"].shape == (40, M) and out["weights0"].shape == (40, n_coarse) and out["raw"].shape == (40, M, 6)
     for k in ("rgb0", "depth0", "weights0", "semantics0"):
         close(N(out[k]), ref[k].numpy(), atol=1e-4, rtol=1e-4, what=k)
     for k in ("rgb", "acc", "semantics"):   # fine pass: bulk agreement (index flips, SURVEY F7)
         bad = (np.abs(N(out[k]) - ref[k].numpy()) > 1e-4 * (1 + np.abs(ref[k].numpy()))).any(-1).mean()
         assert bad <= 0.05, (k, bad)
+    net.train()                              # train mode: jitter + noise draws at the overridden count
+    tr = net(rays.to(DEV), (tp.NEAR, tp.FAR), N_samples=n_coarse, raw_noise_std=1.0)
+    assert tr["weights"].shape == (40, M) and bool(torch.isfinite(tr["rgb"]).all())
+    assert bool((tr["weights"] >= 0).all())
 
 
 def test_per_call_kwargs_follow_the_reference(manifest):
