@@ -49,7 +49,7 @@ def test_validation_returns_before_launch():
     assert lib.nsos_ray_setup(one, one, one, null, -1, 64, one, null, null) == -2
     assert lib.nsos_ray_setup(one, one, one, null, 0, 64, one, null, null) == 0          # empty batch: no launch
     assert lib.nsos_composite(one, one, one, null, 0.0, 4, 64, 7, 0, one, one, one, one, one, one, null) == -3
-    assert lib.nsos_importance_sample(one, one, null, null, 4, 65, 128, one, one, one, null, null, null) == -3   # > 64 coarse samples
+    assert lib.nsos_importance_sample(one, one, null, null, 4, 513, 128, one, one, one, null, null, null) == -3   # > 512 coarse samples
     assert lib.nsos_mlp_forward_points(C.c_void_p(8), 0, one, one, 4, one, null) == -5    # misaligned packed
     assert lib.nsos_mlp_forward_points(one, 0, one, one, 0, one, null) == 0
 
