@@ -178,6 +178,23 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
         off += n
 
 
+def geo_loss_both(geo_loss, depth, code0, code1, ray_o, ray_d, sim, rows, group=None):
+    """geo_loss(depth, code0, ...) + geo_loss(depth, code1, ...) -- the coarse and the fine semantic maps against the same
+    geometry (engines/trainer.py:147-166) -- as ONE evaluation over the 2B stacked patches [code0; code1] with the geometry
+    repeated and a block-diagonal similarity matrix (negatives stay inside their half).  Every term of the loss is a mean over
+    the batch and the batch-wide quantities it subtracts (utils/image.py:316-319) depend on the geometry only, which both halves
+    share, so the stacked mean is exactly (L0 + L1) / 2: half the launches, and in the sharded step four collectives per step
+    instead of eight.  (Not used for the appearance loss: its two calls draw their own sample coordinates, so their batch means
+    differ, and not with rand_neg, where every call draws its own permutation.)"""
+    B = code0.shape[0]
+    big = torch.full_like(sim, float("inf"))
+    sim2 = torch.cat([torch.cat([sim, big], 1), torch.cat([big, sim], 1)], 0)
+    rows2 = list(rows) + [B + int(r) for r in rows]
+    both = geo_loss(depth.repeat(2, 1, 1, 1), torch.cat([code0, code1], 0), [ray_o.repeat(2, 1, 1, 1), ray_d.repeat(2, 1, 1, 1), None],
+                    sim2, rows=rows2, group=group)
+    return 2.0 * both
+
+
 def loss_generator(device, step: int, base_seed: int = 0) -> torch.Generator:
     """The correlation losses draw sample coordinates and permutations (utils/image.py:306-309,343-344,357); in the
     sharded step every rank evaluates the batch-wide losses, and the summed gradients equal the single-process
@@ -255,8 +272,11 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
         depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()       # the geo loss uses the FINE depth for both terms
         ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
         # the O(P^4) geometric loss is evaluated ONCE across the ranks: each rank its own row patches (losses.py)
-        g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim, rows=own, group=group) +
-                     geo_loss(depth, s1, [ro, rd, None], sim, rows=own, group=group))
+        if getattr(geo_loss, "rand_neg", False):
+            g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim, rows=own, group=group) +
+                         geo_loss(depth, s1, [ro, rd, None], sim, rows=own, group=group))
+        else:
+            g = geo_w * geo_loss_both(geo_loss, depth, s0, s1, ro, rd, sim, own, group)
         loss = g if loss is None else loss + g
     if loss is None:
         raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")

@@ -207,3 +207,35 @@ def test_losses_on_rendered_patches_train_the_semantic_head():
     g = net.nerf_fine.mlp.semantic_linear[2].weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
     assert net.nerf_fine.mlp.pts_linears[0].weight.grad is None
+
+
+@pytest.mark.parametrize("tag", ["geo_small", "geo_full"])
+def test_geo_loss_of_two_codes_as_one_stacked_evaluation(tag):
+    """sharding.geo_loss_both: the coarse and the fine semantic map against the same geometry as ONE evaluation over the 2B
+    stacked patches (block-diagonal similarity matrix, geometry repeated) equals the two separate calls of the reference's
+    training step (engines/trainer.py:147-166) in value and in both gradients."""
+    from nerf_sos_amd import sharding
+    mod = nerf_sos_amd.GeoCorrelationLoss(ref_args())
+    depth, sim = T(GOLD[f"{tag}_depth"]), T(GOLD[f"{tag}_sim"])
+    B, _, P, _ = depth.shape
+    ray_o = T(GOLD[f"{tag}_ray_o"])[:, :, None, None].expand(B, 3, P, P).contiguous()
+    ray_d = T(GOLD[f"{tag}_ray_d"])
+    c0 = T(GOLD[f"{tag}_code"]).requires_grad_(True)
+    g = torch.Generator(DEV).manual_seed(5)
+    c1 = (T(GOLD[f"{tag}_code"]) + 0.3 * torch.randn(c0.shape, device=DEV, generator=g)).requires_grad_(True)
+    rows = list(range(B))
+    two = mod(depth.clone(), c0, [ray_o, ray_d, None], sim, rows=rows) + mod(depth.clone(), c1, [ray_o, ray_d, None], sim, rows=rows)
+    two.backward()
+    want0, want1 = c0.grad.clone(), c1.grad.clone()
+    c0.grad = c1.grad = None
+    one = sharding.geo_loss_both(mod, depth.clone(), c0, c1, ray_o, ray_d, sim, rows)
+    one.backward()
+    one_v, two_v = float(one.detach()), float(two.detach())
+    assert abs(one_v - two_v) < 1e-6 * (1 + abs(two_v)), (one_v, two_v)
+    assert rel(c0.grad, want0.cpu().numpy()) < 1e-5 and rel(c1.grad, want1.cpu().numpy()) < 1e-5
+    # a subset of the rows (what one rank of the sharded step evaluates) stacks the same way
+    if B >= 2:
+        sub = [0]
+        a = sharding.geo_loss_both(mod, depth.clone(), c0.detach(), c1.detach(), ray_o, ray_d, sim, sub)
+        b = mod(depth.clone(), c0.detach(), [ray_o, ray_d, None], sim, rows=sub) + mod(depth.clone(), c1.detach(), [ray_o, ray_d, None], sim, rows=sub)
+        assert abs(float(a) - float(b)) < 1e-6 * (1 + abs(float(b)))
