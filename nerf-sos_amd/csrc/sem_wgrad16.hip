@@ -35,7 +35,6 @@ constexpr int kWgradOut = 128 * 320 + 2 * 128 + 2;      // as in backward.hip
 constexpr int kBufBytes = (4 * 2 + 10) * 1024;           // g_hid tiles 0..3 (hi, lo), then sem_in tiles 0..9
 constexpr int kLoadsG = 20, kLoadsX = 16;                // loads per fetch of a g-kind / x-kind wave
 
-typedef const __attribute__((address_space(1))) char* gbytes;
 
 // the operand set of one 16-point step, as one wave holds it
 struct SetG {            // waves 0..3
