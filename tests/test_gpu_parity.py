@@ -869,3 +869,49 @@ def test_fused_composite_importance_equals_the_two_kernels(golden):
         for k in a:
             assert torch.equal(a[k], b[k]), (k, R, S)
         assert torch.equal(zf, zf2) and torch.equal(zs, zs2) and torch.equal(zstd, zstd2)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_fuzz_shapes_module_vs_port(case):
+    """Seeded random shapes through the whole module against the torch port of the reference (eval mode): ray counts that
+    are not multiples of anything, coarse sample counts on both sides of 64 (tuned / general importance kernel, fused /
+    unfused compositing), importance counts from 0 up, every head configuration, white background, tensor bounds, an image-
+    shaped ray batch.  Coarse outputs within 1e-4; the fine pass in bulk (index flips of the sampler); shapes and
+    keys exactly."""
+    rng = np.random.default_rng(1000 + case)
+    R = int(rng.choice([1, 2, 3, 31, 33, 64, 65, 127, 200, 257]))
+    S = int(rng.choice([2, 3, 8, 17, 40, 63, 64, 65, 70, 100, 129]))
+    N_ = int(rng.choice([0, 1, 5, 64, 128, 200]))
+    if S == 2 and N_ > 0:
+        S = 3          # the reference itself cannot importance-sample 2 coarse samples (empty inner-weight cdf, models/sampler.py:93-97)
+    name = str(rng.choice(["nosem", "sem", "semcoord"]))
+    white = bool(rng.integers(0, 2))
+    peaky = bool(rng.integers(0, 2))
+    torch.manual_seed(2000 + case)
+    kw = dict(CFGS[name])
+    net = nerf_sos_amd.NeRFNet(N_samples=S, N_importance=N_, white_bkgd=white, **kw).to(DEV).eval()
+    if peaky:
+        nerf_sos_amd.synthetic.spiky_density_(net, 6.0, 0.3)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rays = tp.synthetic_rays(R, seed=3000 + case)
+    if case % 4 == 3 and R % 2 == 0:                       # image-shaped batch [2, R/2, 2, 3]
+        rays = rays.reshape(2, R // 2, 2, 3)
+    bounds = (tp.NEAR, tp.FAR)
+    if case % 3 == 2:                                       # tensor bounds [R,1]
+        shp = rays[0].shape[:-1] + (1,)
+        bounds = (torch.full(shp, tp.NEAR), torch.full(shp, tp.FAR))
+    with torch.no_grad():
+        out = net(rays.to(DEV), tuple(b.to(DEV) if torch.is_tensor(b) else b for b in bounds))
+    cfg = tp.PortConfig(n_samples=S, n_importance=N_, white_bkgd=white, **kw)
+    ref = tp.render(sd, cfg, rays, bounds)
+    assert set(out) == set(ref), (sorted(out), sorted(ref))
+    for k in ref:
+        assert tuple(out[k].shape) == tuple(ref[k].shape), (k, out[k].shape, ref[k].shape)
+    coarse = [k for k in ref if k.endswith("0")] if N_ > 0 else [k for k in ref if k != "raw"]
+    for k in coarse:
+        close(N(out[k]), ref[k].numpy(), atol=1e-4, rtol=1e-4, what=f"case {case}: {k}")
+    if N_ > 0:
+        for k in ("rgb", "acc"):
+            a, b = N(out[k]).reshape(R, -1), ref[k].numpy().reshape(R, -1)
+            bad = (np.abs(a - b) > 2e-4 * (1 + np.abs(b))).any(-1).mean()
+            assert bad <= max(0.05, 1.5 / R), (case, k, bad, dict(R=R, S=S, N=N_, name=name, white=white, peaky=peaky))
