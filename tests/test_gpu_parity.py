@@ -959,5 +959,8 @@ def test_fuzz_frozen_backbone_gradients_vs_port_autograd(case):
         scale = float(want.abs().max()) + 1e-30
         err = float((g - want).abs().max()) / scale
         assert err < (1e-4 if n.startswith("nerf.") or N_ == 0 else 2e-2), (case, n, err, dict(R=R, S=S, N=N_, name=name))
-        err16 = float((grads["bf16"][n] - g).abs().max()) / (float(g.abs().max()) + 1e-30)
-        assert err16 < 0.2, (case, n, err16)      # 8-bit mantissas through 9 layers, a handful of rays: a sanity bar (test_lp_training_variant holds the format bar)
+        # 16 bit: 8-bit mantissas through 9 layers and a handful of rays (ReLU masks of near-zero units flip): a direction check,
+        # test_lp_training_variant holds the format's error bar
+        a, b = grads["bf16"][n].double().flatten(), g.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        assert cos > 0.97, (case, n, cos)
