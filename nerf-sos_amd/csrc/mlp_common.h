@@ -229,6 +229,54 @@ struct Enc {
                 recv_cs[t] = __shfl_xor(own_cs[t], 32, NSOS_WAVE);
         });
     }
+    // The same for the 16-bit kernels, whose encoded features are rounded to fp16 / bf16 anyway: the hardware's v_sin_f32 /
+    // v_cos_f32 (argument in revolutions) instead of the ~27-instruction Cody-Waite + minimax evaluation.  The reduction keeps
+    // full accuracy for every octave: u = x / 2pi is formed ONCE per coordinate as a two-term sum uh + ul; 2^k uh is exact,
+    // so its fractional part is too, and 2^k ul is a small correction -- the revolution count is good to ~1e-7 whatever the
+    // octave (a plain fract(x 2^k / 2pi) in fp32 is off by 5e-4 rad at 2^9 x 15).  Job t of the hi half evaluates pair
+    // 2t + 1, whose coordinate is the lo half's NEXT one: the coordinates are rotated per lane once instead of selected per job.
+    __device__ __forceinline__ void evaluate_hw(const float (&x)[3], int hi) {
+        constexpr float kInvHi = 0.15915493667125702f, kInvLo = 6.4206382679e-9f;   // 1 / 2pi = kInvHi + kInvLo
+        float uh[3], ul[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uh[c] = x[c] * kInvHi;
+            ul[c] = __fmaf_rn(x[c], kInvHi, -uh[c]) + x[c] * kInvLo;
+        }
+        float yh[3], yl[3], ya[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            yh[j] = hi ? uh[(j + 1) % 3] : uh[j];
+            yl[j] = hi ? ul[(j + 1) % 3] : ul[j];
+            ya[j] = hi ? x[(j + 1) % 3] : x[j];
+        }
+        bool big = false;
+        static_for<0, kJobs>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, pl = 2 * t, ph = 2 * t + 1, kl = pl / 3, kh = ph / 3, j = pl % 3;
+            static_assert(ph % 3 == (j + 1) % 3, "the hi half's coordinate is the lo half's next one");
+            const float sc = kl == kh ? (float)(1 << kl) : (hi ? (float)(1 << kh) : (float)(1 << kl));
+            const float f = __builtin_amdgcn_fractf(yh[j] * sc);            // exact: a power-of-two multiple, then its fraction
+            const float g = __fmaf_rn(yl[j], sc, f);
+            own_sn[t] = __builtin_amdgcn_sinf(g);
+            own_cs[t] = __builtin_amdgcn_cosf(g);
+            big |= !sincos_in_range(ya[j] * sc);
+        });
+        if (__builtin_expect(big, 0)) {            // arguments >= 2^15: as in evaluate()
+            static_for<0, kJobs>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, pl = 2 * t, ph = 2 * t + 1;
+                const float al = x[pl % 3] * (float)(1 << (pl / 3)), ah = x[ph % 3] * (float)(1 << (ph / 3));
+                const float a = hi ? ah : al;
+                if (!sincos_in_range(a)) sincosf(a, &own_sn[t], &own_cs[t]);
+            });
+        }
+        static_for<0, kJobs>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, pl = 2 * t, ph = 2 * t + 1;
+            if constexpr (HALF::of(sin_idx(pl)) == 1 || HALF::of(sin_idx(ph)) == 0)
+                recv_sn[t] = __shfl_xor(own_sn[t], 32, NSOS_WAVE);
+            if constexpr (HALF::of(cos_idx(pl)) == 1 || HALF::of(cos_idx(ph)) == 0)
+                recv_cs[t] = __shfl_xor(own_cs[t], 32, NSOS_WAVE);
+        });
+    }
     // value of encoded feature IDX as seen by a lane of half H (both compile-time); IDX must satisfy HALF::of(IDX) == H
     template <int IDX, int H>
     __device__ __forceinline__ float feature(const float (&x)[3]) const {

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
             }
             {
                 Enc<NSOS_XYZ_FREQS, SliceHalf> e;
-                e.evaluate(x, kg);
+                e.evaluate_hw(x, kg);
                 ex[c][0] = enc_slice<T, NSOS_XYZ_FREQS, 0, true>(e, x, kg);
                 ex[c][1] = enc_slice<T, NSOS_XYZ_FREQS, 1, true>(e, x, kg);
                 ex[c][2] = enc_slice<T, NSOS_XYZ_FREQS, 2, true>(e, x, kg);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3ll * ray_of[c] + k];
             Enc<NSOS_DIR_FREQS, SliceHalf> e;
-            e.evaluate(dv, kg);
+            e.evaluate_hw(dv, kg);
             ed[c][0] = enc_slice<T, NSOS_DIR_FREQS, 0, false>(e, dv, kg);
             ed[c][1] = enc_slice<T, NSOS_DIR_FREQS, 1, false>(e, dv, kg);
         }

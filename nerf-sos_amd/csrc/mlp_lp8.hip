@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 x[k] = P.rays_o[3ll * ray + k] + m;
             }
             Enc<NSOS_XYZ_FREQS, SliceHalf> e;
-            e.evaluate(x, kg);
+            e.evaluate_hw(x, kg);
             ex[0] = enc_slice<T, NSOS_XYZ_FREQS, 0, true>(e, x, kg);
             ex[1] = enc_slice<T, NSOS_XYZ_FREQS, 1, true>(e, x, kg);
             ex[2] = enc_slice<T, NSOS_XYZ_FREQS, 2, true>(e, x, kg);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3ll * ray + k];
             Enc<NSOS_DIR_FREQS, SliceHalf> e;
-            e.evaluate(dv, kg);
+            e.evaluate_hw(dv, kg);
             ed[0] = enc_slice<T, NSOS_DIR_FREQS, 0, false>(e, dv, kg);
             ed[1] = enc_slice<T, NSOS_DIR_FREQS, 1, false>(e, dv, kg);
         }

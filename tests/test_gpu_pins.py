@@ -60,6 +60,34 @@ def test_device_positional_encoding_vs_reference(golden, manifest, precision):
     assert np.array_equal(N(acts[:, ops.ACTS_X + 63]), np.ones(n, np.float32))
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_device_positional_encoding_16_bit_vs_reference(golden, manifest, precision):
+    """The 16-bit kernels evaluate the encoding with the hardware's v_sin_f32 / v_cos_f32 behind a two-term range reduction
+    (Enc::evaluate_hw) and round it to their format.  The training variant stores what the semantic head consumed
+    (sem_in[:, 256:319] = the xyz encoding): against the reference's PositionEncoder on `posenc.npz` (arguments up to
+    7680 rad) every feature must be the correctly rounded 16-bit value or its neighbour (next to a zero crossing:
+    within the hardware sine's 2e-6)."""
+    g = golden("posenc")
+    x, v = g["x"], g["v"]
+    n = x.shape[0]
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=0, **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, False, 0))
+    d = np.tile(np.array([[0.3, -0.2, -1.0]], np.float32), (n, 1))
+    z = torch.zeros((n, 1), device=DEV)
+    _, sem_in, _ = ops.mlp_forward_rays_save(net.nerf.packed_weights(precision), net.nerf.sem_mode, T(x), T(d), T(v), z, precision, compact=True)
+    dt = torch.float16 if precision == "fp16" else torch.bfloat16
+    assert sem_in.dtype == dt
+    got = sem_in[:, 256:319].float().cpu()
+    want = torch.from_numpy(g["e10"]).to(dt).float()                    # the reference's value, rounded to the format
+    # one unit in the last place of the format -- or the hardware sine's absolute accuracy (~1e-6), which is what counts next to
+    # a zero crossing, where fp16 still resolves 1e-7
+    ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -14)) * (2.0 ** -10 if precision == "fp16" else 2.0 ** -7)
+    off = ((got - want).abs() > torch.maximum(ulp, torch.tensor(2e-6)))
+    assert not bool(off.any()), (int(off.sum()), float(((got - want).abs() / ulp).max()))
+    assert float((got != want).float().mean()) < 0.02                   # and almost always the correctly rounded one
+    assert torch.equal(sem_in[:, 319].float().cpu(), torch.ones(n))
+
+
 # ------------------------------------------------------------------- fine pass on the reference's own sample positions
 PINNED = [("nosem", False, False), ("semcoord", False, False), ("semcoord", True, False), ("sem", True, True)]
 
