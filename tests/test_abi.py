@@ -97,7 +97,7 @@ def test_lds_ring_protocol_holds_in_the_built_code():
         # outside its MFMA chunks (harmless as long as no pending register is involved, which `bad` checks)
         limit = 0
         if "mlp_lp_kernel" in name:   # ...ELi<SEM>ELb<SAVE>E...: the training (SAVE) variant unpacks 128 words for its stores
-            limit = 160 if "ELb1EEE" in name else 16
+            limit = 160 if "ELb1EEE" in name else 24   # (21 with the hardware-sine encoder)
         if "mlp_lp8_kernel" in name:  # 256-register budget: a few pointers / per-tile scalars live in scratch OUTSIDE the
             limit = 80 if "ELb1EEE" in name else 24   # MFMA chunks (never a ring register: `bad` above)
         if "mlp_x3_kernel" in name and "ELi0EEE" not in name:   # ...ELi<SEM>ELi<SAVE>E...: the training variants may park a
