@@ -201,12 +201,63 @@ def kernel_roofline(events, n_points: int, mac_per_point: int, peak: float, kern
 MEASURED_PIPE_CEILING_TFLOPS = {"fp16": 1881.0, "bf16": 1898.0}
 
 
-def add_power_note(roof, precision):
+_LP_CLOCK = {}
+
+
+def lp_kernel_clock_ghz(torch, dev, precision: str, R: int):
+    """Shader clock DURING the 16-bit MLP kernel: shader cycles of workgroup 0's first wave from its first to its last
+    instruction (the diagnostics entry nsos_mlp_profile_rays_lp stamps them) over the launch's HIP-event duration, sem+coord
+    net, R rays x 192 samples = the shape of the launch the roofline is quoted on (short launches clock lower than long ones).
+    Outside every timed region; once per process, precision and shape."""
+    if (precision, R) in _LP_CLOCK:
+        return _LP_CLOCK[(precision, R)]
+    import ctypes as C
+    import nerf_sos_amd
+    from nerf_sos_amd import _lib, ops, synthetic as syn
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True).to(dev).eval()
+    rays = syn.synthetic_rays(R, seed=0, device=dev)
+    near, far = torch.full((R,), syn.NEAR, device=dev), torch.full((R,), syn.FAR, device=dev)
+    z, v = ops.ray_setup(rays[1], near, far, N_FINE, None)
+    packed = net.nerf_fine.packed_weights(precision)
+    raw = torch.empty(R, N_FINE, 6, device=dev)
+    stamps = torch.zeros(16 * 64, dtype=torch.int64, device=dev)
+    o, d = rays[0].contiguous(), rays[1].contiguous()
+    P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def launch():
+        _lib.check(_lib.lib().nsos_mlp_profile_rays_lp(P(packed), 2, {"fp16": 1, "bf16": 2}[precision], P(o), P(d), P(v), P(z), R, N_FINE,
+                                                      P(raw), P(stamps), st), "nsos_mlp_profile_rays_lp")
+    for _ in range(3):
+        launch()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(5):
+        launch()
+    ev[1].record()
+    torch.cuda.synchronize()
+    row = stamps.view(16, 64)[0].cpu()
+    cycles = int(row[63] - row[62])
+    _LP_CLOCK[(precision, R)] = round(cycles / (ev[0].elapsed_time(ev[1]) / 5) / 1e6, 3)
+    return _LP_CLOCK[(precision, R)]
+
+
+def add_power_note(roof, precision, ctx=None, rays=4096):
     if roof and precision in MEASURED_PIPE_CEILING_TFLOPS:
         c = MEASURED_PIPE_CEILING_TFLOPS[precision]
         roof["measured_pipe_ceiling"] = {"tflops": c, "frac_of_it": round(roof["achieved"] / c, 4),
                                          "what": "pure MFMA stream, two waves per SIMD, random operands with half of them zero, whole chip "
                                                  "(power-limited clock); profiles/r02/c_mfma_power.txt"}
+        if ctx is not None:
+            try:
+                ghz = lp_kernel_clock_ghz(ctx.torch, ctx.dev, precision, rays)
+                roof["shader_clock_during_kernel"] = {
+                    "ghz": ghz, "nominal_ghz": 2.4, "frac_of_peak_at_that_clock": round(roof["frac"] * 2.4 / ghz, 4),
+                    "what": f"shader cycles of a whole launch of this kernel / its HIP-event duration ({rays} rays x 192 samples, outside "
+                            "the timed region; non-SAVE variant): the chip runs the 16-bit matrix pipe at its power limit, not at 2.4 GHz; `frac` stays "
+                            "against the nominal 2.5 PFLOP/s"}
+            except Exception as e:   # diagnostics only: never fail the bench line over it
+                roof["shader_clock_during_kernel"] = {"error": repr(e)}
     return roof
 
 
@@ -304,7 +355,7 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
     res = speed_fields(ctx, n_rays, steps, dt, per_rank)
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
     kname = {"fp32": "mlp_fused_kernel<2,true,1>", "fp16x3": "mlp_x3_kernel<2,1>"}.get(precision, f"mlp_lp8_kernel<{precision},2,SAVE>")
-    roof = add_power_note(kernel_roofline(events, n_rays * N_FINE, MAC_SEMCOORD, peak, f"{kname} (fine pass of the rank's {n_rays} rays, {n_rays * N_FINE} points)"), precision)
+    roof = add_power_note(kernel_roofline(events, n_rays * N_FINE, MAC_SEMCOORD, peak, f"{kname} (fine pass of the rank's {n_rays} rays, {n_rays * N_FINE} points)"), precision, ctx, n_rays)
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
         roof["whole_step_frac_forward_flops_only"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
@@ -353,7 +404,7 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int):
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
     full_chunk = min(chunk, n_rays)
     roof = add_power_note(kernel_roofline(events, full_chunk * N_FINE, MAC_SEMCOORD, peak,
-                                          f"mlp_lp8_kernel<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)"), precision)
+                                          f"mlp_lp8_kernel<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)"), precision, ctx, full_chunk)
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
         roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
