@@ -178,6 +178,16 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
         off += n
 
 
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def geo_loss_both(geo_loss, depth, code0, code1, ray_o, ray_d, sim, rows, group=None):
     """geo_loss(depth, code0, ...) + geo_loss(depth, code1, ...) -- the coarse and the fine semantic maps against the same
     geometry (engines/trainer.py:147-166) -- as ONE evaluation over the 2B stacked patches [code0; code1] with the geometry
@@ -215,7 +225,8 @@ def similarity_matrix(cls_tokens: torch.Tensor) -> torch.Tensor:
 
 def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: torch.Tensor, cls_tokens: torch.Tensor,
                        corr_loss=None, geo_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01, step: int = 0,
-                       seed: Optional[int] = 0, group=None, timings: Optional[dict] = None) -> torch.Tensor:
+                       seed: Optional[int] = 0, group=None, timings: Optional[dict] = None,
+                       overlap_losses: bool = True) -> torch.Tensor:
     """One patch-mode training step of the path with the patch batch sharded over the ranks -- the loss section of
     `train_one_step` (engines/trainer.py:101-166) re-stated for one process per GPU:
 
@@ -261,11 +272,25 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     s1 = full["semantics"].permute(0, 3, 1, 2)
     loss = None
     gen = loss_generator(dev, step, seed) if seed is not None else None   # None: the global generator (single process only)
+    # The appearance loss is a train of small launches (121 sample points per patch: grids of a few hundred threads), the
+    # geometric one a few chip-filling ones with one workgroup per CU: on a stream of its own the former runs in the latter's
+    # shadow (forward here, and backward too -- autograd runs a node on the stream its forward ran on).  The draws of both
+    # come from the host-side generator state in program order, so the values do not depend on the overlap.
+    side = _side_stream(dev) if (overlap_losses and dev.type == "cuda" and corr_loss is not None and geo_loss is not None) else None
+    app = None
     if corr_loss is not None:
         if gen is not None:
             corr_loss.generator = gen
         f = full["feat"]
-        loss = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for t in (f, s0, s1, sim):
+                    t.record_stream(side)
+                app = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
+        else:
+            loss = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
     if geo_loss is not None:
         if gen is not None:
             geo_loss.generator = gen
@@ -278,6 +303,10 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
         else:
             g = geo_w * geo_loss_both(geo_loss, depth, s0, s1, ro, rd, sim, own, group)
         loss = g if loss is None else loss + g
+    if app is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        app.record_stream(torch.cuda.current_stream(dev))
+        loss = app + loss
     if loss is None:
         raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")
     if loss.requires_grad:

@@ -81,7 +81,7 @@ def _loss_args():
                                  app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
 
 
-def _c4_step(precision, manifest, seed_draws=7):
+def _c4_step(precision, manifest, seed_draws=7, **step_kw):
     torch.manual_seed(0)
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0, ray_chunk=1 << 20,
                                **CFGS["semcoord"]).to(DEV)
@@ -97,7 +97,7 @@ def _c4_step(precision, manifest, seed_draws=7):
     cls_ = torch.randn(B, 384, generator=torch.Generator().manual_seed(2)).to(DEV)
     corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
     torch.manual_seed(seed_draws)                                # the render's jitter / noise draws
-    loss = sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, step=3, seed=11)
+    loss = sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, step=3, seed=11, **step_kw)
     grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
     return net, rays, feat, cls_, loss, grads
 
@@ -144,3 +144,13 @@ def test_c4_per_gpu_workload_bf16_vs_fp32(manifest):
         a, b = g32[k].flatten().double(), g16[k].flatten().double()
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
         assert cos > 0.98, f"{k}: bf16 gradient direction differs from fp32 (cos {cos:.4f})"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c4_loss_overlap_does_not_change_a_bit(manifest, precision):
+    """The appearance loss on a stream of its own (in the shadow of the geometric one, forward and backward) against the same
+    step on one stream: identical loss and gradients, bit for bit."""
+    _, _, _, _, la, ga = _c4_step(precision, manifest, overlap_losses=True)
+    _, _, _, _, lb, gb = _c4_step(precision, manifest, overlap_losses=False)
+    assert torch.equal(la, lb)
+    assert all(torch.equal(ga[k], gb[k]) for k in ga)
