@@ -50,7 +50,14 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current device's current stream as a hipStream_t.  (torch.cuda.current_stream() builds a Stream object through four
+    Python layers: ~10 us per call, ~15 calls per training step.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

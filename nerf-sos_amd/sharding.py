@@ -161,8 +161,10 @@ def device_index(values, dtype, device) -> torch.Tensor:
 def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
     """ONE flat all-reduce (sum, or mean with average=True) of the gradients of `params`, in place.  82 436 floats for
     the frozen-backbone recipe, 1.27 M for the full model: latency-bound, so a single bucket."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
     ps = [p for p in params if p.requires_grad]
-    if not ps or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not ps:
         return
     for p in ps:
         if p.grad is None:

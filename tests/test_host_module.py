@@ -158,3 +158,21 @@ def test_fused_adam_does_not_bump_versions():
     opt.step()
     assert not torch.equal(p.detach(), torch.ones(4))
     assert p._version in (v, v + 1)
+
+
+def test_cached_parameter_walk_equals_named_parameters():
+    """nerf_net._named_params (slots resolved once, objects looked up per call) against nn.Module.named_parameters: same
+    names, same order, same objects -- with both nets, coarse-only (nerf_fine is nerf: de-duplicated), after a deepcopy, and
+    after parameters were replaced by load_state_dict(assign=True)."""
+    import copy
+    from nerf_sos_amd.nerf_net import _named_params
+    for kw in (dict(N_importance=128, use_semantics=True, sem_with_coord=True), dict(N_importance=0), dict(N_importance=64, use_semantics=True)):
+        net = nerf_sos_amd.NeRFNet(N_samples=64, **kw)
+        for mod in (net, net.nerf.mlp, net.nerf_fine.mlp, copy.deepcopy(net)):
+            for _ in range(2):           # second call: from the cache
+                a, b = _named_params(mod), list(mod.named_parameters())
+                assert [n for n, _ in a] == [n for n, _ in b] and all(x is y for (_, x), (_, y) in zip(a, b))
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        net.load_state_dict(sd, assign=True)
+        a, b = _named_params(net), list(net.named_parameters())
+        assert all(x is y for (_, x), (_, y) in zip(a, b)) and len(a) == len(b)
