@@ -44,8 +44,45 @@ def run(mode: str, precision: str):
     return {n: p.detach().clone() for n, p in net.named_parameters()}, losses
 
 
+def run_sharded_step(precision: str):
+    """The C4 step (two 64x64 patches, both correlation losses, the appearance loss on its side stream, fused Adam): the
+    multi-stream part of the path."""
+    import types
+    from nerf_sos_amd import sharding
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True, perturb=1.0,
+                               raw_noise_std=1.0, ray_chunk=1 << 20).to(dev).train()
+    for n_, p_ in net.named_parameters():
+        p_.requires_grad = "semantic_linear" in n_
+    net.mlp_precision = precision
+    net.rng, net.rng_seed = "philox", 1
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4, fused=True)
+    a = types.SimpleNamespace(rand_neg=False, self_corr_w=0, use_sim_matrix=True, patch_stride=6,
+                              app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
+    corr, geo = nerf_sos_amd.CorrelationLoss(a), nerf_sos_amd.GeoCorrelationLoss(a)
+    B = 2
+    rays = syn.synthetic_patches(B, 64, 6, seed=0, device=dev)
+    feat = torch.randn(B, 384, 14, 14, generator=torch.Generator().manual_seed(1)).to(dev)
+    cls_ = torch.randn(B, 384, generator=torch.Generator().manual_seed(2)).to(dev)
+    losses = []
+    for i in range(STEPS):
+        opt.zero_grad(set_to_none=True)
+        losses.append(sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, step=i, seed=0))
+        opt.step()
+    torch.cuda.synchronize()
+    return {n: p.detach().clone() for n, p in net.named_parameters()}, [float(l) for l in losses]
+
+
 out = {}
 ok_all = True
+for precision in ("bf16", "fp32"):
+    a, la = run_sharded_step(precision)
+    b, lb = run_sharded_step(precision)
+    bad = [n for n in a if not torch.equal(a[n], b[n])]
+    ok = not bad and la == lb and all(torch.isfinite(v).all() for v in a.values())
+    ok_all &= ok
+    out[f"c4_step_{precision}"] = {"steps": STEPS, "bit_identical": not bad, "losses_identical": la == lb, "loss_first": la[0], "loss_last": la[-1]}
+    print(f"c4step {precision:7s}: {'OK' if ok else 'MISMATCH'}  loss {la[0]:.5f} -> {la[-1]:.5f}", flush=True)
 for mode, precision in (("full", "fp32"), ("full", "fp16x3"), ("frozen", "fp32"), ("frozen", "fp16x3"), ("frozen", "bf16"), ("frozen", "fp16")):
     a, la = run(mode, precision)
     b, lb = run(mode, precision)
