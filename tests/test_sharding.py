@@ -92,3 +92,34 @@ def test_gloo_world2_shard_and_gather():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_device_index_is_uploaded_once():
+    a = sharding.device_index([3, 1, 2], torch.long, torch.device("cpu"))
+    b = sharding.device_index((3, 1, 2), torch.long, torch.device("cpu"))
+    c = sharding.device_index([3, 1, 2], torch.int32, torch.device("cpu"))
+    assert a is b and a.tolist() == [3, 1, 2] and c.dtype == torch.int32 and c is not a
+
+
+def test_geo_loss_both_stacks_codes_geometry_and_negatives():
+    """What sharding.geo_loss_both hands to the loss module: the two codes stacked as 2B patches, the geometry repeated, the
+    row list repeated with an offset of B, and a similarity matrix whose argmin per column stays inside its own half (so the
+    negatives of the second half are the first half's, shifted by B); the result is twice the stacked mean."""
+    B, P = 3, 4
+    g = torch.Generator().manual_seed(0)
+    depth, ro, rd = torch.rand(B, 1, P, P, generator=g), torch.rand(B, 3, P, P, generator=g), torch.rand(B, 3, P, P, generator=g)
+    c0, c1 = torch.rand(B, 2, P, P, generator=g), torch.rand(B, 2, P, P, generator=g)
+    sim = torch.rand(B, B, generator=g)
+    seen = {}
+
+    def fake(d, code, rays, sim2, rows=None, group=None):
+        seen.update(d=d, code=code, rays=rays, sim=sim2, rows=rows)
+        return code.sum()
+
+    out = sharding.geo_loss_both(fake, depth, c0, c1, ro, rd, sim, rows=[0, 2])
+    assert torch.equal(seen["code"], torch.cat([c0, c1], 0)) and torch.equal(seen["d"], torch.cat([depth, depth], 0))
+    assert torch.equal(seen["rays"][0], torch.cat([ro, ro], 0)) and torch.equal(seen["rays"][1], torch.cat([rd, rd], 0))
+    assert seen["rows"] == [0, 2, 3, 5]
+    neg = torch.min(sim, dim=0)[1]
+    assert torch.equal(torch.min(seen["sim"], dim=0)[1], torch.cat([neg, neg + B]))
+    assert torch.equal(out, 2.0 * (c0.sum() + c1.sum()))
