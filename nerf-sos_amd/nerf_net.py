@@ -256,7 +256,8 @@ class _FullRender(torch.autograd.Function):
             # fused input-gradient chain (K7-X3) for both precisions; "fp32": exact-fp32 weight-gradient reductions and the
             # trunk masks from the saved fp32 activations, "fp16x3": split-fp16 reductions and the forward's bit masks
             by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
-                                   mlp.packed_weights("fp16x3_bwd"), sv["masks"], split_wgrad=net.mlp_precision == "fp16x3")
+                                   mlp.packed_weights("fp16x3_bwd"), sv["masks"],
+                                   split_wgrad=net.mlp_precision == "fp16x3" or not net.exact_weight_gradients)
             grads += [by_name.get(n) for n in names]
         ctx.saved = None   # release 10 KB/point of activations now (the node lives as long as the caller keeps the loss)
         return (None, None, None) + tuple(grads)
@@ -290,6 +291,10 @@ class NeRFNet(nn.Module):
         # Not in the reference (which is fp32 only): "fp32" = exact-fp32 MFMA (parity path, default);
         # "fp16" / "bf16" = 16-bit MFMA inputs with fp32 accumulation (BASELINE configs C5 / C3), inference only.
         self.mlp_precision = "fp32"
+        # Full backward (every parameter trainable): the 256x256 weight-gradient reductions run on the 16-bit matrix pipe with
+        # split-fp16 operands (fp32-grade: <= 1e-6 of scale against fp64, HBM-bound) in BOTH full-training precisions; True keeps
+        # them on the exact-fp32 MFMA when mlp_precision == "fp32" (6.6 ms more per 4096-ray step).  The forward is exact either way.
+        self.exact_weight_gradients = False
         # Train-mode random draws.  "torch" (default): the reference's four torch.rand / torch.randn calls per ray chunk, in
         # its order, from torch's global generator (what the parity tests inject into).  "philox": ONE launch of the
         # package's counter-based generator per chunk (ops.render_draws), keyed by `rng_seed`, advanced per chunk.

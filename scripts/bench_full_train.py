@@ -18,6 +18,7 @@ PREC = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # forward kernel: "fp32
 torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0).to(dev).train()
 net.mlp_precision = PREC
+net.exact_weight_gradients = "--exact-wgrad" in sys.argv     # fp32 mode only: weight-gradient reductions on the exact-fp32 MFMA
 opt = torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.9, 0.999))
 rays = syn.synthetic_rays(R, seed=0, device=dev)
 gt = torch.rand(R, 3, device=dev)
@@ -53,7 +54,7 @@ split = []
 for _ in range(5):
     step(split)
 f, b, o = (sum(x[i] for x in split) / len(split) * 1e3 for i in range(3))
-out = {"rays": R, "forward_kernel": PREC, "ms_per_step": round(ms, 2), "rays_per_s": round(R / ms * 1e3), "forward_ms": round(f, 2), "backward_ms": round(b, 2),
+out = {"rays": R, "forward_kernel": PREC, "exact_weight_gradients": net.exact_weight_gradients, "ms_per_step": round(ms, 2), "rays_per_s": round(R / ms * 1e3), "forward_ms": round(f, 2), "backward_ms": round(b, 2),
        "adam_ms": round(o, 2), "loss_first": round(losses[0], 5), "loss_last": round(float(l.detach()), 5),
        "saved_activations_GB": round(R * 256 * 2656 * 4 / 1e9, 2)}
 print(json.dumps(out))
