@@ -132,7 +132,10 @@ __device__ __forceinline__ void dma_slot(S&& side) {
 // instructions per piece, ~110 cycles).  M0 (LDS destination) is saved/restored inside the statement.
 __device__ __forceinline__ void dma_1k(const void* src_uniform, unsigned dst_lds_uniform, unsigned voff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+    // s_nop 2: with the two s_mov in front of it, five wait states between a v_readfirstlane that produced one of the scalar
+    // operands and the vector-memory instruction that reads it -- hipcc's hazard recognizer does not look at the SGPR operands
+    // of inline asm (found in sem_wgrad16.hip as a memory fault when the compiler put the readfirstlane right in front)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(dst_lds_uniform), "v"(voff), "s"(src_uniform) : "memory");
 }
 

@@ -14,8 +14,13 @@
 //     three operand sets in flight per wave (48 points ahead), the set of step s+1 is staged while step s is multiplied and
 //     refilled with step s+4 right away;
 //   * 8 waves = two per SIMD at <= 256 registers: wave w multiplies g_hid tile (w & 3) by the five sem_in column tiles of
-//     half (w >> 2).  Waves 0..3 fetch and form the g_hid tiles (and one sem_in tile: 8 + (w & 1)), waves 4..7 fetch two
-//     sem_in tiles each; a SIMD's two waves are one of each kind, so the staging VALU of one runs under the MFMAs of the other.
+//     half (w >> 2).  Waves 0..3 fetch and form the g_hid tiles (the long instruction chain of a step), waves 4..7 move sem_in;
+//   * sem_in goes to LDS as it lies in memory -- [16 points][320 channels], rows padded to 672 B -- with three coalesced
+//     dwordx4 loads per wave and step (a 32-channel x 8-point MFMA operand gathered from global memory was 8 two-byte loads per
+//     lane: 80 load instructions per CU and step), and the MFMA operand (8 consecutive POINTS of one channel per lane) comes out
+//     of LDS through the transposing read: a 16-lane group of ds_read_b64_tr_b16 turns a [4 rows][16 columns] block into
+//     column-per-lane order (scripts/ubench/tr_read.hip prints what it returns), two reads per operand.  The 672-byte row
+//     stride puts the four rows of a group 8 banks apart.
 // Launch: grid = #CUs, 512 threads, n_samples >= 8 (at most one ray crossing inside 8 consecutive points), n_pts < 2^31.
 #include "common.h"
 #include "x3_common.h"
@@ -29,11 +34,14 @@ int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const f
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int kWgradOut = 128 * 320 + 2 * 128 + 2;      // as in backward.hip
-constexpr int kBufBytes = (4 * 2 + 10) * 1024;           // g_hid tiles 0..3 (hi, lo), then sem_in tiles 0..9
-constexpr int kLoadsG = 20, kLoadsX = 16;                // loads per fetch of a g-kind / x-kind wave
+constexpr int kRowBytes = 672;                           // LDS row of one point's 320 channels (640 B) + 32 B: rows 8 banks apart
+constexpr int kGBytes = 4 * 2 * 1024;                    // g_hid tiles 0..3 (hi, lo), MFMA operand order
+constexpr int kBufBytes = kGBytes + 16 * kRowBytes;      // ... then the step's 16 sem_in rows as they lie in memory
+constexpr int kLoadsG = 12, kLoadsX = 3;                 // loads per fetch of a g-kind / x-kind wave
 
 
 // the operand set of one 16-point step, as one wave holds it
@@ -41,17 +49,15 @@ struct SetG {            // waves 0..3
     f32x4 wt[2];         // compositing weights of the lane half's 8 points
     f32x2 ga, gb;        // dL/dsemantics of the ray of the first point and of the next ray
     float h[8];          // sem_hid column 32 gt + i
-    unsigned x[8];       // sem_in column of the extra tile, raw 16 bit
     int cross;           // points e >= cross belong to the next ray
 };
-struct SetX {            // waves 4..7
-    unsigned x[2][8];
+struct SetX {            // waves 4..7: 3 x 16 B of the wave's four sem_in rows (160 chunks of 16 B over 64 lanes)
+    u32x4 x[3];
 };
 
-template <int OFF>
-__device__ __forceinline__ unsigned ld_u16(unsigned voff, unsigned long long base) {
-    unsigned v;
-    asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "i"(OFF));
+__device__ __forceinline__ u32x4 ld_u32x4(unsigned voff, unsigned long long base) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base));
     return v;
 }
 template <int OFF>
@@ -73,45 +79,50 @@ __device__ __forceinline__ f32x2 ld_f32x2(unsigned voff, unsigned long long base
 }
 __device__ __forceinline__ unsigned long long uniform64(const void* p) {   // the pointer is wave-uniform: say so
     const unsigned long long b = (unsigned long long)p;
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
-           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    // A v_readfirstlane result read by a vector-memory instruction as its scalar base needs five wait states, and hipcc's
+    // hazard recognizer does not look at the SGPR operands of inline asm: when the address arithmetic happens to run on the
+    // VALU, the readfirstlane lands directly in front of the asm load, which then reads the stale pair (memory fault).
+    asm volatile("s_nop 4" : "+s"(u));
+    return u;
 }
 
-// s_waitcnt vmcnt(N) that owns the registers it releases: nothing that reads them can be scheduled above it.  ("+v" operands
-// count twice towards the 30 an asm statement may have: the set is pinned in two statements, which keep their order.)
+// s_waitcnt vmcnt(N) that owns the registers it releases: nothing that reads them can be scheduled above it.
 template <int N>
 __device__ __forceinline__ void wait_set(SetG& s) {
-    asm volatile("s_waitcnt vmcnt(%10)"
+    asm volatile("s_waitcnt vmcnt(%12)"
                  : "+v"(s.wt[0]), "+v"(s.wt[1]), "+v"(s.ga), "+v"(s.gb), "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]),
-                   "+v"(s.h[4]), "+v"(s.h[5])
+                   "+v"(s.h[4]), "+v"(s.h[5]), "+v"(s.h[6]), "+v"(s.h[7])
                  : "i"(N));
-    asm volatile("" : "+v"(s.h[6]), "+v"(s.h[7]), "+v"(s.x[0]), "+v"(s.x[1]), "+v"(s.x[2]), "+v"(s.x[3]), "+v"(s.x[4]), "+v"(s.x[5]),
-                      "+v"(s.x[6]), "+v"(s.x[7]));
 }
 template <int N>
 __device__ __forceinline__ void wait_set(SetX& s) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(s.x[0][0]), "+v"(s.x[0][1]), "+v"(s.x[0][2]), "+v"(s.x[0][3]), "+v"(s.x[0][4]), "+v"(s.x[0][5]),
-                   "+v"(s.x[0][6]), "+v"(s.x[0][7])
-                 : "i"(N));
-    asm volatile("" : "+v"(s.x[1][0]), "+v"(s.x[1][1]), "+v"(s.x[1][2]), "+v"(s.x[1][3]), "+v"(s.x[1][4]), "+v"(s.x[1][5]),
-                      "+v"(s.x[1][6]), "+v"(s.x[1][7]));
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.x[0]), "+v"(s.x[1]), "+v"(s.x[2]) : "i"(N));
 }
 
+// 8 consecutive 16-bit values as fp16 words: fp16 as they are; bf16 widened and re-rounded (exact from 2^-14 up: 8 significant
+// bits into 11; below that the error is < 2^-25 absolute)
 template <int XFMT>
-__device__ __forceinline__ u32x4 pack16(const unsigned (&v)[8]) {
+__device__ __forceinline__ u32x4 to_f16(u32x4 v) {
+    if constexpr (XFMT == 1) return v;
     u32x4 h;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if constexpr (XFMT == 1) {
-            h[q] = v[2 * q] | (v[2 * q + 1] << 16);
-        } else {
-            unsigned w;
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(v[2 * q] << 16), "v"(v[2 * q + 1] << 16));
-            h[q] = w;
-        }
+        unsigned w;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(v[q] << 16), "v"(v[q] & 0xffff0000u));
+        h[q] = w;
     }
     return h;
+}
+
+// the transposing LDS read: lane (r = (l & 15) >> 2, q = l & 3) of a 16-lane group passes the address of row r, columns 4q..4q+3
+// of a [4][16] block of 16-bit elements; lane c = l & 15 receives the block's column c, rows 0..3
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");   // stays behind the barrier
+    return v;
 }
 
 template <int XFMT>   // 1: fp16, 2: bf16
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int gt = wave & 3, ch = wave >> 2;
     const bool kind_g = wave < 4;
-    const int xt0 = kind_g ? 8 + (wave & 1) : wave - 4, xt1 = wave;      // sem_in tiles this wave stages (x-kind: w - 4 and w)
+    const int xw = wave - 4;                       // x-kind: this wave moves rows 4 xw .. 4 xw + 3 of every step
 
     const long long n_full = n_pts / 16;
     const long long per = (n_full + gridDim.x - 1) / gridDim.x;
@@ -143,8 +154,24 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     float gw2[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f};
 
     // lane offsets (bytes) inside a step's rows; the half-wave's 8-point shift is part of them
-    const unsigned off_w = 32u * kg, off_h = (8u * kg * 128u + i) * 4u, off_x = (8u * kg * 320u + i) * 2u;
+    const unsigned off_w = 32u * kg, off_h = (8u * kg * 128u + i) * 4u;
     const unsigned long long g_base = uniform64(g_sem);
+    // x-kind: chunk c = lane + 64 j (j = 0..2) of the wave's 4 rows x 40 chunks of 16 B; chunks past 159 repeat chunk 159 (the
+    // load is issued by every lane so that the vmcnt arithmetic holds; the duplicate is not written to LDS)
+    unsigned xg_off[3], xl_off[3];
+    bool x_own[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c_raw = lane + 64 * j, c = c_raw < 160 ? c_raw : 159, row = 4 * xw + c / 40, col = c % 40;
+        x_own[j] = c_raw < 160;
+        xg_off[j] = (unsigned)(row * 640 + col * 16);
+        xl_off[j] = (unsigned)(kGBytes + row * kRowBytes + col * 16);
+        asm volatile("" : "+v"(xg_off[j]), "+v"(xl_off[j]));     // per-lane constants: keep them in registers (no re-derivation per fetch)
+    }
+    // operand fetch of column tile T: lane (r = (l & 15) >> 2, q = l & 3) of 16-lane group g = l >> 4 passes the address of point
+    // 8 (g >> 1) + r, channels 32 T + 16 (g & 1) + 4 q .. + 3; a second read four rows further gives points + 4 .. + 7
+    const unsigned tr_off = (unsigned)(kGBytes + (8 * (lane >> 5) + ((lane & 15) >> 2)) * kRowBytes + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     auto fetch_g = [&](long long step, SetG& s) {
         const unsigned p0 = (unsigned)(step * 16) + 8u * (unsigned)kg;
@@ -153,7 +180,6 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         s.cross = (int)((q0 + 1) * (unsigned)S - p0);
         const unsigned long long wb = uniform64(weights + step * 16);
         const unsigned long long hb = uniform64(hid + step * 16 * 128 + 32 * gt);
-        const unsigned long long xb = uniform64(sem_in + step * 16 * 320 + 4 * 320 + 32 * xt0);   // row of point 4: offsets fit 13 bits
         s.wt[0] = ld_f32x4<0>(off_w, wb);
         s.wt[1] = ld_f32x4<16>(off_w, wb);
         s.ga = ld_f32x2(q0 * 8u, g_base);
@@ -161,34 +187,24 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         s.h[0] = ld_f32<0 * 512>(off_h, hb); s.h[1] = ld_f32<1 * 512>(off_h, hb); s.h[2] = ld_f32<2 * 512>(off_h, hb);
         s.h[3] = ld_f32<3 * 512>(off_h, hb); s.h[4] = ld_f32<4 * 512>(off_h, hb); s.h[5] = ld_f32<5 * 512>(off_h, hb);
         s.h[6] = ld_f32<6 * 512>(off_h, hb); s.h[7] = ld_f32<7 * 512>(off_h, hb);
-        s.x[0] = ld_u16<-4 * 640>(off_x, xb); s.x[1] = ld_u16<-3 * 640>(off_x, xb); s.x[2] = ld_u16<-2 * 640>(off_x, xb);
-        s.x[3] = ld_u16<-1 * 640>(off_x, xb); s.x[4] = ld_u16<0>(off_x, xb);        s.x[5] = ld_u16<640>(off_x, xb);
-        s.x[6] = ld_u16<2 * 640>(off_x, xb);  s.x[7] = ld_u16<3 * 640>(off_x, xb);
     };
     auto fetch_x = [&](long long step, SetX& s) {
-        const unsigned long long xa = uniform64(sem_in + step * 16 * 320 + 4 * 320 + 32 * xt0);
-        const unsigned long long xb = uniform64(sem_in + step * 16 * 320 + 4 * 320 + 32 * xt1);
-        s.x[0][0] = ld_u16<-4 * 640>(off_x, xa); s.x[0][1] = ld_u16<-3 * 640>(off_x, xa); s.x[0][2] = ld_u16<-2 * 640>(off_x, xa);
-        s.x[0][3] = ld_u16<-1 * 640>(off_x, xa); s.x[0][4] = ld_u16<0>(off_x, xa);        s.x[0][5] = ld_u16<640>(off_x, xa);
-        s.x[0][6] = ld_u16<2 * 640>(off_x, xa);  s.x[0][7] = ld_u16<3 * 640>(off_x, xa);
-        s.x[1][0] = ld_u16<-4 * 640>(off_x, xb); s.x[1][1] = ld_u16<-3 * 640>(off_x, xb); s.x[1][2] = ld_u16<-2 * 640>(off_x, xb);
-        s.x[1][3] = ld_u16<-1 * 640>(off_x, xb); s.x[1][4] = ld_u16<0>(off_x, xb);        s.x[1][5] = ld_u16<640>(off_x, xb);
-        s.x[1][6] = ld_u16<2 * 640>(off_x, xb);  s.x[1][7] = ld_u16<3 * 640>(off_x, xb);
+        const unsigned long long xb = uniform64(sem_in + step * 16 * 320);
+        s.x[0] = ld_u32x4(xg_off[0], xb);
+        s.x[1] = ld_u32x4(xg_off[1], xb);
+        s.x[2] = ld_u32x4(xg_off[2], xb);
     };
     auto tile = [&](int buf, int slot) { return reinterpret_cast<u32x4*>(lds + buf * kBufBytes + slot * 1024 + lane * 16); };
-    auto stage_g = [&](const SetG& s, int buf) {
-        float a[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool next = e >= s.cross;
-            const float wte = s.wt[e >> 2][e & 3];
-            const float gl0 = wte * (next ? s.gb[0] : s.ga[0]), gl1 = wte * (next ? s.gb[1] : s.ga[1]);   // g_logits (models/renderer.py:64-66)
-            a[e] = s.h[e] > 0.0f ? __fmaf_rn(gl1, w2b, gl0 * w2a) : 0.0f;                              // g_hid x scale
-            gw2[0] = __fmaf_rn(gl0, s.h[e], gw2[0]);                                                      // hid is stored after its ReLU
-            gw2[1] = __fmaf_rn(gl1, s.h[e], gw2[1]);
-            gb2[0] += gl0;
-            gb2[1] += gl1;
-        }
+    // g_hid of one point from its compositing weight, the ray's dL/dsemantics (g0, g1) and the hidden activation
+    auto form = [&](float wte, float g0, float g1, float hv, float& a) {
+        const float gl0 = wte * g0, gl1 = wte * g1;                                  // g_logits (models/renderer.py:64-66)
+        a = hv > 0.0f ? __fmaf_rn(gl1, w2b, gl0 * w2a) : 0.0f;                       // g_hid x scale (models/nerf_mlp.py:61)
+        gw2[0] = __fmaf_rn(gl0, hv, gw2[0]);                                         // hid is stored after its ReLU
+        gw2[1] = __fmaf_rn(gl1, hv, gw2[1]);
+        gb2[0] += gl0;
+        gb2[1] += gl1;
+    };
+    auto put_g = [&](const float (&a)[8], int buf) {
         u32x4 h, l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -198,17 +214,36 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         }
         *tile(buf, 2 * gt) = h;
         *tile(buf, 2 * gt + 1) = l;
-        *tile(buf, 8 + xt0) = pack16<XFMT>(s.x);
+    };
+    auto stage_g = [&](const SetG& s, int buf) {
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool next = e >= s.cross;
+            form(s.wt[e >> 2][e & 3], next ? s.gb[0] : s.ga[0], next ? s.gb[1] : s.ga[1], s.h[e], a[e]);
+        }
+        put_g(a, buf);
     };
     auto stage_x = [&](const SetX& s, int buf) {
-        *tile(buf, 8 + xt0) = pack16<XFMT>(s.x[0]);
-        *tile(buf, 8 + xt1) = pack16<XFMT>(s.x[1]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (x_own[j]) *reinterpret_cast<u32x4*>(lds + buf * kBufBytes + xl_off[j]) = to_f16<XFMT>(s.x[j]);
     };
     auto compute = [&](int buf) {
         const u32x4 ah = *tile(buf, 2 * gt), al = *tile(buf, 2 * gt + 1);
+        const unsigned ta = lds_base + (unsigned)(buf * kBufBytes) + tr_off + (unsigned)(5 * ch * 64);
+        u32x2 lo[5], hi[5];
+        lo[0] = lds_read_tr<0 * 64>(ta); hi[0] = lds_read_tr<0 * 64 + 4 * kRowBytes>(ta);
+        lo[1] = lds_read_tr<1 * 64>(ta); hi[1] = lds_read_tr<1 * 64 + 4 * kRowBytes>(ta);
+        lo[2] = lds_read_tr<2 * 64>(ta); hi[2] = lds_read_tr<2 * 64 + 4 * kRowBytes>(ta);
+        lo[3] = lds_read_tr<3 * 64>(ta); hi[3] = lds_read_tr<3 * 64 + 4 * kRowBytes>(ta);
+        lo[4] = lds_read_tr<4 * 64>(ta); hi[4] = lds_read_tr<4 * 64 + 4 * kRowBytes>(ta);
+        // the reads above are asm: hipcc does not count them.  One wait that owns their registers.
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4]));
         u32x4 b[5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) b[c] = *tile(buf, 8 + 5 * ch + c);
+        for (int c = 0; c < 5; ++c) b[c] = u32x4{lo[c][0], lo[c][1], hi[c][0], hi[c][1]};
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[c] = mfma16(ah, b[c], acc[c]);
 #pragma unroll
@@ -218,7 +253,8 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     if (nf > 0) {
         const long long base = __builtin_amdgcn_readfirstlane((int)s0);
         auto at = [&](int j) { return base + (j < nf ? j : nf - 1); };       // past the end: re-fetch the last step (never staged)
-        // One k-step of a wave of either kind.  J: the operand set that holds step s + 1 (sets rotate with the step)
+        // Step s: stage the operand set J that holds step s + 1 (sets rotate A, B, C with the step), refill it with step s + 4,
+        // multiply step s.  Two fetches have been issued since J's own: vmcnt(2 x loads per fetch) releases it.
         if (kind_g) {
             SetG A, B, C;
             fetch_g(at(0), A); fetch_g(at(1), B); fetch_g(at(2), C);
@@ -266,45 +302,26 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     }
     // the ragged step (n_pts % 16 points), by workgroup 0: rows clamped, out-of-range points get weight 0 (their g_hid is 0)
     if (blockIdx.x == 0 && (n_pts & 15)) {
-        const unsigned p0 = (unsigned)(n_full * 16) + 8u * (unsigned)kg;
-        auto row = [&](int e) { const unsigned p = p0 + e; return p < (unsigned)n_pts ? p : (unsigned)n_pts - 1u; };
         if (kind_g) {
+            const unsigned p0 = (unsigned)(n_full * 16) + 8u * (unsigned)kg;
             float a[8];
-            unsigned xv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const unsigned p = row(e);
+                const unsigned p = p0 + e < (unsigned)n_pts ? p0 + e : (unsigned)n_pts - 1u;
                 const float wte = p0 + e < (unsigned)n_pts ? weights[p] : 0.0f;
                 const unsigned r = p / (unsigned)S;
-                const float gl0 = wte * g_sem[2ull * r], gl1 = wte * g_sem[2ull * r + 1];
-                const float hv = hid[(unsigned long long)p * 128 + 32 * gt + i];
-                a[e] = hv > 0.0f ? __fmaf_rn(gl1, w2b, gl0 * w2a) : 0.0f;
-                gw2[0] = __fmaf_rn(gl0, hv, gw2[0]);
-                gw2[1] = __fmaf_rn(gl1, hv, gw2[1]);
-                gb2[0] += gl0;
-                gb2[1] += gl1;
-                xv[e] = sem_in[(unsigned long long)p * 320 + 32 * xt0 + i];
+                form(wte, g_sem[2ull * r], g_sem[2ull * r + 1], hid[(unsigned long long)p * 128 + 32 * gt + i], a[e]);
             }
-            u32x4 h, l;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned x, y;
-                split2(a[2 * q], a[2 * q + 1], x, y);
-                h[q] = x; l[q] = y;
-            }
-            *tile(0, 2 * gt) = h;
-            *tile(0, 2 * gt + 1) = l;
-            *tile(0, 8 + xt0) = pack16<XFMT>(xv);
+            put_g(a, 0);
         } else {
-            unsigned xa[8], xb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned long long r = (unsigned long long)row(e) * 320 + i;
-                xa[e] = sem_in[r + 32 * xt0];
-                xb[e] = sem_in[r + 32 * xt1];
+            for (int j = 0; j < 3; ++j) {
+                const int c_raw = lane + 64 * j, c = c_raw < 160 ? c_raw : 159, row = 4 * xw + c / 40, col = c % 40;
+                const unsigned long long p = (unsigned long long)(n_full * 16 + row) < (unsigned long long)n_pts ? (unsigned long long)(n_full * 16 + row)
+                                                                                                                : (unsigned long long)n_pts - 1;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(sem_in + p * 320 + col * 8);
+                if (x_own[j]) *reinterpret_cast<u32x4*>(lds + xl_off[j]) = to_f16<XFMT>(v);
             }
-            *tile(0, 8 + xt0) = pack16<XFMT>(xa);
-            *tile(0, 8 + xt1) = pack16<XFMT>(xb);
         }
         __syncthreads();
         compute(0);
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         for (int o = 0; o < 2; ++o) {
             const float s = gw2[o] + __shfl_xor(gw2[o], 32, NSOS_WAVE);
             if (kg == 0) out[128 * 320 + o * 128 + 32 * gt + i] = s;
-            const float sb = gb2[o] + __shfl_xor(gb2[o], 32, NSOS_WAVE);
+            const float sb = gb2[o] + __shfl_xor(gb2[o], 32, NSOS_WAVE);     // every lane of a half holds the same sum
             if (wave == 0 && lane == 0) out[128 * 320 + 256 + o] = sb;
         }
     }
