@@ -897,9 +897,8 @@ def test_fuzz_shapes_module_vs_port(case):
     if case % 4 == 3 and R % 2 == 0:                       # image-shaped batch [2, R/2, 2, 3]
         rays = rays.reshape(2, R // 2, 2, 3)
     bounds = (tp.NEAR, tp.FAR)
-    if case % 3 == 2:                                       # tensor bounds [R,1]
-        shp = rays[0].shape[:-1] + (1,)
-        bounds = (torch.full(shp, tp.NEAR), torch.full(shp, tp.FAR))
+    if case % 3 == 2:                                       # tensor bounds: [R,1] whatever the ray batch's shape (models/nerf_net.py:161-165)
+        bounds = (torch.full((R, 1), tp.NEAR), torch.full((R, 1), tp.FAR))
     with torch.no_grad():
         out = net(rays.to(DEV), tuple(b.to(DEV) if torch.is_tensor(b) else b for b in bounds))
     cfg = tp.PortConfig(n_samples=S, n_importance=N_, white_bkgd=white, **kw)
