@@ -304,6 +304,26 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_
     if (threadIdx.x == 0) A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// What used to be PASS 2: scal[2 + set] = sum over the evaluated pairs of (fd - rowmean), the numerator of the mean the
+// reference subtracts after centring (fd - fd.mean() + old_mean, utils/image.py:319).  That mean is what is left of a sum that
+// is zero in exact arithmetic: per row, rowsum - N * fl32(rowsum / N) (the rounding of the row mean) plus per-element rounding
+// noise of order 1e-11 of fd.  The first part is available from the row sums -- one thread block per set instead of a fourth
+// pass over all N^2 pairs (69 of 530 us in the C4 step); the second is below anything the loss can see (|m1| <~ 1e-8 |fd|
+// against a parity bar of 1e-4) and differs between the reference's own CPU and GPU reductions anyway.
+__global__ __launch_bounds__(256) void rowmean_residual_kernel(const PairArgs A) {
+    __shared__ double red[4];
+    const int set = blockIdx.x, N = A.N, nr = A.rows ? A.n_rows : A.B;
+    double s = 0.0;
+    for (long long k = threadIdx.x; k < (long long)nr * N; k += blockDim.x) {
+        const int n = A.rows ? A.rows[k / N] : (int)(k / N), p = (int)(k % N);
+        const double rs = A.rowsum[((size_t)set * A.B + n) * N + p];
+        const float rm = (float)(rs / (double)N);                       // fd.mean([3,4]) as the row passes use it
+        s += rs - (double)N * (double)rm;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) A.scal[2 + set] = s;
+}
+
 // scal[slot + set] = sum of the block partials, fixed order (64 lanes, each a strided sub-sum, then a fixed tree)
 __global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, int slot) {
     const int set = blockIdx.x, lane = threadIdx.x;
@@ -670,10 +690,7 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
         hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1, NARROW>), grid, dim3(tb), lds_rows12, st, A);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
     }
-    if (phases & 2) {
-        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 2, NARROW>), grid, dim3(tb), lds_rows12, st, A);
-        hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 2);
-    }
+    if (phases & 2) hipLaunchKernelGGL(rowmean_residual_kernel, dim3(2), dim3(256), 0, st, A);
     if (phases & 4) {
         hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
