@@ -187,7 +187,7 @@ __device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, in
     return (set == 0 ? A.cn2 : A.cn) + (size_t)n * A.N * kMaxC;
 }
 
-// PASS 1: row sums.  PASS 2: sum fl32(fd - rowmean).  PASS 3: loss + row-code gradient.
+// PASS 1: row sums.  PASS 3: loss + row-code gradient.  (PASS 2, sum fl32(fd - rowmean), is no longer launched: rowmean_residual_kernel.)
 // GEO: a workgroup = kRows row points x kSlabs column slabs, 1024 threads = four waves per SIMD (thread (row, slab) loops over
 // the slab's N / kSlabs columns); the slabs' fp64 partials are folded in slab order through LDS -- the dynamic region, reused
 // once every wave is done with the column image.  The column image (up to 144 KiB) allows ONE workgroup per CU, so the
@@ -676,7 +676,6 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
     static size_t configured_rows = 0, configured_cols = 0;      // the largest dynamic size each kernel has been allowed so far
     if (lds_rows3 > configured_rows || lds_cols > configured_cols) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 1, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 2, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_cols_kernel<GEO, C, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols);
         if (e != hipSuccess) return (int32_t)e;
