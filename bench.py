@@ -466,23 +466,23 @@ def main():
                           "flop_per_ray": res["flop_per_ray"]}
         line["roofline"] = roof
         if not args.no_variants:
-            vsteps = max(3, min(args.steps, 10))
+            vsteps = max(3, min(args.steps, 20))      # the variants ride along briefly, outside the headline's timed region
             if ctx.world == 1 and prec == "fp32":
                 exact_c = res["out"]["rgb0"]
-                alt = run_c2(ctx, args, "fp16x3", steps=vsteps, warmup=2)
+                alt = run_c2(ctx, args, "fp16x3", steps=vsteps, warmup=3)
                 v = _strip(alt)
                 v["what"] = "the c2 step with the MLP on the 16-bit matrix pipe, split-fp16 operands (3 MFMAs per product, fp32 accumulate)"
                 v["max_abs_rgb0_vs_exact_fp32"] = float((alt["out"]["rgb0"] - exact_c).abs().max())
                 v["parity"] = "same tests and bars as the exact kernel (2e-5 vs the reference goldens)"
                 variants["c2_fp16x3"] = v
-                v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 3))
+                v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 6))
                 v["what"] = "BASELINE configs[2]: one 64x64 patch = 4096 rays, sem+coord head, bf16 MFMA: train-mode render + appearance & geometric correlation losses + semantic-head backward + Adam"
                 variants["c3_bf16"] = v
             v = _strip(run_c5(ctx, args, "fp16", 2 if ctx.world == 1 else 4, 1))
             v["what"] = ("BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device "
                          "softmax/argmax; row blocks sharded over the GPUs (strong scaling, no collective); a step = one image")
             variants["c5_fp16"] = v
-            v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 3))
+            v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 6))
             v["what"] = ("BASELINE configs[3]: 8192 rays/GPU (2 patches of 64x64 per GPU), the c3 step sharded over the GPUs: one flat "
                          "all-gather of semantics0/semantics/depth/feat/cls_/ray_o/ray_d, one flat gradient all-reduce")
             variants["c4_bf16"] = v
