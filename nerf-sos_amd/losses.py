@@ -143,6 +143,8 @@ class GeoCorrelationLoss(CorrelationLoss):
         lib = _lib.lib()
         prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
 
+        grad_mode = torch.is_grad_enabled()       # (inside the autograd Function's forward it reads False)
+
         def launch(code, want_grad):
             code = _dev(code.detach(), "orig_code")
             nbytes = lib.nsos_corr_workspace_bytes(1, B, H * W, 0)
@@ -170,7 +172,9 @@ class GeoCorrelationLoss(CorrelationLoss):
                                                               ws.numel() * 8, _stream()), "nsos_geo_correlation_loss_rows")
                 if reduce and phase < 3:
                     dist.all_reduce(scal[2 * phase: 2 * phase + 2], group=group)
-                    if phase == 2 and want_grad:
+                    # every rank or none: a rank that owns no patch has a code without gradient (want_grad False) but must not
+                    # skip a collective its peers issue -- the group-wide condition is the grad mode the loss was called in
+                    if phase == 2 and grad_mode:
                         dist.all_reduce(gsum, group=group)
             return loss, grad
 

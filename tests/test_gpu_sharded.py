@@ -105,22 +105,29 @@ def _worker(rank, world, port, backend, q):
         dist.destroy_process_group()
 
 
-def _run(backend):
+def _run(backend, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if backend == "nccl" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if backend == "nccl" else 0) + 13 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=400) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(r[:2] for r in res) == [(0, True), (1, True)], res
+    assert sorted(r[:2] for r in res) == [(r_, True) for r_ in range(world)], res
 
 
 @pytest.mark.timeout(600)
 def test_two_ranks_sharing_the_gpu_over_gloo():
     _run("gloo")
+
+
+@pytest.mark.timeout(900)
+def test_six_ranks_sharing_the_gpu_over_gloo():
+    """More ranks than patches (5 patches over 6 ranks: one rank renders nothing but takes part in every collective) and a
+    2001-ray image over 6 ranks."""
+    _run("gloo", 6)
 
 
 @pytest.mark.timeout(600)
