@@ -414,3 +414,41 @@ def test_exact_weight_gradients_flag():
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-30, n
         differs |= not torch.equal(a, b)
     assert differs, "the flag selected the same kernels"
+
+
+def test_trainable_subsets_get_the_all_trainable_gradients():
+    """Whichever backward path a subset of trainable parameters selects (heads only -> the one-pass head kernels; anything in
+    the backbone -> the full backward), the subset's gradients are the same parameters' gradients with everything trainable,
+    and nothing else receives one."""
+    import nerf_sos_amd
+    from nerf_sos_amd import synthetic as syn
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    net = syn.spiky_density_(nerf_sos_amd.NeRFNet(N_samples=32, N_importance=32, use_semantics=True, sem_with_coord=True).to(dev).eval(), 2.0, 0.5)
+    rays = syn.synthetic_rays(64, seed=2, device=dev)
+
+    def grads(select):
+        for n, p in net.named_parameters():
+            p.requires_grad_(select(n))
+        net.zero_grad(set_to_none=True)
+        out = net(rays, (syn.NEAR, syn.FAR))
+        ((out["semantics"] ** 2).mean() + (out["semantics0"] ** 2).mean() + (out["rgb"] ** 2).mean()).backward()
+        return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    full = grads(lambda n: True)
+    cases = {
+        "coarse head only": lambda n: n.startswith("nerf.") and "semantic_linear" in n,
+        "fine head only": lambda n: n.startswith("nerf_fine.") and "semantic_linear" in n,
+        "both heads": lambda n: "semantic_linear" in n,
+        "heads + alpha": lambda n: "semantic_linear" in n or "alpha_linear" in n,
+        "one trunk layer": lambda n: "pts_linears.3" in n,
+        "fine net only": lambda n: n.startswith("nerf_fine."),
+        "second head layer only": lambda n: "semantic_linear.2" in n,
+    }
+    for name, sel in cases.items():
+        g = grads(sel)
+        want = {n for n, _ in net.named_parameters() if sel(n)}
+        assert set(g) == want, (name, sorted(set(g) ^ want)[:3])
+        for n in want:
+            err = float((g[n] - full[n]).abs().max()) / (float(full[n].abs().max()) + 1e-30)
+            assert err < 1e-5, (name, n, err)
