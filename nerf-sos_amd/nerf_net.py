@@ -437,6 +437,11 @@ class NeRFNet(nn.Module):
 
         rays_o, rays_d = ray_batch
         assert rays_o.shape == rays_d.shape
+        if torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad):
+            # the reference's autograd would differentiate through o + d z (pose refinement); these kernels do not, and
+            # returning outputs that silently carry no gradient to the rays is worse than refusing
+            raise NotImplementedError("nerf_sos_amd.NeRFNet: gradients with respect to the rays are not implemented "
+                                      "(detach the rays, or render under torch.no_grad())")
         old_shape = rays_d.shape
         rays_o = rays_o.reshape(-1, rays_o.shape[-1]).float().contiguous()
         rays_d = rays_d.reshape(-1, rays_d.shape[-1]).float().contiguous()

@@ -176,3 +176,14 @@ def test_cached_parameter_walk_equals_named_parameters():
         net.load_state_dict(sd, assign=True)
         a, b = _named_params(net), list(net.named_parameters())
         assert all(x is y for (_, x), (_, y) in zip(a, b)) and len(a) == len(b)
+
+
+def test_rays_that_require_grad_are_refused():
+    """The reference's autograd reaches the rays (o + d z); the HIP path has no such backward: refuse instead of returning
+    outputs that silently carry no gradient.  (The check is host-side: no GPU needed.)"""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=0)
+    rays = torch.zeros(2, 4, 3, requires_grad=True)
+    with pytest.raises(NotImplementedError, match="rays"):
+        net(rays, (1.0, 2.0))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):   # without grad mode it gets as far as the device check
+        net(rays, (1.0, 2.0))
