@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Interface edge cases of NeRFNet probed once (chunked frozen-backbone training, retpts/retraw in training, non-contiguous /
+float64 / tuple rays, CPU-tensor bounds, autocast, rays that require grad): prints what happens."""
 import os, sys, traceback
 sys.path.insert(0, os.getcwd())
 import torch, nerf_sos_amd
