@@ -70,6 +70,9 @@ typedef struct nsos_mlp_tensors {
 } nsos_mlp_tensors;
 
 int32_t nsos_abi_version(void);
+/* First 16 hex digits of the sha256 over the kernel sources and headers under csrc, this header and the compiler flags the library was built
+ * from ("unstamped" for a hand-run make): lets a CPU-only check refuse a stale binary (tests/test_abi.py). */
+const char* nsos_source_hash(void);
 const char* nsos_error_string(int32_t code);
 
 /* ---- weight packing ---------------------------------------------------------------------
@@ -90,6 +93,34 @@ int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* p
  * rays_o, rays_d out: device [pix_end-pix_begin, 3].  Removes the [N,H,W,2,3] ray tensors from disk / PCIe. */
 int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w_host,
                            int64_t pix_begin, int64_t pix_end, float* rays_o, float* rays_d, void* stream);
+
+/* ---- training-batch assembly on the device ---------------------------------
+ * The scene's images (rgbs [n_images,H,W,rgb_ch] fp32), masks ([n_images,H,W,*]: `mask_words` 4-byte words per pixel --
+ * int64 labels after the reference's thresholding, data/datasets.py:66-69, are 2 words per channel, float masks 1) and
+ * poses ([n_images,3,pose_cols] fp32, pose_cols 4 or LLFF's 5) stay resident in device memory; a batch is gathered per
+ * step, with the rays generated from the poses by K0's arithmetic (bit-identical to the reference's stored ray files).
+ * Any of (rays_o+rays_d), target, masks_out may be NULL (that output is skipped).
+ *
+ * nsos_patch_batch: PatchNeRFDataset.__getitem__ (data/datasets.py:240-254) for n_patches items + PatchBatchCollater
+ *   (data/collater.py:31-61).  Item b = (image, h_idx, w_idx) = sel[3b..3b+2] -- the caller draws the origins (the reference
+ *   uses Python's random.randint(0, H - crop_size), crop_size = patch*stride) and passes them EITHER as a HOST array
+ *   (sel_host: validated, travels in the kernel arguments, no copy) OR as a DEVICE array (sel_dev: out-of-range values are
+ *   clamped; for captured graphs).  Output pixel (a, c) of item b is image pixel (h_idx + a*stride, w_idx + c*stride):
+ *   rays_o / rays_d [n_patches, patch*patch, 3], target [n_patches, patch*patch, rgb_ch], masks_out [.., mask_words words],
+ *   poses_out [n_patches, 3, pose_cols] (the items' poses, :251) and start_out [n_patches, 2] = (h_idx, w_idx) as floats
+ *   (:252); both optional.
+ * nsos_pixel_batch: the same records for an explicit device list of flat pixel indices pix[k] = (image*H + y)*W + x:
+ *   RayNeRFDataset items + RayBatchCollater (data/datasets.py:149-171, data/collater.py:7-29) and ViewNeRFDataset's
+ *   np.random.choice pixels of one view + ViewBatchCollater (data/datasets.py:279-300, data/collater.py:63-84). */
+int32_t nsos_patch_batch(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* poses,
+                         int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
+                         int32_t mask_words, const int32_t* sel_host, const int32_t* sel_dev, int32_t n_patches,
+                         int32_t patch, int32_t stride, float* rays_o, float* rays_d, float* target, void* masks_out,
+                         float* poses_out, float* start_out, void* stream);
+int32_t nsos_pixel_batch(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* poses,
+                         int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
+                         int32_t mask_words, const int64_t* pix, int64_t n, float* rays_o, float* rays_d, float* target,
+                         void* masks_out, void* stream);
 
 /* ---- K1: ray set-up -----------------------------------------------------------------------
  * viewdirs = d/|d| (models/nerf_net.py:163-166) and the stratified depths z

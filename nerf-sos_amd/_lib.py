@@ -23,9 +23,14 @@ class MlpTensors(C.Structure):
 SIGNATURES = {
     "nsos_abi_version": (_i32, []),
     "nsos_error_string": (C.c_char_p, [_i32]),
+    "nsos_source_hash": (C.c_char_p, []),
     "nsos_mlp_packed_bytes": (_sz, [_i32]),
     "nsos_mlp_pack": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
     "nsos_generate_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, C.POINTER(C.c_float), _i64, _i64, _fp, _fp, _fp]),
+    "nsos_patch_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _fp, _i32, _fp, _i32, C.POINTER(C.c_int32), _fp,
+                                _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "nsos_pixel_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _fp, _fp, _fp,
+                                _fp, _fp]),
     "nsos_ray_setup": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_ray_points": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
@@ -101,6 +106,18 @@ def lib():
             raise NativeLibraryError(f"ABI version mismatch: library {handle.nsos_abi_version()} vs binding {ABI_VERSION}")
         _lib = handle
     return _lib
+
+
+def built_source_hash(fresh: bool = False) -> str:
+    """The source hash the library on disk was built under (`nsos_source_hash`).  fresh=True asks a child process, so a
+    library rebuilt after this process first loaded it is seen (dlopen caches by path)."""
+    if not fresh:
+        return lib().nsos_source_hash().decode()
+    import subprocess
+    import sys
+    code = ("import ctypes,sys; l=ctypes.CDLL(sys.argv[1]); l.nsos_source_hash.restype=ctypes.c_char_p; "
+            "print(l.nsos_source_hash().decode())")
+    return subprocess.check_output([sys.executable, "-c", code, LIB_PATH], text=True).strip()
 
 
 def check(code: int, what: str):

@@ -3,6 +3,13 @@
 
 extern "C" int32_t nsos_abi_version(void) { return NSOS_ABI_VERSION; }
 
+#ifndef NSOS_SOURCE_HASH
+#define NSOS_SOURCE_HASH "unstamped"
+#endif
+// sha256 (first 16 hex digits) over the sources, headers and compiler flags this library was built from
+// (__graft_entry__.source_hash): a stale .so or object is detectable without a GPU (tests/test_abi.py).
+extern "C" const char* nsos_source_hash(void) { return NSOS_SOURCE_HASH; }
+
 extern "C" const char* nsos_error_string(int32_t code) {
     switch (code) {
         case NSOS_OK: return "ok";

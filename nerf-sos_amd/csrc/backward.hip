@@ -366,18 +366,7 @@ __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float*
     else gb2[e - 128 * 320 - 256] = (float)s;
 }
 
-int wgrad_blocks() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        }
-        n = cus;
-    }
-    return n;
-}
+int wgrad_blocks() { return nsos_device_cus(); }
 }  // namespace
 
 // 1024 blocks of partial sums, then one float: the scale nsos_sem_head_wgrad_x3 derives when the caller passes none

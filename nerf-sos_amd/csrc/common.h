@@ -12,6 +12,30 @@
         if (!(cond)) return (code); \
     } while (0)
 
+// Per-DEVICE one-time state.  hipFuncSetAttribute configures the current device's copy of a kernel, and CU counts are a
+// property of the device: function-static flags would be per process, and a process that drives a second GPU would skip
+// the attribute there (launches needing > 64 KiB of LDS then fail).  The usual deployment is one process per GPU; this keeps
+// the library correct when it is not.
+#define NSOS_MAX_DEVICES 64
+static inline int nsos_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= NSOS_MAX_DEVICES) d = 0;
+    return d;
+}
+static inline int nsos_device_cus() {
+    static int cus[NSOS_MAX_DEVICES];
+    const int d = nsos_current_device();
+    if (!cus[d]) {
+        int n = 0;
+        cus[d] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[d];
+}
+struct NsosPerDeviceFlag {   // zero-initialised static: "has this device been configured for this kernel instantiation"
+    bool done[NSOS_MAX_DEVICES];
+    bool& here() { return done[nsos_current_device()]; }
+};
+
 static inline int32_t nsos_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? NSOS_OK : (int32_t)e;

@@ -117,6 +117,25 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    // The merge needs both lists in order.  The reference sorts the concatenation and assumes nothing (models/sampler.py:161):
+    // caller-supplied depths, near > far, or bins that make the inverse cdf non-monotone all reach this point.  Checked per
+    // wave (a handful of LDS reads); an out-of-order ray takes the general rank sort -- O(M^2), correct for any input
+    // (ties and NaNs in index order, NaNs last) -- so every slot of its row is still written exactly once.
+    bool unsorted = false;
+    for (int j = lane; j + 1 < S; j += 64) unsorted |= nan_last_gt(L.vals[j], L.vals[j + 1]);
+    for (int i = lane; i + 1 < N; i += 64) unsorted |= nan_last_gt(smp[i], smp[i + 1]);
+    if (__builtin_amdgcn_ballot_w64(unsorted) != 0ull) {
+        for (int e = lane; e < M; e += 64) {
+            const float v = L.vals[e];
+            int rank = 0;
+            for (int f = 0; f < M; ++f) {
+                const float o = L.vals[f];
+                rank += (nan_last_gt(v, o) || (!nan_last_gt(o, v) && f < e)) ? 1 : 0;
+            }
+            z_fine[r * M + rank] = v;
+        }
+        return;
+    }
     for (int j = lane; j < S; j += 64) {             // coarse z_j: count of samples strictly below it
         const float z = L.vals[j];
         int lo = 0, hi = N;

@@ -673,7 +673,9 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
     const size_t lds_rows12 = lds_rows12_ > kFold ? lds_rows12_ : kFold, lds_rows3 = lds_rows3_ > kFold ? lds_rows3_ : kFold,
                  lds_cols = lds_cols_ > kFold ? lds_cols_ : kFold;
     if (lds_rows3 > kLdsTotal || lds_cols > kLdsTotal) return NSOS_ERR_UNSUPPORTED;
-    static size_t configured_rows = 0, configured_cols = 0;      // the largest dynamic size each kernel has been allowed so far
+    static size_t configured_rows_on[NSOS_MAX_DEVICES], configured_cols_on[NSOS_MAX_DEVICES];   // per device
+    size_t& configured_rows = configured_rows_on[nsos_current_device()];   // the largest dynamic size each kernel has been
+    size_t& configured_cols = configured_cols_on[nsos_current_device()];   // allowed so far on this device
     if (lds_rows3 > configured_rows || lds_cols > configured_cols) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 1, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
@@ -702,13 +704,7 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
 template <bool GEO, int C>
 int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases = 7) {
     if constexpr (GEO) {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                      ? prop.multiProcessorCount : 256;
-        }
+        const int cus = nsos_device_cus();
         const long long wide = (long long)((A.N + 63) / 64) * (A.rows ? A.n_rows : A.B) * 2;   // workgroups at 64 rows each
         if (wide < cus) return run_pair_passes_shape<true, C, true>(A, want_grad, loss, st, phases);
     }

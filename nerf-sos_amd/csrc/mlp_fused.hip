@@ -515,24 +515,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams P) {
     P.chunks[gid] = v;
 }
 
-int g_num_cus = 0;
-int num_cus() {
-    if (g_num_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_num_cus = n;
-        else
-            return 256;
-    }
-    return g_num_cus;
-}
+int num_cus() { return nsos_device_cus(); }
 
 constexpr int kLdsBytes = 3 * kSlotFloats * 4;
 
 template <int SEM, bool RAYS, int SAVE = 0>
 int32_t launch_mlp(const MlpParams& p, hipStream_t stream) {
-    static bool configured = false;
+    static NsosPerDeviceFlag configured_on;
+    bool& configured = configured_on.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<SEM, RAYS, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);

@@ -568,25 +568,20 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
     __syncthreads();
 }
 
-int lp8_num_cus() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        return n;
-    return 256;
-}
 
 constexpr int kLdsBytes8 = kSlots * kSlotBytes + kAuxWords * 4;
 
 template <class T, int SEM, bool SAVE>
 int32_t launch8(const LpParams& p, hipStream_t stream) {
-    static bool configured = false;
+    static NsosPerDeviceFlag configured_on;
+    bool& configured = configured_on.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_lp8_kernel<T, SEM, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes8);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
-    static const int cus = lp8_num_cus();
+    const int cus = nsos_device_cus();
     const int grid = p.n_tiles < cus ? p.n_tiles : cus;
     hipLaunchKernelGGL((mlp_lp8_kernel<T, SEM, SAVE>), dim3(grid), dim3(512), kLdsBytes8, stream, p);
     return nsos_launch_status();

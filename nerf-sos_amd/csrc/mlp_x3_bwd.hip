@@ -283,25 +283,20 @@ __global__ __launch_bounds__(256) void x3_bwd_pack_kernel(const X3BwdPackParams 
     P.chunks[gid] = h;
 }
 
-int x3_bwd_num_cus() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-        return n;
-    return 256;
-}
 
 constexpr int kLdsBytes = kSlots * kSlotBytes + kBAuxWords * 4;
 
 template <int SEM, bool BITS>
 int32_t launch_x3_bwd(const X3BwdParams& p, hipStream_t stream) {
-    static bool configured = false;
+    static NsosPerDeviceFlag configured_on;
+    bool& configured = configured_on.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_bwd_kernel<SEM, BITS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
-    static const int cus = x3_bwd_num_cus();
+    const int cus = nsos_device_cus();
     const int grid = p.n_tiles < cus ? p.n_tiles : cus;
     hipLaunchKernelGGL((mlp_x3_bwd_kernel<SEM, BITS>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();

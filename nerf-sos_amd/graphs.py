@@ -24,6 +24,12 @@ class GraphedRender:
         dev = next(net.parameters()).device
         self._rays = torch.zeros((2, self.n_rays, 3), device=dev, dtype=torch.float32)
         self._rays[1, :, 2] = -1.0
+        # The graph bakes in the ADDRESSES of every tensor the kernels read.  Scalar bounds would come from NeRFNet's
+        # process-wide fill cache, which may evict (and so free) them later: the graph owns its bound tensors instead.
+        near, far = near_far
+        self._bounds = tuple(b.to(device=dev, dtype=torch.float32).reshape(-1).contiguous().clone() if isinstance(b, torch.Tensor)
+                             else torch.full((self.n_rays,), float(b), device=dev, dtype=torch.float32) for b in (near, far))
+        near_far = self._bounds
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():   # warm-up on a side stream: packs weights, sets kernel attributes

@@ -15,6 +15,7 @@ launches (ops.py -> include/nerf_sos_hip.h).  Non-GPU tensors raise; unsupported
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -465,20 +466,26 @@ class NeRFNet(nn.Module):
         out = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
         return {k: v.reshape(list(old_shape[:-1]) + list(v.shape[1:])) for k, v in out.items()}
 
-    _BOUNDS: Dict[tuple, torch.Tensor] = {}
+    _BOUNDS: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
 
     @staticmethod
     def _bound(b, rays_d) -> torch.Tensor:
         """Scalar near / far -> one value per ray (models/nerf_net.py:168-173).  Constant fills are cached per
         (device, ray count, value): the kernels only read them, and a fill launch per bound per call was a visible
-        share of the host-side floor at 16-bit rates."""
+        share of the host-side floor at 16-bit rates.  The cache is LRU (one entry leaves at a time, never a clear),
+        and it is bypassed during stream capture: a HIP graph must own every tensor whose address it bakes in
+        (GraphedRender passes its own bound tensors; any other capture gets a fill node in its private pool)."""
         if isinstance(b, (int, float)):
+            if rays_d.is_cuda and torch.cuda.is_current_stream_capturing():
+                return torch.full((rays_d.shape[0],), float(b), device=rays_d.device, dtype=torch.float32)
             key = (rays_d.device, rays_d.shape[0], float(b))
             t = NeRFNet._BOUNDS.get(key)
             if t is None:
-                if len(NeRFNet._BOUNDS) > 64:
-                    NeRFNet._BOUNDS.clear()
+                while len(NeRFNet._BOUNDS) >= 64:
+                    NeRFNet._BOUNDS.popitem(last=False)
                 t = torch.full((rays_d.shape[0],), float(b), device=rays_d.device, dtype=torch.float32)
                 NeRFNet._BOUNDS[key] = t
+            else:
+                NeRFNet._BOUNDS.move_to_end(key)
             return t
         return b.to(device=rays_d.device, dtype=torch.float32).reshape(-1).contiguous()

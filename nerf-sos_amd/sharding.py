@@ -225,6 +225,51 @@ def similarity_matrix(cls_tokens: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.cosine_similarity(x.unsqueeze(0), x.unsqueeze(1), dim=2)
 
 
+def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses):
+    """The loss section of `sharded_patch_step` (engines/trainer.py:127-166) and the backward through this rank's patches."""
+    loss = None
+    # The appearance loss is a train of small launches (121 sample points per patch: grids of a few hundred threads), the
+    # geometric one a few chip-filling ones with one workgroup per CU: on a stream of its own the former runs in the latter's
+    # shadow (forward here, and backward too -- autograd runs a node on the stream its forward ran on).  The draws of both
+    # come from the host-side generator state in program order, so the values do not depend on the overlap.
+    side = _side_stream(dev) if (overlap_losses and dev.type == "cuda" and corr_loss is not None and geo_loss is not None) else None
+    app = None
+    if corr_loss is not None:
+        if gen is not None:
+            corr_loss.generator = gen
+        f = full["feat"]
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for t in (f, s0, s1, sim):
+                    t.record_stream(side)
+                app = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
+        else:
+            loss = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
+    if geo_loss is not None:
+        if gen is not None:
+            geo_loss.generator = gen
+        depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()       # the geo loss uses the FINE depth for both terms
+        ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
+        # the O(P^4) geometric loss is evaluated ONCE across the ranks: each rank its own row patches (losses.py)
+        if getattr(geo_loss, "rand_neg", False):
+            g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim, rows=own, group=group) +
+                         geo_loss(depth, s1, [ro, rd, None], sim, rows=own, group=group))
+        else:
+            g = geo_w * geo_loss_both(geo_loss, depth, s0, s1, ro, rd, sim, own, group)
+        loss = g if loss is None else loss + g
+    if app is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        app.record_stream(torch.cuda.current_stream(dev))
+        loss = app + loss
+    if loss is None:
+        raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")
+    if loss.requires_grad:
+        loss.backward()
+    return loss
+
+
 def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: torch.Tensor, cls_tokens: torch.Tensor,
                        corr_loss=None, geo_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01, step: int = 0,
                        seed: Optional[int] = 0, group=None, timings: Optional[dict] = None,
@@ -274,45 +319,15 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     s1 = full["semantics"].permute(0, 3, 1, 2)
     loss = None
     gen = loss_generator(dev, step, seed) if seed is not None else None   # None: the global generator (single process only)
-    # The appearance loss is a train of small launches (121 sample points per patch: grids of a few hundred threads), the
-    # geometric one a few chip-filling ones with one workgroup per CU: on a stream of its own the former runs in the latter's
-    # shadow (forward here, and backward too -- autograd runs a node on the stream its forward ran on).  The draws of both
-    # come from the host-side generator state in program order, so the values do not depend on the overlap.
-    side = _side_stream(dev) if (overlap_losses and dev.type == "cuda" and corr_loss is not None and geo_loss is not None) else None
-    app = None
-    if corr_loss is not None:
-        if gen is not None:
-            corr_loss.generator = gen
-        f = full["feat"]
-        if side is not None:
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                for t in (f, s0, s1, sim):
-                    t.record_stream(side)
-                app = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
-        else:
-            loss = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
-    if geo_loss is not None:
-        if gen is not None:
-            geo_loss.generator = gen
-        depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()       # the geo loss uses the FINE depth for both terms
-        ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
-        # the O(P^4) geometric loss is evaluated ONCE across the ranks: each rank its own row patches (losses.py)
-        if getattr(geo_loss, "rand_neg", False):
-            g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim, rows=own, group=group) +
-                         geo_loss(depth, s1, [ro, rd, None], sim, rows=own, group=group))
-        else:
-            g = geo_w * geo_loss_both(geo_loss, depth, s0, s1, ro, rd, sim, own, group)
-        loss = g if loss is None else loss + g
-    if app is not None:
-        torch.cuda.current_stream(dev).wait_stream(side)
-        app.record_stream(torch.cuda.current_stream(dev))
-        loss = app + loss
-    if loss is None:
-        raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")
-    if loss.requires_grad:
-        loss.backward()
+    # the per-step generator is lent to the caller's loss modules for the duration of this step only: a validation loss or a
+    # single-GPU step that uses the same modules afterwards draws from whatever generator they had before
+    lent = [(m, getattr(m, "generator", None)) for m in (corr_loss, geo_loss) if m is not None and gen is not None]
+    try:
+        loss = _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group,
+                                    overlap_losses)
+    finally:
+        for m, g0 in lent:
+            m.generator = g0
     if ev:
         ev[2].record()
     all_reduce_grads(net.parameters(), group)

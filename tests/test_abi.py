@@ -30,6 +30,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.nsos_abi_version() == 1
 
 
+def test_library_was_built_from_the_sources_in_the_tree():
+    """A stale libnerf_sos_hip.so (or a stale object linked into it) must not pass as the current code: the library
+    reports the content hash it was built under (__graft_entry__.build stamps it), compared here with the tree's."""
+    import __graft_entry__ as entry
+    assert _lib.built_source_hash() == entry.source_hash(), (
+        "libnerf_sos_hip.so was built from other sources than the ones in the tree: run __graft_entry__.build()")
+
+
 def test_packed_sizes_and_error_strings():
     lib = _lib.lib()
     # aux (1024 floats) + 73 / 77 / 78 chunk slots of 36 KiB (DESIGN.md "HBM layout")

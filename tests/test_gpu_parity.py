@@ -117,6 +117,32 @@ def test_importance(golden, R, det):
     assert (np.diff(N(zf2), axis=-1) >= 0).all()
 
 
+def test_importance_unsorted_depths_follow_torch_sort():
+    """The reference sorts cat([z, samples]) and assumes nothing about either list (models/sampler.py:161): caller-supplied
+    depths out of order, near > far (descending z), NaNs.  The merge falls back to a general sort per ray; every slot of
+    z_fine is written exactly once and equals torch.sort of the kernel's own (z, samples) -- NaNs last, like torch."""
+    rng = np.random.default_rng(23)
+    for S, n_imp in ((64, 128), (17, 40), (200, 64)):
+        R = 37
+        z = (1.2 + 13 * rng.random((R, S), dtype=np.float32))
+        z[: R // 3] = np.sort(z[: R // 3], -1)[:, ::-1]            # descending (near > far)
+        z[R // 3: 2 * R // 3] = np.sort(z[R // 3: 2 * R // 3], -1)  # in order: the fast path, same launch
+        z[5, 3] = np.nan                                            # a poisoned ray
+        w = rng.random((R, S), dtype=np.float32) ** 4
+        for uu in (None, rng.random((R, n_imp), dtype=np.float32)):
+            zf = torch.full((R, S + n_imp), -7.0, device=DEV)
+            zf_, zs, _ = ops.importance_sample(T(z), T(w), n_imp, None if uu is None else T(uu))
+            want = torch.sort(torch.cat([T(z), zs], -1), -1).values
+            assert torch.equal(torch.nan_to_num(zf_, nan=-1.0), torch.nan_to_num(want, nan=-1.0)), (S, n_imp, uu is None)
+    # through the fused coarse-compositing + importance launch as well
+    R, S, n_imp = 9, 64, 128
+    z = torch.from_numpy(np.sort(1.2 + 13 * rng.random((R, S), dtype=np.float32), -1)[:, ::-1].copy()).to(DEV)
+    raw = torch.randn(R, S, 4, device=DEV)
+    d = torch.randn(R, 3, device=DEV)
+    ret, zf, zs, _ = ops.composite_importance(raw, z, d, n_imp, None, 0.0, False, None)
+    assert torch.equal(zf, torch.sort(torch.cat([z, zs], -1), -1).values)
+
+
 def test_importance_other_counts():
     rng = np.random.default_rng(11)
     R = 33
