@@ -390,6 +390,16 @@ int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float*
                                        float neg_shift, float neg_weight, float max_depth, int32_t filter_in_place, float* loss,
                                        float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- contrastive loss on the batch's class tokens (BASELINE configs[2]: "contrastive loss") ---------------
+ * NeRFContrastive.forward with min_max_contrast=True (utils/image.py:192-218; call site engines/trainer.py:168-170,
+ * `contrast_loss(cls_)`): sim = cosine_similarity of embeddings [n_tokens, dim] (each vector divided by max(|e|, 1e-8)
+ * first), the off-diagonal entries' minimum and maximum (first occurrence in row-major order, like torch.argmin / argmax),
+ * loss [1] = -log(max / (max + min)) -- NaN when max + min < 0, as in the reference.  grad_embeddings (may be NULL):
+ * d loss / d embeddings [n_tokens, dim] (only the two picked pairs carry gradient).  2 <= n_tokens <= 120.  One
+ * single-workgroup launch, deterministic. */
+int32_t nsos_contrastive_loss(const float* embeddings, int32_t n_tokens, int32_t dim, float* loss, float* grad_embeddings,
+                              void* stream);
+
 /* ---- correlation losses on the rendered patches --------------------------------
  * CorrelationLoss.forward (utils/image.py:335-370) and GeoCorrelationLoss.forward (utils/image.py:448-487) for one
  * batch of B patches, with the random choices made by the caller:

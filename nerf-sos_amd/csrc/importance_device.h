@@ -73,14 +73,20 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
     const int M = S + N;
     float* const smp = L.vals + S;
     if (u_in) {
-        // bitonic sort of NP = 2^k >= N values (padding +inf), element e = q * 64 + lane lives in register q of `lane`
+        // bitonic sort of NP = 2^k >= N values (padded), element e = q * 64 + lane lives in register q of `lane`
         constexpr int QMAX = (NSOS_MAX_IMPORTANCE + 63) / 64 + 1;   // 8 registers cover 512 >= 448
         int np = 64;
         while (np < N) np <<= 1;
         const int nq = np >> 6;
         float v[QMAX];
+        // padding orders after EVERYTHING, NaNs included (a +inf pad would sort in front of a poisoned ray's NaN samples and
+        // push them out of the first N slots): a NaN of its own bit pattern, recognised by the comparator.  Should a
+        // sample carry the same pattern it is a NaN like any other, and a NaN is what comes back.
+        const float kPad = __uint_as_float(0x7fffffffu);
+        auto is_pad = [](float x) { return __float_as_uint(x) == 0x7fffffffu; };
+        auto gt = [&](float a, float b) { return is_pad(b) ? false : (is_pad(a) ? true : nan_last_gt(a, b)); };
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) v[q] = (q < nq && q * 64 + lane < N) ? smp[q * 64 + lane] : __builtin_inff();
+        for (int q = 0; q < QMAX; ++q) v[q] = (q < nq && q * 64 + lane < N) ? smp[q * 64 + lane] : kPad;
         for (int k = 2; k <= np; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 if (j >= 64) {                       // partner element lives in another register of the same lane
@@ -91,7 +97,7 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
                             const int e = q * 64 + lane;
                             const bool up = (e & k) == 0;
                             const float a = v[q], b = v[q | dq];
-                            const bool swap = up ? nan_last_gt(a, b) : nan_last_gt(b, a);
+                            const bool swap = up ? gt(a, b) : gt(b, a);
                             v[q] = swap ? b : a;
                             v[q | dq] = swap ? a : b;
                         }
@@ -104,7 +110,7 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
                             const bool up = (e & k) == 0, lower = (lane & j) == 0;
                             const float o = __shfl_xor(v[q], j, NSOS_WAVE);
                             // this lane keeps the smaller of the pair iff (up == lower); select, never fmin/fmax: those drop NaNs
-                            const bool take = (up == lower) ? nan_last_gt(v[q], o) : nan_last_gt(o, v[q]);
+                            const bool take = (up == lower) ? gt(v[q], o) : gt(o, v[q]);
                             v[q] = take ? o : v[q];
                         }
                     }

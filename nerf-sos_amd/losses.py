@@ -183,3 +183,35 @@ class GeoCorrelationLoss(CorrelationLoss):
             changed = dbuf != depth
         depth.copy_(torch.where(changed, dbuf.to(depth.dtype), depth))   # masked assign without the host sync of a bool index
         return out
+
+
+class NeRFContrastive(nn.Module):
+    """utils/image.py:192-218 -- the contrastive loss on the batch's DINO class tokens (`contrast_loss(cls_)`,
+    engines/trainer.py:168-170; `--use_contrast`).  Same constructor; `temperature` is registered and unused, and
+    `min_max_contrast=False` raises, both as in the reference.  forward(embeddings [B,D]) -> 0-dim loss
+    = -log(max / (max + min)) over the off-diagonal cosine similarities; gradient to the embeddings (they come out of the
+    feature extractor that consumed the rendered rgb) from the same single launch (`nsos_contrastive_loss`)."""
+
+    def __init__(self, temperature=1, device=None, verbose=False, min_max_contrast=True):
+        super().__init__()
+        self.device = device
+        self.verbose = verbose
+        self.min_max_contrast = min_max_contrast
+        self.register_buffer("temperature", torch.tensor(temperature).to(device))
+
+    def forward(self, embeddings: torch.Tensor) -> torch.Tensor:
+        self.batch_size = embeddings.shape[0]
+        if not self.min_max_contrast:
+            raise NotImplementedError                                   # utils/image.py:215-216
+        if embeddings.dim() != 2:
+            raise ValueError(f"NeRFContrastive: embeddings must be [B,D], got {tuple(embeddings.shape)}")
+
+        def launch(emb, want_grad):
+            e = _dev(emb.detach(), "embeddings")
+            loss = torch.empty((1,), device=e.device, dtype=torch.float32)
+            grad = torch.empty_like(e) if want_grad else None
+            _lib.check(_lib.lib().nsos_contrastive_loss(_p(e), e.shape[0], e.shape[1], _p(loss), _p(grad), _stream()),
+                       "nsos_contrastive_loss")
+            return loss.reshape(()), grad
+
+        return _CorrFn.apply(embeddings, launch)

@@ -225,7 +225,8 @@ def similarity_matrix(cls_tokens: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.cosine_similarity(x.unsqueeze(0), x.unsqueeze(1), dim=2)
 
 
-def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses):
+def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
+                         contrast_loss=None, contrast_w=0.0):
     """The loss section of `sharded_patch_step` (engines/trainer.py:127-166) and the backward through this rank's patches."""
     loss = None
     # The appearance loss is a train of small launches (121 sample points per patch: grids of a few hundred threads), the
@@ -263,8 +264,11 @@ def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, 
         torch.cuda.current_stream(dev).wait_stream(side)
         app.record_stream(torch.cuda.current_stream(dev))
         loss = app + loss
+    if contrast_loss is not None:
+        c = contrast_w * contrast_loss(full["cls_"])                        # engines/trainer.py:168-170
+        loss = c if loss is None else loss + c
     if loss is None:
-        raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss")
+        raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss / contrast_loss")
     if loss.requires_grad:
         loss.backward()
     return loss
@@ -273,7 +277,7 @@ def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, 
 def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: torch.Tensor, cls_tokens: torch.Tensor,
                        corr_loss=None, geo_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01, step: int = 0,
                        seed: Optional[int] = 0, group=None, timings: Optional[dict] = None,
-                       overlap_losses: bool = True) -> torch.Tensor:
+                       overlap_losses: bool = True, contrast_loss=None, contrast_w: float = 0.0) -> torch.Tensor:
     """One patch-mode training step of the path with the patch batch sharded over the ranks -- the loss section of
     `train_one_step` (engines/trainer.py:101-166) re-stated for one process per GPU:
 
@@ -284,6 +288,9 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
       -> the rank's own gradient-carrying patches are spliced back into the detached batch
       -> appearance + geometric correlation losses on `semantics0` and `semantics` (engines/trainer.py:127-166); the
          O(P^4) geometric one row-partitioned: each rank its own patches' pair sets, four tiny sum-all-reduces
+      -> `contrast_loss` (NeRFContrastive, engines/trainer.py:168-170), if given: contrast_w * contrast_loss(cls_) on the
+         gathered class tokens -- every rank evaluates the same B x 384 values; its gradient goes to the feature extractor's
+         input, which is outside this path, so under the frozen-backbone recipe it only moves the loss value
       -> backward through the rank's own patches -> ONE flat all-reduce (sum) of the parameter gradients.
 
     Returns the (batch-wide) loss; `.grad` of the trainable parameters then holds the single-process gradient.
@@ -324,7 +331,7 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     lent = [(m, getattr(m, "generator", None)) for m in (corr_loss, geo_loss) if m is not None and gen is not None]
     try:
         loss = _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group,
-                                    overlap_losses)
+                                    overlap_losses, contrast_loss, contrast_w)
     finally:
         for m, g0 in lent:
             m.generator = g0

@@ -142,3 +142,16 @@ def geo_correlation_loss(depth, orig_code, ray_o, ray_d, neg_indx, p: CorrParams
         fd_self = _l1_correlation(xyz, xyz, p.max_depth)
     self_loss, _ = _helper(fd_self, orig_code, orig_code, p.self_shift, p, l1)
     return p.neg_weight * neg_loss.mean() + p.self_weight * self_loss.mean()
+
+
+# ------------------------------------------------------------------------------------------ contrastive loss on class tokens
+def nerf_contrastive(embeddings: torch.Tensor) -> torch.Tensor:
+    """NeRFContrastive.forward, min_max_contrast=True (utils/image.py:200-217; call site engines/trainer.py:168-170 on the
+    DINO class tokens `cls_` [B,384]): cosine-similarity matrix, its off-diagonal entries, loss = -log(max / (max + min)).
+    (`temperature` is registered but unused by the reference; `min_max_contrast=False` raises there.)"""
+    sim = F.cosine_similarity(embeddings.unsqueeze(1), embeddings.unsqueeze(0), dim=2)     # :202
+    mask = torch.eye(embeddings.shape[0], dtype=torch.bool)                                # :205
+    sim = sim[~mask]                                                                       # :206
+    mn = sim[torch.argmin(sim)]                                                            # :207
+    mx = sim[torch.argmax(sim)]                                                            # :208
+    return -torch.log(mx / (mx + mn))                                                      # :209

@@ -239,3 +239,34 @@ def test_geo_loss_of_two_codes_as_one_stacked_evaluation(tag):
         a = sharding.geo_loss_both(mod, depth.clone(), c0.detach(), c1.detach(), ray_o, ray_d, sim, sub)
         b = mod(depth.clone(), c0.detach(), [ray_o, ray_d, None], sim, rows=sub) + mod(depth.clone(), c1.detach(), [ray_o, ray_d, None], sim, rows=sub)
         assert abs(float(a) - float(b)) < 1e-6 * (1 + abs(float(b)))
+
+
+_CON = np.load(os.path.join(os.path.dirname(__file__), "golden", "contrastive.npz"))
+
+
+@pytest.mark.parametrize("tag", sorted(k[:-4] for k in _CON.files if k.endswith("_emb")))
+def test_contrastive_loss_vs_reference(tag):
+    """nsos_contrastive_loss / nerf_sos_amd.NeRFContrastive against the REAL class (utils/image.py:192-218; goldens from
+    tests/golden/make_goldens_contrastive.py): loss and d loss / d embeddings within 1e-5 of scale (fp32 rounding of the
+    cosine sums; the picked min / max pairs must be the reference's), NaN where the reference is NaN, run-to-run identical."""
+    e = torch.from_numpy(_CON[f"{tag}_emb"]).to("cuda:0").requires_grad_(True)
+    mod = nerf_sos_amd.NeRFContrastive(device="cuda:0")
+    loss = mod(e)
+    assert loss.shape == () and mod.batch_size == e.shape[0]
+    (2.5 * loss).backward()
+    want_l, want_g = _CON[f"{tag}_loss"][0], _CON[f"{tag}_grad"]
+    if np.isnan(want_l):
+        assert torch.isnan(loss).item()
+        return
+    assert abs(loss.item() - want_l) <= 1e-5 * (1 + abs(want_l)), (loss.item(), want_l)
+    g = e.grad.cpu().numpy() / 2.5
+    assert (np.abs(want_g) > 0).any(-1).sum() <= 4 and np.array_equal(np.abs(g) > 0, np.abs(want_g) > 0)   # the same (<= 4) rows carry gradient
+    assert np.abs(g - want_g).max() <= 1e-5 * np.abs(want_g).max()
+    e2 = e.detach().clone().requires_grad_(True)
+    l2 = mod(e2)
+    l2.backward()
+    assert torch.equal(l2, loss) and np.array_equal(e2.grad.cpu().numpy() * 2.5, e.grad.cpu().numpy())
+    with torch.no_grad():
+        assert torch.equal(mod(e.detach()), loss.detach())
+    with pytest.raises(NotImplementedError):
+        nerf_sos_amd.NeRFContrastive(device="cuda:0", min_max_contrast=False)(e)

@@ -69,11 +69,23 @@ def test_bench_cpu_baseline_leg_runs_on_a_tiny_sample():
     spec.loader.exec_module(bench)
     threads = torch.get_num_threads()
     try:
-        rec = bench.cpu_baseline(16, budget_s=3.0)
+        rec, parity = bench.cpu_baseline(None, 16)
+        # the parity object, on a stand-in "GPU" render: the port's own output with 3e-5 of noise on the fine maps
+        from oracle import torch_port as tp
+        cfg = tp.PortConfig(n_samples=64, n_importance=128, use_semantics=False, pts_chunk=1024 * 256)
+        sd, rays = tp.init_state_dict(cfg, seed=0), tp.synthetic_rays(16, seed=0)
+        with torch.no_grad():
+            ref = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR))
+        got = {k: (v + (3e-4 if k == "rgb" else 0.0) * (torch.arange(v.numel()).reshape(v.shape) % 2)) for k, v in ref.items()}
+        rec2, parity2 = bench.cpu_baseline((sd, rays, got))
     finally:
         torch.set_num_threads(threads)
     assert rec["unit"] == "rays/s" and rec["value"] > 0 and rec["kind"] == "port" and 1 <= rec["cores"] <= 64
-    assert rec["physical_cores"] >= 1
+    assert rec["physical_cores"] >= 1 and rec["runs"] == 5 and rec["warmups"] == 2 and parity is None      # SURVEY 8(d) protocol
+    assert {"anomaly_mode_on", "anomaly_mode_off"} <= set(rec["train_fwd_bwd"]) and rec["train_fwd_bwd"]["anomaly_mode_on"]["value"] > 0
+    assert parity2["coarse_pass_all_rays_inside_1e-4"] and parity2["per_key"]["depth"]["frac_rays_outside_1e-4"] == 0.0
+    assert parity2["per_key"]["rgb"]["frac_rays_outside_1e-4"] == 1.0 and 60 < parity2["psnr_db"]["rgb"] < 80
+    assert parity2["frac_rays_outside_1e-4_any_fine_map"] == 1.0 and parity2["psnr_db"]["rgb0"] > 200
     assert 2 * bench.MAC_NOSEM * bench.EVALS_PER_RAY == 2 * 593408 * 256
 
 

@@ -45,3 +45,18 @@ def test_geo_correlation_loss_port():
     assert np.array_equal(depth.numpy(), GOLD[f"{tag}_depth_after"])
     g = GOLD[f"{tag}_grad"]
     assert np.abs(code.grad.numpy() - g).max() <= 1e-6 * np.abs(g).max()
+
+
+CON = np.load(os.path.join(os.path.dirname(__file__), "golden", "contrastive.npz"))
+CON_CASES = sorted(k[:-4] for k in CON.files if k.endswith("_emb"))
+
+
+@pytest.mark.parametrize("tag", CON_CASES)
+def test_contrastive_loss_port(tag):
+    """oracle/losses_port.nerf_contrastive vs the real NeRFContrastive (utils/image.py:192-218): bit-identical on CPU
+    (goldens from tests/golden/make_goldens_contrastive.py); the b5_d7 case is the reference's own NaN (max + min < 0)."""
+    e = torch.from_numpy(CON[f"{tag}_emb"]).clone().requires_grad_(True)
+    loss = lp.nerf_contrastive(e)
+    loss.backward()
+    assert np.array_equal(loss.detach().reshape(1).numpy(), CON[f"{tag}_loss"], equal_nan=True)
+    assert np.array_equal(e.grad.numpy(), CON[f"{tag}_grad"], equal_nan=True)
