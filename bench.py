@@ -69,7 +69,7 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
-def cpu_baseline(gpu=None, n_rays: int = 4096):
+def cpu_baseline(gpu=None, n_rays: int = 4096, dense=None):
     """The reference's CPU path = the pure-torch op-for-op port (bit-identical to the reference on CPU,
     tests/golden/make_goldens.py), timed as SURVEY.md section 8(d) prescribes:
       primary   eval-mode `torch.no_grad()` forward over the FULL 4096-ray batch of the headline workload, fp32,
@@ -81,6 +81,10 @@ def cpu_baseline(gpu=None, n_rays: int = 4096):
                 process-wide at models/sampler.py:2 -- and off.
     `gpu` = (state_dict, rays, outputs) of the headline GPU step: the port renders THE SAME rays with THE SAME weights, so the
     comparison of the two renders (`parity`: PSNR, max-abs per key, share of rays outside the 1e-4 band) costs nothing extra.
+    `dense` = (state_dict, outputs) of one more GPU render of the same rays with a DENSE density field (the seed-0 weights with
+    the sigma head scaled: x40, -1.5 -- the "peaky" field of the parity tests): the default-init field is almost empty (sigma
+    < 0 nearly everywhere, so the fine maps are exactly 0 on both sides and their PSNR says nothing), the dense one puts the
+    hierarchical sampler and the compositing to work.  One untimed port render.
     The port is the checker here -- it is timed and compared against, never shipped (the product path has no CPU fallback)."""
     import torch
     from oracle import torch_port as tp            # test infrastructure: the CPU baseline / checker, never the product path
@@ -148,7 +152,13 @@ def cpu_baseline(gpu=None, n_rays: int = 4096):
     res["cpu_seconds_spent"] = round(time.perf_counter() - t_all, 1)
     parity = None
     if gpu is not None:
-        parity = render_parity(gpu[2], ref)
+        parity = {"timed_workload_default_init_field": render_parity(gpu[2], ref)}
+        if dense is not None:
+            torch.set_num_threads(best_threads)
+            with torch.no_grad():
+                ref_dense = tp.render({k: v.detach().cpu() for k, v in dense[0].items()}, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
+            parity["dense_field"] = render_parity(dense[1], ref_dense)
+            parity["psnr_db"] = parity["dense_field"]["psnr_db"]
     return res, parity
 
 
@@ -611,8 +621,17 @@ def main():
         line["variants"] = variants
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c2":
-            gpu = (res["net"].state_dict(), res["rays"], res["out"]) if prec in ("fp32", "fp16x3") else None
-            line["cpu_baseline"], parity = cpu_baseline(gpu)
+            gpu = dense = None
+            if prec in ("fp32", "fp16x3"):
+                net = res["net"]
+                gpu = ({k: v.detach().clone() for k, v in net.state_dict().items()}, res["rays"], res["out"])
+                with torch.no_grad():       # the same rays through a dense field (sigma head x40, -1.5), outside every timed region
+                    for m in (net.nerf.mlp, net.nerf_fine.mlp):
+                        m.alpha_linear.weight.mul_(40.0)
+                        m.alpha_linear.bias.mul_(40.0).sub_(1.5)
+                    dense = ({k: v.detach().clone() for k, v in net.state_dict().items()}, net(res["rays"], (1.2, 14.72)))
+                torch.cuda.synchronize()
+            line["cpu_baseline"], parity = cpu_baseline(gpu, dense=dense)
             if parity is not None:
                 line["parity"] = parity
         print(json.dumps(line), flush=True)

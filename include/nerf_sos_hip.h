@@ -345,6 +345,11 @@ int32_t nsos_composite_importance(const float* raw, const float* z_vals, const f
  * the reference's captured draws can be injected (tests/golden/end_to_end.npz). */
 int32_t nsos_render_draws(uint64_t seed, uint64_t call, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
                           float* t_rand, float* noise0, float* u, float* noise1, void* stream);
+/* The same draws with the call counter in DEVICE memory: uses call = *calls_so_far + 1 and then advances *calls_so_far by one
+ * (a second, one-thread launch), so that a captured HIP graph of a training step draws fresh numbers on every replay -- and
+ * the same numbers as eager calls of nsos_render_draws with call = 1, 2, 3, ... under the same seed. */
+int32_t nsos_render_draws_counted(uint64_t seed, uint64_t* calls_so_far, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
+                                  float* t_rand, float* noise0, float* u, float* noise1, void* stream);
 
 /* ---- K4: hierarchical sampling ----------------------------------------------------------------
  * ImportanceSampler.forward / sample_pdf (models/sampler.py:91-167) + z_std (models/nerf_net.py:124):

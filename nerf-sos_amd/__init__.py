@@ -10,7 +10,7 @@ from . import sharding  # noqa: F401
 from . import losses  # noqa: F401
 from . import io  # noqa: F401
 from . import synthetic  # noqa: F401
-from .graphs import GraphedRender  # noqa: F401
+from .graphs import GraphedPatchStep, GraphedRender  # noqa: F401
 from .losses import CorrelationLoss, GeoCorrelationLoss, NeRFContrastive  # noqa: F401
 
-__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding", "losses", "io", "synthetic", "CorrelationLoss", "GeoCorrelationLoss", "NeRFContrastive", "GraphedRender"]
+__all__ = ["NeRFNet", "NeRFMLP", "MLP", "ops", "sharding", "losses", "io", "synthetic", "CorrelationLoss", "GeoCorrelationLoss", "NeRFContrastive", "GraphedRender", "GraphedPatchStep"]

@@ -80,6 +80,7 @@ SIGNATURES = {
     "nsos_geo_correlation_loss_rows": (_i32, [_i32, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32,
                                               _f32, _i32, _fp, _fp, _fp, _sz, _fp]),
     "nsos_render_draws": (_i32, [C.c_uint64, C.c_uint64, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
+    "nsos_render_draws_counted": (_i32, [C.c_uint64, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 

@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256) void render_draws_kernel(unsigned long long se
                                                            long long n_uniform0, long long n_normal0, long long n_uniform1,
                                                            long long n_normal1, float* __restrict__ t_rand,
                                                            float* __restrict__ noise0, float* __restrict__ u,
-                                                           float* __restrict__ noise1) {
+                                                           float* __restrict__ noise1,
+                                                           const unsigned long long* __restrict__ calls_so_far) {
+    // a device-resident call counter (captured graphs: a by-value `call` would be baked into the graph and every replay
+    // would draw the same numbers); the kernel after this one advances it
+    if (calls_so_far) call = *calls_so_far + 1ull;
     // one thread = one Philox block = 4 consecutive elements of one of the four tensors (each padded to a multiple of 4)
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long q0 = (n_uniform0 + 3) >> 2, q1 = (n_normal0 + 3) >> 2, q2 = (n_uniform1 + 3) >> 2, q3 = (n_normal1 + 3) >> 2;
@@ -166,6 +170,8 @@ __global__ __launch_bounds__(256) void render_draws_kernel(unsigned long long se
     for (int k = 0; k < 4; ++k)
         if (e + k < n) dst[e + k] = v[k];
 }
+
+__global__ void counter_add_kernel(unsigned long long* counter, unsigned long long inc) { *counter += inc; }
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy,
@@ -232,16 +238,31 @@ extern "C" int32_t nsos_importance_sample(const float* z_vals, const float* weig
     return nsos_launch_status();
 }
 
-extern "C" int32_t nsos_render_draws(uint64_t seed, uint64_t call, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
-                                     float* t_rand, float* noise0, float* u, float* noise1, void* stream) {
+static int32_t render_draws(uint64_t seed, uint64_t call, uint64_t* counter, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
+                            float* t_rand, float* noise0, float* u, float* noise1, void* stream) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(n_rays > 0 && n_coarse >= 1 && n_importance >= 0, NSOS_ERR_BAD_SHAPE);
     const long long n0 = t_rand ? (long long)n_rays * n_coarse : 0, n1 = noise0 ? (long long)n_rays * n_coarse : 0;
     const long long n2 = u ? (long long)n_rays * n_importance : 0, n3 = noise1 ? (long long)n_rays * (n_coarse + n_importance) : 0;
     const long long blocks4 = ((n0 + 3) >> 2) + ((n1 + 3) >> 2) + ((n2 + 3) >> 2) + ((n3 + 3) >> 2);
-    if (blocks4 == 0) return NSOS_OK;
-    NSOS_REQUIRE((blocks4 + 255) / 256 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
-    hipLaunchKernelGGL(render_draws_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (unsigned long long)seed, (unsigned long long)call, n0, n1, n2, n3, t_rand, noise0, u, noise1);
+    if (blocks4 != 0) {
+        NSOS_REQUIRE((blocks4 + 255) / 256 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+        hipLaunchKernelGGL(render_draws_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (unsigned long long)seed, (unsigned long long)call, n0, n1, n2, n3, t_rand, noise0, u, noise1,
+                           reinterpret_cast<const unsigned long long*>(counter));
+    }
+    if (counter) hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(counter), 1ull);
     return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_render_draws(uint64_t seed, uint64_t call, int64_t n_rays, int32_t n_coarse, int32_t n_importance,
+                                     float* t_rand, float* noise0, float* u, float* noise1, void* stream) {
+    return render_draws(seed, call, nullptr, n_rays, n_coarse, n_importance, t_rand, noise0, u, noise1, stream);
+}
+
+extern "C" int32_t nsos_render_draws_counted(uint64_t seed, uint64_t* calls_so_far, int64_t n_rays, int32_t n_coarse,
+                                             int32_t n_importance, float* t_rand, float* noise0, float* u, float* noise1,
+                                             void* stream) {
+    NSOS_REQUIRE(calls_so_far, NSOS_ERR_NULL_POINTER);
+    return render_draws(seed, 0, calls_so_far, n_rays, n_coarse, n_importance, t_rand, noise0, u, noise1, stream);
 }

@@ -59,3 +59,95 @@ class GraphedRender:
         self._rays[1].copy_(rays_d.reshape(self.n_rays, 3))
         self.graph.replay()
         return self._out
+
+
+class GraphedPatchStep:
+    """The WHOLE single-process patch-training step as one HIP graph: train-mode render of the patch batch (SAVE variant of
+    the MLP kernels) -> correlation (+ contrastive) losses -> backward of the trainable parameters -> optimizer update
+    (`sharding.sharded_patch_step` + `optimizer.step()`; engines/trainer.py:32-213 is the reference's step).
+
+    Why: at 16-bit rates the step is ~1-2 ms of GPU work behind ~1.8 ms of Python and ~136 launches -- host-bound.  A replay is
+    one `hipGraphLaunch`.  What a capture needs, and where it comes from:
+      * train-mode render draws: the package's Philox stream with its call counter in device memory
+        (`NeRFNet.use_device_rng_counter`, nsos_render_draws_counted) -- a by-value counter would be baked into the graph;
+      * the losses' draws (`torch.rand` of the sample coordinates): ONE persistent `torch.Generator`, registered with the
+        graph (`CUDAGraph.register_generator_state`): torch keeps its Philox offset in device memory and advances it per replay;
+      * the optimizer: `capturable=True` (step count on the device);  parameters re-packed inside the graph (trainable nets
+        re-pack on every call), so a replay renders with the weights the previous replay's update produced;
+      * static inputs: `rays`, `feat`, `cls_tokens` are the graph's own buffers -- `load()` copies a new batch into them.
+    `eager_step()` runs the very same function without the graph (same generator, same counter): replay k and eager step k
+    produce the same bits (tests/test_gpu_sharded.py).  Single process only: with a process group the collectives between
+    the segments are host-driven (gloo) or would need RCCL's capture support, which this build could not be tested against.
+    """
+
+    def __init__(self, net, optimizer, rays: torch.Tensor, bounds: Tuple[float, float], feat: torch.Tensor, cls_tokens: torch.Tensor,
+                 corr_loss=None, geo_loss=None, contrast_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01,
+                 contrast_w: float = 0.0, seed: int = 0, overlap_losses: bool = True, warmup: int = 3, capture: bool = True):
+        import torch.distributed as dist
+        from . import sharding
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError("GraphedPatchStep captures the single-process step; run sharding.sharded_patch_step eagerly "
+                                      "under a process group")
+        if not net.training:
+            raise ValueError("GraphedPatchStep captures the train-mode step: call net.train() first")
+        if net.rng != "philox":
+            raise ValueError("GraphedPatchStep needs net.rng = 'philox' (torch's global generator cannot serve the render's "
+                             "draws from inside a graph without changing their values)")
+        for grp in optimizer.param_groups:
+            if not grp.get("capturable", False):
+                raise ValueError("GraphedPatchStep: construct the optimizer with capturable=True (its step counter must live on the device)")
+        dev = rays.device
+        self.net, self.opt, self._sharding = net, optimizer, sharding
+        self.n_patches = int(rays.shape[1])
+        self.rays, self.feat, self.cls = rays.clone(), feat.clone(), cls_tokens.clone()
+        near, far = bounds
+        n_rays = self.rays[0].numel() // 3
+        self.bounds = tuple(torch.full((n_rays,), float(b), device=dev, dtype=torch.float32) for b in (near, far))
+        self.losses = dict(corr_loss=corr_loss, geo_loss=geo_loss, contrast_loss=contrast_loss, correlation_w=correlation_w,
+                           geo_w=geo_w, contrast_w=contrast_w, overlap_losses=overlap_losses)
+        self.generator = torch.Generator(device=dev)
+        self.generator.manual_seed(int(seed))
+        if net.rng_counter is None:
+            net.use_device_rng_counter(dev)
+        self.loss = torch.zeros((), device=dev)
+        self.graph = None
+        self.steps = 0
+        if capture:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                # warm-up off the capture stream: kernel attributes, index uploads, allocator
+                for _ in range(warmup):
+                    self.eager_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.opt.zero_grad(set_to_none=True)          # the captured backward allocates the gradients in the graph's pool
+            self.graph = torch.cuda.CUDAGraph()
+            self.graph.register_generator_state(self.generator)
+            with torch.cuda.graph(self.graph):
+                self._step()
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self._sharding.sharded_patch_step(self.net, self.rays, self.bounds, self.n_patches, self.feat, self.cls,
+                                                 generator=self.generator, group=None, **self.losses)
+        self.opt.step()
+        self.loss.copy_(loss)
+
+    def eager_step(self) -> torch.Tensor:
+        """One step without the graph (the reference for the bit-identity test, and the warm-up)."""
+        self._step()
+        self.steps += 1
+        return self.loss
+
+    def load(self, rays: torch.Tensor, feat: torch.Tensor, cls_tokens: torch.Tensor) -> None:
+        """Copy the next batch into the graph's static input buffers (device-to-device, on the current stream)."""
+        self.rays.copy_(rays)
+        self.feat.copy_(feat)
+        self.cls.copy_(cls_tokens)
+
+    def __call__(self) -> torch.Tensor:
+        """One training step on the loaded batch; returns the loss (a static 0-dim tensor, valid until the next call)."""
+        if self.graph is None:
+            return self.eager_step()
+        self.graph.replay()
+        self.steps += 1
+        return self.loss

@@ -302,6 +302,17 @@ class NeRFNet(nn.Module):
         self.rng = "torch"
         self.rng_seed = 0
         self._rng_calls = 0
+        # With rng == "philox": None keeps the call counter on the host (`_rng_calls`, passed by value); a 1-element int64
+        # device tensor moves it into device memory (`use_device_rng_counter()`), which a captured graph of the training step
+        # needs -- a by-value counter would be baked in and every replay would draw the same numbers.  Same draws either way.
+        self.rng_counter: Optional[torch.Tensor] = None
+
+    def use_device_rng_counter(self, device=None) -> torch.Tensor:
+        """Move the Philox call counter of `rng = "philox"` into device memory, continuing from the host count (see
+        `rng_counter`).  Returns the counter tensor (number of draw launches so far)."""
+        dev = device if device is not None else next(self.parameters()).device
+        self.rng_counter = torch.full((1,), int(self._rng_calls), dtype=torch.int64, device=dev)
+        return self.rng_counter
 
     def invalidate_packed(self) -> None:
         """Forget the packed weight streams of both networks (needed only after edits through ``param.data``, which
@@ -377,7 +388,8 @@ class NeRFNet(nn.Module):
         pre = None
         if self.rng == "philox" and (perturb != 0. or raw_noise_std > 0.) and R > 0:
             self._rng_calls += 1
-            pre = ops.render_draws(self.rng_seed, self._rng_calls, R, n_samples, self.N_importance if fine else 0, dev,
+            call = self._rng_calls if self.rng_counter is None else self.rng_counter
+            pre = ops.render_draws(self.rng_seed, call, R, n_samples, self.N_importance if fine else 0, dev,
                                    jitter=perturb > 0., noise=raw_noise_std > 0., importance=perturb != 0.)
         elif self.rng not in ("torch", "philox"):
             raise ValueError(f"NeRFNet.rng must be 'torch' or 'philox', got {self.rng!r}")

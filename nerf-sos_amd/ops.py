@@ -353,10 +353,12 @@ def mlp_forward_points(packed: torch.Tensor, sem_mode: int, pts: torch.Tensor, d
 
 
 # ------------------------------------------------------------------------------------------ train-mode draws
-def render_draws(seed: int, call: int, n_rays: int, n_coarse: int, n_importance: int, device, jitter: bool = True,
+def render_draws(seed: int, call, n_rays: int, n_coarse: int, n_importance: int, device, jitter: bool = True,
                  noise: bool = True, importance: bool = True):
     """The four random tensors of one train-mode ray chunk in one launch (nsos_render_draws): (t_rand [R,S] or None,
-    noise0 [R,S] or None, u [R,N] or None, noise1 [R,S+N] or None) from a Philox stream keyed by `seed`, block `call`."""
+    noise0 [R,S] or None, u [R,N] or None, noise1 [R,S+N] or None) from a Philox stream keyed by `seed`, block `call`.
+    `call` may be a 1-element int64 device tensor holding the number of calls made SO FAR: the kernel then uses that + 1
+    and advances the tensor (nsos_render_draws_counted) -- what a captured graph needs, same values as call = 1, 2, ..."""
     dev = torch.device(device)
     f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     fine = n_importance > 0
@@ -364,6 +366,12 @@ def render_draws(seed: int, call: int, n_rays: int, n_coarse: int, n_importance:
     n0 = f(n_rays, n_coarse) if noise else None
     u = f(n_rays, n_importance) if (importance and fine) else None
     n1 = f(n_rays, n_coarse + n_importance) if (noise and fine) else None
+    if isinstance(call, torch.Tensor):
+        if call.dtype != torch.int64 or call.numel() != 1 or call.device != dev:
+            raise TypeError("render_draws: a device call counter is a 1-element int64 tensor on the rays' device")
+        _lib.check(_lib.lib().nsos_render_draws_counted(int(seed) & (2 ** 64 - 1), _p(call), n_rays, n_coarse, n_importance,
+                                                        _p(t), _p(n0), _p(u), _p(n1), _stream()), "nsos_render_draws_counted")
+        return t, n0, u, n1
     _lib.check(_lib.lib().nsos_render_draws(int(seed) & (2 ** 64 - 1), int(call) & (2 ** 64 - 1), n_rays, n_coarse, n_importance,
                                             _p(t), _p(n0), _p(u), _p(n1), _stream()), "nsos_render_draws")
     return t, n0, u, n1

@@ -277,7 +277,8 @@ def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, 
 def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: torch.Tensor, cls_tokens: torch.Tensor,
                        corr_loss=None, geo_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01, step: int = 0,
                        seed: Optional[int] = 0, group=None, timings: Optional[dict] = None,
-                       overlap_losses: bool = True, contrast_loss=None, contrast_w: float = 0.0) -> torch.Tensor:
+                       overlap_losses: bool = True, contrast_loss=None, contrast_w: float = 0.0,
+                       generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """One patch-mode training step of the path with the patch batch sharded over the ranks -- the loss section of
     `train_one_step` (engines/trainer.py:101-166) re-stated for one process per GPU:
 
@@ -296,7 +297,9 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     Returns the (batch-wide) loss; `.grad` of the trainable parameters then holds the single-process gradient.
     With no process group it is the plain single-GPU step over `n_patches` local patches.  The losses' random draws come
     from `loss_generator(device, step, seed)` -- identical on every rank; seed=None uses torch's global generator like the
-    reference (single process only: ranks would draw different coordinates).
+    reference (single process only: ranks would draw different coordinates).  `generator`, if given, is used INSTEAD (a
+    persistent generator the caller advances step after step -- what a captured graph of this step needs, graphs.py:
+    a fresh per-step generator cannot be registered with a graph).
     `timings`, if a dict, receives HIP event pairs under 'gather' and 'allreduce' (recorded on the current stream;
     RCCL's own stream is joined by the non-async collectives before the second event) and the gather `stats`."""
     rank, world = _world(group)
@@ -325,8 +328,9 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     s0 = full["semantics0"].permute(0, 3, 1, 2)
     s1 = full["semantics"].permute(0, 3, 1, 2)
     loss = None
-    gen = loss_generator(dev, step, seed) if seed is not None else None   # None: the global generator (single process only)
-    # the per-step generator is lent to the caller's loss modules for the duration of this step only: a validation loss or a
+    gen = generator if generator is not None else (loss_generator(dev, step, seed) if seed is not None else None)
+    # (None: the global generator, single process only.)  The generator is lent to the caller's loss modules for the
+    # duration of this step only: a validation loss or a
     # single-GPU step that uses the same modules afterwards draws from whatever generator they had before
     lent = [(m, getattr(m, "generator", None)) for m in (corr_loss, geo_loss) if m is not None and gen is not None]
     try:

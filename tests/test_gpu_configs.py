@@ -154,3 +154,63 @@ def test_c4_loss_overlap_does_not_change_a_bit(manifest, precision):
     _, _, _, _, lb, gb = _c4_step(precision, manifest, overlap_losses=False)
     assert torch.equal(la, lb)
     assert all(torch.equal(ga[k], gb[k]) for k in ga)
+
+
+def _graphed(precision, manifest, capture, overlap, B=2, contrast=True):
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0, ray_chunk=1 << 20,
+                               **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
+    for n_, p_ in net.named_parameters():
+        p_.requires_grad = "semantic_linear" in n_
+    net.train()
+    net.mlp_precision = precision
+    net.rng, net.rng_seed = "philox", 5
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4, fused=True, capturable=True)
+    rays = syn.synthetic_patches(B, 64, 6, seed=0, device=DEV)
+    feat = torch.randn(B, 384, 14, 14, generator=torch.Generator().manual_seed(1)).to(DEV)
+    cls_ = (torch.randn(B, 384, generator=torch.Generator().manual_seed(2)) + 3 * torch.randn(1, 384, generator=torch.Generator().manual_seed(3))).to(DEV)
+    corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+    con = nerf_sos_amd.NeRFContrastive(device=DEV) if contrast and B >= 2 else None
+    g = nerf_sos_amd.GraphedPatchStep(net, opt, rays, (syn.NEAR, syn.FAR), feat, cls_, corr, geo, con, contrast_w=0.01, seed=9,
+                                      overlap_losses=overlap, warmup=2, capture=capture)
+    return net, g, (rays, feat, cls_)
+
+
+@pytest.mark.parametrize("precision,overlap", [("bf16", True), ("bf16", False), ("fp32", True)])
+def test_whole_training_step_as_one_graph_equals_eager_bit_for_bit(manifest, precision, overlap):
+    """GraphedPatchStep: render (train mode, SAVE kernels, Philox draws from a device counter) -> appearance + geometric +
+    contrastive losses (torch draws from a generator registered with the graph) -> semantic-head backward -> fused capturable
+    Adam, captured once and replayed.  Against the very same function run eagerly (same generator, same counter): after 2
+    warm-up + 5 steps the losses of every step and all parameters are identical bit for bit; the step really trains (loss
+    and parameters move); a new batch loaded into the static buffers is what the next replay renders."""
+    net_g, g, batch = _graphed(precision, manifest, True, overlap)
+    net_e, e, _ = _graphed(precision, manifest, False, overlap)
+    assert g.graph is not None and e.graph is None
+    e.eager_step(); e.eager_step()                       # the graphed instance's two warm-up steps
+    p0 = {n: p.detach().clone() for n, p in net_g.named_parameters() if p.requires_grad}
+    lg, le = [], []
+    for k in range(5):
+        if k == 3:                                       # a different batch through the static buffers
+            rays2 = syn.synthetic_patches(2, 64, 6, seed=1, device=DEV)
+            g.load(rays2, batch[1] * 0.5, batch[2])
+            e.load(rays2, batch[1] * 0.5, batch[2])
+        lg.append(g().clone())
+        le.append(e().clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(lg, le)), (lg, le)
+    assert len({float(x) for x in lg}) == 5, "every step draws new numbers and sees updated weights: five different losses"
+    for (n, a), (_, b) in zip(net_g.named_parameters(), net_e.named_parameters()):
+        assert torch.equal(a, b), n
+    assert any(not torch.equal(p0[n], p) for n, p in net_g.named_parameters() if p.requires_grad)
+    assert int(net_g.rng_counter.item()) == 7 and int(net_e.rng_counter.item()) == 7       # one draw launch per step
+
+
+def test_device_rng_counter_draws_equal_host_counter_draws():
+    """nsos_render_draws_counted with the counter in device memory draws what nsos_render_draws draws for call = 1, 2, 3."""
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for call in (1, 2, 3):
+        a = ops.render_draws(77, call, 300, 64, 128, DEV)
+        b = ops.render_draws(77, cnt, 300, 64, 128, DEV)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and int(cnt.item()) == call
+    assert not torch.equal(ops.render_draws(77, 1, 300, 64, 128, DEV)[0], ops.render_draws(77, 2, 300, 64, 128, DEV)[0])

@@ -77,7 +77,9 @@ def test_bench_cpu_baseline_leg_runs_on_a_tiny_sample():
         with torch.no_grad():
             ref = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR))
         got = {k: (v + (3e-4 if k == "rgb" else 0.0) * (torch.arange(v.numel()).reshape(v.shape) % 2)) for k, v in ref.items()}
-        rec2, parity2 = bench.cpu_baseline((sd, rays, got))
+        rec2, parity2 = bench.cpu_baseline((sd, rays, got), dense=(sd, ref))
+        assert parity2["dense_field"]["frac_rays_outside_1e-4_any_fine_map"] == 0.0 and parity2["psnr_db"]["rgb"] > 200
+        parity2 = parity2["timed_workload_default_init_field"]
     finally:
         torch.set_num_threads(threads)
     assert rec["unit"] == "rays/s" and rec["value"] > 0 and rec["kind"] == "port" and 1 <= rec["cores"] <= 64
