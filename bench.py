@@ -227,10 +227,16 @@ class Ctx:
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             self.backend = "gloo" if one_gpu else "nccl"
+            # a diverged collective sequence must fail, not hang: a bounded process-group timeout (RCCL's watchdog aborts the job
+            # when a collective exceeds it) and the package's own per-collective wait (gloo honours it; sharding.collective)
+            import datetime
+            from nerf_sos_amd import sharding
+            pg_timeout = datetime.timedelta(seconds=int(os.environ.get("NSOS_PG_TIMEOUT_S", "300")))
+            sharding.COLLECTIVE_TIMEOUT_S = sharding.COLLECTIVE_TIMEOUT_S or 120.0
             if self.backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=pg_timeout)
             else:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=pg_timeout)
 
     def barrier(self):
         if self.world > 1:
@@ -450,7 +456,9 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
     for i in range(warmup):
         step(i)
     state["timed"] = True
+    sharding.reset_collective_counts()
     dt, per_rank, events = timed(ctx, step, 0, steps)
+    per_step = {k: round(v / steps, 3) for k, v in sorted(sharding.reset_collective_counts().items())}
     n_rays = len(own) * PATCH * PATCH
     res = speed_fields(ctx, n_rays, steps, dt, per_rank)
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
@@ -472,6 +480,9 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
                             "all_reduce_ms": mean_ms(timings.get("allreduce", [])),
                             "gathered_bytes_per_patch": st.get("bytes_per_patch"),
                             "gathered_keys": list(sharding.PATCH_KEYS), "all_gathers_per_step": st.get("collectives", 0 if ctx.world == 1 else None),
+                            # every collective this rank issued in the timed steps, by kind (sharding.collective counts them): the
+                            # flat patch gather, the geometric loss's three phase reductions + its role-sum reduction, the gradient all-reduce
+                            "calls_per_step_by_kind": per_step, "calls_per_step": round(sum(per_step.values()), 3),
                             "all_reduce_floats": sum(p.numel() for p in net.parameters() if p.requires_grad)})
     return res
 

@@ -171,11 +171,13 @@ class GeoCorrelationLoss(CorrelationLoss):
                                                               float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
                                                               ws.numel() * 8, _stream()), "nsos_geo_correlation_loss_rows")
                 if reduce and phase < 3:
-                    dist.all_reduce(scal[2 * phase: 2 * phase + 2], group=group)
+                    from .sharding import collective
+                    part = scal[2 * phase: 2 * phase + 2]
+                    collective("geo_loss_phase_all_reduce", lambda async_op: dist.all_reduce(part, group=group, async_op=async_op), group)
                     # every rank or none: a rank that owns no patch has a code without gradient (want_grad False) but must not
                     # skip a collective its peers issue -- the group-wide condition is the grad mode the loss was called in
                     if phase == 2 and grad_mode:
-                        dist.all_reduce(gsum, group=group)
+                        collective("geo_loss_role_sum_all_reduce", lambda async_op: dist.all_reduce(gsum, group=group, async_op=async_op), group)
             return loss, grad
 
         out = _CorrFn.apply(orig_code, launch)

@@ -11,6 +11,7 @@ one flat all-gather (RCCL picks the direct algorithm at this size), never a hand
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -39,6 +40,44 @@ def patch_owner(b: int, world: int) -> int:
 
 def local_patches(n_patches: int, rank: int, world: int) -> List[int]:
     return [b for b in range(n_patches) if patch_owner(b, world) == rank]
+
+
+# ---- collectives: counted, and never allowed to hang silently ---------------------------------------------------------
+# Every collective of the sharded paths goes through `collective()`: it counts the calls by kind (bench.py reports them
+# per step, the geometric loss's phase reductions included) and puts a watchdog on each one.  A rank that skips a
+# collective its peers issue (a mismatch of the call sequences -- e.g. a rank that owns no patch taking a short cut) is a
+# hang, not an error, in torch.distributed: with COLLECTIVE_TIMEOUT_S set, the host waits on the work handle for at most that
+# long and then raises with the name of the collective and the rank (gloo honours the wait timeout; with RCCL the wait only
+# orders streams, and the process group's own timeout -- set it at init_process_group -- aborts the job through its watchdog).
+COLLECTIVE_TIMEOUT_S: Optional[float] = float(os.environ.get("NSOS_COLLECTIVE_TIMEOUT_S", "0")) or None
+COLLECTIVE_COUNTS: Dict[str, int] = {}
+
+
+def reset_collective_counts() -> Dict[str, int]:
+    """Returns the counts so far (kind -> calls on this rank) and clears them."""
+    out = dict(COLLECTIVE_COUNTS)
+    COLLECTIVE_COUNTS.clear()
+    return out
+
+
+def collective(kind: str, launch: Callable[..., "dist.Work"], group=None):
+    """Run `launch(async_op=True)` (a torch.distributed collective) under the watchdog and count it under `kind`."""
+    COLLECTIVE_COUNTS[kind] = COLLECTIVE_COUNTS.get(kind, 0) + 1
+    work = launch(async_op=True)
+    if work is None:
+        return
+    if COLLECTIVE_TIMEOUT_S is None:
+        work.wait()
+        return
+    import datetime
+    try:
+        done = work.wait(datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
+    except RuntimeError as e:   # gloo raises on timeout
+        raise RuntimeError(f"nerf_sos_amd.sharding: collective `{kind}` did not complete within {COLLECTIVE_TIMEOUT_S:.0f} s on rank "
+                           f"{dist.get_rank(group)} of {dist.get_world_size(group)} -- the ranks' collective sequences have diverged "
+                           f"(a rank skipped or added a call)") from e
+    if done is False:
+        raise RuntimeError(f"nerf_sos_amd.sharding: collective `{kind}` timed out after {COLLECTIVE_TIMEOUT_S:.0f} s on rank {dist.get_rank(group)}")
 
 
 def _world(group) -> Tuple[int, int]:
@@ -80,7 +119,7 @@ def all_gather_rows(t: torch.Tensor, rows_per_rank: Sequence[int], group=None) -
         pad = torch.cat([t, t.new_zeros((m - t.shape[0],) + tuple(t.shape[1:]))], 0)
     pad = pad.contiguous()
     buf = pad.new_empty((world * m,) + tuple(pad.shape[1:]))
-    dist.all_gather_into_tensor(buf, pad, group=group)
+    collective("all_gather", lambda async_op: dist.all_gather_into_tensor(buf, pad, group=group, async_op=async_op), group)
     if all(r == m for r in rows_per_rank):
         return buf
     return torch.cat([buf[r * m:r * m + rows_per_rank[r]] for r in range(world)], 0)
@@ -170,7 +209,7 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
         if p.grad is None:
             p.grad = torch.zeros_like(p)
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    collective("grad_all_reduce", lambda async_op: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op), group)
     if average:
         flat /= dist.get_world_size(group)
     off = 0

@@ -93,6 +93,12 @@ def check_kernel(ins_list):
         if is_lds_read:
             n_reads += 1
             pending.append((regs_of(rest.split(",")[0]), idx))
+        elif op.startswith("ds_"):
+            # every LDS operation occupies a slot of the in-order queue that lgkmcnt counts: writes and ds_swizzle / ds_permute /
+            # ds_bpermute (their results carry a destination) as well as reads.  A wait of lgkmcnt(n) that a compiler-issued
+            # ds_bpermute pair makes look loose is not: the two youngest slots are theirs, an older ds_read has landed.
+            has_dest = op.startswith(("ds_bpermute", "ds_permute", "ds_swizzle")) or "_rtn" in op
+            pending.append((regs_of(rest.split(",")[0]) if has_dest else set(), idx))
     return bad, n_reads, n_scratch
 
 
