@@ -199,11 +199,40 @@ def render_parity(got: dict, ref: dict, tol: float = 1e-4):
             "per_key": per_key}
 
 
-def kernel_source_hash() -> str:
+KERNEL_SOURCES = {   # traffic.json key -> the files whose content decides the dominant kernel's memory traffic
+    "c2_fp32": ("mlp_fused.hip", "mlp_common.h"),
+    "c2_fp16x3": ("mlp_x3.hip", "x3_common.h", "mlp_common.h"),
+    "lp8": ("mlp_lp8.hip", "lp_common.h", "mlp_common.h"),
+}
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "traffic.json")
+
+
+def kernel_source_hash(key: str = "c2_fp32") -> str:
     h = hashlib.sha256()
-    for f in ("mlp_fused.hip", "mlp_common.h"):
+    for f in KERNEL_SOURCES.get(key, KERNEL_SOURCES["lp8"]):
         h.update(open(os.path.join(ROOT, "nerf-sos_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def add_traffic(roof, key: str):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r03/traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate rocprofv3 --pmc runs and corrected as MI355X_MICROARCH.md prescribes), reported only
+    while the kernel's sources still hash to the build the passes were measured on."""
+    if roof is None or not os.path.exists(TRAFFIC_JSON):
+        return roof
+    t = json.load(open(TRAFFIC_JSON)).get("kernels", {}).get(key)
+    if not t:
+        return roof
+    if t.get("kernel_source_sha16") == kernel_source_hash(key):
+        roof["traffic"] = t["hbm_bytes_per_launch"]
+        roof["traffic_detail"] = {"fetch_size_kb": t["fetch_size_kb"], "write_size_kb": t["write_size_kb"],
+                                  "algorithmic_bytes_per_launch_without_weights": t["algorithmic_bytes_per_launch_without_weights"],
+                                  "ratio_to_algorithmic": t["ratio"], "scratch_bytes": t.get("scratch_bytes"),
+                                  "source": "profiles/r03/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                            "2 x FETCH_SIZE + WRITE_SIZE)"}
+    else:
+        roof["traffic_note"] = "profiles/r03/traffic.json was measured on a different build of this kernel: not reported"
+    return roof
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -560,15 +589,7 @@ def main():
             raise SystemExit("bench.py: c2 is the fp32 configuration: --precision fp32 (exact) or fp16x3 (split-fp16, fp32-grade)")
         res = run_c2(ctx, args, prec)
         roof = res["roofline"]
-        if prec == "fp32":
-            tj = os.path.join(ROOT, "profiles", "r02", "traffic.json")       # PMC passes of this same command (separate runs)
-            if os.path.exists(tj):
-                t = json.load(open(tj))
-                if t.get("kernel_source_sha16") == kernel_source_hash():
-                    roof["traffic"] = t.get("hbm_bytes_per_launch")
-                    roof["traffic_note"] = t.get("note")
-                else:
-                    roof["traffic_note"] = "profiles/r02/traffic.json was measured on a different build of the kernel: not reported"
+        add_traffic(roof, "c2_fp32" if prec == "fp32" else "c2_fp16x3")
         line.update({k: res[k] for k in ("value", "ms_per_step", "host_enqueue_ms_per_step", "per_rank_rays_per_s")})
         line["dtype"] = "f32" if prec == "fp32" else "f16x3 (split-fp16 operands, fp32 accumulate, fp32-grade results)"
         line["config"] = {"workload": "BASELINE configs[1]: LLFF flower_full shape, 4096 rays/GPU x (64 coarse + 192 fine MLP "
@@ -587,17 +608,21 @@ def main():
                 v["what"] = "the c2 step with the MLP on the 16-bit matrix pipe, split-fp16 operands (3 MFMAs per product, fp32 accumulate)"
                 v["max_abs_rgb0_vs_exact_fp32"] = float((alt["out"]["rgb0"] - exact_c).abs().max())
                 v["parity"] = "same tests and bars as the exact kernel (2e-5 vs the reference goldens)"
+                add_traffic(v.get("roofline"), "c2_fp16x3")
                 variants["c2_fp16x3"] = v
                 v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 6))
                 v["what"] = "BASELINE configs[2]: one 64x64 patch = 4096 rays, sem+coord head, bf16 MFMA: train-mode render + appearance & geometric correlation losses + semantic-head backward + Adam"
+                add_traffic(v.get("roofline"), "c3_bf16")
                 variants["c3_bf16"] = v
             v = _strip(run_c5(ctx, args, "fp16", 2 if ctx.world == 1 else 4, 1))
             v["what"] = ("BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device "
                          "softmax/argmax; row blocks sharded over the GPUs (strong scaling, no collective); a step = one image")
+            add_traffic(v.get("roofline"), "c5_fp16")
             variants["c5_fp16"] = v
             v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 6))
             v["what"] = ("BASELINE configs[3]: 8192 rays/GPU (2 patches of 64x64 per GPU), the c3 step sharded over the GPUs: one flat "
                          "all-gather of semantics0/semantics/depth/feat/cls_/ray_o/ray_d, one flat gradient all-reduce")
+            add_traffic(v.get("roofline"), "c4_bf16")
             variants["c4_bf16"] = v
     elif args.config in ("c3", "c4"):
         if args.config == "c3" and ctx.world != 1:
@@ -612,7 +637,7 @@ def main():
                                       "correlation losses, semantic-head backward (--fix_backbone recipe), Adam; train-mode draws from the package's one-launch Philox stream",
                           "rays_per_gpu": res["rays_per_gpu"], "patches": res["patches"], "parallelism": f"patch-sharded x{ctx.world}",
                           "flop_per_ray_forward": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
-        line["roofline"] = res["roofline"]
+        line["roofline"] = add_traffic(res["roofline"], "c3_bf16" if args.config == "c3" else "c4_bf16") if prec == "bf16" else res["roofline"]
         line["collectives"] = res["collectives"]
         line["loss"] = res["loss"]
     else:
@@ -624,7 +649,7 @@ def main():
                                       f"eval mode, sem+coord head, {prec} MLP, rays generated on device, on-device post-processing; step = one image",
                           "rays_per_gpu": res["rays_per_gpu"], "parallelism": f"row blocks sharded x{ctx.world}, no collective",
                           "flop_per_ray": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
-        line["roofline"] = res["roofline"]
+        line["roofline"] = add_traffic(res["roofline"], "c5_fp16") if prec == "fp16" else res["roofline"]
         line["finite"] = res["finite"]
 
     line["distributed"] = dist_info

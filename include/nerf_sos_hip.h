@@ -204,9 +204,10 @@ int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, cons
  * the way out: `scale` = that power of two as a device scalar, or NULL to have it derived on the device from
  * max |g_semantics| * max_m (|W_sem2[0,m]| + |W_sem2[1,m]|) (one extra small launch).  gw2 / gb2 are plain fp32 sums.
  * sem_in_dtype: NSOS_DTYPE_F32 for the fp32 matrix (three MFMAs per product), NSOS_DTYPE_F16 / NSOS_DTYPE_BF16 for the
- * compact 16-bit matrix of nsos_mlp_forward_rays_save16_lp (half the operand traffic; a 16-bit operand has no lo part:
+ * compact 16-bit matrices of nsos_mlp_forward_rays_save16_lp -- sem_hid is then 16-bit [P,128] in the same format too, fp32
+ * [P,128] otherwise -- (half the operand traffic; a 16-bit operand has no lo part:
  * two MFMAs per product; csrc/sem_wgrad16.hip).  n_samples >= 8, n_rays * n_samples < 2^31. */
-int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                                const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
                                const float* scale, float* gw1_aug, float* gw2, float* gb2, void* workspace,
                                size_t workspace_bytes, void* stream);
@@ -228,11 +229,14 @@ int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t d
 int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                       const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                       int32_t n_samples, float* raw, float* sem_in, float* sem_hid, void* stream);
-/* The same with sem_in kept in its 16-bit format (`dtype`): sem_in16 [P,320] halves (640 B per point instead of 1280);
- * consumer: nsos_sem_head_wgrad_x3 with the matching sem_in_dtype. */
+/* The same with BOTH saved matrices kept in the 16-bit format `dtype`: sem_in16 [P,320] halves (640 B per point instead of
+ * 1280: the values are 16-bit anyway) and sem_hid16 [P,128] halves (256 B instead of 512: relu of the fp32 accumulators,
+ * rounded to nearest even -- the ReLU pattern is unchanged, the values feed only d semantic_linear.2.weight, at the
+ * format's precision like everything else on this path).  896 B per point in all (round 2: 1152).
+ * Consumer: nsos_sem_head_wgrad_x3 with the matching sem_in_dtype. */
 int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                         const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
-                                        int32_t n_samples, float* raw, void* sem_in16, float* sem_hid, void* stream);
+                                        int32_t n_samples, float* raw, void* sem_in16, void* sem_hid16, void* stream);
 
 /* ---- K2-X3: the same fused network on the 16-bit matrix pipe with SPLIT-fp16 operands (fp32-grade results) -------
  * Every weight and activation is carried as hi = fp16(v), lo = fp16(v - hi) and every product as the three MFMAs

@@ -394,7 +394,7 @@ extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_sema
 }
 
 namespace nsos_detail {
-int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                          const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples, const float* scale,
                          float* partial, int blocks, hipStream_t st);   // sem_wgrad16.hip
 }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(1024) void sem_head_scale_kernel(const float* __res
 }  // namespace
 
 extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w,
-                                          const float* sem_hid, const void* sem_in, int32_t sem_in_dtype, int64_t n_rays,
+                                          const void* sem_hid, const void* sem_in, int32_t sem_in_dtype, int64_t n_rays,
                                           int32_t n_samples, const float* scale, float* gw1_aug, float* gw2, float* gb2,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     NSOS_REQUIRE(sem_in_dtype >= 0 && sem_in_dtype <= 2, NSOS_ERR_UNSUPPORTED);
@@ -450,7 +450,7 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
         scale = derived;
     }
     switch (sem_in_dtype) {
-        case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, static_cast<const float*>(sem_in), scale, n_pts, (int)n_samples, ws); break;
+        case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, static_cast<const float*>(sem_hid), static_cast<const float*>(sem_in), scale, n_pts, (int)n_samples, ws); break;
         default: {
             const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype, n_rays, n_samples, scale, ws, blocks, st);
             if (rc != NSOS_OK) return rc;

@@ -125,6 +125,7 @@ struct LpParams {
     float* sem_in;   // SAVE: [P,320] = [relu(h7) | x63 | 1.0] as the 16-bit values the semantic head consumed, widened to fp32
     unsigned* sem_in16;   // ... or (if not NULL) the same matrix kept in its 16-bit format T: [P,320] halves = 160 words per point
     float* sem_hid;  // SAVE: [P,128] = relu(semantic_linear.0(...)) (fp32 accumulators)
+    unsigned* sem_hid16;  // ... or, with sem_in16 (the compact path), the same rounded to the 16-bit format T: [P,128] halves = 64 words per point
 };
 constexpr int kProfSlots = 64;
 

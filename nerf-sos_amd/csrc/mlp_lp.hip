@@ -258,6 +258,16 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                                         *reinterpret_cast<f32x4*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
                                     }
                                 }
+                                if (P.sem_in16) {   // compact: the hidden activations in the 16-bit format too (features 32t + 8q + 4kg + {0..3} = 2 words)
+                                    unsigned* hrow16 = P.sem_hid16 + gp * 64;
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                            *reinterpret_cast<u32x2*>(hrow16 + 16 * t + 4 * q + 2 * kg) =
+                                                u32x2{T::pack2(relu_acc(sacc[c][t][4 * q]), relu_acc(sacc[c][t][4 * q + 1])),
+                                                      T::pack2(relu_acc(sacc[c][t][4 * q + 2]), relu_acc(sacc[c][t][4 * q + 3]))};
+                                } else {
 #pragma unroll
                                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
                                         *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
                                             f32x4{relu_acc(sacc[c][t][4 * q]), relu_acc(sacc[c][t][4 * q + 1]),
                                                   relu_acc(sacc[c][t][4 * q + 2]), relu_acc(sacc[c][t][4 * q + 3])};
+                                }
                             }
                         }
                     }
@@ -535,7 +546,7 @@ extern "C" int32_t nsos_mlp_lp_select_kernel(int32_t waves_per_simd) {
 static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                int32_t n_samples, float* raw, unsigned long long* prof, float* sem_in, float* sem_hid,
-                               void* stream, unsigned* sem_in16 = nullptr) {
+                               void* stream, unsigned* sem_in16 = nullptr, unsigned* sem_hid16 = nullptr) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && rays_o && rays_d && viewdirs && z_vals && raw, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
@@ -554,17 +565,18 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     p.sem_in = sem_in;
     p.sem_in16 = sem_in16;
     p.sem_hid = sem_hid;
+    p.sem_hid16 = sem_hid16;
     const hipStream_t st = (hipStream_t)stream;
     // NSOS_LP_WAVES=4 selects the one-wave-per-SIMD kernel of round 1 (A/B measurements); default: two waves per SIMD
     // (mlp_lp8_kernel indexes its points with 32 bits: launches of 2^31 points or more -- 11 M rays x 192 samples -- take the
     //  round-1 kernel, whose results are bit-identical)
     if (lp_waves_per_simd() == 2 && n_pts < (1ll << 31)) {
-        if (sem_in || sem_in16) NSOS_REQUIRE(sem_hid && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
+        if (sem_in || sem_in16) NSOS_REQUIRE((sem_in16 ? (void*)sem_hid16 : (void*)sem_hid) && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
         p.chunks += (size_t)lp_chunks(sem_mode) * kSlotBytes;   // the second stream: tile-pair-major hidden layers
         return launch_lp8(p, sem_mode, dtype == NSOS_DTYPE_F16, sem_in || sem_in16, st);
     }
     if (sem_in || sem_in16) {
-        NSOS_REQUIRE(sem_hid && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
+        NSOS_REQUIRE((sem_in16 ? (void*)sem_hid16 : (void*)sem_hid) && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
         if (dtype == NSOS_DTYPE_F16) return sem_mode == 1 ? launch_lp<F16, 1, true>(p, st) : launch_lp<F16, 2, true>(p, st);
         return sem_mode == 1 ? launch_lp<BF16, 1, true>(p, st) : launch_lp<BF16, 2, true>(p, st);
     }
@@ -603,12 +615,12 @@ extern "C" int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem
 extern "C" int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                                    const float* rays_d, const float* viewdirs, const float* z_vals,
                                                    int64_t n_rays, int32_t n_samples, float* raw, void* sem_in16,
-                                                   float* sem_hid, void* stream) {
+                                                   void* sem_hid16, void* stream) {
     if (n_rays == 0) return NSOS_OK;
-    NSOS_REQUIRE(sem_in16 && sem_hid, NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(((uintptr_t)sem_in16 & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
+    NSOS_REQUIRE(sem_in16 && sem_hid16, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(((uintptr_t)sem_in16 & 15) == 0 && ((uintptr_t)sem_hid16 & 15) == 0, NSOS_ERR_MISALIGNED);
     return forward_rays_lp(packed, sem_mode, dtype, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr,
-                           sem_hid, stream, static_cast<unsigned*>(sem_in16));
+                           nullptr, stream, static_cast<unsigned*>(sem_in16), static_cast<unsigned*>(sem_hid16));
 }
 
 extern "C" int32_t nsos_mlp_profile_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,

@@ -140,6 +140,48 @@ __device__ __forceinline__ void heads_partial_v(const f32x16 (&h)[NT], const flo
 
 // PROF: the phase stamps (nsos_mlp_profile_rays_lp / nsos_mlp_lp_set_stamp_buffer) are compiled into their own instantiations:
 // in the production kernels they cost a scalar branch per phase and kept the stamp pointer and slot counter in scratch.
+// Where the SAVE variant's twenty 16-byte stores of a point's sem_in row ride (compact path).  Sites: 0 = layer 0's chunk
+// (the four encoding slices, k = 16..19), 1..3 = the semantic head's chunks, 4..6 = the first three chunks of layer 8 (relu(h7),
+// half-tiles k = 0..15: H is overwritten only in that layer's last chunk).  Returns k for group g of the site, or -1.
+#ifndef NSOS_SAVE_SCHED
+#define NSOS_SAVE_SCHED 0
+#endif
+template <int SEM>
+constexpr int save_slot(int site, int g) {
+#if NSOS_SAVE_SCHED == 0
+    // at most three per chunk, six groups apart
+    if (site == 0) return (g >= 3 && g < 15 && g % 3 == 0) ? 16 + g / 3 - 1 : -1;
+    if (site >= 1 && site <= 3) {
+        const int ch = site - 1, cnt = SEM == 2 ? (ch == 2 ? 2 : 3) : 4, first = SEM == 2 ? 3 * ch : 4 * ch, step = ch == 2 ? 4 : 6;
+        if (SEM != 2 && ch == 2) return -1;
+        return (g >= 3 && (g - 3) % step == 0 && (g - 3) / step < cnt) ? first + (g - 3) / step : -1;
+    }
+    const int ch = site - 4;
+    return (g >= 3 && (g - 3) % 6 == 0 && (g - 3) / 6 < (ch == 2 ? 2 : 3)) ? 8 + 3 * ch + (g - 3) / 6 : -1;
+#elif NSOS_SAVE_SCHED == 1
+    // whole 128-byte lines (four consecutive k) in consecutive groups of ONE chunk: sem1, sem2, L8c1, L8c2; x63 in layer 0
+    if (site == 0) return (g >= 3 && g < 7) ? 16 + g - 3 : -1;
+    const int line = site == 1 ? 0 : site == 2 ? 1 : site == 4 ? 2 : site == 5 ? 3 : -1;
+    return (line >= 0 && g >= 3 && g < 7) ? 4 * line + g - 3 : -1;
+#elif NSOS_SAVE_SCHED == 3
+    // like 0, but layer 8's first chunk stays free (the eight stores of the hidden activations land right in front of it)
+    if (site == 0) return (g >= 3 && g < 15 && g % 3 == 0) ? 16 + g / 3 - 1 : -1;
+    if (site >= 1 && site <= 3) {
+        const int ch = site - 1, cnt = SEM == 2 ? (ch == 2 ? 2 : 3) : 4, first = SEM == 2 ? 3 * ch : 4 * ch, step = ch == 2 ? 4 : 6;
+        if (SEM != 2 && ch == 2) return -1;
+        return (g >= 3 && (g - 3) % step == 0 && (g - 3) / step < cnt) ? first + (g - 3) / step : -1;
+    }
+    const int ch = site - 4;
+    if (ch == 0) return -1;
+    return (g >= 3 && (g - 3) % 6 == 0 && (g - 3) / 6 < 4) ? 8 + 4 * (ch - 1) + (g - 3) / 6 : -1;
+#elif NSOS_SAVE_SCHED == 2
+    // whole lines, but two groups apart
+    if (site == 0) return (g >= 3 && g < 11 && (g - 3) % 2 == 0) ? 16 + (g - 3) / 2 : -1;
+    const int line = site == 1 ? 0 : site == 2 ? 1 : site == 4 ? 2 : site == 5 ? 3 : -1;
+    return (line >= 0 && g >= 3 && g < 11 && (g - 3) % 2 == 0) ? 4 * line + (g - 3) / 2 : -1;
+#endif
+}
+
 template <class T, int SEM, bool SAVE = false, bool PROF = false>
 __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights + 6 KiB output stage
@@ -353,13 +395,31 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         float sigma = 0.0f, sem_out[2] = {0.0f, 0.0f};
         auto from_ex = [&](auto sc) { return ex[decltype(sc)::value]; };
         auto from_H = [&](auto sc) { return H[decltype(sc)::value]; };
+        // SAVE, compact sem_in: half-tile k of relu(h7) (features 32t + 16j + {0..15}, t = k / 2, j = k & 1) as one 16-byte
+        // store per lane.  Full-sector stores: a lane holds, per 32-feature tile, the 4-feature quads q0,q2,q4,q6 (lane half 0) or
+        // q1,q3,q5,q7 (half 1) of its point -- written as they are, every store put 8 B per lane = two HALF 32-byte sectors
+        // per point (and the training kernel was bound by write transactions: +33 k cycles per tile).  Two v_permlane32_swap
+        // per word pair hand q2 <-> q1 and q6 <-> q5 across the halves, after which half 0 owns features 0..7 / 16..23 and
+        // half 1 owns 8..15 / 24..31 of the tile: one dwordx4 per lane, 32 contiguous bytes per point and instruction.
+        auto store_h7 = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, t = k >> 1, j = k & 1;
+            static_assert(k >= 0 && k < 16, "sixteen half-tile stores of relu(h7)");
+            if constexpr (SAVE) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][0], H[2 * t + j][2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][1], H[2 * t + j][3], false, false);
+#ifndef NSOS_LP8_SKIP_IN    // (A/B builds only: scripts/diag/build_variant.sh)
+                if (save_ok)   // halves: features 32t + 16j + 8kg + {0..7} = words 16t + 8j + 4kg + {0..3}
+                    *reinterpret_cast<u32x4*>(save_row + 16 * t + 8 * j + 4 * kg) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+#endif
+            }
+        };
 
         stamp();  // 1: inputs + xyz encoding
         hi_prio();   // (lag build only) this wave issues its MFMAs first in the interval that ends with its activation pass
         run_chunk(IC(32), IC(8), IC(0), IC(0), IC(32), IC(1), IC(0), Z, from_ex, [&](auto gc_) {
             constexpr int g = decltype(gc_)::value;      // SAVE, compact sem_in: the x63 slices (features 16s + 8kg + {0..7}; 63 is the 1.0 pad)
-            if constexpr (SAVE && SEM != 0 && g >= 3 && g < 15 && g % 3 == 0) {
-                constexpr int sl = g / 3 - 1;
+            if constexpr (SAVE && SEM != 0 && save_slot<SEM>(0, g) >= 16) {
+                constexpr int sl = save_slot<SEM>(0, g) - 16;
                 if (save_ok) *reinterpret_cast<u32x4*>(save_row + 128 + 8 * sl + 4 * kg) = ex[sl];
             }
         });
@@ -392,9 +452,15 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                     Ho[BASE + 2 * tt + u][q] = T::pack2(Zp[SRC][tt][8 * u + 2 * q], Zp[SRC][tt][8 * u + 2 * q + 1]);
                 }
             };
-            run_pair(IC(0), Zp[0], from_H, no_ride);
-            run_pair(IC(2), Zp[1], from_H, [&](auto gc_) { ride_act(gc_, IC(0), IC(0)); });
-            run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_act(gc_, IC(1), IC(4)); });
+            // (SAVE: the second half of relu(h7)'s stores rides in layer 8's first three chunks -- a scalar branch per site)
+            auto ride_save = [&](auto gc_, auto ch_c) {
+                constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
+                if constexpr (SAVE && SEM != 0 && save_slot<SEM>(4 + CH, g) >= 0)
+                    if (l == 8) store_h7(IC(save_slot<SEM>(4 + CH, g)));
+            };
+            run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_save(gc_, IC(0)); });
+            run_pair(IC(2), Zp[1], from_H, [&](auto gc_) { ride_act(gc_, IC(0), IC(0)); ride_save(gc_, IC(1)); });
+            run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_act(gc_, IC(1), IC(4)); ride_save(gc_, IC(2)); });
             run_pair(IC(2), Zp[1], from_H, [&](auto gc_) {
                 constexpr int g = decltype(gc_)::value;
                 if constexpr (g >= 4 && g <= 18 && (g & 1) == 0) {       // slice s = (g - 4) / 2 was last used by groups 2+2s, 3+2s
@@ -471,20 +537,13 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                     // bytes per point and instruction.
                     // Spread: the store path of a CU takes 64 B per clock and HBM drains the whole chip's burst at its own rate; with
                     // 18 stores per wave behind ONE barrier the next barrier's vmcnt(0) waited for all of it (the SAVE variant cost
-                    // what its bytes cost at the full HBM write rate, nothing overlapped).  Now six per chunk (sem+coord: 6 + 6 + 4
-                    // over the head's three chunks), every third group, and the four encoding slices ride in layer 0's chunk.
+                    // what its bytes cost at the full HBM write rate, nothing overlapped).  Now at most three per chunk: the sixteen
+                    // half-tile stores of relu(h7) ride in the head's chunks (3 + 3 + 2; without the coordinate chunk 4 + 4) and in
+                    // the first three chunks of layer 8 (3 + 3 + 2 -- H is overwritten only in that layer's last chunk), the four
+                    // encoding slices in layer 0's chunk.
                     auto ride_sem = [&](auto gc_, auto ch_c) {
                         constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
-                        constexpr int kPer = SEM == 2 ? 6 : 8, kStep = SEM == 2 ? (CH == 2 ? 2 : 3) : 2;
-                        if constexpr (SAVE && g >= 3 && (g - 3) % kStep == 0 && (g - 3) / kStep < (CH == 2 ? 4 : kPer)) {
-                            constexpr int k = CH * kPer + (g - 3) / kStep;   // tile t = k / 2, half-tile j = k & 1 (features 32t + 16j + {0..15})
-                            static_assert(k < 16, "sixteen half-tile stores of relu(h7)");
-                            constexpr int t = k >> 1, j = k & 1;
-                            const auto s0 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][0], H[2 * t + j][2], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][1], H[2 * t + j][3], false, false);
-                            if (save_ok)   // halves: features 32t + 16j + 8kg + {0..7} = words 16t + 8j + 4kg + {0..3}
-                                *reinterpret_cast<u32x4*>(save_row + 16 * t + 8 * j + 4 * kg) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                        }
+                        if constexpr (SAVE && save_slot<SEM>(1 + CH, g) >= 0) store_h7(IC(save_slot<SEM>(1 + CH, g)));
                     };
                     run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), IC(0), sacc, from_H, [&](auto gc_) { ride_sem(gc_, IC(0)); });
                     run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), IC(2), sacc, from_H, [&](auto gc_) { ride_sem(gc_, IC(1)); });
@@ -513,6 +572,29 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                                         *reinterpret_cast<f32x4*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
                                     }
                             }
+#ifndef NSOS_LP8_SKIP_HID   // (A/B builds only)
+                            if (P.sem_in16) {
+                                // compact: the hidden activations in the 16-bit format too (256 B per point instead of 512).  Per
+                                // tile a lane holds quads Qk = features 32t + 8k + 4kg + {0..3} (two packed words each); four
+                                // half-wave swaps give half 0 features 32t + {0..15} and half 1 {16..31}: two 16-byte stores per lane
+                                // and tile, 64 contiguous bytes per point.
+                                unsigned* hrow16 = P.sem_hid16 + (long long)gp * 64;
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    unsigned w[4][2];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        w[q][0] = T::pack2(relu_acc(sacc[t][4 * q]), relu_acc(sacc[t][4 * q + 1]));
+                                        w[q][1] = T::pack2(relu_acc(sacc[t][4 * q + 2]), relu_acc(sacc[t][4 * q + 3]));
+                                    }
+                                    const auto a = __builtin_amdgcn_permlane32_swap(w[0][0], w[2][0], false, false);
+                                    const auto b = __builtin_amdgcn_permlane32_swap(w[0][1], w[2][1], false, false);
+                                    const auto c = __builtin_amdgcn_permlane32_swap(w[1][0], w[3][0], false, false);
+                                    const auto d = __builtin_amdgcn_permlane32_swap(w[1][1], w[3][1], false, false);
+                                    *reinterpret_cast<u32x4*>(hrow16 + 16 * t + 8 * kg) = u32x4{a[0], b[0], a[1], b[1]};
+                                    *reinterpret_cast<u32x4*>(hrow16 + 16 * t + 8 * kg + 4) = u32x4{c[0], d[0], c[1], d[1]};
+                                }
+                            } else {
 #pragma unroll
                             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -520,6 +602,8 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                                     *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
                                         f32x4{relu_acc(sacc[t][4 * q]), relu_acc(sacc[t][4 * q + 1]),
                                               relu_acc(sacc[t][4 * q + 2]), relu_acc(sacc[t][4 * q + 3])};
+                            }
+#endif
                         }
                     }
                     float ps[2];

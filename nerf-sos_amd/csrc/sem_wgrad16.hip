@@ -26,7 +26,7 @@
 #include "x3_common.h"
 
 namespace nsos_detail {
-int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                          const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples, const float* scale,
                          float* partial, int blocks, hipStream_t st);
 }
@@ -48,7 +48,7 @@ constexpr int kLoadsG = 12, kLoadsX = 3;                 // loads per fetch of a
 struct SetG {            // waves 0..3
     f32x4 wt[2];         // compositing weights of the lane half's 8 points
     f32x2 ga, gb;        // dL/dsemantics of the ray of the first point and of the next ray
-    float h[8];          // sem_hid column 32 gt + i
+    unsigned h[8];       // sem_hid column 32 gt + i of the 8 points: the 16-bit word as loaded (zero-extended)
     int cross;           // points e >= cross belong to the next ray
 };
 struct SetX {            // waves 4..7: 3 x 16 B of the wave's four sem_in rows (160 chunks of 16 B over 64 lanes)
@@ -64,6 +64,12 @@ template <int OFF>
 __device__ __forceinline__ float ld_f32(unsigned voff, unsigned long long base) {
     float v;
     asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "i"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ unsigned ld_u16(unsigned voff, unsigned long long base) {
+    unsigned v;
+    asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "i"(OFF));
     return v;
 }
 template <int OFF>
@@ -127,7 +133,7 @@ __device__ __forceinline__ u32x2 lds_read_tr(unsigned addr) {
 
 template <int XFMT>   // 1: fp16, 2: bf16
 __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* __restrict__ weights, const float* __restrict__ g_sem,
-                                                                  const float* __restrict__ w2, const float* __restrict__ hid,
+                                                                  const float* __restrict__ w2, const unsigned short* __restrict__ hid,
                                                                   const unsigned short* __restrict__ sem_in,
                                                                   const float* __restrict__ scale_p, long long n_pts,
                                                                   long long n_rays, int S, float* __restrict__ partial) {
@@ -154,7 +160,8 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     float gw2[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f};
 
     // lane offsets (bytes) inside a step's rows; the half-wave's 8-point shift is part of them
-    const unsigned off_w = 32u * kg, off_h = (8u * kg * 128u + i) * 4u;
+    const unsigned off_w = 32u * kg, off_h = (8u * kg * 128u + i) * 2u;     // hid: 16-bit like sem_in (nsos_mlp_forward_rays_save16_lp)
+    auto widen = [](unsigned w) { return XFMT == 1 ? (float)__builtin_bit_cast(_Float16, (unsigned short)w) : __builtin_bit_cast(float, w << 16); };
     const unsigned long long g_base = uniform64(g_sem);
     // x-kind: chunk c = lane + 64 j (j = 0..2) of the wave's 4 rows x 40 chunks of 16 B; chunks past 159 repeat chunk 159 (the
     // load is issued by every lane so that the vmcnt arithmetic holds; the duplicate is not written to LDS)
@@ -179,14 +186,14 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         const unsigned q1 = q0 + 1 < (unsigned)n_rays ? q0 + 1 : q0;
         s.cross = (int)((q0 + 1) * (unsigned)S - p0);
         const unsigned long long wb = uniform64(weights + step * 16);
-        const unsigned long long hb = uniform64(hid + step * 16 * 128 + 32 * gt);
+        const unsigned long long hb = uniform64(hid + step * 16 * 128 + 32 * gt);     // (element pointer: 16-bit elements)
         s.wt[0] = ld_f32x4<0>(off_w, wb);
         s.wt[1] = ld_f32x4<16>(off_w, wb);
         s.ga = ld_f32x2(q0 * 8u, g_base);
         s.gb = ld_f32x2(q1 * 8u, g_base);
-        s.h[0] = ld_f32<0 * 512>(off_h, hb); s.h[1] = ld_f32<1 * 512>(off_h, hb); s.h[2] = ld_f32<2 * 512>(off_h, hb);
-        s.h[3] = ld_f32<3 * 512>(off_h, hb); s.h[4] = ld_f32<4 * 512>(off_h, hb); s.h[5] = ld_f32<5 * 512>(off_h, hb);
-        s.h[6] = ld_f32<6 * 512>(off_h, hb); s.h[7] = ld_f32<7 * 512>(off_h, hb);
+        s.h[0] = ld_u16<0 * 256>(off_h, hb); s.h[1] = ld_u16<1 * 256>(off_h, hb); s.h[2] = ld_u16<2 * 256>(off_h, hb);
+        s.h[3] = ld_u16<3 * 256>(off_h, hb); s.h[4] = ld_u16<4 * 256>(off_h, hb); s.h[5] = ld_u16<5 * 256>(off_h, hb);
+        s.h[6] = ld_u16<6 * 256>(off_h, hb); s.h[7] = ld_u16<7 * 256>(off_h, hb);
     };
     auto fetch_x = [&](long long step, SetX& s) {
         const unsigned long long xb = uniform64(sem_in + step * 16 * 320);
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const bool next = e >= s.cross;
-            form(s.wt[e >> 2][e & 3], next ? s.gb[0] : s.ga[0], next ? s.gb[1] : s.ga[1], s.h[e], a[e]);
+            form(s.wt[e >> 2][e & 3], next ? s.gb[0] : s.ga[0], next ? s.gb[1] : s.ga[1], widen(s.h[e]), a[e]);
         }
         put_g(a, buf);
     };
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
                 const unsigned p = p0 + e < (unsigned)n_pts ? p0 + e : (unsigned)n_pts - 1u;
                 const float wte = p0 + e < (unsigned)n_pts ? weights[p] : 0.0f;
                 const unsigned r = p / (unsigned)S;
-                form(wte, g_sem[2ull * r], g_sem[2ull * r + 1], hid[(unsigned long long)p * 128 + 32 * gt + i], a[e]);
+                form(wte, g_sem[2ull * r], g_sem[2ull * r + 1], widen(hid[(unsigned long long)p * 128 + 32 * gt + i]), a[e]);
             }
             put_g(a, 0);
         } else {
@@ -344,16 +351,17 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 }
 }  // namespace
 
-int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
+int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                                       const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
                                       const float* scale, float* partial, int blocks, hipStream_t st) {
     const long long n_pts = (long long)n_rays * n_samples;
     const unsigned short* x = static_cast<const unsigned short*>(sem_in);
+    const unsigned short* h = static_cast<const unsigned short*>(sem_hid);
     if (sem_in_dtype == 1)
-        hipLaunchKernelGGL(sem_head_wgrad16_kernel<1>, dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, sem_hid, x,
+        hipLaunchKernelGGL(sem_head_wgrad16_kernel<1>, dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x,
                            scale, n_pts, (long long)n_rays, (int)n_samples, partial);
     else
-        hipLaunchKernelGGL(sem_head_wgrad16_kernel<2>, dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, sem_hid, x,
+        hipLaunchKernelGGL(sem_head_wgrad16_kernel<2>, dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x,
                            scale, n_pts, (long long)n_rays, (int)n_samples, partial);
     return nsos_launch_status();
 }

@@ -247,8 +247,9 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
                           viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32", compact: bool = False):
     """Training-mode K2 (frozen backbone): raw [R,S,6] plus the semantic head's saved inputs
     sem_in [R*S,320] = [relu(h7) | x63 | 1] and sem_hid [R*S,128] (see nsos_mlp_forward_rays_save[_lp]).
-    `packed` must have been packed for the same `precision`.  compact (16-bit precisions only): sem_in comes back in its
-    own 16-bit dtype (the values are 16-bit anyway), half the bytes to store and to read back in sem_head_wgrad."""
+    `packed` must have been packed for the same `precision`.  compact (16-bit precisions only): sem_in AND sem_hid come back
+    in the precision's own 16-bit dtype (sem_in's values are 16-bit anyway; sem_hid is rounded): 896 B per point instead of
+    1792 to store and to read back in sem_head_wgrad."""
     if sem_mode == SEM_NONE:
         raise ValueError("mlp_forward_rays_save needs a semantic head")
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
@@ -259,7 +260,7 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     compact = compact and precision in ("fp16", "bf16")
     sem_in = torch.empty((R * S, 320), device=dev,
                          dtype=(torch.float16 if precision == "fp16" else torch.bfloat16) if compact else torch.float32)
-    sem_hid = torch.empty((R * S, 128), device=dev, dtype=torch.float32)
+    sem_hid = torch.empty((R * S, 128), device=dev, dtype=sem_in.dtype if compact else torch.float32)
     ev = _ev_begin()
     if precision == "fp32":
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
@@ -308,11 +309,13 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     split_fp16: the big reduction on the 16-bit matrix pipe with split operands (nsos_sem_head_wgrad_x3; needs S >= 8 and
     fewer than 2^31 points, else the exact kernel runs)."""
     weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
-    sem2_w, sem_hid = _dev(sem2_w, "semantic_linear.2.weight"), _dev(sem_hid, "sem_hid")
+    sem2_w = _dev(sem2_w, "semantic_linear.2.weight")
     x_dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}.get(sem_in.dtype)
     if x_dtype is None or not sem_in.is_cuda:
         raise TypeError(f"sem_in must be a float32 / float16 / bfloat16 GPU tensor, got {sem_in.dtype} on {sem_in.device}")
-    sem_in = sem_in.contiguous()
+    if not sem_hid.is_cuda or sem_hid.dtype not in (torch.float32, sem_in.dtype):
+        raise TypeError(f"sem_hid must be a GPU tensor, float32 or of sem_in's dtype {sem_in.dtype}; got {sem_hid.dtype}")
+    sem_in, sem_hid = sem_in.contiguous(), sem_hid.contiguous()
     R, S = weights.shape
     if (tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (R * S, 128) or tuple(sem2_w.shape) != (2, 128)
             or tuple(sem_in.shape) != (R * S, 320)):
@@ -327,6 +330,10 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     use_split = split_fp16 and S >= 8 and R * S < 2 ** 31
     if not use_split and x_dtype != 0:
         sem_in, x_dtype = sem_in.float(), 0          # the exact kernel reads fp32
+    if x_dtype == 0:
+        sem_hid = sem_hid.float()                    # fp32 sem_in: fp32 hid (the 16-bit kernel reads both matrices in one format)
+    elif sem_hid.dtype != sem_in.dtype:
+        sem_hid = sem_hid.to(sem_in.dtype)
     if use_split:   # the power of two that keeps g_hid in fp16 range is derived (and divided out again) on the device
         _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), x_dtype,
                                                      R, S, None, _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,

@@ -281,13 +281,16 @@ def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
         res[split] = [float((x.double() - w).abs().max() / (w.abs().max() + 1e-300)) for x, w in zip(a, (want1, want2, wantb))]
     for k in range(3):
         assert res[True][k] <= max(3e-6, 4 * res[False][k]), (k, res)
-    # the compact 16-bit sem_in of the reduced-precision training path: same numbers when the values are 16-bit to begin with
+    # the compact 16-bit matrices of the reduced-precision training path (sem_in AND sem_hid in the 16-bit format,
+    # nsos_mlp_forward_rays_save16_lp): same numbers as the fp32 kernels fed the same 16-bit VALUES
     for dt in (torch.float16, torch.bfloat16):
-        x16 = sem_in.to(dt)
-        a = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16, split_fp16=True)
-        b = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16.float(), split_fp16=True)
+        x16, h16 = sem_in.to(dt), hid.to(dt)
+        a = ops.sem_head_wgrad(weights, g_sem, w2, h16, x16, split_fp16=True)
+        b = ops.sem_head_wgrad(weights, g_sem, w2, h16.float(), x16.float(), split_fp16=True)
         for x, y in zip(a, b):
             assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max() + 1e-30), dt
+        c = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16, split_fp16=True)      # an fp32 hid is rounded on the way in
+        assert all(torch.equal(x, y) for x, y in zip(a, c)), dt
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16"])
