@@ -158,3 +158,83 @@ def test_bench_launches_its_own_ranks():
     assert c4["patches"] == 4 and c4["rays_per_gpu"] == 8192
     assert c4["collectives"]["all_gathers_per_step"] == 1 and c4["collectives"]["gathered_bytes_per_patch"] > 400_000
     assert c4["collectives"]["all_gather_ms"] > 0 and c4["collectives"]["all_reduce_floats"] == 2 * 41218
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("config,steps", [("c2", 2), ("c4", 2), ("c5", 1)])
+def test_bench_eight_ranks_smoke(config, steps):
+    """`python bench.py --gpus 8 --config ...` -- the driver's 8-GPU command shape -- for the three configurations that
+    shard: c2 (4096 rays per rank, no collective), c4 (B = 16 patches, two per rank: the flat patch all-gather, the
+    geometric loss's phase reductions, the gradient all-reduce) and c5 (95 256 rays per rank, ragged last 65 536-ray
+    chunk).  On a one-GPU box all eight ranks share cuda:0 over gloo (NSOS_BENCH_SHARE_GPU=1): the numbers mean nothing,
+    the launch, the per-rank seeds / shards and the collective sequence are the point; every collective runs under the
+    package's watchdog (a diverged sequence fails instead of hanging)."""
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 8:
+        env["NSOS_BENCH_SHARE_GPU"] = "1"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["NSOS_COLLECTIVE_TIMEOUT_S"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", config, "--steps", str(steps),
+                        "--warmup", "1", "--no-variants"], env=env, capture_output=True, text=True, timeout=1400)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["distributed"]["ranks_seen_by_collective"] == 8 and j["value"] > 0
+    if config == "c2":
+        assert j["scaling"] == "weak" and j["config"]["rays_per_gpu"] == 4096
+    if config == "c4":
+        c = j["collectives"]
+        assert j["config"]["patches"] == 16 and j["config"]["rays_per_gpu"] == 8192
+        assert c["all_gathers_per_step"] == 1 and c["gathered_bytes_per_patch"] == 482816
+        # per step and rank: ONE flat patch gather, the stacked geometric loss's three phase reductions + its role-sum
+        # reduction, ONE flat gradient all-reduce -- counted by sharding.collective, nothing hidden
+        assert c["calls_per_step_by_kind"] == {"all_gather": 1.0, "geo_loss_phase_all_reduce": 3.0,
+                                                "geo_loss_role_sum_all_reduce": 1.0, "grad_all_reduce": 1.0}, c
+        assert c["all_reduce_floats"] == 2 * 41218 and abs(j["loss"]) < 10
+    if config == "c5":
+        assert j["scaling"] == "strong" and j["config"]["rays_per_gpu"] == 95256 and j["finite"] is True
+
+
+def test_collective_watchdog_names_the_diverged_collective():
+    """A rank that skips a collective its peers issue must produce an error naming the collective, not a hang: two gloo
+    ranks, rank 1 leaves out one all-reduce; rank 0's wait gives up after COLLECTIVE_TIMEOUT_S."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 777
+    procs = [ctx.Process(target=_watchdog_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert "grad_all_reduce" in res[0] and "did not complete" in res[0], res
+    assert res[1] == "skipped"
+
+
+def _watchdog_worker(rank, port, q):
+    import datetime
+    from nerf_sos_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=60))
+    sharding.COLLECTIVE_TIMEOUT_S = 5.0
+    p = torch.nn.Parameter(torch.ones(4, device="cuda:0"))
+    p.grad = torch.ones(4, device="cuda:0")
+    try:
+        sharding.all_reduce_grads([p])                     # both ranks: fine
+        if rank == 0:
+            try:
+                sharding.all_reduce_grads([p])             # rank 1 never issues this one
+                q.put((0, "no error"))
+            except RuntimeError as e:
+                q.put((0, str(e)))
+        else:
+            q.put((1, "skipped"))
+            import time
+            time.sleep(8)
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
