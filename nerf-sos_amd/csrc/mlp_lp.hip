@@ -570,7 +570,9 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     // NSOS_LP_WAVES=4 selects the one-wave-per-SIMD kernel of round 1 (A/B measurements); default: two waves per SIMD
     // (mlp_lp8_kernel indexes its points with 32 bits: launches of 2^31 points or more -- 11 M rays x 192 samples -- take the
     //  round-1 kernel, whose results are bit-identical)
-    if (lp_waves_per_simd() == 2 && n_pts < (1ll << 31)) {
+    // (its training variant stores the compact 16-bit operands only: the fp32 sem_in / sem_hid of nsos_mlp_forward_rays_save_lp
+    //  -- tests and the exact-kernel backward -- come from the round-1 kernel as well)
+    if (lp_waves_per_simd() == 2 && n_pts < (1ll << 31) && !(sem_in && !sem_in16)) {
         if (sem_in || sem_in16) NSOS_REQUIRE((sem_in16 ? (void*)sem_hid16 : (void*)sem_hid) && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
         p.chunks += (size_t)lp_chunks(sem_mode) * kSlotBytes;   // the second stream: tile-pair-major hidden layers
         return launch_lp8(p, sem_mode, dtype == NSOS_DTYPE_F16, sem_in || sem_in16, st);

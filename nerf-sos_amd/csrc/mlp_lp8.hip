@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         bool save_ok = false;
         unsigned* save_row = nullptr;
         if constexpr (SAVE) {
-            save_ok = exists && P.sem_in16 != nullptr;
+            save_ok = exists;     // (this kernel's SAVE variant is the compact one: sem_in16 / sem_hid16 are never NULL, see forward_rays_lp)
             save_row = P.sem_in16 + (long long)gc * 160;
         }
         u32x4 ex[4];
@@ -430,7 +430,19 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         // Layers 1..4 and 6..8 are tile-pair-major with a riding activation; the skip layer 5 (its x63 part follows the h part in
         // every accumulator) stays slice-major with one exposed pass.  Two runtime loops with ONE uniform body each (a single
         // loop with both bodies made hipcc reconcile their register assignments with 160 v_mov per layer at the back edge).
-        auto pair_layer = [&](const int l) {
+        // The exposed rest of a pair layer's activation (tiles 6,7 = the accumulators Zp[1], 16 packed words) can wait: the NEXT
+        // pair layer's first chunk accumulates into Zp[0], reads the slices in order (slice 12 = the first of these words
+        // only from group 26 on) and has its MFMA gaps free -- so inside a run of pair layers (1..4, 6..7) the conversion rides
+        // there (groups 4..21) instead of standing between the layers with the matrix pipe idle.  The last layer of a run
+        // (4, 7, 8: what follows needs all of H at once) keeps the exposed pass.  Same values, same order: bit-identical.
+        f32x16 Zp[2][2];
+        // (a value that is only CONDITIONALLY read at the top of a run is live, for the compiler, from its last definition --
+        // through layers 0 and 5, whose 128 accumulators leave no room for 32 more registers: an empty asm "defines" the
+        // accumulators afresh where they are dead, at no cost)
+        auto dead = [&]() {
+            asm volatile("" : "=v"(Zp[0][0]), "=v"(Zp[0][1]), "=v"(Zp[1][0]), "=v"(Zp[1][1]));
+        };
+        auto pair_layer = [&](const int l, const bool tail_pending, const bool leave_tail) {
             // Tile-pair-major: chunk c accumulates output tiles 2c, 2c+1 over all 16 input slices into Zp[c & 1]; the
             // activation of the PREVIOUS pair rides behind this chunk's MFMAs (2 VALU per packed word, one word per MFMA
             // gap: the accumulators are VGPRs, nothing to read back).  The layer's input H stays live until its last
@@ -439,8 +451,26 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
             // (group 26 on); only tiles 6,7 (16 words) remain for after the chunk.  Per accumulator the MFMA order is
             // the round-1 kernel's (bias, slices 0..15): results stay bit-identical.
             const unsigned floor = l < 8 ? 0u : 0x80008000u;     // feature_linear (l == 8) has no activation
-            f32x16 Zp[2][2];
             u32x4 Ho[8];
+            auto ride_tail = [&](auto gc_) {     // the previous layer's tiles 6,7 -> H[12..15] (always a ReLU layer: floor 0)
+                constexpr int g = decltype(gc_)::value;
+                if constexpr (g >= 4 && g <= 21) {
+                    if (tail_pending) {
+                        if constexpr (g >= 5 && g < 21) {
+                            constexpr int k = g - 5;
+                            NSOS_RELU_WORD(H[12 + (k >> 2)][k & 3], 0u);
+                        }
+                        if constexpr (g >= 4 && g < 20) {
+                            constexpr int k = g - 4, tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                            H[12 + 2 * tt + u][q] = T::pack2(Zp[1][tt][8 * u + 2 * q], Zp[1][tt][8 * u + 2 * q + 1]);
+                        }
+                        if constexpr (g == 21) {
+                            NSOS_RELU_WORD(H[11][2], 0u);
+                            NSOS_RELU_WORD(H[11][3], 0u);
+                        }
+                    }
+                }
+            };
             auto ride_act = [&](auto gc_, auto src_c, auto base_c) {   // 16 words of pair buffer src -> Ho[base .. base+3]: convert in groups 4..19, clamp one group later
                 constexpr int g = decltype(gc_)::value, SRC = decltype(src_c)::value, BASE = decltype(base_c)::value;
                 if constexpr (g >= 5 && g < 21) {
@@ -458,7 +488,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 if constexpr (SAVE && SEM != 0 && save_slot<SEM>(4 + CH, g) >= 0)
                     if (l == 8) store_h7(IC(save_slot<SEM>(4 + CH, g)));
             };
-            run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_save(gc_, IC(0)); });
+            run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_tail(gc_); ride_save(gc_, IC(0)); });
             run_pair(IC(2), Zp[1], from_H, [&](auto gc_) { ride_act(gc_, IC(0), IC(0)); ride_save(gc_, IC(1)); });
             run_pair(IC(0), Zp[0], from_H, [&](auto gc_) { ride_act(gc_, IC(1), IC(4)); ride_save(gc_, IC(2)); });
             run_pair(IC(2), Zp[1], from_H, [&](auto gc_) {
@@ -481,20 +511,24 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 }
             });
             stamp();  // 2 + 2l: MFMAs of layer l (with the riding activation of tiles 0..5)
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (asm hides the reads)
+            if (!leave_tail) {
+                asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // MFMA result -> VALU read wait states (asm hides the reads)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {                       // tiles 6,7: 16 conversions, then 16 clamps (+ the last two of tiles 4,5)
-                const int tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
-                H[12 + 2 * tt + u][q] = T::pack2(Zp[1][tt][8 * u + 2 * q], Zp[1][tt][8 * u + 2 * q + 1]);
+                for (int k = 0; k < 16; ++k) {                       // tiles 6,7: 16 conversions, then 16 clamps (+ the last two of tiles 4,5)
+                    const int tt = k >> 3, u = (k >> 2) & 1, q = k & 3;
+                    H[12 + 2 * tt + u][q] = T::pack2(Zp[1][tt][8 * u + 2 * q], Zp[1][tt][8 * u + 2 * q + 1]);
+                }
+                NSOS_RELU_WORD(H[11][2], floor);
+                NSOS_RELU_WORD(H[11][3], floor);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) NSOS_RELU_WORD(H[12 + (k >> 2)][k & 3], floor);
             }
-            NSOS_RELU_WORD(H[11][2], floor);
-            NSOS_RELU_WORD(H[11][3], floor);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) NSOS_RELU_WORD(H[12 + (k >> 2)][k & 3], floor);
-            stamp();  // 3 + 2l: the exposed rest of the activation (tiles 6,7)
+            stamp();  // 3 + 2l: the exposed rest of the activation (tiles 6,7), unless it rides in the next layer
         };
+        dead();
 #pragma unroll 1
-        for (int l = 1; l <= 4; ++l) pair_layer(l);
+        for (int l = 1; l <= 4; ++l) pair_layer(l, l != 1, l != 4);
+        dead();
         {   // l = 5
             // skip layer: slice-major over all 8 tiles (its x63 part follows the h part in every accumulator), one
             // exposed activation pass
@@ -507,10 +541,12 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
             activate1<T, 8, true>(H, Z);
             stamp();  // 3 + 2l: activation pass
         }
+        dead();
 #pragma unroll 1
         for (int l = 6; l <= 8; ++l) {
-            pair_layer(l);
+            pair_layer(l, l == 7, l == 6);
             if (l == 7) {
+                dead();      // layer 7 finished its own tail: nothing of Zp is read again before layer 8 redefines it
                 // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
                 const unsigned* aw = aux_l + kAuxAlphaW + kg * 64;
                 float pa = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]);
@@ -524,23 +560,14 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 sigma = both_halves(pa);
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
                     f32x16 sacc[4];
-                    // SAVE, compact sem_in: the 36 stores of [relu(h7) | x63 | 1] (packed words as they are) ride in these two
-                    // chunks' MFMA shadows, one per group in groups 3..20 -- EARLY in the chunk: the next chunk's barrier waits
-                    // for every outstanding vector-memory operation (its DMA pieces share the counter with the stores), and a
-                    // store issued just ahead of it exposes its whole HBM latency (measured: this phase took 35 k cycles
-                    // instead of 10 k with the stores in groups 11..33)
-                    // Full-sector stores: a lane holds, per 32-feature tile, the 4-feature quads q0,q2,q4,q6 (lane half 0) or
-                    // q1,q3,q5,q7 (half 1) of its point -- written as they are, every store put 8 B per lane = two HALF 32-byte
-                    // sectors per point (and the training kernel was bound by write transactions: +33 k cycles per tile).  Two
-                    // v_permlane32_swap per word pair hand q2 <-> q1 and q6 <-> q5 across the halves, after which half 0 owns
-                    // features 0..7 / 16..23 and half 1 owns 8..15 / 24..31 of the tile: one dwordx4 per lane, 32 contiguous
-                    // bytes per point and instruction.
-                    // Spread: the store path of a CU takes 64 B per clock and HBM drains the whole chip's burst at its own rate; with
-                    // 18 stores per wave behind ONE barrier the next barrier's vmcnt(0) waited for all of it (the SAVE variant cost
-                    // what its bytes cost at the full HBM write rate, nothing overlapped).  Now at most three per chunk: the sixteen
-                    // half-tile stores of relu(h7) ride in the head's chunks (3 + 3 + 2; without the coordinate chunk 4 + 4) and in
-                    // the first three chunks of layer 8 (3 + 3 + 2 -- H is overwritten only in that layer's last chunk), the four
-                    // encoding slices in layer 0's chunk.
+                    // SAVE (compact operands): the twenty 16-byte stores of a point's sem_in row [relu(h7) | x63 | 1] ride in MFMA
+                    // shadows EARLY in their chunks -- the next chunk's barrier waits for every outstanding vector-memory operation
+                    // (its DMA pieces share the counter with the stores), and a store issued just ahead of it exposes its whole HBM
+                    // latency -- and SPREAD: the store path of a CU takes 64 B per clock and HBM drains the whole chip's burst at its
+                    // own rate; with 18 stores per wave behind ONE barrier (round 2) the next barrier's vmcnt(0) waited for all of it
+                    // and the training variant cost what its bytes cost at the full HBM write rate, nothing overlapped (+16.4 %).
+                    // Now at most three per chunk (save_slot): relu(h7) in the head's chunks and in the first three chunks of
+                    // layer 8, the encoding slices in layer 0's chunk; with the hidden activations stored as 16 bits (+7 %).
                     auto ride_sem = [&](auto gc_, auto ch_c) {
                         constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
                         if constexpr (SAVE && save_slot<SEM>(1 + CH, g) >= 0) store_h7(IC(save_slot<SEM>(1 + CH, g)));
@@ -551,29 +578,8 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                     if constexpr (SAVE) {
                         auto relu_acc = [](float a) { return fmaxf(a, 0.0f); };
                         if (exists) {
-                            float* hrow = P.sem_hid + (long long)gp * 128;
-                            if (!P.sem_in16) {
-                                float* row = P.sem_in + (long long)gp * 320;
-#pragma unroll
-                                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                                        for (int q = 0; q < 4; q += 2) {   // words q, q+1 = accumulator elements 8u+2q .. +3 of tile t: 4 consecutive features
-                                            const unsigned w0 = H[2 * t + u][q], w1 = H[2 * t + u][q + 1];
-                                            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
-                                                f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
-                                        }
-#pragma unroll
-                                for (int sl = 0; sl < 4; ++sl)
-#pragma unroll
-                                    for (int q = 0; q < 4; q += 2) {    // slice words q, q+1 = features 16s + 8kg + 2q .. +3; 63 is the 1.0 pad
-                                        const unsigned w0 = ex[sl][q], w1 = ex[sl][q + 1];
-                                        *reinterpret_cast<f32x4*>(row + 256 + 16 * sl + 8 * kg + 2 * q) = f32x4{T::lo(w0), T::hi(w0), T::lo(w1), T::hi(w1)};
-                                    }
-                            }
 #ifndef NSOS_LP8_SKIP_HID   // (A/B builds only)
-                            if (P.sem_in16) {
+                            {
                                 // compact: the hidden activations in the 16-bit format too (256 B per point instead of 512).  Per
                                 // tile a lane holds quads Qk = features 32t + 8k + 4kg + {0..3} (two packed words each); four
                                 // half-wave swaps give half 0 features 32t + {0..15} and half 1 {16..31}: two 16-byte stores per lane
@@ -594,14 +600,6 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                                     *reinterpret_cast<u32x4*>(hrow16 + 16 * t + 8 * kg) = u32x4{a[0], b[0], a[1], b[1]};
                                     *reinterpret_cast<u32x4*>(hrow16 + 16 * t + 8 * kg + 4) = u32x4{c[0], d[0], c[1], d[1]};
                                 }
-                            } else {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
-                                        f32x4{relu_acc(sacc[t][4 * q]), relu_acc(sacc[t][4 * q + 1]),
-                                              relu_acc(sacc[t][4 * q + 2]), relu_acc(sacc[t][4 * q + 3])};
                             }
 #endif
                         }
@@ -616,6 +614,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 stamp();  // 18 (l == 7 only; the later slots shift by one): sigma + semantic heads
             }
         }
+        dead();
         // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
         f32x16 vacc[4];
         run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), IC(0), vacc, from_H, no_ride);
