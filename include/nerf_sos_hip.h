@@ -398,6 +398,20 @@ int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float*
                                        int32_t code_dim, int32_t height, int32_t width, float self_shift, float self_weight,
                                        float neg_shift, float neg_weight, float max_depth, int32_t filter_in_place, float* loss,
                                        float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
+/* The training step's form of the row-partitioned call (engines/trainer.py:147-166 scores the coarse AND the fine semantic map
+ * against the same geometry): TWO codes over ONE set of `batch` geometry patches, evaluated as the stacked batch of 2 * batch
+ * patches [code0; code1] -- every term of the loss is a mean over the batch and the batch-wide quantities it subtracts depend
+ * on the geometry only, so the result is (L(code0) + L(code1)) / 2 -- without materialising the stack (patch n reads geometry
+ * n % batch and code n / batch).  neg_indx [2*batch] and rows index the STACKED batch (neg of patch batch+b = batch + neg of b).
+ * channel_last != 0: code0/1 and grad_code0/1 are [batch,H,W,C], ray_o / ray_d [batch,H,W,3] -- the renderer's own tensors;
+ * 0: [batch,C,H,W] / [batch,3,H,W].  depth [batch,H*W] is read only (values > max_depth are filtered on the fly).
+ * workspace: nsos_corr_workspace_bytes(1, 2*batch, H*W, 0).  Phases and reductions as nsos_geo_correlation_loss_rows. */
+int32_t nsos_geo_correlation_loss_pair(int32_t phase, const float* depth, const float* code0, const float* code1,
+                                       const float* ray_o, const float* ray_d, const int64_t* neg_indx, const int32_t* rows,
+                                       int32_t n_rows, int32_t batch, int32_t channel_last, int32_t code_dim, int32_t height,
+                                       int32_t width, float self_shift, float self_weight, float neg_shift, float neg_weight,
+                                       float max_depth, float* loss, float* grad_code0, float* grad_code1, void* workspace,
+                                       size_t workspace_bytes, void* stream);
 
 /* ---- contrastive loss on the batch's class tokens (BASELINE configs[2]: "contrastive loss") ---------------
  * NeRFContrastive.forward with min_max_contrast=True (utils/image.py:192-218; call site engines/trainer.py:168-170,
@@ -428,6 +442,13 @@ int32_t nsos_app_correlation_loss(const float* feats, const float* code, const i
                                   int32_t code_dim, int32_t code_h, int32_t code_w, int32_t feature_samples,
                                   float self_shift, float self_weight, float neg_shift, float neg_weight, float* loss,
                                   float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with code [B,Hc,Wc,C] and grad_code in that layout: the renderer's own `semantics` tensor as it is (no
+ * permute().contiguous() copy on the way in, none of the gradient on the way out). */
+int32_t nsos_app_correlation_loss_nhwc(const float* feats, const float* code, const int64_t* neg_indx, const float* rand1,
+                                       const float* rand2, int32_t batch, int32_t feat_dim, int32_t feat_h, int32_t feat_w,
+                                       int32_t code_dim, int32_t code_h, int32_t code_w, int32_t feature_samples,
+                                       float self_shift, float self_weight, float neg_shift, float neg_weight, float* loss,
+                                       float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
 int32_t nsos_geo_correlation_loss(float* depth, const float* code, const float* ray_o, const float* ray_d,
                                   const int64_t* neg_indx, int32_t batch, int32_t code_dim, int32_t height,
                                   int32_t width, float self_shift, float self_weight, float neg_shift,

@@ -74,6 +74,10 @@ SIGNATURES = {
     "nsos_corr_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "nsos_app_correlation_loss": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _f32, _f32, _f32, _f32, _fp, _fp, _fp, _sz, _fp]),
+    "nsos_app_correlation_loss_nhwc": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                              _f32, _f32, _f32, _f32, _fp, _fp, _fp, _sz, _fp]),
+    "nsos_geo_correlation_loss_pair": (_i32, [_i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
+                                              _f32, _f32, _f32, _fp, _fp, _fp, _fp, _sz, _fp]),
     "nsos_geo_correlation_loss": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32,
                                          _i32, _fp, _fp, _fp, _sz, _fp]),
     "nsos_corr_workspace_slots": (_i32, [_i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

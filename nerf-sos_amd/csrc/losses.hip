@@ -124,31 +124,51 @@ __global__ void depth_max_finish_kernel(const double* __restrict__ partial, int 
     scal[6] = m;   // -1e300 if no element was below max_depth (torch raises on the empty max; here the filter yields NaN-free -inf)
 }
 
+// How a kernel finds the inputs of patch n of a (possibly stacked) batch.  The training step scores TWO semantic maps (coarse
+// and fine) against the SAME geometry (engines/trainer.py:147-166): the stacked batch of n_codes * Bg patches is never
+// materialised -- patch n takes its depth / rays from geometry patch n % Bg and its code from tensor n / Bg -- and the renderer's
+// own channel-last tensors ([B,P,P,C]: `semantics`, rays [B,P,P,3]) are read as they are (channel_last), so neither the
+// permute().contiguous() copies nor the repeat() / cat() of the stacked evaluation exist.
+struct GeoInputs {
+    const float* code[2];     // n_codes tensors [Bg, C, N] (NCHW) or [Bg, N, C] (channel_last)
+    float* grad[2];           // d loss / d code, same layout (may be NULL)
+    const float* ray_o;       // [Bg, 3, N] or [Bg, N, 3]
+    const float* ray_d;
+    int Bg, n_codes, channel_last;
+    __device__ __forceinline__ size_t code_at(int g, int c, int p, int C, int N) const {
+        return channel_last ? ((size_t)g * N + p) * C + c : ((size_t)g * C + c) * N + p;
+    }
+    __device__ __forceinline__ size_t ray_at(int g, int k, int p, int N) const {
+        return channel_last ? ((size_t)g * N + p) * 3 + k : ((size_t)g * 3 + k) * N + p;
+    }
+};
+
 template <int C>
-__global__ __launch_bounds__(256) void geo_prep_kernel(float* __restrict__ depth, const float* __restrict__ code,
-                                                       const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+__global__ __launch_bounds__(256) void geo_prep_kernel(float* __restrict__ depth, const GeoInputs in,
                                                        int B, int N, float max_depth, int write_back,
                                                        const double* __restrict__ scal, float* __restrict__ pts,
                                                        float* __restrict__ cn, float* __restrict__ dinv) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * N) return;
     const int n = (int)(i / N), p = (int)(i % N);
-    float d = depth[i];
+    const int g = n % in.Bg, which = n / in.Bg;
+    float d = depth[(size_t)g * N + p];
     if (d > max_depth) {  // :455
         d = (float)scal[6];
-        if (write_back) depth[i] = d;
+        if (write_back && which == 0) depth[(size_t)g * N + p] = d;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const long long j = ((long long)n * 3 + k) * N + p;
-        const float m = ray_d[j] * d;
-        pts[i * 4 + k] = ray_o[j] + m;   // depth2pts, :443
+        const size_t j = in.ray_at(g, k, p, N);
+        const float m = in.ray_d[j] * d;
+        pts[i * 4 + k] = in.ray_o[j] + m;   // depth2pts, :443
     }
     pts[i * 4 + 3] = 0.0f;
     float v[C], ss = 0.0f;
+    const float* code = in.code[which];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        v[c] = code[((long long)n * C + c) * N + p];
+        v[c] = code[in.code_at(g, c, p, C, N)];
         ss = c == 0 ? v[c] * v[c] : ss + v[c] * v[c];
     }
     const float nrm = sqrtf(ss), den = fmaxf(nrm, 1e-10f);  // F.normalize(dim=1, eps=1e-10), :301
@@ -448,7 +468,7 @@ __device__ __forceinline__ void normalize_backward(const float (&gy)[C], const f
 template <int C>
 __global__ __launch_bounds__(256) void geo_grad_kernel(int B, int N, const long long* __restrict__ neg, const float* __restrict__ cn,
                                                        const float* __restrict__ dinv, const float* __restrict__ grow,
-                                                       const float* __restrict__ gcol, float* __restrict__ grad_code) {
+                                                       const float* __restrict__ gcol, const GeoInputs in) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * N) return;
     const int m = (int)(i / N), p = (int)(i % N);
@@ -466,8 +486,10 @@ __global__ __launch_bounds__(256) void geo_grad_kernel(int B, int N, const long 
             for (int c = 0; c < C; ++c) gy[c] += gcol[((size_t)(0 * B + n) * N + p) * kMaxC + c];
     float gv[C];
     normalize_backward<C>(gy, cn + i * kMaxC, dinv[i * 2], dinv[i * 2 + 1], gv);
+    float* grad_code = in.grad[m / in.Bg];
+    if (!grad_code) return;
 #pragma unroll
-    for (int c = 0; c < C; ++c) grad_code[((long long)m * C + c) * N + p] = gv[c];
+    for (int c = 0; c < C; ++c) grad_code[in.code_at(m % in.Bg, c, p, C, N)] = gv[c];
 }
 
 // ------------------------------------------------------------------------------------------ appearance loss pieces
@@ -498,13 +520,13 @@ __device__ __forceinline__ void sample_coord(const float* rnd, int n, int p, int
     gx = r[0] * 2.0f - 1.0f;
     gy = r[1] * 2.0f - 1.0f;
 }
-__device__ __forceinline__ float bilinear_fetch(const float* img, int W, int H, const Bilinear& b) {
+__device__ __forceinline__ float bilinear_fetch(const float* img, int W, int H, const Bilinear& b, int px = 1) {   // px: floats between pixels
     float out = 0.0f;
     const bool xin = b.x0 + 1 <= W - 1, yin = b.y0 + 1 <= H - 1;
-    out = img[(size_t)b.y0 * W + b.x0] * b.w[0];
-    if (xin) out = out + img[(size_t)b.y0 * W + b.x0 + 1] * b.w[1];
-    if (yin) out = out + img[(size_t)(b.y0 + 1) * W + b.x0] * b.w[2];
-    if (xin && yin) out = out + img[(size_t)(b.y0 + 1) * W + b.x0 + 1] * b.w[3];
+    out = img[((size_t)b.y0 * W + b.x0) * px] * b.w[0];
+    if (xin) out = out + img[((size_t)b.y0 * W + b.x0 + 1) * px] * b.w[1];
+    if (yin) out = out + img[((size_t)(b.y0 + 1) * W + b.x0) * px] * b.w[2];
+    if (xin && yin) out = out + img[((size_t)(b.y0 + 1) * W + b.x0 + 1) * px] * b.w[3];
     return out;
 }
 
@@ -515,7 +537,8 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
                                                          const long long* __restrict__ neg, const float* __restrict__ rnd1,
                                                          const float* __restrict__ rnd2, int B, int Cf, int Hf, int Wf, int Hc,
                                                          int Wc, int S, float* __restrict__ fn, float* __restrict__ cn,
-                                                         float* __restrict__ cn2, float* __restrict__ dinv, float* __restrict__ dinv2) {
+                                                         float* __restrict__ cn2, float* __restrict__ dinv, float* __restrict__ dinv2,
+                                                         int channel_last) {
     __shared__ double red[2];
     const int p = blockIdx.x, n = blockIdx.y, side = blockIdx.z, N = S * S;
     const int src = side == 0 ? n : (int)neg[n];
@@ -539,7 +562,8 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
         float v[C], s2 = 0.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            v[c] = bilinear_fetch(code + ((size_t)src * C + c) * Hc * Wc, Wc, Hc, bc);
+            v[c] = channel_last ? bilinear_fetch(code + (size_t)src * C * Hc * Wc + c, Wc, Hc, bc, C)     // [B,Hc,Wc,C]: the renderer's own layout
+                                : bilinear_fetch(code + ((size_t)src * C + c) * Hc * Wc, Wc, Hc, bc);
             s2 = c == 0 ? v[c] * v[c] : s2 + v[c] * v[c];
         }
         const float nrm = sqrtf(s2), den = fmaxf(nrm, 1e-10f);
@@ -609,7 +633,7 @@ template <int C>
 __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, int Hc, int Wc, const long long* __restrict__ neg,
                                                           const float* __restrict__ rnd1, const float* __restrict__ rnd2,
                                                           const float* __restrict__ g1, const float* __restrict__ g2,
-                                                          float* __restrict__ grad_code) {
+                                                          float* __restrict__ grad_code, int channel_last) {
     constexpr int kMaxSamples = 1024;
     __shared__ int corner[kMaxSamples];          // x0 | y0 << 16
     __shared__ float weight[kMaxSamples][4];
@@ -654,7 +678,8 @@ __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, i
             }
     if (!live) return;
 #pragma unroll
-    for (int c = 0; c < C; ++c) grad_code[((size_t)m * C + c) * Hc * Wc + (size_t)y * Wc + x] = acc[c];
+    for (int c = 0; c < C; ++c)
+        grad_code[channel_last ? (((size_t)m * Hc + y) * Wc + x) * C + c : ((size_t)m * C + c) * Hc * Wc + (size_t)y * Wc + x] = acc[c];
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -712,22 +737,23 @@ int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStrea
 }
 
 template <int C>
-int32_t geo_impl(float* depth, const float* code, const float* ray_o, const float* ray_d, const long long* neg, int B, int N,
-                 CorrParams prm, float max_depth, int write_back, float* loss, float* grad_code, void* workspace, hipStream_t st) {
+int32_t geo_impl(float* depth, const GeoInputs in, const long long* neg, int B, int N,
+                 CorrParams prm, float max_depth, int write_back, float* loss, void* workspace, hipStream_t st) {
+    const bool want_grad = in.grad[0] != nullptr || in.grad[1] != nullptr;
     Ws w;
     ws_layout(&w, workspace, B, N, 0, false);
-    const long long tot = (long long)B * N;
-    const int rb = (int)((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256);
-    hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot, max_depth, w.partial);
+    const long long tot = (long long)B * N, tot_geo = (long long)in.Bg * N;      // depth: one map per GEOMETRY patch
+    const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
+    hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial);
     hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
-    hipLaunchKernelGGL((geo_prep_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, depth, code, ray_o, ray_d, B, N,
+    hipLaunchKernelGGL((geo_prep_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, depth, in, B, N,
                        max_depth, write_back, w.scal, w.pts, w.cn, w.dinv);
     PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm};
-    const int32_t rc = run_pair_passes<true, C>(A, grad_code != nullptr, loss, st);
+    const int32_t rc = run_pair_passes<true, C>(A, want_grad, loss, st);
     if (rc != NSOS_OK) return rc;
-    if (grad_code)
+    if (want_grad)
         hipLaunchKernelGGL((geo_grad_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, B, N, neg, w.cn, w.dinv, w.grow,
-                           w.gcol, grad_code);
+                           w.gcol, in);
     return nsos_launch_status();
 }
 
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(256) void geo_gsum_kernel(int B, int N, const long 
 
 template <int C>
 __global__ __launch_bounds__(256) void geo_finish_kernel(int B, int N, const float* __restrict__ cn, const float* __restrict__ dinv,
-                                                         const float* __restrict__ gsum, float* __restrict__ grad_code) {
+                                                         const float* __restrict__ gsum, const GeoInputs in) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * N) return;
     const int m = (int)(i / N), p = (int)(i % N);
@@ -774,8 +800,10 @@ __global__ __launch_bounds__(256) void geo_finish_kernel(int B, int N, const flo
 #pragma unroll
     for (int c = 0; c < C; ++c) gy[c] = gsum[i * kMaxC + c];
     normalize_backward<C>(gy, cn + i * kMaxC, dinv[i * 2], dinv[i * 2 + 1], gv);
+    float* grad_code = in.grad[m / in.Bg];
+    if (!grad_code) return;
 #pragma unroll
-    for (int c = 0; c < C; ++c) grad_code[((long long)m * C + c) * N + p] = gv[c];
+    for (int c = 0; c < C; ++c) grad_code[in.code_at(m % in.Bg, c, p, C, N)] = gv[c];
 }
 
 // phase 0: depth filter + points + normalised codes of the WHOLE batch (cheap, every rank), pass 1 over own rows -> scal[0..1]
@@ -783,19 +811,20 @@ __global__ __launch_bounds__(256) void geo_finish_kernel(int B, int N, const flo
 // phase 2: (scal[2..3] all-reduced) passes 3 and 4 over own rows -> scal[4..5] (loss sums), gsum
 // phase 3: (scal[4..5], gsum all-reduced) loss value and d loss / d code for every patch of the batch
 template <int C>
-int32_t geo_rows_impl(int phase, float* depth, const float* code, const float* ray_o, const float* ray_d, const long long* neg,
+int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long long* neg,
                       const int* rows, int n_rows, int B, int N, CorrParams prm, float max_depth, int write_back, float* loss,
-                      float* grad_code, void* workspace, hipStream_t st) {
+                      void* workspace, hipStream_t st) {
     Ws w;
     ws_layout(&w, workspace, B, N, 0, false);
     const long long tot = (long long)B * N;
     const unsigned gb = (unsigned)((tot + 255) / 256);
     PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, rows, n_rows};
     if (phase == 0) {
-        const int rb = (int)(gb < 256 ? gb : 256);
-        hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot, max_depth, w.partial);
+        const long long tot_geo = (long long)in.Bg * N;                            // depth: one map per GEOMETRY patch
+        const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
+        hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial);
         hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
-        hipLaunchKernelGGL((geo_prep_kernel<C>), dim3(gb), dim3(256), 0, st, depth, code, ray_o, ray_d, B, N, max_depth, write_back,
+        hipLaunchKernelGGL((geo_prep_kernel<C>), dim3(gb), dim3(256), 0, st, depth, in, B, N, max_depth, write_back,
                            w.scal, w.pts, w.cn, w.dinv);
     }
     if (phase <= 2) {
@@ -812,18 +841,19 @@ int32_t geo_rows_impl(int phase, float* depth, const float* code, const float* r
         return nsos_launch_status();
     }
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss);
-    if (grad_code) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, grad_code);
+    if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, in);
     return nsos_launch_status();
 }
 
 template <int C>
 int32_t app_impl(const float* feats, const float* code, const long long* neg, const float* rnd1, const float* rnd2, int B, int Cf,
-                 int Hf, int Wf, int Hc, int Wc, int S, CorrParams prm, float* loss, float* grad_code, void* workspace, hipStream_t st) {
+                 int Hf, int Wf, int Hc, int Wc, int S, CorrParams prm, float* loss, float* grad_code, void* workspace, hipStream_t st,
+                 int channel_last) {
     const int N = S * S;
     Ws w;
     ws_layout(&w, workspace, B, N, Cf, true);
     hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, B, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
-                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2);
+                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last);
     hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(256), 0, st, w.fn, B, N, Cf, w.fdmat);
     PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm};
     const int32_t rc = run_pair_passes<false, C>(A, grad_code != nullptr, loss, st);
@@ -837,7 +867,7 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
                            w.dinv2, w.grow, w.gcol, g1, g2);
         const long long px = (long long)B * Hc * Wc;
         hipLaunchKernelGGL((app_scatter_kernel<C>), dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, B, N, S, Hc, Wc, neg, rnd1, rnd2,
-                           g1, g2, grad_code);
+                           g1, g2, grad_code, channel_last);
     }
     return nsos_launch_status();
 }
@@ -867,11 +897,12 @@ extern "C" int32_t nsos_geo_correlation_loss(float* depth, const float* code, co
     const CorrParams prm = {self_shift, self_weight, neg_shift, neg_weight};
     const long long* neg = reinterpret_cast<const long long*>(neg_indx);
     const hipStream_t st = (hipStream_t)stream;
+    const GeoInputs in = {{code, nullptr}, {grad_code, nullptr}, ray_o, ray_d, batch, 1, 0};
     switch (code_dim) {
-        case 1: return geo_impl<1>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
-        case 2: return geo_impl<2>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
-        case 3: return geo_impl<3>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
-        default: return geo_impl<4>(depth, code, ray_o, ray_d, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        case 1: return geo_impl<1>(depth, in, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        case 2: return geo_impl<2>(depth, in, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        case 3: return geo_impl<3>(depth, in, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        default: return geo_impl<4>(depth, in, neg, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
     }
 }
 
@@ -886,15 +917,14 @@ extern "C" int32_t nsos_corr_workspace_slots(int32_t batch, int32_t n_points, in
     return NSOS_OK;
 }
 
-extern "C" int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float* code, const float* ray_o,
-                                                  const float* ray_d, const int64_t* neg_indx, const int32_t* rows, int32_t n_rows,
-                                                  int32_t batch, int32_t code_dim, int32_t height, int32_t width,
-                                                  float self_shift, float self_weight, float neg_shift, float neg_weight,
-                                                  float max_depth, int32_t filter_in_place, float* loss, float* grad_code,
-                                                  void* workspace, size_t workspace_bytes, void* stream) {
-    if (batch == 0) return NSOS_OK;
+static int32_t geo_rows_entry(int32_t phase, float* depth, const GeoInputs in, const int64_t* neg_indx, const int32_t* rows, int32_t n_rows,
+                              int32_t code_dim, int32_t height, int32_t width, float self_shift, float self_weight, float neg_shift,
+                              float neg_weight, float max_depth, int32_t filter_in_place, float* loss, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    const int batch = in.Bg * in.n_codes;
     NSOS_REQUIRE(phase >= 0 && phase <= 3, NSOS_ERR_UNSUPPORTED);
-    NSOS_REQUIRE(depth && code && ray_o && ray_d && neg_indx && workspace && (n_rows == 0 || rows), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(depth && in.code[0] && (in.n_codes == 1 || in.code[1]) && in.ray_o && in.ray_d && neg_indx && workspace && (n_rows == 0 || rows),
+                 NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(phase < 3 || loss, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(batch > 0 && height > 0 && width > 0 && n_rows >= 0 && n_rows <= batch, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
@@ -906,19 +936,44 @@ extern "C" int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, c
     const long long* neg = reinterpret_cast<const long long*>(neg_indx);
     const hipStream_t st = (hipStream_t)stream;
     switch (code_dim) {
-        case 1: return geo_rows_impl<1>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
-        case 2: return geo_rows_impl<2>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
-        case 3: return geo_rows_impl<3>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
-        default: return geo_rows_impl<4>(phase, depth, code, ray_o, ray_d, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, grad_code, workspace, st);
+        case 1: return geo_rows_impl<1>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        case 2: return geo_rows_impl<2>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        case 3: return geo_rows_impl<3>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        default: return geo_rows_impl<4>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
     }
 }
 
-extern "C" int32_t nsos_app_correlation_loss(const float* feats, const float* code, const int64_t* neg_indx,
-                                             const float* rand1, const float* rand2, int32_t batch, int32_t feat_dim,
-                                             int32_t feat_h, int32_t feat_w, int32_t code_dim, int32_t code_h,
-                                             int32_t code_w, int32_t feature_samples, float self_shift,
-                                             float self_weight, float neg_shift, float neg_weight, float* loss,
-                                             float* grad_code, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float* code, const float* ray_o,
+                                                  const float* ray_d, const int64_t* neg_indx, const int32_t* rows, int32_t n_rows,
+                                                  int32_t batch, int32_t code_dim, int32_t height, int32_t width,
+                                                  float self_shift, float self_weight, float neg_shift, float neg_weight,
+                                                  float max_depth, int32_t filter_in_place, float* loss, float* grad_code,
+                                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch == 0) return NSOS_OK;
+    const GeoInputs in = {{code, nullptr}, {grad_code, nullptr}, ray_o, ray_d, batch, 1, 0};
+    return geo_rows_entry(phase, depth, in, neg_indx, rows, n_rows, code_dim, height, width, self_shift, self_weight, neg_shift,
+                          neg_weight, max_depth, filter_in_place, loss, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t nsos_geo_correlation_loss_pair(int32_t phase, const float* depth, const float* code0, const float* code1,
+                                                  const float* ray_o, const float* ray_d, const int64_t* neg_indx,
+                                                  const int32_t* rows, int32_t n_rows, int32_t batch, int32_t channel_last,
+                                                  int32_t code_dim, int32_t height, int32_t width, float self_shift,
+                                                  float self_weight, float neg_shift, float neg_weight, float max_depth, float* loss,
+                                                  float* grad_code0, float* grad_code1, void* workspace, size_t workspace_bytes,
+                                                  void* stream) {
+    if (batch == 0) return NSOS_OK;
+    NSOS_REQUIRE(batch > 0, NSOS_ERR_BAD_SHAPE);
+    const GeoInputs in = {{code0, code1}, {grad_code0, grad_code1}, ray_o, ray_d, batch, 2, channel_last != 0};
+    // the depth filter (values > max_depth -> the largest value below it) is applied on the fly, never written back
+    return geo_rows_entry(phase, const_cast<float*>(depth), in, neg_indx, rows, n_rows, code_dim, height, width, self_shift, self_weight,
+                          neg_shift, neg_weight, max_depth, 0, loss, workspace, workspace_bytes, stream);
+}
+
+static int32_t app_entry(const float* feats, const float* code, const int64_t* neg_indx, const float* rand1, const float* rand2,
+                         int32_t batch, int32_t feat_dim, int32_t feat_h, int32_t feat_w, int32_t code_dim, int32_t code_h, int32_t code_w,
+                         int32_t feature_samples, float self_shift, float self_weight, float neg_shift, float neg_weight, float* loss,
+                         float* grad_code, void* workspace, size_t workspace_bytes, void* stream, int channel_last) {
     if (batch == 0) return NSOS_OK;
     NSOS_REQUIRE(feats && code && neg_indx && rand1 && rand2 && loss && workspace, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(batch > 0 && feat_dim > 0 && feat_h > 0 && feat_w > 0 && code_h > 0 && code_w > 0 && feature_samples > 0,
@@ -932,9 +987,29 @@ extern "C" int32_t nsos_app_correlation_loss(const float* feats, const float* co
     const long long* neg = reinterpret_cast<const long long*>(neg_indx);
     const hipStream_t st = (hipStream_t)stream;
     switch (code_dim) {
-        case 1: return app_impl<1>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
-        case 2: return app_impl<2>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
-        case 3: return app_impl<3>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
-        default: return app_impl<4>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st);
+        case 1: return app_impl<1>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st, channel_last);
+        case 2: return app_impl<2>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st, channel_last);
+        case 3: return app_impl<3>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st, channel_last);
+        default: return app_impl<4>(feats, code, neg, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, prm, loss, grad_code, workspace, st, channel_last);
     }
+}
+
+extern "C" int32_t nsos_app_correlation_loss(const float* feats, const float* code, const int64_t* neg_indx,
+                                             const float* rand1, const float* rand2, int32_t batch, int32_t feat_dim,
+                                             int32_t feat_h, int32_t feat_w, int32_t code_dim, int32_t code_h,
+                                             int32_t code_w, int32_t feature_samples, float self_shift,
+                                             float self_weight, float neg_shift, float neg_weight, float* loss,
+                                             float* grad_code, void* workspace, size_t workspace_bytes, void* stream) {
+    return app_entry(feats, code, neg_indx, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_dim, code_h, code_w, feature_samples,
+                     self_shift, self_weight, neg_shift, neg_weight, loss, grad_code, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int32_t nsos_app_correlation_loss_nhwc(const float* feats, const float* code, const int64_t* neg_indx,
+                                                  const float* rand1, const float* rand2, int32_t batch, int32_t feat_dim,
+                                                  int32_t feat_h, int32_t feat_w, int32_t code_dim, int32_t code_h,
+                                                  int32_t code_w, int32_t feature_samples, float self_shift,
+                                                  float self_weight, float neg_shift, float neg_weight, float* loss,
+                                                  float* grad_code, void* workspace, size_t workspace_bytes, void* stream) {
+    return app_entry(feats, code, neg_indx, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_dim, code_h, code_w, feature_samples,
+                     self_shift, self_weight, neg_shift, neg_weight, loss, grad_code, workspace, workspace_bytes, stream, 1);
 }

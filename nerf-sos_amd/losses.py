@@ -23,6 +23,30 @@ def _params_of(values: Sequence, defaults):
     return tuple(vals)
 
 
+def _is_channel_last_view(t: torch.Tensor) -> bool:
+    """[B,C,H,W] that is a permuted view of a dense [B,H,W,C] tensor (what `ret['semantics'].permute(0,3,1,2)` is)."""
+    return t.dim() == 4 and t.shape[1] > 1 and not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+class _PairFn(torch.autograd.Function):
+    """loss = f(code0, code1); the forward launches already produce both gradients, backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, code0, code1, launch):
+        loss, g0, g1 = launch(code0, code1, code0.requires_grad or code1.requires_grad)
+        ctx.has_grad = g0 is not None
+        if ctx.has_grad:
+            ctx.save_for_backward(g0, g1)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.has_grad:
+            return None, None, None
+        g0, g1 = ctx.saved_tensors
+        return g0 * g, g1 * g, None
+
+
 class _CorrFn(torch.autograd.Function):
     """loss = f(code); the forward launch already produces d loss / d code, backward only scales it."""
 
@@ -92,10 +116,19 @@ class CorrelationLoss(nn.Module):
         prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
 
         def launch(code, want_grad):
-            code = _dev(code.detach(), "orig_code")
+            code = code.detach()
             nbytes = lib.nsos_corr_workspace_bytes(0, B, S * S, Cf)
             ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
             loss = torch.empty((), device=dev, dtype=torch.float32)
+            if _is_channel_last_view(code):
+                # the renderer's `semantics` [B,P,P,C] seen through .permute(0,3,1,2): read (and differentiated) in place
+                nhwc = _dev(code.permute(0, 2, 3, 1), "orig_code")
+                g = torch.empty_like(nhwc) if want_grad else None
+                _lib.check(lib.nsos_app_correlation_loss_nhwc(_p(feats), _p(nhwc), neg.data_ptr(), _p(rand1), _p(rand2), B, Cf, Hf, Wf,
+                                                              C, Hc, Wc, S, *prm, _p(loss), _p(g), ws.data_ptr(), ws.numel() * 8,
+                                                              _stream()), "nsos_app_correlation_loss_nhwc")
+                return loss, (g.permute(0, 3, 1, 2) if want_grad else None)
+            code = _dev(code, "orig_code")
             grad = torch.empty_like(code) if want_grad else None
             _lib.check(lib.nsos_app_correlation_loss(_p(feats), _p(code), neg.data_ptr(), _p(rand1), _p(rand2), B, Cf, Hf, Wf, C,
                                                      Hc, Wc, S, *prm, _p(loss), _p(grad), ws.data_ptr(), ws.numel() * 8,
@@ -185,6 +218,64 @@ class GeoCorrelationLoss(CorrelationLoss):
             changed = dbuf != depth
         depth.copy_(torch.where(changed, dbuf.to(depth.dtype), depth))   # masked assign without the host sync of a bool index
         return out
+
+
+    def forward_pair(self, depth: torch.Tensor, code0: torch.Tensor, code1: torch.Tensor, ray_o: torch.Tensor, ray_d: torch.Tensor,
+                     sim_matrix: Optional[torch.Tensor], rows: Optional[Sequence[int]] = None, group=None) -> torch.Tensor:
+        """forward(depth, code0, ...) + forward(depth, code1, ...) -- the coarse and the fine semantic map against the same
+        geometry, as `train_one_step` scores them (engines/trainer.py:147-166) -- in ONE evaluation over the stacked batch
+        [code0; code1] that is never materialised (`nsos_geo_correlation_loss_pair`), on the renderer's own channel-last
+        tensors: depth [B,P,P,1], code0 / code1 [B,P,P,C], ray_o / ray_d [B,P,P,3].  The stacked mean is exactly
+        (L0 + L1) / 2 (every batch-wide quantity of the loss depends on the geometry only), so 2 x it is returned; with
+        `sim_matrix` the negatives stay inside their half.  `rows` / `group` as in forward (row-partitioned over the ranks; rows
+        index the B geometry patches).  Not for rand_neg (each call of the reference draws its own permutation there).
+        The depth is only read: the reference's in-place filter of the caller's tensor (utils/image.py:454) is left to forward."""
+        if self.rand_neg:
+            raise NotImplementedError("forward_pair: with rand_neg every call draws its own negatives -- call forward twice")
+        B, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
+        C = code0.shape[-1]
+        if tuple(code0.shape) != (B, H, W, C) or tuple(code1.shape) != (B, H, W, C) or tuple(ray_o.shape) != (B, H, W, 3):
+            raise ValueError("forward_pair takes channel-last tensors: depth [B,P,P,1], codes [B,P,P,C], rays [B,P,P,3]")
+        dev = depth.device
+        d = _dev(depth.detach().reshape(B, H * W), "depth")
+        ro, rd = _dev(ray_o.detach(), "ray_o"), _dev(ray_d.detach(), "ray_d")
+        neg = self._neg_index(sim_matrix, B, dev)
+        neg2 = torch.cat([neg, neg + B])
+        own = list(range(B)) if rows is None else [int(r) for r in rows]
+        rows2 = own + [B + r for r in own]
+        lib = _lib.lib()
+        prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
+        grad_mode = torch.is_grad_enabled()
+
+        def launch(c0, c1, want_grad):
+            import ctypes as C_
+            import torch.distributed as dist
+            from .sharding import collective, device_index
+            c0, c1 = _dev(c0.detach(), "code0"), _dev(c1.detach(), "code1")
+            nbytes = lib.nsos_corr_workspace_bytes(1, 2 * B, H * W, 0)
+            ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            g0 = torch.empty_like(c0) if want_grad else None
+            g1 = torch.empty_like(c1) if want_grad else None
+            so, go, gn = C_.c_int64(), C_.c_int64(), C_.c_int64()
+            _lib.check(lib.nsos_corr_workspace_slots(2 * B, H * W, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
+            scal = ws[so.value // 8: so.value // 8 + 6]
+            gsum = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
+            rows_t = device_index(rows2, torch.int32, dev)
+            reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+            for phase in range(4):
+                _lib.check(lib.nsos_geo_correlation_loss_pair(phase, _p(d), _p(c0), _p(c1), _p(ro), _p(rd), neg2.data_ptr(),
+                                                              rows_t.data_ptr() if len(rows2) else None, len(rows2), B, 1, C, H, W, *prm,
+                                                              float(self.max_depth), _p(loss), _p(g0), _p(g1), ws.data_ptr(),
+                                                              ws.numel() * 8, _stream()), "nsos_geo_correlation_loss_pair")
+                if reduce and phase < 3:
+                    part = scal[2 * phase: 2 * phase + 2]
+                    collective("geo_loss_phase_all_reduce", lambda async_op: dist.all_reduce(part, group=group, async_op=async_op), group)
+                    if phase == 2 and grad_mode:
+                        collective("geo_loss_role_sum_all_reduce", lambda async_op: dist.all_reduce(gsum, group=group, async_op=async_op), group)
+            return loss, g0, g1
+
+        return 2.0 * _PairFn.apply(code0, code1, launch)
 
 
 class NeRFContrastive(nn.Module):

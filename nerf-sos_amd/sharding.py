@@ -290,13 +290,20 @@ def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, 
     if geo_loss is not None:
         if gen is not None:
             geo_loss.generator = gen
-        depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()       # the geo loss uses the FINE depth for both terms
-        ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
-        # the O(P^4) geometric loss is evaluated ONCE across the ranks: each rank its own row patches (losses.py)
+        # the O(P^4) geometric loss is evaluated ONCE across the ranks: each rank its own row patches (losses.py); it uses the
+        # FINE depth for both terms (engines/trainer.py:159-160)
         if getattr(geo_loss, "rand_neg", False):
+            depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()
+            ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
             g = geo_w * (geo_loss(depth, s0, [ro, rd, None], sim, rows=own, group=group) +
                          geo_loss(depth, s1, [ro, rd, None], sim, rows=own, group=group))
+        elif hasattr(geo_loss, "forward_pair"):
+            # both codes in one evaluation on the renderer's own channel-last tensors: no stacked copies, no layout copies
+            g = geo_w * geo_loss.forward_pair(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
+                                              sim, rows=own, group=group)
         else:
+            depth = full["depth"].detach().permute(0, 3, 1, 2).contiguous()
+            ro, rd = full["ray_o"].permute(0, 3, 1, 2), full["ray_d"].permute(0, 3, 1, 2)
             g = geo_w * geo_loss_both(geo_loss, depth, s0, s1, ro, rd, sim, own, group)
         loss = g if loss is None else loss + g
     if app is not None:

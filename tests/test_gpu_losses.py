@@ -241,6 +241,59 @@ def test_geo_loss_of_two_codes_as_one_stacked_evaluation(tag):
         assert abs(float(a) - float(b)) < 1e-6 * (1 + abs(float(b)))
 
 
+@pytest.mark.parametrize("tag", ["geo_small", "geo_full"])
+def test_geo_loss_pair_on_channel_last_tensors_equals_the_stacked_evaluation(tag):
+    """GeoCorrelationLoss.forward_pair (nsos_geo_correlation_loss_pair: both codes against one geometry, stacked batch never
+    materialised, the renderer's channel-last tensors read in place) is the SAME computation as sharding.geo_loss_both on
+    permuted / repeated / concatenated copies: loss and both gradients bit for bit, all rows and a subset; the depth the
+    caller hands in is left untouched."""
+    from nerf_sos_amd import sharding
+    mod = nerf_sos_amd.GeoCorrelationLoss(ref_args())
+    depth, sim = T(GOLD[f"{tag}_depth"]), T(GOLD[f"{tag}_sim"])
+    B, _, P, _ = depth.shape
+    ray_o = T(GOLD[f"{tag}_ray_o"])[:, :, None, None].expand(B, 3, P, P).contiguous()
+    ray_d = T(GOLD[f"{tag}_ray_d"])
+    g = torch.Generator(DEV).manual_seed(5)
+    code = T(GOLD[f"{tag}_code"])
+    for rows in ([*range(B)], [0]) if B >= 2 else ([*range(B)],):
+        c0 = code.clone().requires_grad_(True)
+        c1 = (code + 0.3 * torch.randn(code.shape, device=DEV, generator=g)).requires_grad_(True)
+        want = sharding.geo_loss_both(mod, depth.clone(), c0, c1, ray_o, ray_d, sim, rows)
+        (3.0 * want).backward()
+        # channel-last: what the renderer returns -- depth [B,P,P,1], semantics [B,P,P,C], rays [B,P,P,3]
+        n0 = c0.detach().permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        n1 = c1.detach().permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        d_cl = depth.permute(0, 2, 3, 1).contiguous()
+        keep = d_cl.clone()
+        got = mod.forward_pair(d_cl, n0, n1, ray_o.permute(0, 2, 3, 1).contiguous(), ray_d.permute(0, 2, 3, 1).contiguous(), sim, rows=rows)
+        (3.0 * got).backward()
+        assert torch.equal(got.detach(), want.detach()), (float(got), float(want))
+        assert torch.equal(n0.grad.permute(0, 3, 1, 2), c0.grad) and torch.equal(n1.grad.permute(0, 3, 1, 2), c1.grad)
+        assert torch.equal(d_cl, keep)
+    with torch.no_grad():      # no gradient wanted: same value
+        assert torch.equal(mod.forward_pair(d_cl, n0, n1, ray_o.permute(0, 2, 3, 1).contiguous(), ray_d.permute(0, 2, 3, 1).contiguous(), sim, rows=rows), got.detach())
+
+
+@pytest.mark.parametrize("tag", ["app_small", "app_full"])
+def test_appearance_loss_reads_a_channel_last_code_in_place(tag):
+    """CorrelationLoss on `semantics.permute(0,3,1,2)` -- a view of the renderer's [B,P,P,C] tensor -- takes the channel-last
+    kernel path (no copy in, gradient written channel-last): loss and gradient bit-identical to the NCHW call with the same draws."""
+    mod = nerf_sos_amd.CorrelationLoss(ref_args())
+    feats, sim = T(GOLD[f"{tag}_feats"]), T(GOLD[f"{tag}_sim"])
+    code = T(GOLD[f"{tag}_code"])
+    a = code.clone().requires_grad_(True)
+    mod.generator = torch.Generator(DEV).manual_seed(3)
+    la = mod(feats, a, sim)
+    la.backward()
+    nhwc = code.permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    view = nhwc.permute(0, 3, 1, 2)
+    assert not view.is_contiguous()
+    mod.generator = torch.Generator(DEV).manual_seed(3)
+    lb = mod(feats, view, sim)
+    lb.backward()
+    assert torch.equal(la.detach(), lb.detach()) and torch.equal(nhwc.grad.permute(0, 3, 1, 2), a.grad)
+
+
 _CON = np.load(os.path.join(os.path.dirname(__file__), "golden", "contrastive.npz"))
 
 
