@@ -501,8 +501,31 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
         v = [a.elapsed_time(b) for a, b in pairs]
         return round(sum(v) / max(1, len(v)), 4)
 
+    # The same step as ONE HIP graph (single process only: graphs.GraphedPatchStep -- device-side Philox counter, loss generator
+    # registered with the graph, capturable fused Adam; bit-identical to the eager step, tests/test_gpu_configs.py): one
+    # hipGraphLaunch per step, the host out of the loop.  Timed over `steps` replays, outside the eager timed region.
+    graph = None
+    if ctx.world == 1:
+        try:
+            opt_g = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4, fused=True, capturable=True)
+            g = nerf_sos_amd.GraphedPatchStep(net, opt_g, rays, (syn.NEAR, syn.FAR), feat, cls_, corr, geo, contrast, correlation_w=1.0,
+                                              geo_w=0.01, contrast_w=0.01, seed=0, warmup=2)
+            for _ in range(3):
+                g()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g()
+            host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - t0
+            graph = {"ms_per_step": round(1e3 * dtg / steps, 4), "host_enqueue_ms_per_step": round(1e3 * host / steps, 4),
+                     "rays_per_s": round(n_rays * steps / dtg, 1), "loss": round(float(g.loss), 6),
+                     "what": "the whole step (render, losses, backward, Adam) captured once and replayed: GraphedPatchStep"}
+        except Exception as e:   # the eager numbers above stand on their own
+            graph = {"error": repr(e)[:300]}
     st = timings.get("stats", {})
-    res.update(roofline=roof, rays_per_gpu=n_rays, patches=B, loss=round(float(state["loss"]), 6), precision=precision,
+    res.update(roofline=roof, whole_step_graph=graph, rays_per_gpu=n_rays, patches=B, loss=round(float(state["loss"]), 6), precision=precision,
                contrastive_loss=("NeRFContrastive on the batch's class tokens, weight 0.01" if contrast is not None else
                                  "not evaluated: one patch has no off-diagonal similarity (the reference's argmin fails on B = 1)"),
                collectives={"backend": ctx.backend, "all_gather_ms": mean_ms(timings.get("gather", [])),
@@ -640,6 +663,8 @@ def main():
         line["roofline"] = add_traffic(res["roofline"], "c3_bf16" if args.config == "c3" else "c4_bf16") if prec == "bf16" else res["roofline"]
         line["collectives"] = res["collectives"]
         line["loss"] = res["loss"]
+        line["whole_step_graph"] = res.get("whole_step_graph")
+        line["contrastive_loss"] = res.get("contrastive_loss")
     else:
         res = _strip(run_c5(ctx, args, prec, args.steps, args.warmup))
         line.update({k: res[k] for k in ("value", "ms_per_step", "host_enqueue_ms_per_step", "per_rank_rays_per_s")})
