@@ -188,20 +188,25 @@ __global__ __launch_bounds__(256, 1) void mlp_lp_kernel(const LpParams P) {
             if (l == 7) {
                 // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
                 const unsigned* aw = aux_l + kAuxAlphaW + kg * 64;
-                float pa[2] = {kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]), 0.0f};
-                pa[1] = pa[0];
+                // four chains per column (one per packed word q), then (p0 + p1) + (p2 + p3): the order mlp_lp8_kernel sums in
+                float pq[2][4];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    pq[c][0] = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]);
+                    pq[c][1] = pq[c][2] = pq[c][3] = 0.0f;
+                }
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const u32x4 w = *reinterpret_cast<const u32x4*>(aw + 4 * s);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        pa[0] = T::dot2(H[0][s][q], w[q], pa[0]);
-                        pa[1] = T::dot2(H[1][s][q], w[q], pa[1]);
+                        pq[0][q] = T::dot2(H[0][s][q], w[q], pq[0][q]);
+                        pq[1][q] = T::dot2(H[1][s][q], w[q], pq[1][q]);
                     }
                 }
                 asm volatile("s_nop 3" ::: "memory");  // v_dot2c result -> non-dot VALU read: 3 wait states hipcc cannot see (asm)
-                sigma[0] = both_halves(pa[0]);
-                sigma[1] = both_halves(pa[1]);
+                sigma[0] = both_halves((pq[0][0] + pq[0][1]) + (pq[0][2] + pq[0][3]));
+                sigma[1] = both_halves((pq[1][0] + pq[1][1]) + (pq[1][2] + pq[1][3]));
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
                     f32x16 sacc[2][4];
                     // SAVE, compact sem_in: the 72 stores of [relu(h7) | x63 | 1] (packed words as they are) ride in these two chunks'

@@ -548,15 +548,19 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
             if (l == 7) {
                 dead();      // layer 7 finished its own tail: nothing of Zp is read again before layer 8 redefines it
                 // sigma head: dot of the packed activations with packed weights (models/nerf_mlp.py:77)
+                // four independent chains (one per packed word q of a slice), then (p0 + p1) + (p2 + p3): one chain of 64 dependent
+                // v_dot2c was 1.8 k cycles per tile with nothing else for the SIMD to issue (round 3; the round-1 kernel sums in
+                // the same order: bit-identical)
                 const unsigned* aw = aux_l + kAuxAlphaW + kg * 64;
-                float pa = kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]);
+                float pq[4] = {kg ? 0.0f : __builtin_bit_cast(float, aux_l[kAuxScalars]), 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const u32x4 w = *reinterpret_cast<const u32x4*>(aw + 4 * s);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) pa = T::dot2(H[s][q], w[q], pa);
+                    for (int q = 0; q < 4; ++q) pq[q] = T::dot2(H[s][q], w[q], pq[q]);
                 }
                 asm volatile("s_nop 3" ::: "memory");  // v_dot2c result -> non-dot VALU read: 3 wait states hipcc cannot see (asm)
+                const float pa = (pq[0] + pq[1]) + (pq[2] + pq[3]);
                 sigma = both_halves(pa);
                 if constexpr (SEM != 0) {  // semantic head (models/nerf_mlp.py:79-80)
                     f32x16 sacc[4];
@@ -617,21 +621,38 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         dead();
         // view branch: cat([feature, dir27]) -> 128 -> rgb   (H = feature, no activation)
         f32x16 vacc[4];
+        // the ray's view direction is needed right after the two view chunks: requested here, its latency (L2) runs under their
+        // MFMAs instead of in front of the direction encoding
+        float dv[3];
+        const int ray_d = *park;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3ll * ray_d + k];
         run_chunk(IC(34), IC(4), IC(4), IC(0), IC(34), IC(0), IC(0), vacc, from_H, no_ride);
         run_chunk(IC(34), IC(4), IC(4), IC(34), IC(34), IC(0), IC(2), vacc, from_H, no_ride);
         stamp();  // 21: view-branch MFMAs on the feature
         u32x4 ed[2];
         {
-            float dv[3];
-            const int ray_d = *park;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dv[k] = P.viewdirs[3ll * ray_d + k];
             Enc<NSOS_DIR_FREQS, SliceHalf> e;
             e.evaluate_hw(dv, kg);
             ed[0] = enc_slice<T, NSOS_DIR_FREQS, 0, false>(e, dv, kg);
             ed[1] = enc_slice<T, NSOS_DIR_FREQS, 1, false>(e, dv, kg);
         }
         auto from_ed = [&](auto sc) { return ed[decltype(sc)::value]; };
+        // the inputs of the NaN check at the tile's end, re-read (L2 hits) rather than kept alive across the tile: `ray` comes
+        // back from its LDS parking slot and the point index is re-derived (otherwise four 64-bit address pairs stay alive --
+        // in scratch -- from the top of the tile); requested HERE, before the direction chunk, not in front of their use
+        float nz, no[3], nd[3];
+        {
+            int pj_b = pj;
+            asm volatile("" : "+v"(pj_b));
+            const int gc_b = (pj_b < n_here) ? wave_first + pj_b : n_pts - 1;
+            nz = P.z_vals[gc_b];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                no[k] = P.rays_o[3ll * ray_d + k];
+                nd[k] = P.rays_d[3ll * ray_d + k];
+            }
+        }
         stamp();  // 22: direction encoding
         run_chunk(IC(16), IC(4), IC(0), IC(0), IC(8), IC(0), IC(0), vacc, from_ed, no_ride);  // 2 slices x 4 tiles; groups 8..15 are padding
         stamp();  // 23: direction MFMAs
@@ -644,19 +665,10 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
             for (int o = 0; o < 3; ++o) rgb[o] = both_halves(rgb[o]);
             {   // NaN / Inf in the point's inputs must come out as NaN (the reference propagates them; the packed integer
                 // ReLU would launder them).  The inputs are re-read here (L2 hits) rather than kept alive across the tile.
-                // (`ray` comes back from its LDS parking slot and the point index is re-derived: otherwise four 64-bit address
-                // pairs stay alive -- in scratch -- from the top of the tile)
-                const int ray_b = *park;
-                int pj_b = pj;
-                asm volatile("" : "+v"(pj_b));
-                const int gc_b = (pj_b < n_here) ? wave_first + pj_b : n_pts - 1;
-                const float z = P.z_vals[gc_b];
-                float chk = z - z;
+                // (requested before the direction chunk -- see there -- so that the L2 round trips run under its MFMAs)
+                float chk = nz - nz;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float o = P.rays_o[3ll * ray_b + k], d = P.rays_d[3ll * ray_b + k], v = P.viewdirs[3ll * ray_b + k];
-                    chk += ((o - o) + (d - d)) + (v - v);
-                }
+                for (int k = 0; k < 3; ++k) chk += ((no[k] - no[k]) + (nd[k] - nd[k])) + (dv[k] - dv[k]);
                 if (chk != chk) {
                     const float qnan = __builtin_nanf("");
                     rgb[0] = rgb[1] = rgb[2] = sigma = sem_out[0] = sem_out[1] = qnan;
