@@ -573,8 +573,30 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int):
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
         roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
+    # quality of the 16-bit render ("PSNR vs ref" for this configuration): one 65 536-ray chunk through a DENSE field (the seed-0
+    # weights with the sigma head x40, -1.5: the default-init field is empty and its PSNR says nothing) in this precision and
+    # through the exact-fp32 kernels (= the reference within 1e-4, tests/test_gpu_parity.py); outside the timed region
+    quality = None
+    if precision != "fp32" and ctx.rank == 0:
+        with torch.no_grad():
+            for m in (net.nerf.mlp, net.nerf_fine.mlp):
+                m.alpha_linear.weight.mul_(40.0)
+                m.alpha_linear.bias.mul_(40.0).sub_(1.5)
+            net.invalidate_packed()
+            rays = syn.image_rays(ctx.dev, (s, min(s + chunk, e)))
+            lo = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+            net.mlp_precision = "fp32"
+            hi = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+            net.mlp_precision = precision
+            mse = float(((lo["rgb"] - hi["rgb"]) ** 2).mean())
+            agree = float((ops.eval_postprocess(semantics=lo["semantics"])["sem"] == ops.eval_postprocess(semantics=hi["semantics"])["sem"]).float().mean())
+            import math
+            quality = {"psnr_db_rgb_vs_exact_fp32": round(-10.0 * math.log10(max(mse, 1e-30)), 2),
+                       "max_abs_rgb": float((lo["rgb"] - hi["rgb"]).abs().max()), "label_agreement": round(agree, 5),
+                       "mean_acc": round(float(hi["acc"].mean()), 4),
+                       "what": f"{rays.shape[1]} rays of the image through a dense field, {precision} vs the exact-fp32 kernels"}
     res.update(roofline=roof, rays_per_gpu=n_rays, precision=precision, image=f"{syn.W}x{syn.H}", chunk=chunk,
-               finite=bool(torch.isfinite(state["rgb"]).all().item()))
+               finite=bool(torch.isfinite(state["rgb"]).all().item()), quality=quality)
     return res
 
 
@@ -676,6 +698,7 @@ def main():
                           "flop_per_ray": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
         line["roofline"] = add_traffic(res["roofline"], "c5_fp16") if prec == "fp16" else res["roofline"]
         line["finite"] = res["finite"]
+        line["quality"] = res.get("quality")
 
     line["distributed"] = dist_info
     if variants:
