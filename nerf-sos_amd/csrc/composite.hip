@@ -14,6 +14,8 @@
 #include "common.h"
 #include "importance_device.h"
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 // exp rounded correctly to fp32 (fp64 evaluation, one rounding).  alpha = 1 - exp(-sigma*delta) cancels: for a thin
 // sample the result lives on the 6e-8 grid of fl(exp) near 1, so an ulp of libm difference in exp moves a small alpha by
 // 1e-3 of itself -- and with it the coarse weights, the cdf and the importance samples (tests/test_gpu_pins.py::
@@ -30,7 +32,9 @@ __device__ __forceinline__ float composite_ray(const int64_t r, const int lane, 
                                                const float* __restrict__ noise, float noise_std, int S, int C, int white_bkgd,
                                                float* __restrict__ weights, float* __restrict__ rgb, float* __restrict__ sem,
                                                float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ disp,
-                                               float* z_first) {
+                                               float* z_first, const float* staged = nullptr) {
+    // `staged`: this ray's raw row [S, C] in LDS (composite_kernel stages it with coalesced 16-byte loads when a lane owns
+    // several samples: read per lane from global memory, every dword load gathered 64 values 4 C IPL bytes apart)
     float w_first = 0.0f;
     const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
     const float norm = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);  // :38
@@ -49,7 +53,16 @@ __device__ __forceinline__ float composite_ray(const int64_t r, const int lane, 
     for (int i = 0; i < IPL; ++i) {
         const int s = s0 + i;
         const bool live = s < S;
-        const float* c = rr + (int64_t)(live ? s : 0) * C;
+        float c[6];
+        if (staged) {
+            const float* lp = staged + (live ? s : 0) * C;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c[k] = k < C ? lp[k] : 0.0f;
+        } else {
+            const float* gp = rr + (int64_t)(live ? s : 0) * C;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c[k] = k < C ? gp[k] : 0.0f;
+        }
         float dist = (s + 1 < S) ? (z[i + 1] - z[i]) : 1e10f;  // :35-37
         dist = dist * norm;
         float sigma = c[3];
@@ -129,9 +142,26 @@ __global__ __launch_bounds__(256) void composite_kernel(const float* __restrict_
                                                         float* __restrict__ weights, float* __restrict__ rgb,
                                                         float* __restrict__ sem, float* __restrict__ depth,
                                                         float* __restrict__ acc, float* __restrict__ disp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= n_rays) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= n_rays) return;   // whole wave exits together; only wave-level synchronisation below
+    if constexpr (IPL >= 2 && IPL <= 4) {
+        // the ray's raw row (S x C floats, contiguous, 16-byte aligned when S C is a multiple of 4) through LDS: 64 lanes x 16 B
+        // per load instruction instead of 64 strided dwords
+        __shared__ __attribute__((aligned(16))) float stage[4][IPL * 64 * 6];
+        const int n = S * C;
+        if ((n & 3) == 0) {
+            const f32x4v* src = reinterpret_cast<const f32x4v*>(raw + r * (int64_t)n);
+            f32x4v* dst = reinterpret_cast<f32x4v*>(stage[wave]);
+            for (int i = lane; i < (n >> 2); i += 64) dst[i] = src[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            composite_ray<IPL>(r, lane, raw, z_vals, rays_d, noise, noise_std, S, C, white_bkgd, weights, rgb, sem, depth, acc, disp, nullptr,
+                               stage[wave]);
+            return;
+        }
+    }
     composite_ray<IPL>(r, lane, raw, z_vals, rays_d, noise, noise_std, S, C, white_bkgd, weights, rgb, sem, depth, acc, disp, nullptr);
 }
 
