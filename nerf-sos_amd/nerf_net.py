@@ -182,6 +182,9 @@ class _FrozenBackboneRender(torch.autograd.Function):
         keys = list(ret.keys())
         outs = tuple(ret[k] for k in keys)
         ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if k not in ("semantics", "semantics0")])
+        # autograd hands backward() a freshly ZERO-FILLED tensor for every output that received no gradient -- the eleven
+        # non-differentiable maps included ([R,192] weights ...): eleven fill launches per step for values nobody reads
+        ctx.set_materialize_grads(False)
         ctx.keys, ctx.saved, ctx.net = keys, saved, net
         net._last_keys = keys
         return outs
@@ -228,6 +231,7 @@ class _FullRender(torch.autograd.Function):
         keys = list(ret.keys())
         outs = tuple(ret[k] for k in keys)
         ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if k.rstrip("0") in ("z_std", "pts")])
+        ctx.set_materialize_grads(False)     # outputs without a gradient arrive as None (backward filters them), not as zero fills
         ctx.keys, ctx.saved, ctx.net = keys, saved, net
         net._last_keys = keys
         return outs
