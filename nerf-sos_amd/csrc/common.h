@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 NeRF-SOS kernels.  gfx950 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "nerf_sos_hip.h"
@@ -31,6 +32,12 @@ static inline int nsos_device_cus() {
     }
     return cus[d];
 }
+// diagnostic switches ("NSOS_..." = anything but empty / 0); read at call time, so a test can flip one inside a process
+inline bool nsos_env_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] && !(e[0] == '0' && !e[1]);
+}
+
 struct NsosPerDeviceFlag {   // zero-initialised static: "has this device been configured for this kernel instantiation"
     bool done[NSOS_MAX_DEVICES];
     bool& here() { return done[nsos_current_device()]; }

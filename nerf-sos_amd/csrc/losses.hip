@@ -19,6 +19,7 @@
 // The forward call also produces d(loss)/d(code) (the loss is only ever back-propagated with a scalar upstream
 // gradient), so autograd's backward is one scaling.
 // Compiled with -ffp-contract=off: element-wise fp32 expressions follow the reference's op order.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -45,6 +46,7 @@ struct Ws {
     float* fdmat;      // app only: [2][B][N][N]
     float* fn;         // app only: normalised sampled features [2][B][N][Cf]  (0: coords1 of n, 1: coords2 of neg[n])
     float* gsum;       // geo only: [B][N][kMaxC] gradient w.r.t. the normalised codes, summed over roles (row-partitioned call)
+    float* gcolp;      // geo only: [2][B][ceil(N / 64)][kMaxC][N] column-code gradient partials, one per block of 64 rows (fused pass 3)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -65,7 +67,8 @@ inline size_t ws_layout(Ws* w, void* base, int B, int N, int Cf, bool app) {
     float* fdmat = (float*)take(app ? sizeof(float) * 2 * B * N * N : 0);
     float* fn = (float*)take(app ? sizeof(float) * 2 * B * N * Cf : 0);
     float* gsum = (float*)take(app ? 0 : sizeof(float) * B * N * kMaxC);
-    if (w) *w = Ws{rowsum, partial, scal, pts, cn, cn2, dinv, dinv2, grow, gcol, fdmat, fn, gsum};
+    float* gcolp = (float*)take(app ? 0 : sizeof(float) * 2 * B * ((N + 63) / 64) * kMaxC * N);
+    if (w) *w = Ws{rowsum, partial, scal, pts, cn, cn2, dinv, dinv2, grow, gcol, fdmat, fn, gsum, gcolp};
     return off;
 }
 
@@ -89,15 +92,35 @@ __device__ __forceinline__ float recip(float x) {
     return __fmaf_rn(r, __fmaf_rn(-x, r, 1.0f), r);
 }
 
-// clamped inverse L1 distance, GeoCorrelationLoss.tensor_correlation (utils/image.py:404-413)
+// clamped inverse L1 distance, GeoCorrelationLoss.tensor_correlation (utils/image.py:404-413).  The clamp is one v_min_f32
+// (a compare + select costs two VALU slots and a wait state in a VALU-bound loop); v_min drops a NaN operand, so NaN inputs
+// are caught per POINT in geo_prep_kernel instead (scal[7]) and poison the loss there.
 template <int D>
-__device__ __forceinline__ float inv_l1(const float (&a)[D], const float* b, float max_depth, bool* clamped = nullptr) {
+__device__ __forceinline__ float inv_l1(const float (&a)[D], const float* b, float max_depth) {
     float s = fabsf(a[0] - b[0]);
 #pragma unroll
     for (int k = 1; k < D; ++k) s = s + fabsf(a[k] - b[k]);   // torch.sum over dim 1, in order
+    return __builtin_fminf(recip(s + 5e-2f), max_depth);
+}
+
+// The code side of one pair of the geometric loss: cd = clamped inverse L1 affinity of row code c1 and column code c2, and
+// v[c] = gt * d cd / d c1[c]  (gt = d total / d cd for this pair; 0 where the clamp is active) -- the term the ROW code's
+// gradient collects; the column code's is -v[c].  d cd / d c1[c] = -cd^2 sign(c1[c] - c2[c]) with sign(0) = 0 (torch.abs):
+// the sign is med3(df * 2^126, -1, 1) -- exact -1 / 0 / +1 for every normal df -- instead of compare + select + two bit ops.
+template <int C>
+__device__ __forceinline__ float geo_code_pair(const float (&c1)[C], const float* c2, float max_depth, float gt, float (&v)[C]) {
+    float df[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) df[c] = c1[c] - c2[c];
+    float s = fabsf(df[0]);
+#pragma unroll
+    for (int c = 1; c < C; ++c) s = s + fabsf(df[c]);
     const float r = recip(s + 5e-2f);
-    if (clamped) *clamped = r > max_depth;
-    return r > max_depth ? max_depth : r;
+    const float cd = __builtin_fminf(r, max_depth);
+    const float k = (r > max_depth ? 0.0f : gt) * (cd * cd);
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = k * -__builtin_amdgcn_fmed3f(df[c] * 0x1p126f, -1.0f, 1.0f);
+    return cd;
 }
 
 // ------------------------------------------------------------------------------------------ geometric loss: prep
@@ -122,6 +145,7 @@ __global__ void depth_max_finish_kernel(const double* __restrict__ partial, int 
     double m = -1.0e300;
     for (int i = 0; i < nb; ++i) m = partial[i] > m ? partial[i] : m;
     scal[6] = m;   // -1e300 if no element was below max_depth (torch raises on the empty max; here the filter yields NaN-free -inf)
+    scal[7] = 0.0; // set by geo_prep_kernel when a point's depth / ray / code holds a NaN: the loss is NaN then, as the reference's is
 }
 
 // How a kernel finds the inputs of patch n of a (possibly stacked) batch.  The training step scores TWO semantic maps (coarse
@@ -176,6 +200,10 @@ __global__ __launch_bounds__(256) void geo_prep_kernel(float* __restrict__ depth
     for (int c = 0; c < kMaxC; ++c) cn[i * kMaxC + c] = c < C ? v[c] / den : 0.0f;
     dinv[i * 2] = den;
     dinv[i * 2 + 1] = nrm;
+    float probe = d + ss;                                         // NaN anywhere in this point's inputs? (the pair passes clamp with
+#pragma unroll                                                    //  v_min_f32, which would drop it)
+    for (int k = 0; k < 3; ++k) probe += pts[i * 4 + k];
+    if (probe != probe) const_cast<double*>(scal)[7] = 1.0;       // same value from every writer
 }
 
 // ------------------------------------------------------------------------------------------ the four pair passes
@@ -197,9 +225,28 @@ struct PairArgs {
     CorrParams prm;
     const int* rows;       // row patches this call evaluates (blockIdx.y indexes it), or NULL = all B patches
     int n_rows;
+    float* gcolp;          // geo, fused pass 3: column-gradient partials [2][row slots][row blocks][C][N]
+    int Bg;                // geo: geometry patches behind the B code patches (patch n -> geometry n % Bg); 0 = B
 };
 
 __device__ __forceinline__ int row_patch(const PairArgs& A) { return A.rows ? A.rows[blockIdx.y] : (int)blockIdx.y; }
+
+// Pass 1 of the geometric loss (row sums of fd) depends on the GEOMETRY of the row and the column patch only.  When several
+// code maps are scored against one geometry (GeoInputs: B = n_codes * Bg), pair sets with the same (row geometry, column
+// geometry) have bit-identical row sums: only the first such (set, row slot) in launch order computes them, the others copy
+// (pair_rowsum_copy_kernel).  In the C3 step all four pair sets share one fd matrix.
+__device__ __forceinline__ bool first_with_same_geometry(const PairArgs& A, int set, int slot, int* cset, int* cslot) {
+    if (A.Bg <= 0 || A.Bg >= A.B) return false;
+    const int nr = A.rows ? A.n_rows : A.B;
+    const int n = A.rows ? A.rows[slot] : slot, m = set == 0 ? (int)A.neg[n] : n;
+    const int kr = n % A.Bg, kc = m % A.Bg;
+    for (int z = 0; z <= set; ++z)
+        for (int y = 0; y < (z < set ? nr : slot); ++y) {
+            const int n2 = A.rows ? A.rows[y] : y, m2 = z == 0 ? (int)A.neg[n2] : n2;
+            if (n2 % A.Bg == kr && m2 % A.Bg == kc) { *cset = z; *cslot = y; return true; }
+        }
+    return false;
+}
 
 template <bool GEO>
 __device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, int n) {
@@ -221,21 +268,83 @@ struct PairShape {
     static constexpr int kSlabs = kThreads / kRows;
 };
 
-template <bool GEO, int C, int PASS, bool NARROW = false>
+// Sum over the wave's 64 lanes (= 64 row points) of R registers (= R consecutive columns), leaving the R totals in v[0]:
+// a transposing reduction -- each stage pairs register i with register i + n/2, lanes of one class keep the first and hand
+// the second to a lane of the other class (v_permlane32_swap / v_permlane16_swap exchange whole halves / 16-lane rows of a
+// register pair; quad permutes for lane bits 0 and 1), so the register count halves while every sum stays complete -- then
+// rotations inside the 16-lane rows add the lanes that hold the same column.  ~2.2 VALU per summed value instead of the 6
+// of a butterfly per register; fixed order.  Column j ends in EVERY lane with  col_of_lane(lane) == j.
+template <int R>
+__device__ __forceinline__ void wave_transpose_sum(float (&v)[R]) {
+    static_assert(R == 8 || R == 16, "8 or 16 columns per group");
+    const unsigned lane = threadIdx.x & 63;
+    // (asm: through the builtin every swap cost two register copies and a wait state; the operands here were written
+    //  many instructions earlier, and the leading s_nop covers the first one)
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {                      // lane bit 5: lanes 0-31 keep i, lanes 32-63 keep i + R/2
+        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(v[i]), "+v"(v[i + R / 2]));
+    }
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) v[i] = v[i] + v[i + R / 2];
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) {                      // lane bit 4: even rows of 16 keep i, odd rows keep i + R/4
+        asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(v[i]), "+v"(v[i + R / 4]));
+    }
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) v[i] = v[i] + v[i + R / 4];
+    const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < R / 8; ++i) {                      // lane bit 0 (quad_perm [1,0,3,2])
+        const float keep = b0 ? v[i + R / 8] : v[i], give = b0 ? v[i] : v[i + R / 8];
+        v[i] = keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(give), 0xB1, 0xF, 0xF, false));
+    }
+    if (R == 16) {                                         // lane bit 1 (quad_perm [2,3,0,1])
+        const float keep = b1 ? v[1] : v[0], give = b1 ? v[0] : v[1];
+        v[0] = keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(give), 0x4E, 0xF, 0xF, false));
+    } else {
+        v[0] = v[0] + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[0]), 0x4E, 0xF, 0xF, false));
+    }
+    v[0] = v[0] + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[0]), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v[0] = v[0] + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[0]), 0x128, 0xF, 0xF, false));   // row_ror:8
+}
+template <int R>
+__device__ __forceinline__ int col_of_lane(unsigned lane) {
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b0 = lane & 1, b1 = (lane >> 1) & 1;
+    return R == 16 ? 8 * b5 + 4 * b4 + 2 * b0 + b1 : 4 * b5 + 2 * b4 + b0;
+}
+
+// FUSE (GEO, PASS 3, 64 rows): the gradient w.r.t. the COLUMN codes comes out of this pass too.  For the clamped inverse L1
+// affinity d cd / d c2 = -d cd / d c1, so the column-side term of pair (p, q) is minus the row-side term the thread just
+// formed: every group of R columns is summed over the wave's 64 rows (wave_transpose_sum) and written as one partial per
+// (block of 64 rows, column); pair_cols_fold_kernel adds the row blocks in fp64, in order.  That replaces the fourth pass
+// over all N^2 pairs (pair_cols_kernel: 88 of the 220 us the geometric loss took per C3 step) by ~4 VALU per pair here.
+__host__ __device__ inline int pair_padded_columns(int N, int slabs) { return ((N + slabs * 32 - 1) / (slabs * 32)) * 32 * slabs; }
+
+template <bool GEO, int C, int PASS, bool NARROW = false, bool FUSE = false>
 __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_kernel(const PairArgs A) {
+    static_assert(!FUSE || (GEO && PASS == 3 && !NARROW), "the fused column gradient needs 64-row waves of the geometric pass 3");
     extern __shared__ __attribute__((aligned(16))) float lds[];   // columns: GEO xyz [N][4] then codes [N][kMaxC]
     __shared__ double red[4];
     constexpr int kSlabs = PairShape<GEO, NARROW>::kSlabs, kRows = PairShape<GEO, NARROW>::kRows;
     double* const slab = reinterpret_cast<double*>(lds);   // the slab fold reuses the column image once every wave is done with it
     const int set = blockIdx.z, n = row_patch(A), N = A.N;
     const int m = set == 0 ? (int)A.neg[n] : n;
+    if constexpr (GEO && PASS == 1) {
+        int cset, cslot;
+        if (first_with_same_geometry(A, set, blockIdx.y, &cset, &cslot)) return;   // whole workgroup: copied afterwards
+    }
+    // FUSE: the image is padded with zeros to whole slabs (<= 4096 columns whenever N <= 4096), so that the pair loop reads
+    // column q + j unconditionally at  scalar base + immediate  (a pair past N contributes through a zeroed t only)
+    const int Nimg = FUSE ? pair_padded_columns(N, kSlabs) : N;
     float* lx = lds;
-    float* lc = lds + (GEO ? (size_t)N * 4 : 0);
+    float* lc = lds + (GEO ? (size_t)Nimg * 4 : 0);
     if (GEO)
-        for (int i = threadIdx.x; i < N * 4; i += blockDim.x) lx[i] = A.pts[(size_t)m * N * 4 + i];
+        for (int i = threadIdx.x; i < Nimg * 4; i += blockDim.x) lx[i] = (!FUSE || i < N * 4) ? A.pts[(size_t)m * N * 4 + i] : 0.0f;
     if (PASS == 3) {
         const float* cc = col_codes<GEO>(A, set, n);
-        for (int i = threadIdx.x; i < N * kMaxC; i += blockDim.x) lc[i] = cc[i];
+        for (int i = threadIdx.x; i < Nimg * kMaxC; i += blockDim.x) lc[i] = (!FUSE || i < N * kMaxC) ? cc[i] : 0.0f;
     }
     __syncthreads();
     const int rl = threadIdx.x % kRows, sl = threadIdx.x / kRows;       // row within the block, column slab
@@ -262,6 +371,51 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_
     double g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = 0.0;
+    if constexpr (FUSE) {
+        constexpr int R = C <= 2 ? 16 : 8;                 // columns per transposed group: R * C values live per lane
+        const unsigned lane = threadIdx.x & 63;
+        const bool store_lane = (lane & 12) == 0 && (R == 16 || (lane & 2) == 0);
+        const int jcol = col_of_lane<R>(lane);
+        float* const gp = A.gcolp + (((size_t)set * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C * N;
+        const float gs = live ? gscale : 0.0f;             // rows past N are copies of row N - 1: no column terms from them
+        const int qb_u = __builtin_amdgcn_readfirstlane(qb), qend_u = __builtin_amdgcn_readfirstlane(qend);   // 64 rows: slab = wave,
+        for (int q0 = qb_u; q0 < qend_u; q0 += kBlk) {                 // so q is wave-uniform: LDS addresses are scalar + immediate
+            const int qe = q0 + kBlk < qend_u ? q0 + kBlk : qend_u;
+            float acc32 = 0.0f, g32[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) g32[c] = 0.0f;
+#pragma unroll 1
+            for (int q = q0; q < qe; q += R) {
+                float val[C][R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const bool ok = q + j < qe;             // ragged last block: the pair does not exist (scalar test)
+                    const int qq = q + j;
+                    const float fd = inv_l1<3>(x, lx + qq * 4, A.max_depth);
+                    const float fd1 = fd - rm;
+                    const float fd2 = (fd1 - m1) + old_mean;
+                    const float t = ok ? fd2 - shift : 0.0f;
+                    float v[C];
+                    const float cd = geo_code_pair<C>(c1, lc + qq * kMaxC, A.max_depth, gs * t, v);
+                    acc32 += -cd * t;                       // cd > 0: the reference's clamp(0) never acts on this affinity
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        val[c][j] = v[c];
+                        g32[c] += v[c];
+                    }
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four pairs in flight, not sixteen (VGPR budget: 128; measured: no slower)
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    wave_transpose_sum<R>(val[c]);
+                    if (store_lane && q + jcol < qe) gp[(size_t)c * N + q + jcol] = val[c][0];
+                }
+            }
+            acc += (double)acc32;
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[c] += (double)g32[c];
+        }
+    } else
     for (int q0 = qb; q0 < qend; q0 += kBlk) {
         const int qe = q0 + kBlk < qend ? q0 + kBlk : qend;
         float acc32 = 0.0f, g32[C];
@@ -275,25 +429,21 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_
             if (PASS == 2) { acc32 += fd1; continue; }
             const float fd2 = (fd1 - m1) + old_mean;           // fd - fd.mean() + old_mean, :319
             const float t = fd2 - shift;
-            float cd;
-            bool clamped = false;
-            if (GEO) cd = inv_l1<C>(c1, lc + q * kMaxC, A.max_depth, &clamped);   // overridden tensor_correlation, :427
-            else {
-                cd = c1[0] * lc[q * kMaxC];
+            if constexpr (GEO) {
+                float v[C];
+                const float cd = geo_code_pair<C>(c1, lc + q * kMaxC, A.max_depth, gscale * t, v);   // overridden tensor_correlation, :427
+                acc32 += -cd * t;                              // cd.clamp(0) is the identity here, :330
+#pragma unroll
+                for (int c = 0; c < C; ++c) g32[c] += v[c];
+            } else {
+                float cd = c1[0] * lc[q * kMaxC];
 #pragma unroll
                 for (int c = 1; c < C; ++c) cd = cd + c1[c] * lc[q * kMaxC + c];
-            }
-            const float cdc = cd < 0.0f ? 0.0f : cd;           // cd.clamp(0), :330
-            acc32 += -cdc * t;
-            const float gcd = (cd >= 0.0f && !clamped) ? gscale * t : 0.0f;   // d total / d cd
+                const float cdc = cd < 0.0f ? 0.0f : cd;       // cd.clamp(0), :330
+                acc32 += -cdc * t;
+                const float gcd = cd >= 0.0f ? gscale * t : 0.0f;   // d total / d cd
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float dc;
-                if (GEO) {
-                    const float df = c1[c] - lc[q * kMaxC + c];
-                    dc = df == 0.0f ? 0.0f : copysignf(cd * cd, -df);   // d cd / d c1 = -cd^2 sign(c1 - c2)
-                } else dc = lc[q * kMaxC + c];
-                g32[c] += gcd * dc;
+                for (int c = 0; c < C; ++c) g32[c] += gcd * lc[q * kMaxC + c];
             }
         }
         acc += (double)acc32;
@@ -322,6 +472,18 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_
         for (int c = 0; c < kMaxC; ++c) A.grow[(((size_t)set * A.B + n) * N + p) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
     const double s = block_sum(owner ? acc : 0.0, red);
     if (threadIdx.x == 0) A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void pair_rowsum_copy_kernel(const PairArgs A, int row_blocks) {
+    int cset, cslot;
+    const int set = blockIdx.z, N = A.N;
+    if (!first_with_same_geometry(A, set, blockIdx.y, &cset, &cslot)) return;
+    const int n = row_patch(A), cn = A.rows ? A.rows[cslot] : cslot;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < N) A.rowsum[((size_t)set * A.B + n) * N + p] = A.rowsum[((size_t)cset * A.B + cn) * N + p];
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < row_blocks; k += blockDim.x)
+            A.partial[(size_t)set * kRedBlocks + blockIdx.y * row_blocks + k] = A.partial[(size_t)cset * kRedBlocks + cslot * row_blocks + k];
 }
 
 // What used to be PASS 2: scal[2 + set] = sum over the evaluated pairs of (fd - rowmean), the numerator of the mean the
@@ -403,26 +565,21 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_cols_
             else fd = fdcol[(size_t)p * N];
             const float fd2 = ((fd - lr[p]) - m1) + old_mean;
             const float t = fd2 - shift;
-            float cd;
-            bool clamped = false;
             float c1[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) c1[c] = lc[p * kMaxC + c];
-            if (GEO) cd = inv_l1<C>(c1, c2, A.max_depth, &clamped);
-            else {
-                cd = c1[0] * c2[0];
+            if constexpr (GEO) {
+                float v[C];
+                geo_code_pair<C>(c1, c2, A.max_depth, gscale * t, v);
+#pragma unroll
+                for (int c = 0; c < C; ++c) g32[c] += -v[c];   // d cd / d c2 = -d cd / d c1
+            } else {
+                float cd = c1[0] * c2[0];
 #pragma unroll
                 for (int c = 1; c < C; ++c) cd = cd + c1[c] * c2[c];
-            }
-            const float gcd = (cd >= 0.0f && !clamped) ? gscale * t : 0.0f;
+                const float gcd = cd >= 0.0f ? gscale * t : 0.0f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float dc;
-                if (GEO) {
-                    const float df = c1[c] - c2[c];
-                    dc = df == 0.0f ? 0.0f : copysignf(cd * cd, df);   // d cd / d c2 = +cd^2 sign(c1 - c2)
-                } else dc = c1[c];
-                g32[c] += gcd * dc;
+                for (int c = 0; c < C; ++c) g32[c] += gcd * c1[c];
             }
         }
 #pragma unroll
@@ -444,9 +601,40 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_cols_
         for (int c = 0; c < kMaxC; ++c) A.gcol[(((size_t)set * A.B + n) * N + q) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
 }
 
-__global__ void loss_finish_kernel(const double* __restrict__ scal, double cnt, CorrParams prm, float* __restrict__ loss) {
+// gcol[set][n][q][c] = - sum over the row blocks of the fused pass's partials: fp64, block order (each of the four thread
+// groups of a workgroup adds a contiguous quarter of the row blocks, the quarters are added in order)
+template <int C>
+__global__ __launch_bounds__(256) void pair_cols_fold_kernel(const PairArgs A, int n_row_blocks) {
+    __shared__ double part[3][64][C];
+    const int ql = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + ql, set = blockIdx.z, n = row_patch(A), N = A.N;
+    const float* gp = A.gcolp + ((size_t)set * gridDim.y + blockIdx.y) * n_row_blocks * C * N;
+    const int per = (n_row_blocks + 3) / 4, r0 = k * per, r1 = r0 + per < n_row_blocks ? r0 + per : n_row_blocks;
+    double s[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] = 0.0;
+    if (q < N)
+#pragma unroll 4
+        for (int rb = r0; rb < r1; ++rb)
+#pragma unroll
+            for (int c = 0; c < C; ++c) s[c] += (double)gp[((size_t)rb * C + c) * N + q];
+    if (k > 0)
+#pragma unroll
+        for (int c = 0; c < C; ++c) part[k - 1][ql][c] = s[c];
+    __syncthreads();
+    if (k > 0 || q >= N) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] += part[j][ql][c];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) A.gcol[(((size_t)set * A.B + n) * N + q) * kMaxC + c] = c < C ? (float)-s[c] : 0.0f;
+}
+
+__global__ void loss_finish_kernel(const double* __restrict__ scal, double cnt, CorrParams prm, float* __restrict__ loss, int geo) {
     const float l_neg = (float)(scal[4] / cnt), l_self = (float)(scal[5] / cnt);   // .mean(), :370
     loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
+    if (geo && scal[7] != 0.0) loss[0] = __builtin_nanf("");                      // NaN inputs (geo_prep_kernel)
 }
 
 // backward of F.normalize for one point: g_v = (g - y (g.y)) / d  if ||v|| >= eps, else g / eps
@@ -691,7 +879,8 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
     const int nb = (int)(grid.x * grid.y);
     if (nb > kRedBlocks) return NSOS_ERR_UNSUPPORTED;
     const size_t lds_rows12_ = GEO ? (size_t)N * 4 * 4 : 0;
-    const size_t lds_rows3_ = lds_rows12_ + (size_t)N * kMaxC * 4;
+    const size_t lds_rows3_ = GEO && !NARROW ? (size_t)pair_padded_columns(N, PairShape<GEO, NARROW>::kSlabs) * (4 + kMaxC) * 4   // the fused pass pads
+                                             : lds_rows12_ + (size_t)N * kMaxC * 4;
     const size_t lds_cols_ = lds_rows3_ + (size_t)N * 4;
     // the slab folds reuse the dynamic region after the pair loops: it must hold them even when N is small
     constexpr size_t kLdsTotal = 160 * 1024 - 256, kFold = (size_t)(PairShape<GEO, NARROW>::kSlabs - 1) * PairShape<GEO, NARROW>::kRows * (1 + kMaxC) * 8;
@@ -704,6 +893,8 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
     if (lds_rows3 > configured_rows || lds_cols > configured_cols) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 1, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
+        if constexpr (GEO && !NARROW)
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_rows_kernel<GEO, C, 3, NARROW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows3);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_cols_kernel<GEO, C, NARROW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cols);
         if (e != hipSuccess) return (int32_t)e;
         configured_rows = lds_rows3;
@@ -714,14 +905,24 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
     // means of fd and fd1 couple every patch of the batch, utils/image.py:316-319).
     if (phases & 1) {
         hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1, NARROW>), grid, dim3(tb), lds_rows12, st, A);
+        if (GEO && A.Bg > 0 && A.Bg < B)
+            hipLaunchKernelGGL(pair_rowsum_copy_kernel, dim3((N + 255) / 256, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
     }
     if (phases & 2) hipLaunchKernelGGL(rowmean_residual_kernel, dim3(2), dim3(256), 0, st, A);
     if (phases & 4) {
-        hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
+        constexpr bool kCanFuse = GEO && !NARROW;
+        const bool fuse = kCanFuse && want_grad && A.gcolp && !nsos_env_flag("NSOS_GEO_SEPARATE_COLS");
+        if constexpr (kCanFuse) {
+            if (fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW, true>), grid, dim3(tb), lds_rows3, st, A);
+        }
+        if (!fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
         hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
-        if (loss) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss);
-        if (want_grad) hipLaunchKernelGGL((pair_cols_kernel<GEO, C, NARROW>), grid, dim3(tb), lds_cols, st, A);
+        if (loss) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0);
+        if constexpr (kCanFuse) {
+            if (fuse) hipLaunchKernelGGL((pair_cols_fold_kernel<C>), dim3((N + 63) / 64, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
+        }
+        if (want_grad && !fuse) hipLaunchKernelGGL((pair_cols_kernel<GEO, C, NARROW>), grid, dim3(tb), lds_cols, st, A);
     }
     return nsos_launch_status();
 }
@@ -731,7 +932,7 @@ int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStrea
     if constexpr (GEO) {
         const int cus = nsos_device_cus();
         const long long wide = (long long)((A.N + 63) / 64) * (A.rows ? A.n_rows : A.B) * 2;   // workgroups at 64 rows each
-        if (wide < cus) return run_pair_passes_shape<true, C, true>(A, want_grad, loss, st, phases);
+        if (wide < cus && !nsos_env_flag("NSOS_GEO_FORCE_WIDE")) return run_pair_passes_shape<true, C, true>(A, want_grad, loss, st, phases);
     }
     return run_pair_passes_shape<GEO, C, false>(A, want_grad, loss, st, phases);
 }
@@ -748,7 +949,7 @@ int32_t geo_impl(float* depth, const GeoInputs in, const long long* neg, int B, 
     hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
     hipLaunchKernelGGL((geo_prep_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, depth, in, B, N,
                        max_depth, write_back, w.scal, w.pts, w.cn, w.dinv);
-    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm};
+    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, nullptr, 0, w.gcolp, in.Bg};
     const int32_t rc = run_pair_passes<true, C>(A, want_grad, loss, st);
     if (rc != NSOS_OK) return rc;
     if (want_grad)
@@ -818,7 +1019,7 @@ int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long lo
     ws_layout(&w, workspace, B, N, 0, false);
     const long long tot = (long long)B * N;
     const unsigned gb = (unsigned)((tot + 255) / 256);
-    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, rows, n_rows};
+    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, rows, n_rows, w.gcolp, in.Bg};
     if (phase == 0) {
         const long long tot_geo = (long long)in.Bg * N;                            // depth: one map per GEOMETRY patch
         const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
@@ -840,7 +1041,7 @@ int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long lo
             hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, w.gsum);
         return nsos_launch_status();
     }
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss, 1);
     if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, in);
     return nsos_launch_status();
 }
@@ -855,7 +1056,7 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
     hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, B, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
                        w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last);
     hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(256), 0, st, w.fn, B, N, Cf, w.fdmat);
-    PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm};
+    PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm, nullptr, 0, nullptr, 0};
     const int32_t rc = run_pair_passes<false, C>(A, grad_code != nullptr, loss, st);
     if (rc != NSOS_OK) return rc;
     if (grad_code) {

@@ -323,3 +323,39 @@ def test_contrastive_loss_vs_reference(tag):
         assert torch.equal(mod(e.detach()), loss.detach())
     with pytest.raises(NotImplementedError):
         nerf_sos_amd.NeRFContrastive(device="cuda:0", min_max_contrast=False)(e)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 2), (3, 9, 11, 2), (2, 20, 20, 3), (2, 16, 16, 1), (2, 13, 17, 4), (1, 64, 64, 2)])
+def test_geo_column_gradient_from_the_row_pass_equals_the_separate_pass(shape, monkeypatch):
+    """Pass 3 of the geometric loss also produces the gradient w.r.t. the column codes (a transposing wave reduction of the
+    row-side terms, one partial per block of 64 rows, folded in fp64) instead of a fourth pass over all N^2 pairs
+    (pair_cols_kernel, kept as the checker here and for the 32-row shape): same loss bit for bit, same gradient up to the
+    summation order (fp32 over 64 rows then fp64, vs fp32 over 32 rows then fp64).  Ragged N, 1-4 channels, and the wide shape
+    forced on patches small enough that the launcher would pick 32-row workgroups."""
+    B, H, W, C = shape
+    g = torch.Generator(DEV).manual_seed(11 + B + H)
+    depth = 0.5 + 4.0 * torch.rand(B, 1, H, W, device=DEV, generator=g)
+    depth[0, 0, 0, :3] = 50.0                                         # beyond max_depth: filtered
+    code = torch.randn(B, C, H, W, device=DEV, generator=g)
+    code[0, :, 1, 1] = code[0, :, 1, 2]                               # equal codes: the sign(0) branch
+    ray_o = torch.randn(B, 3, device=DEV, generator=g)[:, :, None, None].expand(B, 3, H, W).contiguous()
+    ray_d = torch.nn.functional.normalize(torch.randn(B, 3, H, W, device=DEV, generator=g), dim=1)
+    sim = torch.rand(B, B, device=DEV, generator=g)
+    mod = nerf_sos_amd.GeoCorrelationLoss(ref_args())
+    monkeypatch.setenv("NSOS_GEO_FORCE_WIDE", "1")
+    out = {}
+    for kind in ("fused", "separate"):
+        if kind == "separate":
+            monkeypatch.setenv("NSOS_GEO_SEPARATE_COLS", "1")
+        c = code.clone().requires_grad_(True)
+        loss = mod(depth.clone(), c, [ray_o, ray_d, None], sim)
+        loss.backward()
+        out[kind] = (loss.detach().clone(), c.grad.clone())
+    assert torch.equal(out["fused"][0], out["separate"][0])
+    assert torch.isfinite(out["fused"][1]).all() and (C == 1 or out["separate"][1].abs().max() > 0)   # one channel: normalised code = +-1, no gradient
+    assert (out["fused"][1] - out["separate"][1]).abs().max() <= 2e-6 * out["separate"][1].abs().max()
+    # the fused pass is deterministic
+    c = code.clone().requires_grad_(True)
+    monkeypatch.delenv("NSOS_GEO_SEPARATE_COLS")
+    mod(depth.clone(), c, [ray_o, ray_d, None], sim).backward()
+    assert torch.equal(c.grad, out["fused"][1])
