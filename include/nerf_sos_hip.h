@@ -390,6 +390,7 @@ int32_t nsos_eval_postprocess(const float* semantics, const float* rgb, const fl
  *   phase 1: pass 2                   -> all-reduce scal[2..3]
  *   phase 2: passes 3, 4 + role sums  -> all-reduce scal[4..5] and gsum (gsum_floats fp32 at gsum_offset_bytes)
  *   phase 3: loss (the batch-wide value, identical on every rank) and grad_code [B,C,H,W] for every patch.
+ *   phase 4: phases 0..3 in one call, for a single process (nothing to reduce in between): fewer, merged finishing launches.
  * With rows = all patches and no reductions the four phases equal nsos_geo_correlation_loss up to summation order. */
 int32_t nsos_corr_workspace_slots(int32_t batch, int32_t n_points, int64_t* scal_offset_bytes, int64_t* gsum_offset_bytes,
                                   int64_t* gsum_floats);

@@ -492,9 +492,8 @@ __global__ __launch_bounds__(256) void pair_rowsum_copy_kernel(const PairArgs A,
 // noise of order 1e-11 of fd.  The first part is available from the row sums -- one thread block per set instead of a fourth
 // pass over all N^2 pairs (69 of 530 us in the C4 step); the second is below anything the loss can see (|m1| <~ 1e-8 |fd|
 // against a parity bar of 1e-4) and differs between the reference's own CPU and GPU reductions anyway.
-__global__ __launch_bounds__(256) void rowmean_residual_kernel(const PairArgs A) {
-    __shared__ double red[4];
-    const int set = blockIdx.x, N = A.N, nr = A.rows ? A.n_rows : A.B;
+__device__ __forceinline__ double rowmean_residual_sum(const PairArgs& A, int set) {
+    const int N = A.N, nr = A.rows ? A.n_rows : A.B;
     double s = 0.0;
     for (long long k = threadIdx.x; k < (long long)nr * N; k += blockDim.x) {
         const int n = A.rows ? A.rows[k / N] : (int)(k / N), p = (int)(k % N);
@@ -502,17 +501,35 @@ __global__ __launch_bounds__(256) void rowmean_residual_kernel(const PairArgs A)
         const float rm = (float)(rs / (double)N);                       // fd.mean([3,4]) as the row passes use it
         s += rs - (double)N * (double)rm;
     }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) A.scal[2 + set] = s;
+    return s;
+}
+__global__ __launch_bounds__(256) void rowmean_residual_kernel(const PairArgs A) {
+    __shared__ double red[4];
+    const double s = block_sum(rowmean_residual_sum(A, blockIdx.x), red);
+    if (threadIdx.x == 0) A.scal[2 + blockIdx.x] = s;
 }
 
 // scal[slot + set] = sum of the block partials, fixed order (64 lanes, each a strided sub-sum, then a fixed tree)
-__global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, int slot) {
-    const int set = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ double partial_sum(const double* __restrict__ partial, int nb, int set) {   // wave 0; valid in every lane
     double s = 0.0;
-    for (int i = lane; i < nb; i += 64) s += partial[(size_t)set * kRedBlocks + i];
-    s = nsos_wave_sum(s);
-    if (lane == 0) scal[slot + set] = s;
+    for (int i = threadIdx.x; i < nb; i += 64) s += partial[(size_t)set * kRedBlocks + i];
+    return nsos_wave_sum(s);
+}
+__global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, int slot) {
+    const double s = partial_sum(partial, nb, blockIdx.x);
+    if (threadIdx.x == 0) scal[slot + blockIdx.x] = s;
+}
+// single-process call: what follows pass 1 in ONE launch (block = set): scal[set] = sum of the pass's block partials (wave 0,
+// the same order as pair_finish_kernel) and scal[2 + set] = the row-mean residual (all 1024 threads)
+__global__ __launch_bounds__(1024) void pass1_finish_kernel(const PairArgs A, int nb) {
+    __shared__ double red[16];
+    const int set = blockIdx.x;
+    if (threadIdx.x < 64) {
+        const double s = partial_sum(A.partial, nb, set);
+        if (threadIdx.x == 0) A.scal[set] = s;
+    }
+    const double r = block_sum(rowmean_residual_sum(A, set), red);
+    if (threadIdx.x == 0) A.scal[2 + set] = r;
 }
 
 // PASS 4: gradient w.r.t. the column codes: thread = column point q of pair (n -> m), loop over the row points p
@@ -635,6 +652,17 @@ __global__ void loss_finish_kernel(const double* __restrict__ scal, double cnt, 
     const float l_neg = (float)(scal[4] / cnt), l_self = (float)(scal[5] / cnt);   // .mean(), :370
     loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
     if (geo && scal[7] != 0.0) loss[0] = __builtin_nanf("");                      // NaN inputs (geo_prep_kernel)
+}
+// single-process call: pair_finish_kernel(slot 4) for both sets + loss_finish_kernel in one launch of 64 threads
+__global__ void pass3_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, double cnt, CorrParams prm,
+                                    float* __restrict__ loss, int geo) {
+    const double s0 = partial_sum(partial, nb, 0), s1 = partial_sum(partial, nb, 1);
+    if (threadIdx.x != 0) return;
+    scal[4] = s0;
+    scal[5] = s1;
+    const float l_neg = (float)(s0 / cnt), l_self = (float)(s1 / cnt);
+    loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
+    if (geo && scal[7] != 0.0) loss[0] = __builtin_nanf("");
 }
 
 // backward of F.normalize for one point: g_v = (g - y (g.y)) / d  if ||v|| >= eps, else g / eps
@@ -907,9 +935,9 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
         hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1, NARROW>), grid, dim3(tb), lds_rows12, st, A);
         if (GEO && A.Bg > 0 && A.Bg < B)
             hipLaunchKernelGGL(pair_rowsum_copy_kernel, dim3((N + 255) / 256, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
-        hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
-    }
-    if (phases & 2) hipLaunchKernelGGL(rowmean_residual_kernel, dim3(2), dim3(256), 0, st, A);
+        if (phases & 2) hipLaunchKernelGGL(pass1_finish_kernel, dim3(2), dim3(1024), 0, st, A, nb);
+        else hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
+    } else if (phases & 2) hipLaunchKernelGGL(rowmean_residual_kernel, dim3(2), dim3(256), 0, st, A);
     if (phases & 4) {
         constexpr bool kCanFuse = GEO && !NARROW;
         const bool fuse = kCanFuse && want_grad && A.gcolp && !nsos_env_flag("NSOS_GEO_SEPARATE_COLS");
@@ -917,8 +945,8 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
             if (fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW, true>), grid, dim3(tb), lds_rows3, st, A);
         }
         if (!fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
-        hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
-        if (loss) hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0);
+        if (loss) hipLaunchKernelGGL(pass3_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0);
+        else hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
         if constexpr (kCanFuse) {
             if (fuse) hipLaunchKernelGGL((pair_cols_fold_kernel<C>), dim3((N + 63) / 64, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
         }
@@ -1020,13 +1048,28 @@ int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long lo
     const long long tot = (long long)B * N;
     const unsigned gb = (unsigned)((tot + 255) / 256);
     PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, rows, n_rows, w.gcolp, in.Bg};
-    if (phase == 0) {
+    if (phase == 0 || phase == 4) {
         const long long tot_geo = (long long)in.Bg * N;                            // depth: one map per GEOMETRY patch
         const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
         hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial);
         hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
         hipLaunchKernelGGL((geo_prep_kernel<C>), dim3(gb), dim3(256), 0, st, depth, in, B, N, max_depth, write_back,
                            w.scal, w.pts, w.cn, w.dinv);
+    }
+    if (phase == 4) {   // single process: nothing to reduce between the phases -- every launch of the loss from one call
+        if (n_rows == 0) {
+            hipError_t e = hipMemsetAsync(w.scal, 0, 6 * sizeof(double), st);
+            if (e == hipSuccess) e = hipMemsetAsync(w.gsum, 0, sizeof(float) * tot * kMaxC, st);
+            if (e != hipSuccess) return (int32_t)e;
+            hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss, 1);
+        } else {
+            const bool want_grad = in.grad[0] || in.grad[1];
+            const int32_t rc = run_pair_passes<true, C>(A, want_grad, loss, st, 7);
+            if (rc != NSOS_OK) return rc;
+            if (want_grad) hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, w.gsum);
+        }
+        if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, in);
+        return nsos_launch_status();
     }
     if (phase <= 2) {
         const int slot = phase * 2;
@@ -1123,10 +1166,10 @@ static int32_t geo_rows_entry(int32_t phase, float* depth, const GeoInputs in, c
                               float neg_weight, float max_depth, int32_t filter_in_place, float* loss, void* workspace,
                               size_t workspace_bytes, void* stream) {
     const int batch = in.Bg * in.n_codes;
-    NSOS_REQUIRE(phase >= 0 && phase <= 3, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(phase >= 0 && phase <= 4, NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(depth && in.code[0] && (in.n_codes == 1 || in.code[1]) && in.ray_o && in.ray_d && neg_indx && workspace && (n_rows == 0 || rows),
                  NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(phase < 3 || loss, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(phase < 3 || loss, NSOS_ERR_NULL_POINTER);   // phases 3 and 4 write the loss
     NSOS_REQUIRE(batch > 0 && height > 0 && width > 0 && n_rows >= 0 && n_rows <= batch, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
     const long long N = (long long)height * width;

@@ -14,7 +14,13 @@
 //     three operand sets in flight per wave (48 points ahead), the set of step s+1 is staged while step s is multiplied and
 //     refilled with step s+4 right away;
 //   * 8 waves = two per SIMD at <= 256 registers: wave w multiplies g_hid tile (w & 3) by the five sem_in column tiles of
-//     half (w >> 2).  Waves 0..3 fetch and form the g_hid tiles (the long instruction chain of a step), waves 4..7 move sem_in;
+//     half (w >> 2).  Waves 0..3 fetch and form g_hid, waves 4..7 move sem_in;
+//   * g_hid is formed in the order the hidden activations lie in memory: a lane owns ONE point and 8 consecutive features
+//     (one coalesced dwordx4 of `hid`, one weight, one ray gradient: three loads per step and lane, ~70 VALU), writes the
+//     split words row-major ([16 points][128 features], rows padded to 288 B) and the MFMA operand comes back through the same
+//     transposing LDS read as sem_in.  (Round 2 formed it in operand order -- a lane owned one feature of 8 points: eight
+//     2-byte loads, per-point ray bookkeeping with an integer division per fetch, ~190 VALU per step on the four waves every
+//     barrier waited for: 2.1 k cycles per 16-point step against 0.64 k of MFMA.)
 //   * sem_in goes to LDS as it lies in memory -- [16 points][320 channels], rows padded to 672 B -- with three coalesced
 //     dwordx4 loads per wave and step (a 32-channel x 8-point MFMA operand gathered from global memory was 8 two-byte loads per
 //     lane: 80 load instructions per CU and step), and the MFMA operand (8 consecutive POINTS of one channel per lane) comes out
@@ -39,17 +45,17 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int kWgradOut = 128 * 320 + 2 * 128 + 2;      // as in backward.hip
 constexpr int kRowBytes = 672;                           // LDS row of one point's 320 channels (640 B) + 32 B: rows 8 banks apart
-constexpr int kGBytes = 4 * 2 * 1024;                    // g_hid tiles 0..3 (hi, lo), MFMA operand order
+constexpr int kGRow = 288;                               // LDS row of one point's 128 g_hid words (256 B) + 32 B
+constexpr int kGBytes = 2 * 16 * kGRow;                  // g_hid of the step's 16 points, row-major: hi words, then lo words
 constexpr int kBufBytes = kGBytes + 16 * kRowBytes;      // ... then the step's 16 sem_in rows as they lie in memory
-constexpr int kLoadsG = 12, kLoadsX = 3;                 // loads per fetch of a g-kind / x-kind wave
+constexpr int kLoadsG = 3, kLoadsX = 3;                  // loads per fetch of a g-kind / x-kind wave
 
 
 // the operand set of one 16-point step, as one wave holds it
-struct SetG {            // waves 0..3
-    f32x4 wt[2];         // compositing weights of the lane half's 8 points
-    f32x2 ga, gb;        // dL/dsemantics of the ray of the first point and of the next ray
-    unsigned h[8];       // sem_hid column 32 gt + i of the 8 points: the 16-bit word as loaded (zero-extended)
-    int cross;           // points e >= cross belong to the next ray
+struct SetG {            // waves 0..3: lane = (point 4 w + (l >> 4), features 8 (l & 15) .. + 7)
+    float wt;            // compositing weight of the point
+    f32x2 g;             // dL/dsemantics of its ray
+    u32x4 h;             // its 8 hidden activations, 16-bit words as stored
 };
 struct SetX {            // waves 4..7: 3 x 16 B of the wave's four sem_in rows (160 chunks of 16 B over 64 lanes)
     u32x4 x[3];
@@ -97,10 +103,7 @@ __device__ __forceinline__ unsigned long long uniform64(const void* p) {   // th
 // s_waitcnt vmcnt(N) that owns the registers it releases: nothing that reads them can be scheduled above it.
 template <int N>
 __device__ __forceinline__ void wait_set(SetG& s) {
-    asm volatile("s_waitcnt vmcnt(%12)"
-                 : "+v"(s.wt[0]), "+v"(s.wt[1]), "+v"(s.ga), "+v"(s.gb), "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]),
-                   "+v"(s.h[4]), "+v"(s.h[5]), "+v"(s.h[6]), "+v"(s.h[7])
-                 : "i"(N));
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.wt), "+v"(s.g), "+v"(s.h) : "i"(N));
 }
 template <int N>
 __device__ __forceinline__ void wait_set(SetX& s) {
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
                                                                   const unsigned short* __restrict__ sem_in,
                                                                   const float* __restrict__ scale_p, long long n_pts,
                                                                   long long n_rays, int S, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kBufBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kBufBytes];
     const int lane = threadIdx.x & 63, i = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int gt = wave & 3, ch = wave >> 2;
@@ -150,19 +153,27 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     const long long s1 = s0 + per < n_full ? s0 + per : n_full;
     const int nf = __builtin_amdgcn_readfirstlane((int)(s1 > s0 ? s1 - s0 : 0));
     const float scale = *scale_p;
-    const float w2a = w2[32 * gt + i] * scale, w2b = w2[128 + 32 * gt + i] * scale;   // scale is a power of two: exact
+    // g-kind lane: point pl of the step, features 8 fo .. 8 fo + 7
+    const int pl = 4 * gt + (lane >> 4), fo = lane & 15;
+    float w2a[8], w2b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { w2a[k] = w2[8 * fo + k] * scale; w2b[k] = w2[128 + 8 * fo + k] * scale; }   // scale is a power of two: exact
 
     f32x16 acc[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    float gw2[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f};
+    float gw2[2][8], gb2[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gw2[0][k] = gw2[1][k] = 0.0f;
 
-    // lane offsets (bytes) inside a step's rows; the half-wave's 8-point shift is part of them
-    const unsigned off_w = 32u * kg, off_h = (8u * kg * 128u + i) * 2u;     // hid: 16-bit like sem_in (nsos_mlp_forward_rays_save16_lp)
+    const unsigned off_w = 4u * (unsigned)pl, off_h = ((unsigned)pl * 128u + 8u * (unsigned)fo) * 2u;   // hid: 16-bit like sem_in
     auto widen = [](unsigned w) { return XFMT == 1 ? (float)__builtin_bit_cast(_Float16, (unsigned short)w) : __builtin_bit_cast(float, w << 16); };
     const unsigned long long g_base = uniform64(g_sem);
+    // the ray of the lane's point, kept by increments: point s0 * 16 + pl now, + 16 per fetched step (n_samples >= 8: two wraps at most)
+    unsigned ray_q = (unsigned)((unsigned long long)(s0 * 16 + pl) / (unsigned)S), ray_r = (unsigned)((unsigned long long)(s0 * 16 + pl) % (unsigned)S);
+    if (nf == 0) ray_q = 0;
     // x-kind: chunk c = lane + 64 j (j = 0..2) of the wave's 4 rows x 40 chunks of 16 B; chunks past 159 repeat chunk 159 (the
     // load is issued by every lane so that the vmcnt arithmetic holds; the duplicate is not written to LDS)
     unsigned xg_off[3], xl_off[3];
@@ -176,24 +187,24 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         asm volatile("" : "+v"(xg_off[j]), "+v"(xl_off[j]));     // per-lane constants: keep them in registers (no re-derivation per fetch)
     }
     // operand fetch of column tile T: lane (r = (l & 15) >> 2, q = l & 3) of 16-lane group g = l >> 4 passes the address of point
-    // 8 (g >> 1) + r, channels 32 T + 16 (g & 1) + 4 q .. + 3; a second read four rows further gives points + 4 .. + 7
+    // 8 (g >> 1) + r, channels 32 T + 16 (g & 1) + 4 q .. + 3; a second read four rows further gives points + 4 .. + 7.
+    // The g_hid operand (feature tile gt) is fetched the same way from its own rows.
     const unsigned tr_off = (unsigned)(kGBytes + (8 * (lane >> 5) + ((lane & 15) >> 2)) * kRowBytes + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const unsigned tr_off_g = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * kGRow + (32 * gt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
-    auto fetch_g = [&](long long step, SetG& s) {
-        const unsigned p0 = (unsigned)(step * 16) + 8u * (unsigned)kg;
-        const unsigned q0 = p0 / (unsigned)S;
-        const unsigned q1 = q0 + 1 < (unsigned)n_rays ? q0 + 1 : q0;
-        s.cross = (int)((q0 + 1) * (unsigned)S - p0);
+    // fetch of step `step` for a lane whose point lies on ray ray_q; `advance`: move the ray bookkeeping on to the next step
+    auto fetch_g = [&](long long step, bool advance, SetG& s) {
         const unsigned long long wb = uniform64(weights + step * 16);
-        const unsigned long long hb = uniform64(hid + step * 16 * 128 + 32 * gt);     // (element pointer: 16-bit elements)
-        s.wt[0] = ld_f32x4<0>(off_w, wb);
-        s.wt[1] = ld_f32x4<16>(off_w, wb);
-        s.ga = ld_f32x2(q0 * 8u, g_base);
-        s.gb = ld_f32x2(q1 * 8u, g_base);
-        s.h[0] = ld_u16<0 * 256>(off_h, hb); s.h[1] = ld_u16<1 * 256>(off_h, hb); s.h[2] = ld_u16<2 * 256>(off_h, hb);
-        s.h[3] = ld_u16<3 * 256>(off_h, hb); s.h[4] = ld_u16<4 * 256>(off_h, hb); s.h[5] = ld_u16<5 * 256>(off_h, hb);
-        s.h[6] = ld_u16<6 * 256>(off_h, hb); s.h[7] = ld_u16<7 * 256>(off_h, hb);
+        const unsigned long long hb = uniform64(hid + step * 16 * 128);     // (element pointer: 16-bit elements)
+        s.wt = ld_f32<0>(off_w, wb);
+        s.g = ld_f32x2(ray_q * 8u, g_base);
+        s.h = ld_u32x4(off_h, hb);
+        if (advance) {
+            ray_r += 16u;
+            if (ray_r >= (unsigned)S) { ray_r -= (unsigned)S; ++ray_q; }
+            if (ray_r >= (unsigned)S) { ray_r -= (unsigned)S; ++ray_q; }
+        }
     };
     auto fetch_x = [&](long long step, SetX& s) {
         const unsigned long long xb = uniform64(sem_in + step * 16 * 320);
@@ -201,17 +212,21 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         s.x[1] = ld_u32x4(xg_off[1], xb);
         s.x[2] = ld_u32x4(xg_off[2], xb);
     };
-    auto tile = [&](int buf, int slot) { return reinterpret_cast<u32x4*>(lds + buf * kBufBytes + slot * 1024 + lane * 16); };
-    // g_hid of one point from its compositing weight, the ray's dL/dsemantics (g0, g1) and the hidden activation
-    auto form = [&](float wte, float g0, float g1, float hv, float& a) {
-        const float gl0 = wte * g0, gl1 = wte * g1;                                  // g_logits (models/renderer.py:64-66)
-        a = hv > 0.0f ? __fmaf_rn(gl1, w2b, gl0 * w2a) : 0.0f;                       // g_hid x scale (models/nerf_mlp.py:61)
-        gw2[0] = __fmaf_rn(gl0, hv, gw2[0]);                                         // hid is stored after its ReLU
-        gw2[1] = __fmaf_rn(gl1, hv, gw2[1]);
+    // g_hid of the lane's point for its 8 features, from the compositing weight, the ray's dL/dsemantics and the hidden
+    // activations; split words to the step's row-major image
+    auto stage_g = [&](const SetG& s, int buf) {
+        const float gl0 = s.wt * s.g[0], gl1 = s.wt * s.g[1];                        // g_logits (models/renderer.py:64-66)
         gb2[0] += gl0;
         gb2[1] += gl1;
-    };
-    auto put_g = [&](const float (&a)[8], int buf) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned w = s.h[k >> 1];
+            const float hv = (k & 1) ? (XFMT == 1 ? widen(w >> 16) : __builtin_bit_cast(float, w & 0xffff0000u)) : widen(w);
+            a[k] = hv > 0.0f ? __fmaf_rn(gl1, w2b[k], gl0 * w2a[k]) : 0.0f;         // g_hid x scale (models/nerf_mlp.py:61)
+            gw2[0][k] = __fmaf_rn(gl0, hv, gw2[0][k]);                               // hid is stored after its ReLU
+            gw2[1][k] = __fmaf_rn(gl1, hv, gw2[1][k]);
+        }
         u32x4 h, l;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -219,69 +234,87 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
             split2(a[2 * q], a[2 * q + 1], x, y);
             h[q] = x; l[q] = y;
         }
-        *tile(buf, 2 * gt) = h;
-        *tile(buf, 2 * gt + 1) = l;
-    };
-    auto stage_g = [&](const SetG& s, int buf) {
-        float a[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool next = e >= s.cross;
-            form(s.wt[e >> 2][e & 3], next ? s.gb[0] : s.ga[0], next ? s.gb[1] : s.ga[1], widen(s.h[e]), a[e]);
-        }
-        put_g(a, buf);
+        unsigned char* row = lds + buf * kBufBytes + pl * kGRow + fo * 16;
+        *reinterpret_cast<u32x4*>(row) = h;
+        *reinterpret_cast<u32x4*>(row + 16 * kGRow) = l;
     };
     auto stage_x = [&](const SetX& s, int buf) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (x_own[j]) *reinterpret_cast<u32x4*>(lds + buf * kBufBytes + xl_off[j]) = to_f16<XFMT>(s.x[j]);
     };
-    auto compute = [&](int buf) {
-        const u32x4 ah = *tile(buf, 2 * gt), al = *tile(buf, 2 * gt + 1);
+    // The MFMA operands of one step as a wave holds them: 14 transposing reads, issued one step ahead of their MFMAs (the image
+    // of step s + 1 is complete at the barrier that opens step s: three LDS images rotate) and released by ONE wait at the end
+    // of the step, behind the MFMAs and the staging they overlap with.
+    struct Ops { u32x2 lo[5], hi[5], gq[4]; };
+    auto read_ops = [&](int buf, Ops& o) {
+        const unsigned tg = lds_base + (unsigned)(buf * kBufBytes) + tr_off_g;
         const unsigned ta = lds_base + (unsigned)(buf * kBufBytes) + tr_off + (unsigned)(5 * ch * 64);
-        u32x2 lo[5], hi[5];
-        lo[0] = lds_read_tr<0 * 64>(ta); hi[0] = lds_read_tr<0 * 64 + 4 * kRowBytes>(ta);
-        lo[1] = lds_read_tr<1 * 64>(ta); hi[1] = lds_read_tr<1 * 64 + 4 * kRowBytes>(ta);
-        lo[2] = lds_read_tr<2 * 64>(ta); hi[2] = lds_read_tr<2 * 64 + 4 * kRowBytes>(ta);
-        lo[3] = lds_read_tr<3 * 64>(ta); hi[3] = lds_read_tr<3 * 64 + 4 * kRowBytes>(ta);
-        lo[4] = lds_read_tr<4 * 64>(ta); hi[4] = lds_read_tr<4 * 64 + 4 * kRowBytes>(ta);
-        // the reads above are asm: hipcc does not count them.  One wait that owns their registers.
+        o.gq[0] = lds_read_tr<0>(tg); o.gq[1] = lds_read_tr<4 * kGRow>(tg);                  // hi words: points + 0..3, + 4..7
+        o.gq[2] = lds_read_tr<16 * kGRow>(tg); o.gq[3] = lds_read_tr<20 * kGRow>(tg);        // lo words
+        o.lo[0] = lds_read_tr<0 * 64>(ta); o.hi[0] = lds_read_tr<0 * 64 + 4 * kRowBytes>(ta);
+        o.lo[1] = lds_read_tr<1 * 64>(ta); o.hi[1] = lds_read_tr<1 * 64 + 4 * kRowBytes>(ta);
+        o.lo[2] = lds_read_tr<2 * 64>(ta); o.hi[2] = lds_read_tr<2 * 64 + 4 * kRowBytes>(ta);
+        o.lo[3] = lds_read_tr<3 * 64>(ta); o.hi[3] = lds_read_tr<3 * 64 + 4 * kRowBytes>(ta);
+        o.lo[4] = lds_read_tr<4 * 64>(ta); o.hi[4] = lds_read_tr<4 * 64 + 4 * kRowBytes>(ta);
+    };
+    // the reads are asm: hipcc does not count them.  One wait that owns their registers.
+    auto wait_ops = [&](Ops& o) {
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4]));
+                     : "+v"(o.lo[0]), "+v"(o.hi[0]), "+v"(o.lo[1]), "+v"(o.hi[1]), "+v"(o.lo[2]), "+v"(o.hi[2]), "+v"(o.lo[3]), "+v"(o.hi[3]),
+                       "+v"(o.lo[4]), "+v"(o.hi[4]), "+v"(o.gq[0]), "+v"(o.gq[1]), "+v"(o.gq[2]), "+v"(o.gq[3]));
+    };
+    auto mfmas = [&](const Ops& o) {
+        const u32x4 ah = u32x4{o.gq[0][0], o.gq[0][1], o.gq[1][0], o.gq[1][1]}, al = u32x4{o.gq[2][0], o.gq[2][1], o.gq[3][0], o.gq[3][1]};
         u32x4 b[5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) b[c] = u32x4{lo[c][0], lo[c][1], hi[c][0], hi[c][1]};
+        for (int c = 0; c < 5; ++c) b[c] = u32x4{o.lo[c][0], o.lo[c][1], o.hi[c][0], o.hi[c][1]};
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[c] = mfma16(ah, b[c], acc[c]);
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[c] = mfma16(al, b[c], acc[c]);
     };
+    auto compute = [&](int buf) { Ops o; read_ops(buf, o); wait_ops(o); mfmas(o); };
 
     if (nf > 0) {
         const long long base = __builtin_amdgcn_readfirstlane((int)s0);
         auto at = [&](int j) { return base + (j < nf ? j : nf - 1); };       // past the end: re-fetch the last step (never staged)
-        // Step s: stage the operand set J that holds step s + 1 (sets rotate A, B, C with the step), refill it with step s + 4,
-        // multiply step s.  Two fetches have been issued since J's own: vmcnt(2 x loads per fetch) releases it.
+        // Step s: request the operands of step s + 1 from image (s + 1) % 3, stage the fetched set J that holds step s + 2 into
+        // image (s + 2) % 3 (sets rotate C, A, B with the step), refill it with step s + 5, multiply step s from the operands
+        // requested a step ago.  Two fetches have been issued since J's own: vmcnt(2 x loads per fetch) releases it.  The g-kind
+        // wave of a SIMD stages before its MFMAs, the x-kind wave after: one feeds the matrix pipe while the other is on the VALU.
+        Ops O0, O1;
         if (kind_g) {
             SetG A, B, C;
-            fetch_g(at(0), A); fetch_g(at(1), B); fetch_g(at(2), C);
+            auto fetch = [&](int j, SetG& J) { fetch_g(at(j), j + 1 < nf, J); };    // consecutive steps; past the end the last one again
+            fetch(0, A); fetch(1, B); fetch(2, C);
             wait_set<2 * kLoadsG>(A);
             stage_g(A, 0);
-            fetch_g(at(3), A);
+            fetch(3, A);
+            wait_set<2 * kLoadsG>(B);
+            if (nf > 1) stage_g(B, 1);
+            fetch(4, B);
             __syncthreads();
-            auto step = [&](int s, SetG& J) {
-                if (s + 1 < nf) {
+            read_ops(0, O0);
+            wait_ops(O0);
+            auto step = [&](int s, int b1, int b2, SetG& J, Ops& cur, Ops& nxt) {
+                if (s + 1 < nf) read_ops(b1, nxt);
+                if (s + 2 < nf) {
                     wait_set<2 * kLoadsG>(J);
-                    stage_g(J, (s + 1) & 1);
+                    stage_g(J, b2);
                 }
-                fetch_g(at(s + 4), J);
-                compute(s & 1);
+                fetch(s + 5, J);
+                mfmas(cur);
+                wait_ops(nxt);
                 __syncthreads();
             };
-            for (int s = 0; s < nf; s += 3) {
-                step(s, B);
-                if (s + 1 < nf) step(s + 1, C);
-                if (s + 2 < nf) step(s + 2, A);
+            for (int s = 0; s < nf; s += 6) {
+                step(s, 1, 2, C, O0, O1);
+                if (s + 1 < nf) step(s + 1, 2, 0, A, O1, O0);
+                if (s + 2 < nf) step(s + 2, 0, 1, B, O0, O1);
+                if (s + 3 < nf) step(s + 3, 1, 2, C, O1, O0);
+                if (s + 4 < nf) step(s + 4, 2, 0, A, O0, O1);
+                if (s + 5 < nf) step(s + 5, 0, 1, B, O1, O0);
             }
         } else {
             SetX A, B, C;
@@ -289,20 +322,30 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
             wait_set<2 * kLoadsX>(A);
             stage_x(A, 0);
             fetch_x(at(3), A);
+            wait_set<2 * kLoadsX>(B);
+            if (nf > 1) stage_x(B, 1);
+            fetch_x(at(4), B);
             __syncthreads();
-            auto step = [&](int s, SetX& J) {
-                compute(s & 1);
-                if (s + 1 < nf) {
+            read_ops(0, O0);
+            wait_ops(O0);
+            auto step = [&](int s, int b1, int b2, SetX& J, Ops& cur, Ops& nxt) {
+                if (s + 1 < nf) read_ops(b1, nxt);
+                mfmas(cur);
+                if (s + 2 < nf) {
                     wait_set<2 * kLoadsX>(J);
-                    stage_x(J, (s + 1) & 1);
+                    stage_x(J, b2);
                 }
-                fetch_x(at(s + 4), J);
+                fetch_x(at(s + 5), J);
+                wait_ops(nxt);
                 __syncthreads();
             };
-            for (int s = 0; s < nf; s += 3) {
-                step(s, B);
-                if (s + 1 < nf) step(s + 1, C);
-                if (s + 2 < nf) step(s + 2, A);
+            for (int s = 0; s < nf; s += 6) {
+                step(s, 1, 2, C, O0, O1);
+                if (s + 1 < nf) step(s + 1, 2, 0, A, O1, O0);
+                if (s + 2 < nf) step(s + 2, 0, 1, B, O0, O1);
+                if (s + 3 < nf) step(s + 3, 1, 2, C, O1, O0);
+                if (s + 4 < nf) step(s + 4, 2, 0, A, O0, O1);
+                if (s + 5 < nf) step(s + 5, 0, 1, B, O1, O0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the re-fetched sets are still landing in registers
@@ -310,16 +353,14 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     // the ragged step (n_pts % 16 points), by workgroup 0: rows clamped, out-of-range points get weight 0 (their g_hid is 0)
     if (blockIdx.x == 0 && (n_pts & 15)) {
         if (kind_g) {
-            const unsigned p0 = (unsigned)(n_full * 16) + 8u * (unsigned)kg;
-            float a[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned p = p0 + e < (unsigned)n_pts ? p0 + e : (unsigned)n_pts - 1u;
-                const float wte = p0 + e < (unsigned)n_pts ? weights[p] : 0.0f;
-                const unsigned r = p / (unsigned)S;
-                form(wte, g_sem[2ull * r], g_sem[2ull * r + 1], widen(hid[(unsigned long long)p * 128 + 32 * gt + i]), a[e]);
-            }
-            put_g(a, 0);
+            const unsigned p = (unsigned)(n_full * 16) + (unsigned)pl;
+            const bool valid = p < (unsigned)n_pts;
+            const unsigned pc = valid ? p : (unsigned)n_pts - 1u, r = pc / (unsigned)S;
+            SetG t;
+            t.wt = valid ? weights[pc] : 0.0f;
+            t.g = f32x2{g_sem[2ull * r], g_sem[2ull * r + 1]};
+            t.h = *reinterpret_cast<const u32x4*>(hid + (unsigned long long)pc * 128 + 8 * fo);
+            stage_g(t, 0);
         } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -339,14 +380,26 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 16; ++r)   // accumulator element r of lane (i, kg): row (r&3) + 8(r>>2) + 4kg, column i
             out[(size_t)(32 * gt + (r & 3) + 8 * (r >> 2) + 4 * kg) * 320 + 32 * (5 * ch + t) + i] = acc[t][r];
+    // dW2 / db2: the g-kind lanes' sums, folded over the 16 point slots in slot order through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);              // [16 slots][2][128] then [16][2]
     if (kind_g) {
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const float s = gw2[o] + __shfl_xor(gw2[o], 32, NSOS_WAVE);
-            if (kg == 0) out[128 * 320 + o * 128 + 32 * gt + i] = s;
-            const float sb = gb2[o] + __shfl_xor(gb2[o], 32, NSOS_WAVE);     // every lane of a half holds the same sum
-            if (wave == 0 && lane == 0) out[128 * 320 + 256 + o] = sb;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[(pl * 2 + o) * 128 + 8 * fo + k] = gw2[o][k];
+            if (fo == 0) red[16 * 256 + pl * 2 + o] = gb2[o];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        float t = 0.0f;
+        for (int k = 0; k < 16; ++k) t += red[k * 256 + threadIdx.x];
+        out[128 * 320 + threadIdx.x] = t;
+    } else if (threadIdx.x < 258) {
+        float t = 0.0f;
+        for (int k = 0; k < 16; ++k) t += red[16 * 256 + k * 2 + (threadIdx.x - 256)];
+        out[128 * 320 + 256 + (threadIdx.x - 256)] = t;
     }
 }
 }  // namespace

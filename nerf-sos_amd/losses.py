@@ -101,19 +101,25 @@ class CorrelationLoss(nn.Module):
             neg = torch.randperm(sim_matrix.shape[0], device=device, dtype=torch.long, generator=self.generator)   # :357
         return neg.to(device=device, dtype=torch.int64).contiguous()
 
-    def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor]):
+    def _launcher(self, orig_feats: torch.Tensor, code_shape, sim_matrix: Optional[torch.Tensor], weight: float = 1.0,
+                  neg: Optional[torch.Tensor] = None):
+        """Draws the sample coordinates and the negatives (the reference's order: rand1, rand2, negatives) and returns
+        launch(code, want_grad) -> (weight * loss, weight * d loss / d code or None).  `weight` rides on the kernel's own
+        self / negative weights (no extra launch); `neg`: negatives computed by the caller (one argmin per step, not per call)."""
         feats = _dev(orig_feats.detach(), "orig_feats")
         B, Cf, Hf, Wf = feats.shape
-        Bc, C, Hc, Wc = orig_code.shape
+        Bc, C, Hc, Wc = code_shape
         if Bc != B:
             raise ValueError(f"orig_feats has {B} patches, orig_code {Bc}")
         S = self.feature_samples
         dev = feats.device
         rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :343 (the kernel applies *2-1)
         rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :344
-        neg = self._neg_index(sim_matrix, B, dev)
+        if neg is None:
+            neg = self._neg_index(sim_matrix, B, dev)
         lib = _lib.lib()
-        prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
+        w = float(weight)
+        prm = (self.self_shift, self.self_weight * w, self.neg_shift, self.neg_weight * w)
 
         def launch(code, want_grad):
             code = code.detach()
@@ -135,7 +141,16 @@ class CorrelationLoss(nn.Module):
                                                      _stream()), "nsos_app_correlation_loss")
             return loss, grad
 
-        return _CorrFn.apply(orig_code, launch)
+        return launch
+
+    def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor]):
+        return _CorrFn.apply(orig_code, self._launcher(orig_feats, orig_code.shape, sim_matrix))
+
+    def value_and_grad(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor],
+                       weight: float = 1.0, neg: Optional[torch.Tensor] = None, want_grad: bool = True):
+        """(weight * loss, weight * d loss / d orig_code) straight from the launch, outside autograd -- for a training step that
+        sums the gradients of several losses itself and enters autograd once (sharding._losses_and_backward)."""
+        return self._launcher(orig_feats, orig_code.shape, sim_matrix, weight, neg)(orig_code, want_grad)
 
 
 class GeoCorrelationLoss(CorrelationLoss):
@@ -198,7 +213,7 @@ class GeoCorrelationLoss(CorrelationLoss):
             from .sharding import device_index
             rows_t = device_index(rows, torch.int32, dev)     # uploaded once (a fresh torch.tensor(..., device=) synchronises)
             reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-            for phase in range(4):
+            for phase in (range(4) if reduce else (4,)):      # single process: every launch from one call (phase 4)
                 _lib.check(lib.nsos_geo_correlation_loss_rows(phase, dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(),
                                                               rows_t.data_ptr() if len(rows) else None, len(rows), B, C, H, W, *prm,
                                                               float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
@@ -220,16 +235,10 @@ class GeoCorrelationLoss(CorrelationLoss):
         return out
 
 
-    def forward_pair(self, depth: torch.Tensor, code0: torch.Tensor, code1: torch.Tensor, ray_o: torch.Tensor, ray_d: torch.Tensor,
-                     sim_matrix: Optional[torch.Tensor], rows: Optional[Sequence[int]] = None, group=None) -> torch.Tensor:
-        """forward(depth, code0, ...) + forward(depth, code1, ...) -- the coarse and the fine semantic map against the same
-        geometry, as `train_one_step` scores them (engines/trainer.py:147-166) -- in ONE evaluation over the stacked batch
-        [code0; code1] that is never materialised (`nsos_geo_correlation_loss_pair`), on the renderer's own channel-last
-        tensors: depth [B,P,P,1], code0 / code1 [B,P,P,C], ray_o / ray_d [B,P,P,3].  The stacked mean is exactly
-        (L0 + L1) / 2 (every batch-wide quantity of the loss depends on the geometry only), so 2 x it is returned; with
-        `sim_matrix` the negatives stay inside their half.  `rows` / `group` as in forward (row-partitioned over the ranks; rows
-        index the B geometry patches).  Not for rand_neg (each call of the reference draws its own permutation there).
-        The depth is only read: the reference's in-place filter of the caller's tensor (utils/image.py:454) is left to forward."""
+    def _pair_launcher(self, depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, weight: float = 1.0,
+                       neg: Optional[torch.Tensor] = None, grad_mode: Optional[bool] = None):
+        """launch(code0, code1, want_grad) -> (weight * stacked-mean loss, its gradients) of forward_pair's evaluation.
+        `grad_mode`: the group-wide switch for the gradient's role-sum all-reduce (default: the caller's autograd mode)."""
         if self.rand_neg:
             raise NotImplementedError("forward_pair: with rand_neg every call draws its own negatives -- call forward twice")
         B, H, W = depth.shape[0], depth.shape[1], depth.shape[2]
@@ -239,13 +248,16 @@ class GeoCorrelationLoss(CorrelationLoss):
         dev = depth.device
         d = _dev(depth.detach().reshape(B, H * W), "depth")
         ro, rd = _dev(ray_o.detach(), "ray_o"), _dev(ray_d.detach(), "ray_d")
-        neg = self._neg_index(sim_matrix, B, dev)
+        if neg is None:
+            neg = self._neg_index(sim_matrix, B, dev)
         neg2 = torch.cat([neg, neg + B])
         own = list(range(B)) if rows is None else [int(r) for r in rows]
         rows2 = own + [B + r for r in own]
         lib = _lib.lib()
-        prm = (self.self_shift, self.self_weight, self.neg_shift, self.neg_weight)
-        grad_mode = torch.is_grad_enabled()
+        w = float(weight)
+        prm = (self.self_shift, self.self_weight * w, self.neg_shift, self.neg_weight * w)
+        if grad_mode is None:
+            grad_mode = torch.is_grad_enabled()
 
         def launch(c0, c1, want_grad):
             import ctypes as C_
@@ -263,7 +275,7 @@ class GeoCorrelationLoss(CorrelationLoss):
             gsum = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
             rows_t = device_index(rows2, torch.int32, dev)
             reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-            for phase in range(4):
+            for phase in (range(4) if reduce else (4,)):      # single process: every launch from one call (phase 4)
                 _lib.check(lib.nsos_geo_correlation_loss_pair(phase, _p(d), _p(c0), _p(c1), _p(ro), _p(rd), neg2.data_ptr(),
                                                               rows_t.data_ptr() if len(rows2) else None, len(rows2), B, 1, C, H, W, *prm,
                                                               float(self.max_depth), _p(loss), _p(g0), _p(g1), ws.data_ptr(),
@@ -275,7 +287,28 @@ class GeoCorrelationLoss(CorrelationLoss):
                         collective("geo_loss_role_sum_all_reduce", lambda async_op: dist.all_reduce(gsum, group=group, async_op=async_op), group)
             return loss, g0, g1
 
-        return 2.0 * _PairFn.apply(code0, code1, launch)
+        return launch
+
+
+    def forward_pair(self, depth: torch.Tensor, code0: torch.Tensor, code1: torch.Tensor, ray_o: torch.Tensor, ray_d: torch.Tensor,
+                     sim_matrix: Optional[torch.Tensor], rows: Optional[Sequence[int]] = None, group=None) -> torch.Tensor:
+        """forward(depth, code0, ...) + forward(depth, code1, ...) -- the coarse and the fine semantic map against the same
+        geometry, as `train_one_step` scores them (engines/trainer.py:147-166) -- in ONE evaluation over the stacked batch
+        [code0; code1] that is never materialised (`nsos_geo_correlation_loss_pair`), on the renderer's own channel-last
+        tensors: depth [B,P,P,1], code0 / code1 [B,P,P,C], ray_o / ray_d [B,P,P,3].  The stacked mean is exactly
+        (L0 + L1) / 2 (every batch-wide quantity of the loss depends on the geometry only), so 2 x it is returned; with
+        `sim_matrix` the negatives stay inside their half.  `rows` / `group` as in forward (row-partitioned over the ranks; rows
+        index the B geometry patches).  Not for rand_neg (each call of the reference draws its own permutation there).
+        The depth is only read: the reference's in-place filter of the caller's tensor (utils/image.py:454) is left to forward."""
+        return 2.0 * _PairFn.apply(code0, code1, self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group))
+
+    def pair_value_and_grads(self, depth, code0, code1, ray_o, ray_d, sim_matrix, rows=None, group=None, weight: float = 1.0,
+                             neg: Optional[torch.Tensor] = None, grad_mode: Optional[bool] = None):
+        """(weight * forward_pair(...), weight * d / d code0, weight * d / d code1) straight from the launches, outside autograd
+        (see CorrelationLoss.value_and_grad); the factor 2 of the stacked mean and `weight` ride on the kernel's weights."""
+        launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, 2.0 * float(weight), neg, grad_mode)
+        want = torch.is_grad_enabled() if grad_mode is None else bool(grad_mode)
+        return launch(code0, code1, want)
 
 
 class NeRFContrastive(nn.Module):

@@ -264,9 +264,60 @@ def similarity_matrix(cls_tokens: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.cosine_similarity(x.unsqueeze(0), x.unsqueeze(1), dim=2)
 
 
+def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
+                   contrast_loss=None, contrast_w=0.0):
+    """The loss section with the gradient bookkeeping done here instead of by autograd: every loss launch already returns
+    d loss / d code, the loss weights ride on the kernels' own weights, the negatives are found once, the four gradients are
+    summed by one multi-tensor launch, and autograd is entered ONCE, at the two rendered semantic maps
+    (torch.autograd.backward(tensors, grad_tensors)).  The same numbers as the autograd formulation below up to the rounding
+    of `weight * (self_weight, neg_weight)`, with sixteen element-wise launches fewer per step (three scalar products and sums
+    of the total, their three backward products, ones_like, four gradient scalings, two gradient accumulations, two argmin
+    reductions).  The condition for this path is the same on every rank (modules + autograd mode), as is the sequence of
+    collectives inside the geometric loss."""
+    side = _side_stream(dev) if (overlap_losses and dev.type == "cuda") else None
+    with torch.no_grad():
+        for m in (corr_loss, geo_loss):
+            if gen is not None:
+                m.generator = gen
+        f = full["feat"]
+        B = s0.shape[0]
+        neg = corr_loss._neg_index(sim, B, dev) if sim is not None else None     # utils/image.py:354, once for the three evaluations
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for t in (f, s0, s1, sim, neg):
+                    if t is not None:
+                        t.record_stream(side)
+                la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
+                la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
+        else:
+            la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
+            la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
+        lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
+                                                      sim, rows=own, group=group, weight=geo_w, neg=neg, grad_mode=True)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for t in (la0, la1, ga0, ga1):
+                t.record_stream(torch.cuda.current_stream(dev))
+        # gradients w.r.t. the channel-last maps: the appearance loss hands back [B,C,P,P] views of [B,P,P,C] buffers
+        torch._foreach_add_([gg0, gg1], [ga0.permute(0, 2, 3, 1), ga1.permute(0, 2, 3, 1)])
+        loss = torch.stack([la0, la1, lg]).sum() if contrast_loss is None else \
+            torch.stack([la0, la1, lg, contrast_w * contrast_loss(full["cls_"]).reshape(())]).sum()
+    roots = [(t, g) for t, g in ((full["semantics0"], gg0), (full["semantics"], gg1)) if t.requires_grad]
+    if roots:
+        torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
+    return loss
+
+
 def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
                          contrast_loss=None, contrast_w=0.0):
     """The loss section of `sharded_patch_step` (engines/trainer.py:127-166) and the backward through this rank's patches."""
+    if (corr_loss is not None and geo_loss is not None and torch.is_grad_enabled() and hasattr(corr_loss, "value_and_grad")
+            and hasattr(geo_loss, "pair_value_and_grads") and not getattr(geo_loss, "rand_neg", False)
+            and not getattr(corr_loss, "rand_neg", False) and os.environ.get("NSOS_STEP_AUTOGRAD_LOSSES", "") in ("", "0")):
+        return _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
+                              contrast_loss, contrast_w)
     loss = None
     # The appearance loss is a train of small launches (121 sample points per patch: grids of a few hundred threads), the
     # geometric one a few chip-filling ones with one workgroup per CU: on a stream of its own the former runs in the latter's

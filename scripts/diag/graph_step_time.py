@@ -7,8 +7,10 @@ import nerf_sos_amd
 from nerf_sos_amd import synthetic as syn
 DEV = "cuda:0"
 args = types.SimpleNamespace(rand_neg=False, self_corr_w=0, use_sim_matrix=True, patch_stride=6, app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
-for B in (1, 2):
-    for capture, overlap in ((False, True), (True, False), (True, True)):
+# optional: graph_step_time.py <B> <capture 0|1> <overlap 0|1>  -> that one mode only (for a kernel trace)
+MODES = [(int(sys.argv[1]), bool(int(sys.argv[2])), bool(int(sys.argv[3])))] if len(sys.argv) > 3 else [(B, c, o) for B in (1, 2) for c, o in ((False, True), (True, False), (True, True))]
+for B, capture, overlap in MODES:
+    if True:
         torch.manual_seed(0)
         net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True, perturb=1.0, raw_noise_std=1.0, ray_chunk=1 << 20).to(DEV)
         for n_, p_ in net.named_parameters():
