@@ -424,6 +424,15 @@ int32_t nsos_geo_correlation_loss_pair(int32_t phase, const float* depth, const 
 int32_t nsos_contrastive_loss(const float* embeddings, int32_t n_tokens, int32_t dim, float* loss, float* grad_embeddings,
                               void* stream);
 
+/* The negatives of the correlation losses: similarity = F.cosine_similarity(x[None], x[:, None], dim=2) of the batch's class
+ * tokens [n_tokens, dim] (get_similarity_matrix, utils/image.py:186-189; call site engines/trainer.py:125) and
+ * negatives[j] = torch.min(similarity, dim=0)[1][j] (utils/image.py:354; first occurrence, a NaN wins) in ONE launch (torch:
+ * thirteen).  similarity float [n_tokens, n_tokens] may be NULL.  negatives int64 [copies * n_tokens]: copy c holds
+ * negatives + c * n_tokens (the stacked two-map evaluation of nsos_geo_correlation_loss_pair takes copies = 2).
+ * 1 <= n_tokens <= 120. */
+int32_t nsos_similarity_negatives(const float* tokens, int32_t n_tokens, int32_t dim, float* similarity, int64_t* negatives,
+                                  int32_t copies, void* stream);
+
 /* ---- correlation losses on the rendered patches --------------------------------
  * CorrelationLoss.forward (utils/image.py:335-370) and GeoCorrelationLoss.forward (utils/image.py:448-487) for one
  * batch of B patches, with the random choices made by the caller:

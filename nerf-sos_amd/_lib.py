@@ -32,6 +32,7 @@ SIGNATURES = {
     "nsos_pixel_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _fp, _fp, _fp,
                                 _fp, _fp]),
     "nsos_contrastive_loss": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp]),
+    "nsos_similarity_negatives": (_i32, [_fp, _i32, _i32, _fp, _fp, _i32, _fp]),
     "nsos_ray_setup": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_ray_points": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),

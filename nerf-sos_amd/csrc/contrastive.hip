@@ -102,3 +102,56 @@ extern "C" int32_t nsos_contrastive_loss(const float* embeddings, int32_t n_toke
     hipLaunchKernelGGL(contrastive_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, embeddings, n_tokens, dim, loss, grad_embeddings);
     return nsos_launch_status();
 }
+
+// The negatives of the correlation losses for a patch batch: similarity_matrix = F.cosine_similarity(x[None], x[:, None], dim=2)
+// of the B class tokens (utils/image.py:186-189, engines/trainer.py:125) and neg[j] = torch.min(similarity_matrix, dim=0)[1][j]
+// (utils/image.py:354) -- thirteen element-wise / reduction launches of B x B values in torch, one single-workgroup launch here.
+// Same arithmetic as contrastive_kernel (both vectors normalised first, fp64 sums); first occurrence wins, a NaN wins.
+// neg is written `copies` times, copy c offset by c * B: the stacked two-map evaluation of the geometric loss wants [neg, neg + B].
+__global__ __launch_bounds__(256) void similarity_negatives_kernel(const float* __restrict__ emb, int B, int D, float* __restrict__ sim_out,
+                                                                   long long* __restrict__ neg, int copies) {
+    extern __shared__ float lds[];
+    float* sim = lds;                       // [B,B]
+    float* nrm = lds + B * B;               // [B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < B; i += 4) {
+        double s = 0.0;
+        for (int k = lane; k < D; k += 64) { const double x = emb[(size_t)i * D + k]; s += x * x; }
+        s = nsos_wave_sum(s);
+        if (lane == 0) nrm[i] = fmaxf((float)sqrt(s), 1e-8f);
+    }
+    __syncthreads();
+    const int n_pairs = B * (B + 1) / 2;
+    for (int p = wave; p < n_pairs; p += 4) {
+        int i = 0, rem = p;
+        while (rem >= B - i) { rem -= B - i; ++i; }
+        const int j = i + rem;
+        const float ni = nrm[i], nj = nrm[j];
+        double s = 0.0;
+        for (int k = lane; k < D; k += 64) s += (double)((emb[(size_t)i * D + k] / ni) * (emb[(size_t)j * D + k] / nj));
+        s = nsos_wave_sum(s);
+        if (lane == 0) { sim[i * B + j] = (float)s; sim[j * B + i] = (float)s; }
+    }
+    __syncthreads();
+    if (sim_out)
+        for (int e = tid; e < B * B; e += 256) sim_out[e] = sim[e];
+    for (int j = tid; j < B; j += 256) {
+        Pick best = {sim[j], 0};
+        for (int i = 1; i < B; ++i) {
+            const Pick c = {sim[i * B + j], i};
+            if (better_min(c, best)) best = c;
+        }
+        for (int c = 0; c < copies; ++c) neg[(size_t)c * B + j] = (long long)best.idx + (long long)c * B;
+    }
+}
+
+extern "C" int32_t nsos_similarity_negatives(const float* tokens, int32_t n_tokens, int32_t dim, float* similarity, int64_t* negatives,
+                                             int32_t copies, void* stream) {
+    NSOS_REQUIRE(tokens && negatives, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_tokens >= 1 && dim >= 1 && copies >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_tokens <= NSOS_CONTRASTIVE_MAX_B, NSOS_ERR_UNSUPPORTED);
+    const size_t lds = ((size_t)n_tokens * n_tokens + n_tokens) * sizeof(float);
+    hipLaunchKernelGGL(similarity_negatives_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, tokens, n_tokens, dim, similarity,
+                       reinterpret_cast<long long*>(negatives), copies);
+    return nsos_launch_status();
+}

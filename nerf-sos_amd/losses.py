@@ -250,7 +250,7 @@ class GeoCorrelationLoss(CorrelationLoss):
         ro, rd = _dev(ray_o.detach(), "ray_o"), _dev(ray_d.detach(), "ray_d")
         if neg is None:
             neg = self._neg_index(sim_matrix, B, dev)
-        neg2 = torch.cat([neg, neg + B])
+        neg2 = neg if neg.numel() == 2 * B else torch.cat([neg, neg + B])      # (similarity_negatives(copies=2) is already stacked)
         own = list(range(B)) if rows is None else [int(r) for r in rows]
         rows2 = own + [B + r for r in own]
         lib = _lib.lib()
@@ -309,6 +309,18 @@ class GeoCorrelationLoss(CorrelationLoss):
         launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, 2.0 * float(weight), neg, grad_mode)
         want = torch.is_grad_enabled() if grad_mode is None else bool(grad_mode)
         return launch(code0, code1, want)
+
+
+def similarity_negatives(cls_tokens: torch.Tensor, copies: int = 1, want_similarity: bool = False):
+    """negatives [copies * B] int64 (copy c = negatives + c * B) and, if asked for, the [B,B] cosine-similarity matrix of the
+    class tokens -- get_similarity_matrix (utils/image.py:186-189) followed by torch.min(sim, dim=0)[1] (:354) as one launch
+    (`nsos_similarity_negatives`)."""
+    x = _dev(cls_tokens.detach().reshape(cls_tokens.shape[0], -1), "cls_tokens")
+    B, D = x.shape
+    neg = torch.empty(copies * B, device=x.device, dtype=torch.int64)
+    sim = torch.empty((B, B), device=x.device, dtype=torch.float32) if want_similarity else None
+    _lib.check(_lib.lib().nsos_similarity_negatives(_p(x), B, D, _p(sim), neg.data_ptr(), copies, _stream()), "nsos_similarity_negatives")
+    return (neg, sim) if want_similarity else neg
 
 
 class NeRFContrastive(nn.Module):

@@ -264,6 +264,14 @@ def similarity_matrix(cls_tokens: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.cosine_similarity(x.unsqueeze(0), x.unsqueeze(1), dim=2)
 
 
+def _direct_losses(corr_loss, geo_loss) -> bool:
+    """Whether the step takes `_losses_direct` -- a function of the modules and the autograd mode only: the same on every rank."""
+    return (corr_loss is not None and geo_loss is not None and torch.is_grad_enabled() and hasattr(corr_loss, "value_and_grad")
+            and hasattr(geo_loss, "pair_value_and_grads") and not getattr(geo_loss, "rand_neg", False)
+            and not getattr(corr_loss, "rand_neg", False) and getattr(corr_loss, "use_sim_matrix", True)
+            and os.environ.get("NSOS_STEP_AUTOGRAD_LOSSES", "") in ("", "0"))
+
+
 def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
                    contrast_loss=None, contrast_w=0.0):
     """The loss section with the gradient bookkeeping done here instead of by autograd: every loss launch already returns
@@ -281,21 +289,26 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
                 m.generator = gen
         f = full["feat"]
         B = s0.shape[0]
-        neg = corr_loss._neg_index(sim, B, dev) if sim is not None else None     # utils/image.py:354, once for the three evaluations
+        # utils/image.py:354, once for the three evaluations: [neg, neg + B] straight from the class tokens (one launch)
+        from .losses import similarity_negatives
+        neg2 = similarity_negatives(full["cls_"], copies=2) if full["cls_"].shape[0] <= 120 else None
+        if neg2 is None:
+            n_ = corr_loss._neg_index(similarity_matrix(full["cls_"]) if sim is None else sim, B, dev)
+            neg2 = torch.cat([n_, n_ + B])
+        neg = neg2[:B]
         if side is not None:
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for t in (f, s0, s1, sim, neg):
-                    if t is not None:
-                        t.record_stream(side)
+                for t in (f, s0, s1, neg2):
+                    t.record_stream(side)
                 la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
                 la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
         else:
             la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
             la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
         lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
-                                                      sim, rows=own, group=group, weight=geo_w, neg=neg, grad_mode=True)
+                                                      sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
             for t in (la0, la1, ga0, ga1):
@@ -313,9 +326,7 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
 def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
                          contrast_loss=None, contrast_w=0.0):
     """The loss section of `sharded_patch_step` (engines/trainer.py:127-166) and the backward through this rank's patches."""
-    if (corr_loss is not None and geo_loss is not None and torch.is_grad_enabled() and hasattr(corr_loss, "value_and_grad")
-            and hasattr(geo_loss, "pair_value_and_grads") and not getattr(geo_loss, "rand_neg", False)
-            and not getattr(corr_loss, "rand_neg", False) and os.environ.get("NSOS_STEP_AUTOGRAD_LOSSES", "") in ("", "0")):
+    if _direct_losses(corr_loss, geo_loss):
         return _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
                               contrast_loss, contrast_w)
     loss = None
@@ -421,7 +432,7 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     if ev:
         ev[1].record()
     full = splice_local_patches(full, local, n_patches, group)
-    sim = similarity_matrix(full["cls_"])
+    sim = None if _direct_losses(corr_loss, geo_loss) else similarity_matrix(full["cls_"])   # (the direct path finds the negatives itself)
     s0 = full["semantics0"].permute(0, 3, 1, 2)
     s1 = full["semantics"].permute(0, 3, 1, 2)
     loss = None

@@ -34,5 +34,5 @@ for s, e, n in sel:
     dur[n][0] += e - s
     dur[n][1] += 1
 print("kernel time per step (us, launches per step):")
-for n, (t, c) in sorted(dur.items(), key=lambda kv: -kv[1][0])[:30]:
+for n, (t, c) in sorted(dur.items(), key=lambda kv: -kv[1][0])[:70]:
     print(f"  {t / steps / 1e3:7.1f} {c / steps:5.1f}  {short(n)}")

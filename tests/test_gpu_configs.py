@@ -147,6 +147,20 @@ def test_c4_per_gpu_workload_bf16_vs_fp32(manifest):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c4_direct_loss_gradients_equal_the_autograd_formulation(manifest, precision, monkeypatch):
+    """The step sums the loss launches' gradients itself and enters autograd once, at the rendered semantic maps
+    (sharding._losses_direct: weights on the kernels' weights, negatives from nsos_similarity_negatives); the formulation that
+    mirrors the reference's trainer line by line (w * (L(s0) + L(s1)) + ..., loss.backward(); NSOS_STEP_AUTOGRAD_LOSSES=1) must
+    give the same loss and parameter gradients up to the rounding of the folded weights."""
+    _, _, _, _, loss_d, g_d = _c4_step(precision, manifest)
+    monkeypatch.setenv("NSOS_STEP_AUTOGRAD_LOSSES", "1")
+    _, _, _, _, loss_a, g_a = _c4_step(precision, manifest)
+    assert abs(float(loss_d) - float(loss_a)) <= 2e-6 * (1 + abs(float(loss_a))), (float(loss_d), float(loss_a))
+    for k in g_a:
+        assert float((g_d[k] - g_a[k]).abs().max()) <= 2e-5 * float(g_a[k].abs().max()), k
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_c4_loss_overlap_does_not_change_a_bit(manifest, precision):
     """The appearance loss on a stream of its own (in the shadow of the geometric one, forward and backward) against the same
     step on one stream: identical loss and gradients, bit for bit."""

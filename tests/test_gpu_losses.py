@@ -359,3 +359,25 @@ def test_geo_column_gradient_from_the_row_pass_equals_the_separate_pass(shape, m
     monkeypatch.delenv("NSOS_GEO_SEPARATE_COLS")
     mod(depth.clone(), c, [ray_o, ray_d, None], sim).backward()
     assert torch.equal(c.grad, out["fused"][1])
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 16, 120])
+def test_similarity_negatives_vs_torch(B):
+    """nsos_similarity_negatives against the reference's two steps in torch: get_similarity_matrix (utils/image.py:186-189) and
+    torch.min(sim, dim=0)[1] (:354).  Tokens with a common offset (like DINO class tokens: similarities near 1, small gaps)."""
+    from nerf_sos_amd.losses import similarity_negatives
+    g = torch.Generator(DEV).manual_seed(B)
+    x = torch.randn(B, 384, device=DEV, generator=g) + 3.0 * torch.randn(1, 384, device=DEV, generator=g)
+    want_sim = torch.nn.functional.cosine_similarity(x.unsqueeze(0), x.unsqueeze(1), dim=2)
+    neg2, sim = similarity_negatives(x, copies=2, want_similarity=True)
+    assert neg2.dtype == torch.int64 and neg2.shape == (2 * B,) and sim.shape == (B, B)
+    assert float((sim - want_sim).abs().max()) < 2e-6
+    assert torch.equal(neg2[B:], neg2[:B] + B)
+    want_neg = torch.min(want_sim, dim=0)[1]
+    # equal picks wherever the column's two smallest entries are further apart than the two evaluations' rounding
+    srt = torch.sort(want_sim, dim=0)[0]
+    clear = (srt[1] - srt[0] > 1e-5) if B > 1 else torch.ones(B, dtype=torch.bool, device=DEV)
+    assert bool(clear.float().mean() > 0.9) and torch.equal(neg2[:B][clear], want_neg[clear])
+    picked = sim[neg2[:B], torch.arange(B, device=DEV)]
+    assert float((picked - sim.min(dim=0)[0]).abs().max()) == 0.0          # always an arg-min of its own matrix
+    assert torch.equal(similarity_negatives(x), neg2[:B])                   # deterministic, copies = 1
