@@ -3,9 +3,10 @@
 // sem_head_wgrad_x3_kernel (backward.hip):
 //   [dW1 | db1] [128,320] = sum_p g_hid[p,:]^T sem_in[p,:],   dW2 [2,128] = sum_p g_logits[p,:]^T hid[p,:],   db2 = sum_p g_logits
 //   g_logits[p,k] = w[p] G[ray(p),k],   g_hid[p,f] = (hid[p,f] > 0) sum_k g_logits[p,k] W2[k,f]          (models/nerf_mlp.py:61,79-80)
-// g_hid is split into fp16 hi + lo; a 16-bit sem_in IS its own fp16 image (fp16: the stored word; bf16: widened and
-// re-rounded -- exact from 2^-14 up, 8 significant bits into 11; below that the error is < 2^-25 absolute), so a product is
-// TWO MFMAs (hi.x + lo.x), not three.
+// g_hid is split into a hi + lo pair of sem_in's OWN 16-bit format and multiplied on that format's MFMA (fp16: 22 significant
+// bits of g_hid; bf16: 16 -- against a sem_in that carries 8), so sem_in goes from memory to LDS to the matrix pipe as it is
+// stored and a product is TWO MFMAs (hi.x + lo.x), not three.  (Until round 3 a bf16 sem_in was re-rounded to fp16 on the
+// way into LDS: 36 VALU instructions per wave and step on a kernel whose step was VALU-bound, see below.)
 //
 // Why a kernel of its own.  The 4-wave kernel reads 1.16 KB per point and ran at 2.3 TB/s -- neither HBM- nor MFMA-bound
 // (L2-resident inputs: -19 %; MFMAs removed: -17 %).  At 248 live VGPRs hipcc sinks half of each operand fetch next to its
@@ -42,6 +43,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef NSOS_WG_PROF   // diagnostic build (scripts/diag/wg_prof.py): s_memtime stamps around the phases of a step
+__device__ unsigned long long nsos_wg_prof[8][8];
+#endif
 namespace {
 constexpr int kWgradOut = 128 * 320 + 2 * 128 + 2;      // as in backward.hip
 constexpr int kRowBytes = 672;                           // LDS row of one point's 320 channels (640 B) + 32 B: rows 8 banks apart
@@ -110,6 +114,23 @@ __device__ __forceinline__ void wait_set(SetX& s) {
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s.x[0]), "+v"(s.x[1]), "+v"(s.x[2]) : "i"(N));
 }
 
+template <int XFMT>
+__device__ __forceinline__ f32x16 mfma_fmt(u32x4 a, u32x4 b, f32x16 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    if constexpr (XFMT == 1) return mfma16(a, b, c);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// (hi, lo) packed words of the fp32 pair (v0, v1) in format XFMT: hi = round(v), lo = round(v - hi)
+template <int XFMT>
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+    if constexpr (XFMT == 1) split2(v0, v1, hi, lo);
+    else {
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+        const float r0 = v0 - __builtin_bit_cast(float, hi << 16), r1 = v1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+    }
+}
+
 // 8 consecutive 16-bit values as fp16 words: fp16 as they are; bf16 widened and re-rounded (exact from 2^-14 up: 8 significant
 // bits into 11; below that the error is < 2^-25 absolute)
 template <int XFMT>
@@ -155,18 +176,22 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     const float scale = *scale_p;
     // g-kind lane: point pl of the step, features 8 fo .. 8 fo + 7
     const int pl = 4 * gt + (lane >> 4), fo = lane & 15;
-    float w2a[8], w2b[8];
+    f32x2 w2a[4], w2b[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { w2a[k] = w2[8 * fo + k] * scale; w2b[k] = w2[128 + 8 * fo + k] * scale; }   // scale is a power of two: exact
+    for (int q = 0; q < 4; ++q) {                                                    // scale is a power of two: exact
+        w2a[q] = f32x2{w2[8 * fo + 2 * q] * scale, w2[8 * fo + 2 * q + 1] * scale};
+        w2b[q] = f32x2{w2[128 + 8 * fo + 2 * q] * scale, w2[128 + 8 * fo + 2 * q + 1] * scale};
+    }
 
     f32x16 acc[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    float gw2[2][8], gb2[2] = {0.0f, 0.0f};
+    f32x2 gw2[2][4];
+    float gb2[2] = {0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gw2[0][k] = gw2[1][k] = 0.0f;
+    for (int q = 0; q < 4; ++q) gw2[0][q] = gw2[1][q] = f32x2{0.0f, 0.0f};
 
     const unsigned off_w = 4u * (unsigned)pl, off_h = ((unsigned)pl * 128u + 8u * (unsigned)fo) * 2u;   // hid: 16-bit like sem_in
     auto widen = [](unsigned w) { return XFMT == 1 ? (float)__builtin_bit_cast(_Float16, (unsigned short)w) : __builtin_bit_cast(float, w << 16); };
@@ -194,23 +219,28 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
     // fetch of step `step` for a lane whose point lies on ray ray_q; `advance`: move the ray bookkeeping on to the next step
-    auto fetch_g = [&](long long step, bool advance, SetG& s) {
-        const unsigned long long wb = uniform64(weights + step * 16);
-        const unsigned long long hb = uniform64(hid + step * 16 * 128);     // (element pointer: 16-bit elements)
-        s.wt = ld_f32<0>(off_w, wb);
+    // The three input streams advance by one 16-point step per fetch: their wave-uniform base addresses live in SGPRs and move
+    // on the scalar unit (`advance` is false once the last step is reached: it is fetched again, never staged).  (A base
+    // re-derived per fetch from the step index was two v_readfirstlane + s_nop 4 + 64-bit multiplies: 316 of the 2 000 cycles
+    // a step took on the g-kind waves.)
+    unsigned long long wb_run = uniform64(weights + s0 * 16), hb_run = uniform64(hid + s0 * 16 * 128), xb_run = uniform64(sem_in + s0 * 16 * 320);
+    auto fetch_g = [&](bool advance, SetG& s) {
+        s.wt = ld_f32<0>(off_w, wb_run);
         s.g = ld_f32x2(ray_q * 8u, g_base);
-        s.h = ld_u32x4(off_h, hb);
+        s.h = ld_u32x4(off_h, hb_run);
         if (advance) {
+            wb_run += 16 * 4;
+            hb_run += 16 * 128 * 2;
             ray_r += 16u;
             if (ray_r >= (unsigned)S) { ray_r -= (unsigned)S; ++ray_q; }
             if (ray_r >= (unsigned)S) { ray_r -= (unsigned)S; ++ray_q; }
         }
     };
-    auto fetch_x = [&](long long step, SetX& s) {
-        const unsigned long long xb = uniform64(sem_in + step * 16 * 320);
-        s.x[0] = ld_u32x4(xg_off[0], xb);
-        s.x[1] = ld_u32x4(xg_off[1], xb);
-        s.x[2] = ld_u32x4(xg_off[2], xb);
+    auto fetch_x = [&](bool advance, SetX& s) {
+        s.x[0] = ld_u32x4(xg_off[0], xb_run);
+        s.x[1] = ld_u32x4(xg_off[1], xb_run);
+        s.x[2] = ld_u32x4(xg_off[2], xb_run);
+        if (advance) xb_run += 16 * 320 * 2;
     };
     // g_hid of the lane's point for its 8 features, from the compositing weight, the ray's dL/dsemantics and the hidden
     // activations; split words to the step's row-major image
@@ -218,20 +248,19 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         const float gl0 = s.wt * s.g[0], gl1 = s.wt * s.g[1];                        // g_logits (models/renderer.py:64-66)
         gb2[0] += gl0;
         gb2[1] += gl1;
-        float a[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned w = s.h[k >> 1];
-            const float hv = (k & 1) ? (XFMT == 1 ? widen(w >> 16) : __builtin_bit_cast(float, w & 0xffff0000u)) : widen(w);
-            a[k] = hv > 0.0f ? __fmaf_rn(gl1, w2b[k], gl0 * w2a[k]) : 0.0f;         // g_hid x scale (models/nerf_mlp.py:61)
-            gw2[0][k] = __fmaf_rn(gl0, hv, gw2[0][k]);                               // hid is stored after its ReLU
-            gw2[1][k] = __fmaf_rn(gl1, hv, gw2[1][k]);
-        }
+        const f32x2 gl0v = {gl0, gl0}, gl1v = {gl1, gl1};
         u32x4 h, l;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {                                                // features 8 fo + 2 q, + 1: packed fp32 math
+            const unsigned w = s.h[q];
+            const f32x2 hv = {widen(w), XFMT == 1 ? widen(w >> 16) : __builtin_bit_cast(float, w & 0xffff0000u)};
+            f32x2 a = __builtin_elementwise_fma(gl1v, w2b[q], gl0v * w2a[q]);        // g_hid x scale (models/nerf_mlp.py:61)
+            a[0] = (w & 0xffffu) ? a[0] : 0.0f;                                      // hid is stored after its ReLU: > 0 <=> bits != 0
+            a[1] = (w >> 16) ? a[1] : 0.0f;
+            gw2[0][q] = __builtin_elementwise_fma(gl0v, hv, gw2[0][q]);
+            gw2[1][q] = __builtin_elementwise_fma(gl1v, hv, gw2[1][q]);
             unsigned x, y;
-            split2(a[2 * q], a[2 * q + 1], x, y);
+            split_pair<XFMT>(a[0], a[1], x, y);
             h[q] = x; l[q] = y;
         }
         unsigned char* row = lds + buf * kBufBytes + pl * kGRow + fo * 16;
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     auto stage_x = [&](const SetX& s, int buf) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            if (x_own[j]) *reinterpret_cast<u32x4*>(lds + buf * kBufBytes + xl_off[j]) = to_f16<XFMT>(s.x[j]);
+            if (x_own[j]) *reinterpret_cast<u32x4*>(lds + buf * kBufBytes + xl_off[j]) = s.x[j];     // as stored: the MFMA is sem_in's format's
     };
     // The MFMA operands of one step as a wave holds them: 14 transposing reads, issued one step ahead of their MFMAs (the image
     // of step s + 1 is complete at the barrier that opens step s: three LDS images rotate) and released by ONE wait at the end
@@ -270,15 +299,21 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 #pragma unroll
         for (int c = 0; c < 5; ++c) b[c] = u32x4{o.lo[c][0], o.lo[c][1], o.hi[c][0], o.hi[c][1]};
 #pragma unroll
-        for (int c = 0; c < 5; ++c) acc[c] = mfma16(ah, b[c], acc[c]);
+        for (int c = 0; c < 5; ++c) acc[c] = mfma_fmt<XFMT>(ah, b[c], acc[c]);
 #pragma unroll
-        for (int c = 0; c < 5; ++c) acc[c] = mfma16(al, b[c], acc[c]);
+        for (int c = 0; c < 5; ++c) acc[c] = mfma_fmt<XFMT>(al, b[c], acc[c]);
     };
     auto compute = [&](int buf) { Ops o; read_ops(buf, o); wait_ops(o); mfmas(o); };
 
+#ifdef NSOS_WG_PROF   // (the stamps do not wait for anything: s_memtime returns in order with the other scalar-memory results only)
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_T(k) do { pt[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PROF_ACC() do { for (int k_ = 1; k_ < 8; ++k_) pacc[k_] += (pt[k_] >= pt[k_ - 1] ? pt[k_] - pt[k_ - 1] : 0); pacc[0] += 1; } while (0)
+#else
+#define PROF_T(k)
+#define PROF_ACC()
+#endif
     if (nf > 0) {
-        const long long base = __builtin_amdgcn_readfirstlane((int)s0);
-        auto at = [&](int j) { return base + (j < nf ? j : nf - 1); };       // past the end: re-fetch the last step (never staged)
         // Step s: request the operands of step s + 1 from image (s + 1) % 3, stage the fetched set J that holds step s + 2 into
         // image (s + 2) % 3 (sets rotate C, A, B with the step), refill it with step s + 5, multiply step s from the operands
         // requested a step ago.  Two fetches have been issued since J's own: vmcnt(2 x loads per fetch) releases it.  The g-kind
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         Ops O0, O1;
         if (kind_g) {
             SetG A, B, C;
-            auto fetch = [&](int j, SetG& J) { fetch_g(at(j), j + 1 < nf, J); };    // consecutive steps; past the end the last one again
+            auto fetch = [&](int j, SetG& J) { fetch_g(j + 1 < nf, J); };            // consecutive steps; past the end the last one again
             fetch(0, A); fetch(1, B); fetch(2, C);
             wait_set<2 * kLoadsG>(A);
             stage_g(A, 0);
@@ -298,15 +333,24 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
             read_ops(0, O0);
             wait_ops(O0);
             auto step = [&](int s, int b1, int b2, SetG& J, Ops& cur, Ops& nxt) {
+                PROF_T(0);
                 if (s + 1 < nf) read_ops(b1, nxt);
+                PROF_T(1);
                 if (s + 2 < nf) {
                     wait_set<2 * kLoadsG>(J);
+                    PROF_T(2);
                     stage_g(J, b2);
                 }
+                PROF_T(3);
                 fetch(s + 5, J);
+                PROF_T(4);
                 mfmas(cur);
+                PROF_T(5);
                 wait_ops(nxt);
+                PROF_T(6);
                 __syncthreads();
+                PROF_T(7);
+                PROF_ACC();
             };
             for (int s = 0; s < nf; s += 6) {
                 step(s, 1, 2, C, O0, O1);
@@ -318,26 +362,36 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
             }
         } else {
             SetX A, B, C;
-            fetch_x(at(0), A); fetch_x(at(1), B); fetch_x(at(2), C);
+            auto fetch = [&](int j, SetX& J) { fetch_x(j + 1 < nf, J); };
+            fetch(0, A); fetch(1, B); fetch(2, C);
             wait_set<2 * kLoadsX>(A);
             stage_x(A, 0);
-            fetch_x(at(3), A);
+            fetch(3, A);
             wait_set<2 * kLoadsX>(B);
             if (nf > 1) stage_x(B, 1);
-            fetch_x(at(4), B);
+            fetch(4, B);
             __syncthreads();
             read_ops(0, O0);
             wait_ops(O0);
             auto step = [&](int s, int b1, int b2, SetX& J, Ops& cur, Ops& nxt) {
+                PROF_T(0);
                 if (s + 1 < nf) read_ops(b1, nxt);
+                PROF_T(1);
                 mfmas(cur);
+                PROF_T(2);
                 if (s + 2 < nf) {
                     wait_set<2 * kLoadsX>(J);
+                    PROF_T(3);
                     stage_x(J, b2);
                 }
-                fetch_x(at(s + 5), J);
+                PROF_T(4);
+                fetch(s + 5, J);
+                PROF_T(5);
                 wait_ops(nxt);
+                PROF_T(6);
                 __syncthreads();
+                PROF_T(7);
+                PROF_ACC();
             };
             for (int s = 0; s < nf; s += 6) {
                 step(s, 1, 2, C, O0, O1);
@@ -350,6 +404,10 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the re-fetched sets are still landing in registers
     }
+#ifdef NSOS_WG_PROF
+    if (blockIdx.x == 1 && lane == 0)
+        for (int k = 0; k < 8; ++k) nsos_wg_prof[wave][k] = pacc[k];
+#endif
     // the ragged step (n_pts % 16 points), by workgroup 0: rows clamped, out-of-range points get weight 0 (their g_hid is 0)
     if (blockIdx.x == 0 && (n_pts & 15)) {
         if (kind_g) {
@@ -368,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
                 const unsigned long long p = (unsigned long long)(n_full * 16 + row) < (unsigned long long)n_pts ? (unsigned long long)(n_full * 16 + row)
                                                                                                                 : (unsigned long long)n_pts - 1;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(sem_in + p * 320 + col * 8);
-                if (x_own[j]) *reinterpret_cast<u32x4*>(lds + xl_off[j]) = to_f16<XFMT>(v);
+                if (x_own[j]) *reinterpret_cast<u32x4*>(lds + xl_off[j]) = v;
             }
         }
         __syncthreads();
@@ -387,7 +445,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) red[(pl * 2 + o) * 128 + 8 * fo + k] = gw2[o][k];
+            for (int k = 0; k < 8; ++k) red[(pl * 2 + o) * 128 + 8 * fo + k] = gw2[o][k >> 1][k & 1];
             if (fo == 0) red[16 * 256 + pl * 2 + o] = gb2[o];
         }
     }
@@ -418,3 +476,9 @@ int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_seman
                            scale, n_pts, (long long)n_rays, (int)n_samples, partial);
     return nsos_launch_status();
 }
+
+#ifdef NSOS_WG_PROF
+extern "C" int32_t nsos_wg_prof_read(unsigned long long* out) {
+    return (int32_t)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsos_wg_prof), sizeof(unsigned long long) * 64);
+}
+#endif

@@ -1,3 +1,3 @@
-for v in base nosched sched8 sched2 r8 noreduce; do
-  echo "== $v"; NERF_SOS_HIP_LIB=$PWD/exp/lib_geo_$v.so NSOS_SKIP_HASH_CHECK=1 python scripts/diag/geo_fuse_time.py 2>&1 | grep fused
+for v in base nomfma noread nocvt l2 nomfma_noread l2_nomfma_noread; do
+  echo "== $v"; NERF_SOS_HIP_LIB=$PWD/exp/lib_wg_$v.so python scripts/diag/wgrad_time.py 4096 2>&1 | grep "S="
 done

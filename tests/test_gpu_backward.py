@@ -287,8 +287,11 @@ def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
         x16, h16 = sem_in.to(dt), hid.to(dt)
         a = ops.sem_head_wgrad(weights, g_sem, w2, h16, x16, split_fp16=True)
         b = ops.sem_head_wgrad(weights, g_sem, w2, h16.float(), x16.float(), split_fp16=True)
+        # fp16: g_hid enters the MFMA as a hi + lo pair of fp16 words (22 significant bits); bf16: as a pair of bf16 words (16
+        # bits -- against a sem_in of 8) on the bf16 MFMA, so that sem_in is multiplied as stored
+        tol = 1e-6 if dt == torch.float16 else 2e-5
         for x, y in zip(a, b):
-            assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max() + 1e-30), dt
+            assert float((x - y).abs().max()) <= tol * float(y.abs().max() + 1e-30), dt
         c = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16, split_fp16=True)      # an fp32 hid is rounded on the way in
         assert all(torch.equal(x, y) for x, y in zip(a, c)), dt
 
