@@ -263,8 +263,10 @@ __device__ __forceinline__ const float* col_codes(const PairArgs& A, int set, in
 // (one or two row patches per GPU in the sharded step; each workgroup re-stages the image, so narrow only when needed).
 template <bool GEO, bool NARROW = false>
 struct PairShape {
+    // appearance loss (N = 121 sample points): 32 rows x 4 column slabs -- one workgroup of 128 rows looping over all 121
+    // columns was a grid of two workgroups per patch and a chain of 121 dependent iterations (10-18 us per pass for 15 k pairs)
     static constexpr int kThreads = GEO ? 1024 : 128;
-    static constexpr int kRows = GEO ? (NARROW ? 32 : 64) : 128;
+    static constexpr int kRows = GEO ? (NARROW ? 32 : 64) : 32;
     static constexpr int kSlabs = kThreads / kRows;
 };
 
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
 // One workgroup per row point p; a wave takes four column points at a time, lanes across channels (coalesced), so four
 // independent row fetches are in flight per lane (one column per iteration was a chain of dependent L2 round trips: 63 us
 // for 14 MFLOP).  Products are rounded to fp32 and summed in fp64, as before.
-__global__ __launch_bounds__(256) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat) {
+__global__ __launch_bounds__(1024) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat) {
     const int set = blockIdx.z, n = blockIdx.y, p = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const float* a = fn + (((size_t)0 * B + n) * N + p) * Cf;
@@ -1098,7 +1100,7 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
     ws_layout(&w, workspace, B, N, Cf, true);
     hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, B, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
                        w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last);
-    hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(256), 0, st, w.fn, B, N, Cf, w.fdmat);
+    hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(1024), 0, st, w.fn, B, N, Cf, w.fdmat);   // 16 waves x 2 column quads each: a short dependent chain
     PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm, nullptr, 0, nullptr, 0};
     const int32_t rc = run_pair_passes<false, C>(A, grad_code != nullptr, loss, st);
     if (rc != NSOS_OK) return rc;
@@ -1110,7 +1112,7 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
         hipLaunchKernelGGL((app_point_grad_kernel<C>), dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, st, B, N, w.cn, w.cn2, w.dinv,
                            w.dinv2, w.grow, w.gcol, g1, g2);
         const long long px = (long long)B * Hc * Wc;
-        hipLaunchKernelGGL((app_scatter_kernel<C>), dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, B, N, S, Hc, Wc, neg, rnd1, rnd2,
+        hipLaunchKernelGGL((app_scatter_kernel<C>), dim3((unsigned)((px + 63) / 64)), dim3(64), 0, st, B, N, S, Hc, Wc, neg, rnd1, rnd2,   // one wave per workgroup: 64 CUs busy per patch instead of 16
                            g1, g2, grad_code, channel_last);
     }
     return nsos_launch_status();
