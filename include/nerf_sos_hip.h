@@ -206,7 +206,8 @@ int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, cons
  * sem_in_dtype: NSOS_DTYPE_F32 for the fp32 matrix (three MFMAs per product), NSOS_DTYPE_F16 / NSOS_DTYPE_BF16 for the
  * compact 16-bit matrices of nsos_mlp_forward_rays_save16_lp -- sem_hid is then 16-bit [P,128] in the same format too, fp32
  * [P,128] otherwise -- (half the operand traffic; a 16-bit operand has no lo part:
- * two MFMAs per product; csrc/sem_wgrad16.hip).  n_samples >= 8, n_rays * n_samples < 2^31. */
+ * two MFMAs per product on the format's own MFMA; csrc/sem_wgrad16.hip), optionally OR-ed with NSOS_SEM_IN_TILED (below) when
+ * sem_in is in the tile-major layout.  n_samples >= 8, n_rays * n_samples < 2^31. */
 int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                                const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
                                const float* scale, float* gw1_aug, float* gw2, float* gb2, void* workspace,
@@ -233,7 +234,16 @@ int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int3
  * 1280: the values are 16-bit anyway) and sem_hid16 [P,128] halves (256 B instead of 512: relu of the fp32 accumulators,
  * rounded to nearest even -- the ReLU pattern is unchanged, the values feed only d semantic_linear.2.weight, at the
  * format's precision like everything else on this path).  896 B per point in all (round 2: 1152).
- * Consumer: nsos_sem_head_wgrad_x3 with the matching sem_in_dtype. */
+ * Consumer: nsos_sem_head_wgrad_x3 with the matching sem_in_dtype.
+ * LAYOUT of sem_in16 -- nsos_mlp_save16_layout(n_points) says which one the call will write:
+ *   NSOS_SEM_IN_ROWS  (0):  [P, 320] row-major;
+ *   NSOS_SEM_IN_TILED (16): tile-major, the layout the two-waves-per-SIMD kernel (the default) stores without touching 32
+ *     different rows per instruction: groups of 32 consecutive points, [group][K 0..19][kg 0..1][point 0..31][8 channels] --
+ *     channel 16 K + 8 kg + c of point 32 g + i is element ((g * 20 + K) * 64 + kg * 32 + i) * 8 + c.  The buffer must hold
+ *     ceil(P / 32) * 32 rows of 320 elements; rows past P are not written.
+ * OR the layout value into nsos_sem_head_wgrad_x3's sem_in_dtype.  sem_hid16 is row-major in both. */
+enum { NSOS_SEM_IN_ROWS = 0, NSOS_SEM_IN_TILED = 16 };
+int32_t nsos_mlp_save16_layout(int64_t n_points);
 int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                         const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                         int32_t n_samples, float* raw, void* sem_in16, void* sem_hid16, void* stream);

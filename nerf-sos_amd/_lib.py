@@ -51,6 +51,7 @@ SIGNATURES = {
     "nsos_mlp_forward_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays_save_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
     "nsos_mlp_forward_rays_save16_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
+    "nsos_mlp_save16_layout": (_i32, [_i64]),
     "nsos_mlp_profile_rays": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_packed_bytes_x3": (_sz, [_i32]),
     "nsos_mlp_pack_x3": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),

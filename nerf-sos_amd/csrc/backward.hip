@@ -431,7 +431,9 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
                                           const void* sem_hid, const void* sem_in, int32_t sem_in_dtype, int64_t n_rays,
                                           int32_t n_samples, const float* scale, float* gw1_aug, float* gw2, float* gb2,
                                           void* workspace, size_t workspace_bytes, void* stream) {
-    NSOS_REQUIRE(sem_in_dtype >= 0 && sem_in_dtype <= 2, NSOS_ERR_UNSUPPORTED);
+    const int32_t tiled = sem_in_dtype & NSOS_SEM_IN_TILED;
+    sem_in_dtype &= ~NSOS_SEM_IN_TILED;
+    NSOS_REQUIRE(sem_in_dtype >= 0 && sem_in_dtype <= 2 && !(tiled && sem_in_dtype == 0), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(gw1_aug && gw2 && gb2, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_rays == 0 || (weights && g_semantics && sem2_w && sem_hid && sem_in && workspace), NSOS_ERR_NULL_POINTER);
@@ -452,7 +454,7 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
     switch (sem_in_dtype) {
         case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, static_cast<const float*>(sem_hid), static_cast<const float*>(sem_in), scale, n_pts, (int)n_samples, ws); break;
         default: {
-            const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype, n_rays, n_samples, scale, ws, blocks, st);
+            const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype | tiled, n_rays, n_samples, scale, ws, blocks, st);
             if (rc != NSOS_OK) return rc;
         }
     }

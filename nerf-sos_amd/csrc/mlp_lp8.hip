@@ -368,10 +368,25 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
         int* const park = reinterpret_cast<int*>(lds + kSlots * kSlotBytes + kAuxWords * 4) + wave_s * 192 + lane;
         *park = ray;
         bool save_ok = false;
-        unsigned* save_row = nullptr;
+        unsigned long long save_grp = 0;
+        unsigned save_off = 0;
+        // store K of the tile-major sem_in: scalar group base (+ a multiple of 4 KiB) + the lane's constant 32-bit offset + an
+        // immediate -- one VGPR of address for all twenty stores (generic pointers: twenty 64-bit lane addresses, i.e. spills)
+        auto save_store = [&save_grp, &save_off](auto kc, const u32x4& v) {   // (named captures: an operand of an asm statement alone does not capture)
+            constexpr int K = decltype(kc)::value;
+            const unsigned off = save_off;
+            unsigned long long b = save_grp + (unsigned long long)((K * 1024) & ~4095);
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(off), "v"(v), "s"(b), "i"((K * 1024) & 4095) : "memory");
+        };
         if constexpr (SAVE) {
             save_ok = exists;     // (this kernel's SAVE variant is the compact one: sem_in16 / sem_hid16 are never NULL, see forward_rays_lp)
-            save_row = P.sem_in16 + (long long)gc * 160;
+            // TILE-MAJOR sem_in (include/nerf_sos_hip.h, nsos_mlp_forward_rays_save16_lp): the 1 KiB a wave's store instruction holds
+            // -- octet 2K + kg of its 32 points -- is contiguous: [group of 32 points][store K 0..19][kg][point][8 channels].
+            // Row-major, the same instruction touched 32 lines 640 B apart (~32 cycles of the CU's address path each: what was
+            // left of the training variant's overhead); the weight-gradient kernel stages sem_in through LDS anyway and places
+            // the pieces itself.
+            save_grp = reinterpret_cast<unsigned long long>(P.sem_in16 + (long long)(wave_first >> 5) * 5120);   // wave-uniform: scalar unit
+            save_off = (unsigned)(pj * 4 + kg * 128) * 4u;                                                              // bytes
         }
         u32x4 ex[4];
         {
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
                 const auto s1 = __builtin_amdgcn_permlane32_swap(H[2 * t + j][1], H[2 * t + j][3], false, false);
 #ifndef NSOS_LP8_SKIP_IN    // (A/B builds only: scripts/diag/build_variant.sh)
                 if (save_ok)   // halves: features 32t + 16j + 8kg + {0..7} = words 16t + 8j + 4kg + {0..3}
-                    *reinterpret_cast<u32x4*>(save_row + 16 * t + 8 * j + 4 * kg) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    save_store(IC(k), u32x4{s0[0], s1[0], s0[1], s1[1]});
 #endif
             }
         };
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp8_kernel(const LpParams P) {
             constexpr int g = decltype(gc_)::value;      // SAVE, compact sem_in: the x63 slices (features 16s + 8kg + {0..7}; 63 is the 1.0 pad)
             if constexpr (SAVE && SEM != 0 && save_slot<SEM>(0, g) >= 16) {
                 constexpr int sl = save_slot<SEM>(0, g) - 16;
-                if (save_ok) *reinterpret_cast<u32x4*>(save_row + 128 + 8 * sl + 4 * kg) = ex[sl];
+                if (save_ok) save_store(IC(16 + sl), ex[sl]);
             }
         });
         stamp();  // 2: L0 MFMAs

@@ -155,7 +155,7 @@ __device__ __forceinline__ u32x2 lds_read_tr(unsigned addr) {
     return v;
 }
 
-template <int XFMT>   // 1: fp16, 2: bf16
+template <int XFMT, bool TILED>   // XFMT 1: fp16, 2: bf16; TILED: sem_in in the tile-major layout of nsos_mlp_forward_rays_save16_lp
 __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* __restrict__ weights, const float* __restrict__ g_sem,
                                                                   const float* __restrict__ w2, const unsigned short* __restrict__ hid,
                                                                   const unsigned short* __restrict__ sem_in,
@@ -205,9 +205,12 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     bool x_own[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int c_raw = lane + 64 * j, c = c_raw < 160 ? c_raw : 159, row = 4 * xw + c / 40, col = c % 40;
+        const int c_raw = lane + 64 * j, c = c_raw < 160 ? c_raw : 159;
+        // row-major: the wave moves rows 4 xw .. 4 xw + 3 (40 pieces each).  Tile-major: the wave moves stores K = 5 xw .. 5 xw + 4
+        // of the step's half group: piece c = (K - 5 xw, kg, point): 256-byte runs of 16 points; octet 2 K + kg of its point.
+        const int row = TILED ? (c & 15) : 4 * xw + c / 40, col = TILED ? 2 * (5 * xw + (c >> 5)) + ((c >> 4) & 1) : c % 40;
         x_own[j] = c_raw < 160;
-        xg_off[j] = (unsigned)(row * 640 + col * 16);
+        xg_off[j] = TILED ? (unsigned)((5 * xw + (c >> 5)) * 1024 + (((c >> 4) & 1) * 32 + (c & 15)) * 16) : (unsigned)(row * 640 + col * 16);
         xl_off[j] = (unsigned)(kGBytes + row * kRowBytes + col * 16);
         asm volatile("" : "+v"(xg_off[j]), "+v"(xl_off[j]));     // per-lane constants: keep them in registers (no re-derivation per fetch)
     }
@@ -223,7 +226,10 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     // on the scalar unit (`advance` is false once the last step is reached: it is fetched again, never staged).  (A base
     // re-derived per fetch from the step index was two v_readfirstlane + s_nop 4 + 64-bit multiplies: 316 of the 2 000 cycles
     // a step took on the g-kind waves.)
-    unsigned long long wb_run = uniform64(weights + s0 * 16), hb_run = uniform64(hid + s0 * 16 * 128), xb_run = uniform64(sem_in + s0 * 16 * 320);
+    // (tile-major sem_in: step s is half (s & 1) of group s >> 1: + 256 B into the group's second half, then on to the next group)
+    unsigned long long wb_run = uniform64(weights + s0 * 16), hb_run = uniform64(hid + s0 * 16 * 128),
+                       xb_run = uniform64(TILED ? sem_in + (s0 >> 1) * (32 * 320) + (s0 & 1) * (16 * 8) : sem_in + s0 * 16 * 320);
+    int x_half = __builtin_amdgcn_readfirstlane((int)(s0 & 1));
     auto fetch_g = [&](bool advance, SetG& s) {
         s.wt = ld_f32<0>(off_w, wb_run);
         s.g = ld_f32x2(ray_q * 8u, g_base);
@@ -240,7 +246,16 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         s.x[0] = ld_u32x4(xg_off[0], xb_run);
         s.x[1] = ld_u32x4(xg_off[1], xb_run);
         s.x[2] = ld_u32x4(xg_off[2], xb_run);
-        if (advance) xb_run += 16 * 320 * 2;
+        if (advance) {
+            if constexpr (TILED) {
+                unsigned inc = x_half ? 32u * 320u * 2u - 256u : 256u;
+                asm volatile("" : "+s"(inc), "+s"(x_half));        // wave-uniform: keep the stream's base on the scalar unit
+                xb_run += inc;
+                x_half ^= 1;
+                asm volatile("" : "+s"(xb_run));
+            }
+            else xb_run += 16 * 320 * 2;
+        }
     };
     // g_hid of the lane's point for its 8 features, from the compositing weight, the ray's dL/dsemantics and the hidden
     // activations; split words to the step's row-major image
@@ -422,10 +437,12 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
         } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int c_raw = lane + 64 * j, c = c_raw < 160 ? c_raw : 159, row = 4 * xw + c / 40, col = c % 40;
+                const int c_raw = lane + 64 * j, c = c_raw < 160 ? c_raw : 159;
+                const int row = TILED ? (c & 15) : 4 * xw + c / 40, col = TILED ? 2 * (5 * xw + (c >> 5)) + ((c >> 4) & 1) : c % 40;
                 const unsigned long long p = (unsigned long long)(n_full * 16 + row) < (unsigned long long)n_pts ? (unsigned long long)(n_full * 16 + row)
                                                                                                                 : (unsigned long long)n_pts - 1;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(sem_in + p * 320 + col * 8);
+                const unsigned short* src = TILED ? sem_in + (((p >> 5) * 20 + (col >> 1)) * 64 + (col & 1) * 32 + (p & 31)) * 8 : sem_in + p * 320 + col * 8;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(src);
                 if (x_own[j]) *reinterpret_cast<u32x4*>(lds + xl_off[j]) = v;
             }
         }
@@ -468,12 +485,13 @@ int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_seman
     const long long n_pts = (long long)n_rays * n_samples;
     const unsigned short* x = static_cast<const unsigned short*>(sem_in);
     const unsigned short* h = static_cast<const unsigned short*>(sem_hid);
-    if (sem_in_dtype == 1)
-        hipLaunchKernelGGL(sem_head_wgrad16_kernel<1>, dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x,
-                           scale, n_pts, (long long)n_rays, (int)n_samples, partial);
-    else
-        hipLaunchKernelGGL(sem_head_wgrad16_kernel<2>, dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x,
-                           scale, n_pts, (long long)n_rays, (int)n_samples, partial);
+    const bool tiled = (sem_in_dtype & NSOS_SEM_IN_TILED) != 0;
+    const int fmt = sem_in_dtype & ~NSOS_SEM_IN_TILED;
+#define NSOS_WG16_LAUNCH(F, T) hipLaunchKernelGGL((sem_head_wgrad16_kernel<F, T>), dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x, \
+                                                  scale, n_pts, (long long)n_rays, (int)n_samples, partial)
+    if (fmt == 1) { if (tiled) NSOS_WG16_LAUNCH(1, true); else NSOS_WG16_LAUNCH(1, false); }
+    else { if (tiled) NSOS_WG16_LAUNCH(2, true); else NSOS_WG16_LAUNCH(2, false); }
+#undef NSOS_WG16_LAUNCH
     return nsos_launch_status();
 }
 

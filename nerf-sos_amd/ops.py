@@ -258,8 +258,13 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     dev = z_vals.device
     raw = torch.empty((R, S, 6), device=dev, dtype=torch.float32)
     compact = compact and precision in ("fp16", "bf16")
-    sem_in = torch.empty((R * S, 320), device=dev,
-                         dtype=(torch.float16 if precision == "fp16" else torch.bfloat16) if compact else torch.float32)
+    if compact and _lib.lib().nsos_mlp_save16_layout(R * S) == SEM_IN_TILED:
+        # tile-major (what the two-waves-per-SIMD kernel stores contiguously): [group of 32 points][K][kg * 32 + point][8 channels];
+        # sem_head_wgrad recognises it by its four dimensions, sem_in_rows() turns it into [P,320]
+        sem_in = torch.empty(((R * S + 31) // 32, 20, 64, 8), device=dev, dtype=torch.float16 if precision == "fp16" else torch.bfloat16)
+    else:
+        sem_in = torch.empty((R * S, 320), device=dev,
+                             dtype=(torch.float16 if precision == "fp16" else torch.bfloat16) if compact else torch.float32)
     sem_hid = torch.empty((R * S, 128), device=dev, dtype=sem_in.dtype if compact else torch.float32)
     ev = _ev_begin()
     if precision == "fp32":
@@ -282,6 +287,28 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
                    "nsos_mlp_forward_rays_save_lp")
     _ev_end(ev, R * S)
     return raw, sem_in, sem_hid
+
+
+SEM_IN_TILED = 16   # NSOS_SEM_IN_TILED (include/nerf_sos_hip.h)
+
+
+def sem_in_rows(sem_in: torch.Tensor, n_points: int) -> torch.Tensor:
+    """[P,320] row-major from the tile-major sem_in [ceil(P/32), 20, 64, 8] of mlp_forward_rays_save(compact=True)
+    (channel 16 K + 8 kg + c of point 32 g + i at [g, K, 32 kg + i, c]); a row-major tensor is returned as it is.
+    Rows past P of the last group are never written by the kernel."""
+    if sem_in.dim() != 4:
+        return sem_in
+    G = sem_in.shape[0]
+    return sem_in.view(G, 20, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(G * 32, 320)[:n_points]
+
+
+def sem_in_tiled(rows: torch.Tensor) -> torch.Tensor:
+    """The inverse of sem_in_rows: a [P,320] 16-bit matrix in the tile-major layout (zero rows up to a multiple of 32)."""
+    P = rows.shape[0]
+    G = (P + 31) // 32
+    pad = torch.zeros((G * 32, 320), device=rows.device, dtype=rows.dtype)
+    pad[:P] = rows
+    return pad.view(G, 32, 20, 2, 8).permute(0, 2, 3, 1, 4).reshape(G, 20, 64, 8).contiguous()
 
 
 def sem_head_backward(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: torch.Tensor,
@@ -317,8 +344,11 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
         raise TypeError(f"sem_hid must be a GPU tensor, float32 or of sem_in's dtype {sem_in.dtype}; got {sem_hid.dtype}")
     sem_in, sem_hid = sem_in.contiguous(), sem_hid.contiguous()
     R, S = weights.shape
+    tiled = sem_in.dim() == 4                      # the tile-major layout of mlp_forward_rays_save(compact=True), see sem_in_rows
+    if tiled and x_dtype == 0:
+        raise TypeError("sem_head_wgrad: the tile-major sem_in layout is a 16-bit one")
     if (tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (R * S, 128) or tuple(sem2_w.shape) != (2, 128)
-            or tuple(sem_in.shape) != (R * S, 320)):
+            or tuple(sem_in.shape) != (((R * S + 31) // 32, 20, 64, 8) if tiled else (R * S, 320))):
         raise ValueError("sem_head_wgrad: inconsistent shapes")
     dev = weights.device
     if dev not in _WGRAD_WS:
@@ -329,13 +359,14 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     gb2 = torch.empty((2,), device=dev, dtype=torch.float32)
     use_split = split_fp16 and S >= 8 and R * S < 2 ** 31
     if not use_split and x_dtype != 0:
-        sem_in, x_dtype = sem_in.float(), 0          # the exact kernel reads fp32
+        sem_in, x_dtype, tiled = sem_in_rows(sem_in, R * S).float(), 0, False          # the exact kernel reads fp32 rows
     if x_dtype == 0:
         sem_hid = sem_hid.float()                    # fp32 sem_in: fp32 hid (the 16-bit kernel reads both matrices in one format)
     elif sem_hid.dtype != sem_in.dtype:
         sem_hid = sem_hid.to(sem_in.dtype)
     if use_split:   # the power of two that keeps g_hid in fp16 range is derived (and divided out again) on the device
-        _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), x_dtype,
+        _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in),
+                                                     x_dtype | (SEM_IN_TILED if tiled else 0),
                                                      R, S, None, _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
                                                      _stream()),
                    "nsos_sem_head_wgrad_x3")

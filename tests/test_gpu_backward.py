@@ -294,6 +294,9 @@ def test_sem_head_wgrad_split_fp16_vs_exact(R, S):
             assert float((x - y).abs().max()) <= tol * float(y.abs().max() + 1e-30), dt
         c = ops.sem_head_wgrad(weights, g_sem, w2, hid, x16, split_fp16=True)      # an fp32 hid is rounded on the way in
         assert all(torch.equal(x, y) for x, y in zip(a, c)), dt
+        # the tile-major sem_in layout of the default 16-bit training kernel: the same values at other addresses, the same sums
+        t = ops.sem_head_wgrad(weights, g_sem, w2, h16, ops.sem_in_tiled(x16), split_fp16=True)
+        assert all(torch.equal(x, y) for x, y in zip(a, t)), (dt, "tile-major")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16"])

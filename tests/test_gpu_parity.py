@@ -647,7 +647,10 @@ def test_lp_training_variant(golden, manifest, precision, tol):
                                                             rays[1].contiguous(), v, z, precision, compact=True)
     # compact: BOTH saved matrices in the 16-bit format -- sem_in's values are 16-bit anyway (identical), sem_hid is the fp32
     # accumulator's relu rounded to nearest even (what torch's own conversion gives)
-    assert sem_in_c.dtype == dt and torch.equal(sem_in_c.float(), sem_in) and torch.equal(raw_c, raw)
+    # (the default kernel hands sem_in back tile-major -- [groups of 32 points, 20, 64, 8], include/nerf_sos_hip.h -- what its store
+    #  instructions write contiguously; ops.sem_in_rows is the [P,320] view of the same values)
+    assert sem_in_c.dtype == dt and sem_in_c.dim() == 4 and torch.equal(ops.sem_in_rows(sem_in_c, R * 64).float(), sem_in) and torch.equal(raw_c, raw)
+    assert torch.equal(ops.sem_in_rows(ops.sem_in_tiled(sem_in.to(dt)), R * 64), sem_in.to(dt))
     assert sem_hid_c.dtype == dt and torch.equal(sem_hid_c, sem_hid.to(dt)) and torch.equal(sem_hid_c > 0, sem_hid.to(dt) > 0)
     W1 = mlp.semantic_linear[0].weight.detach().to(dt).double()
     b1 = mlp.semantic_linear[0].bias.detach().to(dt).double()
@@ -831,7 +834,10 @@ def test_lp8_equals_lp4_bitwise(manifest, name, precision):
                     for wps in (1, 2):
                         _lib.check(lib.nsos_mlp_lp_select_kernel(wps), "select")
                         sv[wps] = ops.mlp_forward_rays_save(pk, mlp.sem_mode, o, d, v, z, precision, compact=compact)
+                    assert not compact or (sv[1][1].dim() == 2 and sv[2][1].dim() == 4)       # row-major from the round-1 kernel, tile-major from lp8
                     for a, b, what in zip(sv[1], sv[2], ("raw", "sem_in", "sem_hid")):
+                        if what == "sem_in":
+                            a, b = ops.sem_in_rows(a, R * S), ops.sem_in_rows(b, R * S)
                         assert torch.equal(a, b), f"SAVE compact={compact} R={R} S={S}: {what} differs"
                     assert torch.equal(sv[2][0], out[2]), "the training variant renders bit-identically to inference"
     finally:
