@@ -77,6 +77,7 @@ def test_device_positional_encoding_16_bit_vs_reference(golden, manifest, precis
     _, sem_in, _ = ops.mlp_forward_rays_save(net.nerf.packed_weights(precision), net.nerf.sem_mode, T(x), T(d), T(v), z, precision, compact=True)
     dt = torch.float16 if precision == "fp16" else torch.bfloat16
     assert sem_in.dtype == dt
+    sem_in = ops.sem_in_rows(sem_in, n)                                 # (tile-major from the default kernel: the [P,320] view)
     got = sem_in[:, 256:319].float().cpu()
     want = torch.from_numpy(g["e10"]).to(dt).float()                    # the reference's value, rounded to the format
     # one unit in the last place of the format -- or the hardware sine's absolute accuracy (~1e-6), which is what counts next to
