@@ -316,8 +316,15 @@ def timed(ctx, step, warmup: int, steps: int):
     """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides.  Returns
     (max-over-ranks seconds, per-rank seconds, MLP kernel events recorded inside the timed region)."""
     from nerf_sos_amd import ops
+    import gc
     for i in range(warmup):
         step(i)
+    # One c3 run of 20 steps came out at 2.45 ms per step (host share 1.93 ms) and repeated twice at 1.80 (1.16): a single
+    # ~13 ms stall on the host inside a 40 ms timed region.  The interpreter's cyclic collector is one thing that can do that:
+    # collect now and keep it out of the K steps (nothing is skipped: the steps create no reference cycles that need it).
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     ctx.barrier()
     ops.KERNEL_EVENTS = []
     t0 = time.perf_counter()
@@ -328,6 +335,8 @@ def timed(ctx, step, warmup: int, steps: int):
     dt_own = time.perf_counter() - t0
     ctx.barrier()
     dt = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     per_rank = ctx.gather_times(dt_own)
     return max([dt] + per_rank) if ctx.world > 1 else dt, per_rank, events

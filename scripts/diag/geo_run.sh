@@ -1,9 +1,8 @@
-R=$PWD
-for i in 1 2 3; do
-  (cd $R/exp/old_tree && echo "old (row-major):" && python scripts/diag/lp_save_time.py 2>&1 | grep -E "plain|save")
-  (cd $R && echo "new (tile-major):" && python scripts/diag/lp_save_time.py 2>&1 | grep -E "plain|save")
+for i in 1 2; do
+python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'])
+for k,v in d['variants'].items(): print(k, v['ms_per_step'], v.get('host_enqueue_ms_per_step'), (v.get('whole_step_graph') or {}).get('ms_per_step'))
+"
 done
-(cd $R/exp/old_tree && echo "old:" && python scripts/diag/wgrad_time.py 4096 2>&1 | grep "S=" && python scripts/diag/graph_step_time.py 1 1 0 2>&1 | tail -1)
-(cd $R && echo "new:" && python scripts/diag/wgrad_time.py 4096 2>&1 | grep "S=" && python scripts/diag/graph_step_time.py 1 1 0 2>&1 | tail -1)
-(cd $R/exp/old_tree && echo "old:" && python scripts/diag/graph_step_time.py 1 1 0 2>&1 | tail -1)
-(cd $R && echo "new:" && python scripts/diag/graph_step_time.py 1 1 0 2>&1 | tail -1)
