@@ -1,8 +1,4 @@
-for i in 1 2; do
-python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'])
-for k,v in d['variants'].items(): print(k, v['ms_per_step'], v.get('host_enqueue_ms_per_step'), (v.get('whole_step_graph') or {}).get('ms_per_step'))
-"
-done
+python -m pytest tests/test_gpu_backward.py -x -q 2>&1 | tail -3
+python scripts/diag/wgrad_time.py 4096 2>&1 | tail -2
+python scripts/diag/wgrad_time.py 8192 2>&1 | tail -2
+python scripts/diag/wg_prof.py 2>&1 | tail -8
