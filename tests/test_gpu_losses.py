@@ -182,6 +182,21 @@ def test_geo_correlation_loss_row_partitioned_equals_golden(tag):
         assert abs(out_loss[k].item() - want) < 1e-4 * (1 + abs(want))
         assert rel(out_grad[k], GOLD[f"{tag}_grad"]) < 1e-4
     assert torch.equal(out_grad[0], out_grad[1]) and torch.equal(out_loss[0], out_loss[1])
+    # phase 4 = the four phases in one call (what a single process uses: merged finishing launches), rows = every patch, against the
+    # four separate phases over the same rows: the same kernels on the same partial sums -- loss and gradient bit for bit
+    all_rows = torch.arange(B, dtype=torch.int32, device=DEV)
+    res = {}
+    for name, phases in (("one call", (4,)), ("four phases", (0, 1, 2, 3))):
+        ws = torch.zeros((nbytes + 15) // 16 * 2, device=DEV, dtype=torch.float64)
+        db = T(GOLD[f"{tag}_depth"]).contiguous()
+        lo, gr = torch.empty((), device=DEV), torch.empty_like(cd)
+        for ph in phases:
+            _lib.check(lib.nsos_geo_correlation_loss_rows(ph, P_(db), P_(cd), P_(ray_o), P_(ray_d.contiguous()), P_(neg), P_(all_rows), B, B, Cn,
+                                                          P, P, *prm, 15.0, 1, P_(lo), P_(gr), P_(ws), ws.numel() * 8, None), "rows")
+        torch.cuda.synchronize()
+        res[name] = (lo.clone(), gr.clone())
+    assert torch.equal(res["one call"][0], res["four phases"][0]) and torch.equal(res["one call"][1], res["four phases"][1])
+    assert torch.equal(res["one call"][0], loss.detach())
 
 
 def test_losses_on_rendered_patches_train_the_semantic_head():
