@@ -201,3 +201,18 @@ def test_rays_that_require_grad_are_refused():
         net(rays, (1.0, 2.0))
     with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):   # without grad mode it gets as far as the device check
         net(rays, (1.0, 2.0))
+
+
+def test_tile_major_sem_in_views_round_trip():
+    """ops.sem_in_tiled / ops.sem_in_rows (the tile-major layout the 16-bit training kernel stores sem_in in, include/nerf_sos_hip.h
+    NSOS_SEM_IN_TILED): channel 16 K + 8 kg + c of point 32 g + i sits at [g, K, 32 kg + i, c]; rows -> tiles -> rows is the
+    identity for ragged point counts too (pure index arithmetic: checked on the CPU)."""
+    from nerf_sos_amd import ops
+    for P in (1, 31, 32, 33, 100):
+        rows = torch.arange(P * 320, dtype=torch.float32).reshape(P, 320).to(torch.bfloat16)
+        tiled = ops.sem_in_tiled(rows)
+        assert tuple(tiled.shape) == ((P + 31) // 32, 20, 64, 8) and tiled.is_contiguous()
+        assert torch.equal(ops.sem_in_rows(tiled, P), rows)
+        p, ch = P - 1, 16 * 7 + 8 * 1 + 5
+        assert tiled[p // 32, 7, 32 * 1 + p % 32, 5] == rows[p, ch]
+        assert ops.sem_in_rows(rows, P) is rows                      # a row-major matrix passes through
