@@ -152,12 +152,15 @@ def cpu_baseline(gpu=None, n_rays: int = 4096, dense=None):
     res["cpu_seconds_spent"] = round(time.perf_counter() - t_all, 1)
     parity = None
     if gpu is not None:
+        torch.set_num_threads(best_threads)
         parity = {"timed_workload_default_init_field": render_parity(gpu[2], ref)}
+        parity["timed_workload_default_init_field"]["yardstick"] = parity_yardstick(tp, sd, cfg, rays, ref, gpu[2], gpu[3] if len(gpu) > 3 else None)
         if dense is not None:
-            torch.set_num_threads(best_threads)
+            sd_dense = {k: v.detach().cpu() for k, v in dense[0].items()}
             with torch.no_grad():
-                ref_dense = tp.render({k: v.detach().cpu() for k, v in dense[0].items()}, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
+                ref_dense = tp.render(sd_dense, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
             parity["dense_field"] = render_parity(dense[1], ref_dense)
+            parity["dense_field"]["yardstick"] = parity_yardstick(tp, sd_dense, cfg, rays, ref_dense, dense[1], dense[3] if len(dense) > 3 else None)
             parity["dense_field"]["field"] = dict(dense[2] if len(dense) > 2 else {}, mean_acc_cpu=round(float(ref_dense["acc"].mean()), 4),
                                                   what="seed-0 weights, sigma head x gain + shift (bench.make_dense_field)")
             parity["psnr_db"] = parity["dense_field"]["psnr_db"]
@@ -204,9 +207,15 @@ def render_parity(got: dict, ref: dict, tol: float = 1e-4):
         fin = torch.isfinite(b) & torch.isfinite(a)
         # depth = 1e10 on empty rays on both sides (models/renderer.py:72): compare where finite and below that sentinel
         use = fin & (b.abs() < 1e9)
-        out = (diff > tol * (1 + b.abs())) & use
+        # a NaN / Inf on the GPU side where the reference is finite is OUTSIDE the band, not excluded from it;
+        # so is a finite GPU value where the reference holds the 1e10 sentinel or a non-finite value
+        nonfinite = torch.isfinite(b) & ~torch.isfinite(a)
+        sentinel = (b.abs() >= 1e9) & ~((a - b).abs() <= tol * (1 + b.abs()))
+        out = ((diff > tol * (1 + b.abs())) & use) | nonfinite | (torch.isfinite(b) & sentinel)
         rays_out = out.reshape(out.shape[0], -1).any(-1)
         per_key[k] = {"max_abs": float(diff[use].max()) if use.any() else 0.0, "frac_rays_outside_1e-4": round(float(rays_out.float().mean()), 5)}
+        if bool(nonfinite.any()):
+            per_key[k]["gpu_nonfinite_where_ref_finite"] = int(nonfinite.sum())
         if not k.endswith("0") and k != "raw":
             bad_any = rays_out if bad_any is None else (bad_any | rays_out)
 
@@ -221,6 +230,74 @@ def render_parity(got: dict, ref: dict, tol: float = 1e-4):
             "coarse_pass_all_rays_inside_1e-4": coarse_ok,
             "frac_rays_outside_1e-4_any_fine_map": round(float(bad_any.float().mean()), 5) if bad_any is not None else None,
             "per_key": per_key}
+
+
+def parity_yardstick(tp, sd, cfg, rays, ref, got, inds_hip=None, tol: float = 1e-4):
+    """The yardstick beside `frac_rays_outside_1e-4`: how far the REFERENCE moves against ITSELF under its own rounding.
+    The hierarchical sampler is ill-conditioned where the coarse weights are small (alpha = 1 - exp(-sigma * delta) lives on a
+    6e-8 grid: a last-ulp sigma moves an alpha of 1e-4 by 6e-4 of itself and an importance sample by up to 1e-2), so:
+      reference_self_sensitivity  the port with its COARSE network evaluated in fp64 (rounded to fp32 once; everything else
+                                  unchanged fp32) against the port itself: rays outside the same band in rgb/depth/acc (the
+                                  N_self of tests/test_gpu_pins.py::test_free_running_render_at_c2_size);
+      gpu_rays_outside            the same count for the GPU render (same keys);
+      index_flip_rays             rays with at least one right-bisect index (searchsorted, models/sampler.py:112) different
+                                  from the port's, the u = 1 end sample excluded (both indices give the same position there);
+                                  the north star's "bit-exact for sample indices" holds for (cdf, u) -> index
+                                  (tests/test_gpu_parity.py::test_importance); this counts the flips caused by the GPU's
+                                  last-ulp differences in the cdf itself.
+    Host work outside every timed region: one fp64 coarse pass + one fp32 fine pass of the port."""
+    import torch
+    n = rays.shape[1]
+    near, far = torch.full((n, 1), tp.NEAR), torch.full((n, 1), tp.FAR)
+    u = torch.linspace(0.0, 1.0, steps=cfg.n_importance).expand(n, cfg.n_importance)
+    viewdirs = rays[1] / torch.norm(rays[1], dim=-1, keepdim=True)
+    keys = [k for k in ("rgb", "depth", "acc", "semantics") if k in ref and k in got]
+
+    def fine_pass(weights0):
+        z = tp.stratified_z(near, far, cfg.n_samples, None)
+        mids = 0.5 * (z[..., 1:] + z[..., :-1])
+        zs, inds = tp.invert_cdf(mids, tp.pdf_to_cdf(weights0[..., 1:-1]), u)
+        z_fine, _ = torch.sort(torch.cat([z, zs], -1), -1)
+        pts = tp.ray_points(rays[0], rays[1], z_fine)
+        raw = tp.point_query(sd, "nerf_fine", pts, viewdirs[..., None, :].expand(pts.shape), cfg)
+        return inds, tp.composite(raw, z_fine, rays[1], None, cfg)
+
+    def outside(maps):
+        o = torch.zeros(n, dtype=torch.bool)
+        for k in keys:
+            a = maps[k].detach().double().cpu().reshape(ref[k].shape)
+            b = ref[k].double()
+            o |= (~((a - b).abs() <= tol + tol * b.abs())).reshape(n, -1).any(-1)
+        return int(o.sum())
+
+    with torch.no_grad():
+        inds_ref, chk = fine_pass(ref["weights0"])
+        staged_ok = bool(torch.equal(chk["rgb"], ref["rgb"]))
+        z = tp.stratified_z(near, far, cfg.n_samples, None)
+        pts = tp.ray_points(rays[0], rays[1], z)
+        sd64 = {k: v.double() for k, v in sd.items()}
+        raw64 = tp.point_query(sd64, "nerf", pts.double(), viewdirs.double()[..., None, :].expand(pts.shape), cfg).float()
+        n_self = outside(fine_pass(tp.composite(raw64, z, rays[1], None, cfg)["weights"])[1])
+    n_gpu = outside(got)
+    res = {"keys": keys, "band": "|a - ref| <= 1e-4 + 1e-4 * |ref|", "rays": n,
+           "gpu_rays_outside": n_gpu, "reference_self_sensitivity_rays_outside": n_self,
+           "reference_self_sensitivity": "oracle/torch_port.py with its coarse network in fp64 (rounded to fp32 once) vs itself in fp32",
+           "max_abs_raw0_minus_fp64": {"reference_fp32": float((ref["raw0"] - raw64).abs().max()),
+                                       "gpu": float((got["raw0"].detach().float().cpu().reshape(raw64.shape) - raw64).abs().max())},
+           "staged_port_reproduces_port": staged_ok}
+    if inds_hip is not None:
+        res["index_flip_rays"] = int((inds_hip.cpu().reshape(inds_ref.shape) != inds_ref)[:, :-1].any(-1).sum())
+    return res
+
+
+def gpu_bisect_indices(torch, out, rays, n_coarse, n_importance, near, far):
+    """The right-bisect indices the GPU's importance sampler took for the render `out` (its own coarse weights), through the
+    ABI's debug output -- what `parity_yardstick` compares with the port's searchsorted."""
+    from nerf_sos_amd import ops
+    n = rays.shape[1]
+    dev = rays.device
+    zc = ops.ray_setup(rays[1].reshape(-1, 3), torch.full((n,), float(near), device=dev), torch.full((n,), float(far), device=dev), n_coarse)[0]
+    return ops.importance_sample(zc, out["weights0"].reshape(n, n_coarse), n_importance, debug=True)[4].cpu()
 
 
 KERNEL_SOURCES = {   # traffic.json key -> the files whose content decides the dominant kernel's memory traffic
@@ -738,10 +815,13 @@ def main():
             gpu = dense = None
             if prec in ("fp32", "fp16x3"):
                 net = res["net"]
-                gpu = ({k: v.detach().clone() for k, v in net.state_dict().items()}, res["rays"], res["out"])
+                gpu = ({k: v.detach().clone() for k, v in net.state_dict().items()}, res["rays"], res["out"],
+                       gpu_bisect_indices(torch, res["out"], res["rays"], N_COARSE, N_IMPORTANCE, 1.2, 14.72))
                 field = make_dense_field(net, res["rays"], (1.2, 14.72))     # the same rays through a dense field, outside every timed region
                 with torch.no_grad():
-                    dense = ({k: v.detach().clone() for k, v in net.state_dict().items()}, net(res["rays"], (1.2, 14.72)), field)
+                    out_dense = net(res["rays"], (1.2, 14.72))
+                dense = ({k: v.detach().clone() for k, v in net.state_dict().items()}, out_dense, field,
+                         gpu_bisect_indices(torch, out_dense, res["rays"], N_COARSE, N_IMPORTANCE, 1.2, 14.72))
                 torch.cuda.synchronize()
             line["cpu_baseline"], parity = cpu_baseline(gpu, dense=dense)
             if parity is not None:

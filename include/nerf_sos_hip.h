@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define NSOS_ABI_VERSION 1
+/* bumped whenever an existing entry point's arguments or buffer formats change (2: 16-bit / tile-major saved operands of
+ * nsos_mlp_forward_rays_save16_lp and nsos_sem_head_wgrad_x3; 3: pose_rows in nsos_patch_batch / nsos_pixel_batch) */
+#define NSOS_ABI_VERSION 3
 
 enum {
     NSOS_OK = 0,
@@ -97,7 +99,8 @@ int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, f
 /* ---- training-batch assembly on the device ---------------------------------
  * The scene's images (rgbs [n_images,H,W,rgb_ch] fp32), masks ([n_images,H,W,*]: `mask_words` 4-byte words per pixel --
  * int64 labels after the reference's thresholding, data/datasets.py:66-69, are 2 words per channel, float masks 1) and
- * poses ([n_images,3,pose_cols] fp32, pose_cols 4 or LLFF's 5) stay resident in device memory; a batch is gathered per
+ * poses ([n_images,pose_rows,pose_cols] fp32 exactly as poses_<split>.npy holds them: LLFF [3,5], blender / toydesk / tankstemple
+ * [4,4], data/gen_dataset.py:228-233; rays use [:3,:4]) stay resident in device memory; a batch is gathered per
  * step, with the rays generated from the poses by K0's arithmetic (bit-identical to the reference's stored ray files).
  * Any of (rays_o+rays_d), target, masks_out may be NULL (that output is skipped).
  *
@@ -107,18 +110,18 @@ int32_t nsos_generate_rays(int32_t H, int32_t W, float fx, float fy, float cx, f
  *   (sel_host: validated, travels in the kernel arguments, no copy) OR as a DEVICE array (sel_dev: out-of-range values are
  *   clamped; for captured graphs).  Output pixel (a, c) of item b is image pixel (h_idx + a*stride, w_idx + c*stride):
  *   rays_o / rays_d [n_patches, patch*patch, 3], target [n_patches, patch*patch, rgb_ch], masks_out [.., mask_words words],
- *   poses_out [n_patches, 3, pose_cols] (the items' poses, :251) and start_out [n_patches, 2] = (h_idx, w_idx) as floats
+ *   poses_out [n_patches, pose_rows, pose_cols] (the items' poses, :251) and start_out [n_patches, 2] = (h_idx, w_idx) as floats
  *   (:252); both optional.
  * nsos_pixel_batch: the same records for an explicit device list of flat pixel indices pix[k] = (image*H + y)*W + x:
  *   RayNeRFDataset items + RayBatchCollater (data/datasets.py:149-171, data/collater.py:7-29) and ViewNeRFDataset's
  *   np.random.choice pixels of one view + ViewBatchCollater (data/datasets.py:279-300, data/collater.py:63-84). */
 int32_t nsos_patch_batch(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* poses,
-                         int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
+                         int32_t pose_rows, int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
                          int32_t mask_words, const int32_t* sel_host, const int32_t* sel_dev, int32_t n_patches,
                          int32_t patch, int32_t stride, float* rays_o, float* rays_d, float* target, void* masks_out,
                          float* poses_out, float* start_out, void* stream);
 int32_t nsos_pixel_batch(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* poses,
-                         int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
+                         int32_t pose_rows, int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
                          int32_t mask_words, const int64_t* pix, int64_t n, float* rays_o, float* rays_d, float* target,
                          void* masks_out, void* stream);
 

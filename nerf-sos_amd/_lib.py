@@ -27,9 +27,9 @@ SIGNATURES = {
     "nsos_mlp_packed_bytes": (_sz, [_i32]),
     "nsos_mlp_pack": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
     "nsos_generate_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, C.POINTER(C.c_float), _i64, _i64, _fp, _fp, _fp]),
-    "nsos_patch_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _fp, _i32, _fp, _i32, C.POINTER(C.c_int32), _fp,
+    "nsos_patch_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _i32, _fp, _i32, _fp, _i32, C.POINTER(C.c_int32), _fp,
                                 _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "nsos_pixel_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _fp, _fp, _fp,
+    "nsos_pixel_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _fp, _fp, _fp,
                                 _fp, _fp]),
     "nsos_contrastive_loss": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp]),
     "nsos_similarity_negatives": (_i32, [_fp, _i32, _i32, _fp, _fp, _i32, _fp]),
@@ -90,7 +90,7 @@ SIGNATURES = {
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 3          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
 _lib = None
 
 
@@ -105,7 +105,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NativeLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(or `make -C nerf-sos_amd/csrc`).  nerf_sos_amd has no CPU / eager fallback.")
+                "(a bare `make -C nerf-sos_amd/csrc` also works; it stamps the same source hash).  nerf_sos_amd has no CPU / eager fallback.")
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -15,8 +15,8 @@
 struct PixelSource {
     int H, W;
     float fx, fy, cx, cy;
-    const float* poses;   // [n_images, 3, pose_cols] (pose_cols 4, or 5 for LLFF's [R | t | hwf])
-    int pose_cols, n_images;
+    const float* poses;   // [n_images, pose_rows, pose_cols]: rows 3 (LLFF [R | t | hwf], cols 5) or 4 (blender / toydesk /
+    int pose_rows, pose_cols, n_images;   // tankstemple 4x4, data/gen_dataset.py:228-233 saves poses[i_split] unsliced); rays use [:3,:4]
     const float* rgbs;    // [n_images, H, W, rgb_ch] or NULL
     int rgb_ch;
     const unsigned* masks;   // [n_images, H, W, mask_words] 4-byte words (int64 label = 2 words, float = 1) or NULL
@@ -30,7 +30,7 @@ __device__ __forceinline__ void emit_pixel(const PixelSource& S, int n, int y, i
     y = y < 0 ? 0 : (y >= S.H ? S.H - 1 : y);                 // host: clamp instead of reading out of bounds
     x = x < 0 ? 0 : (x >= S.W ? S.W - 1 : x);
     if (rays_o) {
-        const float* c2w = S.poses + (size_t)n * 3 * S.pose_cols;
+        const float* c2w = S.poses + (size_t)n * S.pose_rows * S.pose_cols;
         const float d0 = ((float)x - S.cx) / S.fx, d1 = -(((float)y - S.cy) / S.fy), d2 = -1.0f;   // utils/ray.py:16
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void patch_batch_kernel(const PixelSource S, c
     const int a = q / P, c = q - a * P;                     // rays[h_idx + a*stride, w_idx + c*stride] (data/datasets.py:245)
     const int* d = sel_dev ? sel_dev + 3 * b : sel.v + 3 * b;
     // the item's pose and crop origin (data/datasets.py:251-252: `poses = self.poses[i]`, `start_idx = Tensor([h_idx, w_idx])`);
-    // a patch has >= 1 pixel, so its first thread writes them (strided loop: P*P may be smaller than 3*pose_cols)
+    // a patch has >= 1 pixel, so its first thread writes them (serial loop: P*P may be smaller than pose_rows*pose_cols)
     if (q == 0) {
         const int n = d[0] < 0 ? 0 : (d[0] >= S.n_images ? S.n_images - 1 : d[0]);
         if (poses_out)
-            for (int k = 0; k < 3 * S.pose_cols; ++k) poses_out[(size_t)(patch_base + b) * 3 * S.pose_cols + k] = S.poses[(size_t)n * 3 * S.pose_cols + k];
+            for (int k = 0; k < S.pose_rows * S.pose_cols; ++k)
+                poses_out[(size_t)(patch_base + b) * S.pose_rows * S.pose_cols + k] = S.poses[(size_t)n * S.pose_rows * S.pose_cols + k];
         if (start_out) {
             start_out[2 * (patch_base + b)] = (float)d[1];
             start_out[2 * (patch_base + b) + 1] = (float)d[2];
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void pixel_batch_kernel(const PixelSource S, c
     emit_pixel(S, img, rem / S.W, rem % S.W, gid, rays_o, rays_d, target, masks_out);
 }
 
-static int32_t check_source(int32_t H, int32_t W, float fx, float fy, const float* poses, int32_t pose_cols, int32_t n_images,
+static int32_t check_source(int32_t H, int32_t W, float fx, float fy, const float* poses, int32_t pose_rows, int32_t pose_cols, int32_t n_images,
                             const float* rgbs, int32_t rgb_ch, const void* masks, int32_t mask_words, const float* rays_o,
                             const float* rays_d, const float* target, const void* masks_out) {
     NSOS_REQUIRE(H > 0 && W > 0 && n_images > 0 && fx != 0.0f && fy != 0.0f, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE((rays_o != nullptr) == (rays_d != nullptr), NSOS_ERR_NULL_POINTER);
     if (rays_o) {
         NSOS_REQUIRE(poses, NSOS_ERR_NULL_POINTER);
-        NSOS_REQUIRE(pose_cols >= 4, NSOS_ERR_BAD_SHAPE);
+        NSOS_REQUIRE((pose_rows == 3 || pose_rows == 4) && pose_cols >= 4, NSOS_ERR_BAD_SHAPE);
     }
     if (target) {
         NSOS_REQUIRE(rgbs, NSOS_ERR_NULL_POINTER);
@@ -112,16 +113,16 @@ static int32_t check_source(int32_t H, int32_t W, float fx, float fy, const floa
 }
 
 extern "C" int32_t nsos_patch_batch(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* poses,
-                                    int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
+                                    int32_t pose_rows, int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
                                     int32_t mask_words, const int32_t* sel_host, const int32_t* sel_dev, int32_t n_patches,
                                     int32_t patch, int32_t stride, float* rays_o, float* rays_d, float* target, void* masks_out,
                                     float* poses_out, float* start_out, void* stream) {
     NSOS_REQUIRE(n_patches >= 0 && patch >= 1 && stride >= 1, NSOS_ERR_BAD_SHAPE);
     if (n_patches == 0) return NSOS_OK;
-    const int32_t rc = check_source(H, W, fx, fy, poses, pose_cols, n_images, rgbs, rgb_ch, masks, mask_words, rays_o, rays_d, target, masks_out);
+    const int32_t rc = check_source(H, W, fx, fy, poses, pose_rows, pose_cols, n_images, rgbs, rgb_ch, masks, mask_words, rays_o, rays_d, target, masks_out);
     if (rc != NSOS_OK) return rc;
     NSOS_REQUIRE((sel_host != nullptr) != (sel_dev != nullptr), NSOS_ERR_NULL_POINTER);   // exactly one of the two
-    NSOS_REQUIRE(!poses_out || (poses && pose_cols >= 4), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!poses_out || (poses && (pose_rows == 3 || pose_rows == 4) && pose_cols >= 4), NSOS_ERR_NULL_POINTER);
     const int64_t last = (int64_t)(patch - 1) * stride;
     NSOS_REQUIRE(last < H && last < W, NSOS_ERR_BAD_SHAPE);
     if (sel_host)   // data/datasets.py:240-241: 0 <= h_idx <= H - crop_size; the last sampled row is h_idx + (P-1)*stride
@@ -129,7 +130,7 @@ extern "C" int32_t nsos_patch_batch(int32_t H, int32_t W, float fx, float fy, fl
             const int32_t* d = sel_host + 3 * b;
             NSOS_REQUIRE(d[0] >= 0 && d[0] < n_images && d[1] >= 0 && d[1] + last < H && d[2] >= 0 && d[2] + last < W, NSOS_ERR_BAD_SHAPE);
         }
-    const PixelSource S = {H, W, fx, fy, cx, cy, poses, pose_cols, n_images, rgbs, rgb_ch, static_cast<const unsigned*>(masks), mask_words};
+    const PixelSource S = {H, W, fx, fy, cx, cy, poses, pose_rows, pose_cols, n_images, rgbs, rgb_ch, static_cast<const unsigned*>(masks), mask_words};
     const int64_t per = (int64_t)patch * patch;
     const int step = sel_dev ? n_patches : NSOS_PATCH_SEL_BY_VALUE;
     for (int b0 = 0; b0 < n_patches; b0 += step) {
@@ -147,16 +148,16 @@ extern "C" int32_t nsos_patch_batch(int32_t H, int32_t W, float fx, float fy, fl
 }
 
 extern "C" int32_t nsos_pixel_batch(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* poses,
-                                    int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
+                                    int32_t pose_rows, int32_t pose_cols, int32_t n_images, const float* rgbs, int32_t rgb_ch, const void* masks,
                                     int32_t mask_words, const int64_t* pix, int64_t n, float* rays_o, float* rays_d,
                                     float* target, void* masks_out, void* stream) {
     NSOS_REQUIRE(n >= 0, NSOS_ERR_BAD_SHAPE);
     if (n == 0) return NSOS_OK;
-    const int32_t rc = check_source(H, W, fx, fy, poses, pose_cols, n_images, rgbs, rgb_ch, masks, mask_words, rays_o, rays_d, target, masks_out);
+    const int32_t rc = check_source(H, W, fx, fy, poses, pose_rows, pose_cols, n_images, rgbs, rgb_ch, masks, mask_words, rays_o, rays_d, target, masks_out);
     if (rc != NSOS_OK) return rc;
     NSOS_REQUIRE(pix, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE((n + 255) / 256 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
-    const PixelSource S = {H, W, fx, fy, cx, cy, poses, pose_cols, n_images, rgbs, rgb_ch, static_cast<const unsigned*>(masks), mask_words};
+    const PixelSource S = {H, W, fx, fy, cx, cy, poses, pose_rows, pose_cols, n_images, rgbs, rgb_ch, static_cast<const unsigned*>(masks), mask_words};
     hipLaunchKernelGGL(pixel_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, pix, n, rays_o,
                        rays_d, target, static_cast<unsigned*>(masks_out));
     return nsos_launch_status();

@@ -147,7 +147,11 @@ class DeviceScene:
             raise NotImplementedError("DeviceScene: sub-sampled splits are not the camera meta.json describes (see rays_on_device)")
         self.scene, self.device = scene, dev
         self.height, self.width, self.image_count = scene.height, scene.width, scene.image_count
-        self.poses = torch.from_numpy(np.ascontiguousarray(scene.poses)).float().to(dev)       # [N,3,4 or 5]
+        # poses_<split>.npy as data/gen_dataset.py:228-233 wrote it: LLFF [N,3,5], blender / toydesk / tankstemple [N,4,4]
+        # (unsliced); the kernels take the image stride rows*cols and read [:3,:4]
+        if scene.poses.ndim != 3 or scene.poses.shape[1] not in (3, 4) or scene.poses.shape[2] < 4:
+            raise ValueError(f"DeviceScene: poses must be [N,3,>=4] or [N,4,>=4], got {tuple(scene.poses.shape)}")
+        self.poses = torch.from_numpy(np.ascontiguousarray(scene.poses)).float().to(dev)
         self.rgbs = torch.from_numpy(scene.rgbs).float().to(dev).contiguous() if scene.rgbs is not None else None
         self.masks = torch.from_numpy(scene.masks).to(dev).contiguous() if scene.masks is not None else None
         if self.masks is not None and self.masks.dtype not in (torch.int64, torch.float32):
@@ -159,7 +163,7 @@ class DeviceScene:
         m = self.masks
         words = 0 if m is None else int(m.shape[-1]) * (2 if m.dtype == torch.int64 else 1)
         return (self.height, self.width, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
-                ops._p(self.poses), int(self.poses.shape[-1]), self.image_count,
+                ops._p(self.poses), int(self.poses.shape[-2]), int(self.poses.shape[-1]), self.image_count,
                 ops._p(self.rgbs), 0 if self.rgbs is None else int(self.rgbs.shape[-1]), ops._p(m), words)
 
     def _outputs(self, lead):
@@ -175,7 +179,7 @@ class DeviceScene:
         run_nerf.py:407-408) collated by PatchBatchCollater, in ONE launch:
           rays [B,P*P,2,3] (a view of `rays_planar` [2,B,P,P,3], the layout NeRFNet / sharded_patch_step consume directly:
           the trainer's reshape + permute, engines/trainer.py:63-64, is already done), target_s [B,P*P,3],
-          masks [B,P*P,1], poses [B,3,4|5], start_idx [B,2] float32 -- P = ceil(crop_size / patch_stride).
+          masks [B,P*P,1], poses [B,3,5] or [B,4,4] (= self.poses[i]), start_idx [B,2] float32 -- P = ceil(crop_size / patch_stride).
         `origins`: [(h_idx, w_idx)] per item; None draws them like the reference (`draw_patch_origins`).
         `sel_device`: int32 [B,3] device tensor of (image, h_idx, w_idx) instead (nothing crosses PCIe; graph capture)."""
         P = -(-int(crop_size) // int(patch_stride))

@@ -315,9 +315,18 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
                 t.record_stream(torch.cuda.current_stream(dev))
         # gradients w.r.t. the channel-last maps: the appearance loss hands back [B,C,P,P] views of [B,P,P,C] buffers
         torch._foreach_add_([gg0, gg1], [ga0.permute(0, 2, 3, 1), ga1.permute(0, 2, 3, 1)])
-        loss = torch.stack([la0, la1, lg]).sum() if contrast_loss is None else \
-            torch.stack([la0, la1, lg, contrast_w * contrast_loss(full["cls_"]).reshape(())]).sum()
+    # the contrastive term (engines/trainer.py:168-170) is the one loss here that autograd differentiates itself: the reference
+    # back-propagates it into the feature extractor through `cls_`, so it is evaluated with the graph on (under
+    # no_grad that gradient was silently dropped on this path only)
+    c = None
+    if contrast_loss is not None:
+        with torch.enable_grad():
+            c = (contrast_w * contrast_loss(full["cls_"])).reshape(())
+    with torch.no_grad():
+        loss = torch.stack([la0, la1, lg]).sum() if c is None else torch.stack([la0, la1, lg, c.detach()]).sum()
     roots = [(t, g) for t, g in ((full["semantics0"], gg0), (full["semantics"], gg1)) if t.requires_grad]
+    if c is not None and c.requires_grad:
+        roots.append((c, torch.ones_like(c)))
     if roots:
         torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
     return loss

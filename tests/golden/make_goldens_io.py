@@ -22,6 +22,7 @@ module level by the files above, used only by code not exercised here; `cv2.imwr
 aliased to `np.int64`, and `Tensor.cuda` (data/datasets.py:76 puts K on the GPU in the dataset ctor; there is no GPU here).
 
 Written: tests/golden/io_scene/ (the scene directory: data files), tests/golden/io.npz (expected outputs),
+tests/golden/io_scene44/ + io44.npz (a scene whose poses file is [N,4,4], as the blender / toydesk / tankstemple loaders leave it),
 tests/golden/io_ref.ckpt (the reference-format checkpoint: a dict of tensors).  Only data is written.
 """
 import json
@@ -94,6 +95,59 @@ def write_scene():
             "half_res": False, "white_bkgd": False, "test_skip": 1, "dv_scene": "cube"}   # :235-245
     with open(os.path.join(SCENE, "meta.json"), "w") as f:
         json.dump(meta, f)
+
+
+SCENE44 = os.path.join(HERE, "io_scene44")
+N44, H44, W44 = 3, 10, 12
+
+
+def write_scene44():
+    """A blender / toydesk / tankstemple-type scene: `poses_<split>.npy` is [N,4,4] -- data/gen_dataset.py:228-233 saves
+    `poses[i_split]` unsliced, and load_blender / load_toydesk return 4x4 camera-to-world matrices.  Train split only."""
+    os.makedirs(SCENE44, exist_ok=True)
+    rng = np.random.default_rng(44)
+    poses = np.zeros((N44, 4, 4), np.float32)
+    poses[:, :3, :3] = np.linalg.qr(rng.standard_normal((N44, 3, 3)))[0]
+    poses[:, :3, 3] = rng.standard_normal((N44, 3)) * 0.5
+    poses[:, 3, 3] = 1.0
+    images = rng.random((N44, H44, W44, 3), dtype=np.float32)
+    masks = rng.random((N44, H44, W44, 1), dtype=np.float32)
+    K = get_persp_intrinsic(H44, W44, FOCAL)
+    rays = torch.stack([get_persp_rays(H44, W44, K, torch.tensor(p)) for p in poses[:, :3, :4]], 0)   # gen_dataset.py:189
+    rays = rays.permute([0, 2, 3, 1, 4]).numpy().astype(np.float32)
+    np.save(os.path.join(SCENE44, "rays_train.npy"), rays)
+    np.save(os.path.join(SCENE44, "rgbs_train.npy"), images)
+    np.save(os.path.join(SCENE44, "masks_train.npy"), masks)
+    np.save(os.path.join(SCENE44, "poses_train.npy"), poses)                          # :228-233: [N,4,4]
+    meta = {"H": H44, "W": W44, "focal": float(FOCAL), "near": 2.0, "far": 6.0, "i_train": list(range(N44)), "i_val": [], "i_test": [],
+            "ndc": False, "half_res": False, "white_bkgd": True, "test_skip": 1}
+    with open(os.path.join(SCENE44, "meta.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def goldens44():
+    """What the reference's PatchNeRFDataset + PatchBatchCollater return for the 4x4-pose scene (its own file, io44.npz)."""
+    write_scene44()
+    out, args = {}, types.SimpleNamespace()
+    ds = ref_ds.PatchNeRFDataset(SCENE44, args, split="train", cam_id=False, use_masks=True, crop_size=6, patch_stride=2,
+                                 bin_thres=0.3, ret_k=True)
+    assert ds.poses.shape == (N44, 4, 4)
+    order = [2, 0, 1, 1, 2]
+    random.seed(44)
+    items = [ds[i] for i in order]
+    out["order"] = np.array(order)
+    col = ref_col.PatchBatchCollater()(items)
+    for key, v in zip(("rays", "target_s", "masks", "poses", "start_idx"), col):
+        out[f"batch_{key}"] = t2n(v)
+    assert out["batch_poses"].shape == (5, 4, 4)
+    rt = ref_ds.RayNeRFDataset(SCENE44, args, split="train", use_masks=True, bin_thres=0.3)
+    picks = [0, 119, 120, 200, len(rt) - 1]                                           # pixels of image 0, 0, 1, 1, 2
+    out["ray_picks"] = np.array(picks)
+    col = ref_col.RayBatchCollater()([rt[i] for i in picks])
+    for key, v in zip(("rays", "target_s", "masks"), col):
+        out[f"ray_batch_{key}"] = t2n(v)
+    np.savez_compressed(os.path.join(HERE, "io44.npz"), **out)
+    print(f"wrote io44.npz ({len(out)} arrays), io_scene44/")
 
 
 def t2n(t):
@@ -196,6 +250,7 @@ def main():
                           "sem0_weight_sum": float(net.nerf.mlp.semantic_linear[0].weight.double().sum())}
     json.dump(man, open(man_path, "w"), indent=1)
     print(f"wrote io.npz ({len(out)} arrays), io_scene/, io_ref.ckpt ({os.path.getsize(path)} bytes)")
+    goldens44()
 
 
 if __name__ == "__main__":

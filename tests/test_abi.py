@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.nsos_abi_version() == 1
+    declared = int(re.search(r'#define\s+NSOS_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'nerf_sos_hip.h')).read()).group(1))
+    assert lib.nsos_abi_version() == declared == _lib.ABI_VERSION
 
 
 def test_library_was_built_from_the_sources_in_the_tree():

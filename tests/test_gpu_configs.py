@@ -160,6 +160,33 @@ def test_c4_direct_loss_gradients_equal_the_autograd_formulation(manifest, preci
         assert float((g_d[k] - g_a[k]).abs().max()) <= 2e-5 * float(g_a[k].abs().max()), k
 
 
+def test_contrastive_gradient_reaches_the_class_tokens_on_both_loss_paths(manifest, monkeypatch):
+    """engines/trainer.py:168-170 back-propagates contrast_l into the feature extractor through `cls_`: a `cls_tokens` that
+    requires grad receives the same gradient from the direct path as from the line-by-line autograd formulation (ADVICE r03:
+    the direct path evaluated the term under no_grad and dropped it)."""
+    got = {}
+    for mode in ("", "1"):
+        monkeypatch.setenv("NSOS_STEP_AUTOGRAD_LOSSES", mode)
+        torch.manual_seed(0)
+        net = nerf_sos_amd.NeRFNet(N_samples=16, N_importance=16, perturb=1.0, raw_noise_std=1.0, **CFGS["semcoord"]).to(DEV)
+        for n_, p_ in net.named_parameters():
+            p_.requires_grad = "semantic_linear" in n_
+        net.train()
+        B = 3
+        rays = syn.synthetic_patches(B, 64, 6, seed=0, device=DEV)
+        feat = torch.randn(B, 384, 14, 14, generator=torch.Generator().manual_seed(1)).to(DEV)
+        cls_ = torch.randn(B, 384, generator=torch.Generator().manual_seed(2)).to(DEV).requires_grad_(True)
+        corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+        con = nerf_sos_amd.NeRFContrastive(device=DEV)
+        torch.manual_seed(7)
+        loss = sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, step=1, seed=3,
+                                           contrast_loss=con, contrast_w=0.01)
+        assert cls_.grad is not None and float(cls_.grad.abs().max()) > 0, f"mode {mode!r}: no gradient reached cls_"
+        got[mode] = (float(loss), cls_.grad.clone())
+    assert abs(got[""][0] - got["1"][0]) <= 2e-6 * (1 + abs(got["1"][0]))
+    assert float((got[""][1] - got["1"][1]).abs().max()) <= 1e-6 * float(got["1"][1].abs().max())
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_c4_loss_overlap_does_not_change_a_bit(manifest, precision):
     """The appearance loss on a stream of its own (in the shadow of the geometric one, forward and backward) against the same

@@ -22,6 +22,7 @@ from helpers import state_sha
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SCENE = os.path.join(HERE, "golden", "io_scene")
+SCENE44 = os.path.join(HERE, "golden", "io_scene44")      # poses_train.npy is [N,4,4] (blender / toydesk / tankstemple scenes)
 CKPT = os.path.join(HERE, "golden", "io_ref.ckpt")
 CROP, STRIDE = 8, 2
 
@@ -46,6 +47,13 @@ def test_prepared_scene_reader_vs_reference_dataset(golden):
     ex = nio.PreparedScene(SCENE, split="exhibit", rgb=False, use_masks=False)
     assert ex.num_images() == int(g["exhibit_len"][0])
     assert np.array_equal(ex.view(2)["rays"].numpy(), g["exhibit_item2_rays"]) and np.array_equal(g["exhibit_item2_rays"], g["exhibit_collated_rays"])
+
+
+def test_prepared_scene_with_4x4_poses_reads_like_the_reference(golden):
+    g = golden("io44")
+    sc = nio.PreparedScene(SCENE44, split="train", bin_thres=0.3)
+    assert sc.poses.shape == (3, 4, 4)                                 # data/gen_dataset.py:228-233 saves poses[i_split] unsliced
+    assert np.array_equal(sc.poses[g["order"]], g["batch_poses"])
 
 
 def test_missing_meta_keys_raise(tmp_path):
@@ -142,6 +150,28 @@ def test_device_patch_sampler_equals_the_reference_dataset_and_collater(golden, 
         ds.patch_batch([0], CROP, STRIDE, origins=[(5, 0)])                          # 5 > H - crop = 4
     with pytest.raises(IndexError):
         ds.patch_batch([4], CROP, STRIDE, origins=[(0, 0)])
+
+
+@pytest.mark.gpu
+def test_device_batches_of_a_scene_with_4x4_poses_equal_the_reference(golden):
+    """A `poses_<split>.npy` of [N,4,4] (data/gen_dataset.py:228-233 for blender / toydesk / tankstemple): the image stride is 16
+    floats, rays come from [:3,:4], and the collated `poses` is the reference's [B,4,4] (the stride was 12)."""
+    g = golden("io44")
+    sc = nio.PreparedScene(SCENE44, split="train", bin_thres=0.3)
+    for i in range(sc.num_images()):
+        assert np.array_equal(sc.rays_on_device(i, "cuda:0").cpu().numpy(), sc.rays[i].transpose(2, 0, 1, 3))
+    ds = nio.PreparedScene(SCENE44, split="train", bin_thres=0.3, load_rays=False).to_device("cuda:0")
+    random.seed(44)
+    b = ds.patch_batch(g["order"].tolist(), 6, 2)
+    for key in ("rays", "target_s", "masks", "poses", "start_idx"):
+        assert _eq(b[key], g[f"batch_{key}"]), key
+    r = ds.ray_batch(g["ray_picks"].tolist())
+    for key in ("rays", "target_s", "masks"):
+        assert _eq(r[key], g[f"ray_batch_{key}"]), key
+    bad = nio.PreparedScene(SCENE44, split="train", load_rays=False)
+    bad.poses = bad.poses[:, :2]
+    with pytest.raises(ValueError):
+        bad.to_device("cuda:0")
 
 
 @pytest.mark.gpu
