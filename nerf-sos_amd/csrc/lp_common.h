@@ -46,6 +46,9 @@ struct F16 {
     __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
+    __device__ static __forceinline__ f32x4 mfma_k32(u32x4 a, u32x4 b, f32x4 c) {   // 16x16x32: mlp_lp16.hip
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
     __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
         unsigned r;
         asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -67,6 +70,9 @@ struct BF16 {
     static constexpr unsigned kOnes = 0x3F803F80u;
     __device__ static __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ f32x4 mfma_k32(u32x4 a, u32x4 b, f32x4 c) {   // 16x16x32: mlp_lp16.hip
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
     __device__ static __forceinline__ unsigned pack2(float lo, float hi) {
         unsigned r;
@@ -194,6 +200,14 @@ __device__ __forceinline__ void heads_partial_f32(const f32x16 (&h)[NT], const f
 
 // mlp_lp8.hip: the two-waves-per-SIMD kernel (8 waves x 32 points per 256-point tile), same packed stream and results
 int32_t launch_lp8(const LpParams& p, int32_t sem_mode, bool is_f16, bool save, hipStream_t stream);
+
+// mlp_lp16.hip: the same workgroup shape on v_mfma_f32_16x16x32 (its own packed stream: p.chunks points at it)
+__host__ __device__ constexpr int lp16_chunks(int sem) {
+    // L0 (1) + 7 quad layers x 4 + L5 h (4) + L5 x63 (1) + [sem0 h (2) + tail (1) | sigma (1)] + views (2) + rgb (1)
+    return 1 + 28 + 5 + (sem ? 3 : 1) + 3;
+}
+int32_t launch_lp16(const LpParams& p, int32_t sem_mode, bool is_f16, bool save, hipStream_t stream);
+int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned char* chunks, hipStream_t stream);
 
 }  // namespace lp
 }  // namespace nsos

@@ -463,8 +463,9 @@ int32_t launch_lp(const LpParams& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode) {
     if (sem_mode < 0 || sem_mode > 2) return 0;
-    // aux + the slice-major stream of mlp_lp_kernel + the stream of mlp_lp8_kernel (tile-pair-major hidden layers)
-    return (size_t)kAuxWords * 4 + 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes;
+    // aux + the slice-major stream of mlp_lp_kernel + the stream of mlp_lp8_kernel (tile-pair-major hidden layers) + the stream
+    // of mlp_lp16_kernel (16x16x32 tiles, tile-quad-major hidden layers)
+    return (size_t)kAuxWords * 4 + (2 * (size_t)lp_chunks(sem_mode) + (size_t)lp16_chunks(sem_mode)) * kSlotBytes;
 }
 
 extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
@@ -519,17 +520,25 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
         if (dtype == NSOS_DTYPE_F16) hipLaunchKernelGGL(lp_pack_kernel<F16>, grid, block, 0, (hipStream_t)stream, P);
         else hipLaunchKernelGGL(lp_pack_kernel<BF16>, grid, block, 0, (hipStream_t)stream, P);
     }
-    return nsos_launch_status();
+    const int32_t rc = nsos_launch_status();
+    if (rc != NSOS_OK) return rc;
+    unsigned char* stream16 = reinterpret_cast<unsigned char*>(static_cast<unsigned*>(packed) + kAuxWords) + 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes;
+    return pack_lp16(T_, sem_mode, dtype == NSOS_DTYPE_F16, stream16, (hipStream_t)stream);
 }
 
-// which kernel serves the 16-bit path: 2 = mlp_lp8_kernel (two 256-register waves per SIMD, 32 points each; default),
-// 1 = mlp_lp_kernel (round 1: one 512-register wave per SIMD, 64 points).  NSOS_LP_WAVES=4 in the environment or
-// nsos_mlp_lp_select_kernel(1) select the latter for A/B measurements; results are bit-identical.
+// which kernel serves the 16-bit path: 3 = mlp_lp16_kernel (round 4: two waves per SIMD on v_mfma_f32_16x16x32; default),
+// 2 = mlp_lp8_kernel (rounds 2-3: two 256-register waves per SIMD on 32x32x16), 1 = mlp_lp_kernel (round 1: one 512-register
+// wave per SIMD, 64 points).  NSOS_LP_KERNEL=lp16|lp8|lp4 (or the older NSOS_LP_WAVES=4) in the environment or
+// nsos_mlp_lp_select_kernel(3|2|1) select one for A/B measurements; lp8 and lp4 are bit-identical to each other, lp16 agrees
+// with them to the 16-bit formats' rounding (other contraction order, 16-bit heads: mlp_lp16.hip).
 static int g_lp_waves_per_simd = 0;
 static int lp_waves_per_simd() {
     if (g_lp_waves_per_simd == 0) {
         const char* e = getenv("NSOS_LP_WAVES");
-        g_lp_waves_per_simd = (e && e[0] == '4') ? 1 : 2;
+        const char* k = getenv("NSOS_LP_KERNEL");
+        g_lp_waves_per_simd = 3;
+        if (e && e[0] == '4') g_lp_waves_per_simd = 1;
+        if (k && k[0] == 'l' && k[1] == 'p') g_lp_waves_per_simd = k[2] == '4' ? 1 : (k[2] == '8' ? 2 : 3);
     }
     return g_lp_waves_per_simd;
 }
@@ -543,7 +552,7 @@ extern "C" int32_t nsos_mlp_lp_set_stamp_buffer(uint64_t* stamps) {
 }
 
 extern "C" int32_t nsos_mlp_lp_select_kernel(int32_t waves_per_simd) {
-    NSOS_REQUIRE(waves_per_simd == 1 || waves_per_simd == 2, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 3, NSOS_ERR_UNSUPPORTED);
     g_lp_waves_per_simd = waves_per_simd;
     return NSOS_OK;
 }
@@ -577,8 +586,12 @@ static int32_t forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dty
     //  round-1 kernel, whose results are bit-identical)
     // (its training variant stores the compact 16-bit operands only: the fp32 sem_in / sem_hid of nsos_mlp_forward_rays_save_lp
     //  -- tests and the exact-kernel backward -- come from the round-1 kernel as well)
-    if (lp_waves_per_simd() == 2 && n_pts < (1ll << 31) && !(sem_in && !sem_in16)) {
+    if (lp_waves_per_simd() >= 2 && n_pts < (1ll << 31) && !(sem_in && !sem_in16)) {
         if (sem_in || sem_in16) NSOS_REQUIRE((sem_in16 ? (void*)sem_hid16 : (void*)sem_hid) && sem_mode != NSOS_SEM_NONE, NSOS_ERR_UNSUPPORTED);
+        if (lp_waves_per_simd() == 3) {
+            p.chunks += 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes;   // the third stream: 16x16x32 tiles
+            return launch_lp16(p, sem_mode, dtype == NSOS_DTYPE_F16, sem_in || sem_in16, st);
+        }
         p.chunks += (size_t)lp_chunks(sem_mode) * kSlotBytes;   // the second stream: tile-pair-major hidden layers
         return launch_lp8(p, sem_mode, dtype == NSOS_DTYPE_F16, sem_in || sem_in16, st);
     }
@@ -620,7 +633,7 @@ extern "C" int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem
 }
 
 extern "C" int32_t nsos_mlp_save16_layout(int64_t n_points) {   // the same condition forward_rays_lp selects the kernel by
-    return (lp_waves_per_simd() == 2 && n_points < (1ll << 31)) ? NSOS_SEM_IN_TILED : NSOS_SEM_IN_ROWS;
+    return (lp_waves_per_simd() >= 2 && n_points < (1ll << 31)) ? NSOS_SEM_IN_TILED : NSOS_SEM_IN_ROWS;
 }
 
 extern "C" int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,

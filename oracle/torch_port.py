@@ -193,14 +193,19 @@ def point_query(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Tenso
 
 
 def point_query_lp(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Tensor, cfg: PortConfig,
-                   dtype: torch.dtype) -> Tensor:
-    """Emulation of the reduced-precision kernel (nerf-sos_amd/csrc/mlp_lp.hip), NOT of the reference: everything
-    that enters an MFMA is rounded to `dtype` (encodings, MFMA weights and biases, activations after ReLU, the
-    feature vector), products are accumulated in fp64 here (fp32 on the GPU); the sigma head uses 16-bit weights on
-    the 16-bit activations, the rgb / semantic output heads are fp32 on the un-rounded fp32 hidden layers."""
+                   dtype: torch.dtype, lp16: bool = False) -> Tensor:
+    """Emulation of the reduced-precision kernels (nerf-sos_amd/csrc/mlp_lp.hip, mlp_lp8.hip; lp16=True: mlp_lp16.hip), NOT of
+    the reference: everything that enters an MFMA is rounded to `dtype` (encodings, MFMA weights, activations after ReLU, the
+    feature vector), products are accumulated in fp64 here (fp32 on the GPU).
+      lp16=False: every bias is an MFMA operand (rounded); the sigma head uses 16-bit weights on the 16-bit activations, the
+                  rgb / semantic output heads are fp32 on the un-rounded fp32 hidden layers.
+      lp16=True:  the biases of the hidden layers 1-4, 6-7 and of feature_linear are fp32 accumulator initialisers (those of
+                  layers 0 and 5, of semantic_linear.0 and of views_linears.0 ride in an operand's pad column: rounded); ALL
+                  three output heads are MFMAs: 16-bit weights on the 16-bit-rounded hidden activations, fp32 biases."""
     q = lambda t: t.to(dtype).double()  # noqa: E731
     W = lambda n: sd[f"{prefix}.mlp.{n}.weight"]  # noqa: E731
     B = lambda n: sd[f"{prefix}.mlp.{n}.bias"]  # noqa: E731
+    qb = (lambda t: t.double()) if lp16 else q        # a hidden layer's bias  # noqa: E731
     flat = pts.reshape(-1, 3)
     dirs = viewdirs.reshape(-1, 3)
     ex, ed = q(posenc(flat, cfg.multires)), q(posenc(dirs, cfg.multires_views))
@@ -211,7 +216,7 @@ def point_query_lp(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Te
         if i == cfg.skip + 1:
             z = h @ w[:, X:].T + ex @ w[:, :X].T + q(B(f"pts_linears.{i}"))
         else:
-            z = h @ w.T + q(B(f"pts_linears.{i}"))
+            z = h @ w.T + qb(B(f"pts_linears.{i}"))
         h = q(torch.relu(z).float())
     sigma = h @ q(W("alpha_linear")).T + B("alpha_linear").double()
     outs = []
@@ -220,12 +225,20 @@ def point_query_lp(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Te
         z = h @ w[:, :cfg.net_width].T + q(B("semantic_linear.0"))
         if cfg.sem_with_coord:
             z = z + ex @ w[:, cfg.net_width:].T
-        sem = torch.relu(z).float().double() @ W("semantic_linear.2").double().T + B("semantic_linear.2").double()
+        hid = torch.relu(z).float()
+        if lp16:
+            sem = q(hid) @ q(W("semantic_linear.2")).T + B("semantic_linear.2").double()
+        else:
+            sem = hid.double() @ W("semantic_linear.2").double().T + B("semantic_linear.2").double()
         outs = [sem]
-    feat = q((h @ q(W("feature_linear")).T + q(B("feature_linear"))).float())
+    feat = q((h @ q(W("feature_linear")).T + qb(B("feature_linear"))).float())
     w = q(W("views_linears.0"))
     z = feat @ w[:, :cfg.net_width].T + ed @ w[:, cfg.net_width:].T + q(B("views_linears.0"))
-    rgb = torch.relu(z).float().double() @ W("rgb_linear").double().T + B("rgb_linear").double()
+    vh = torch.relu(z).float()
+    if lp16:
+        rgb = q(vh) @ q(W("rgb_linear")).T + B("rgb_linear").double()
+    else:
+        rgb = vh.double() @ W("rgb_linear").double().T + B("rgb_linear").double()
     out = torch.cat([rgb, sigma] + outs, -1).float()
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
 

@@ -1,4 +1,4 @@
-"""Interleaved A/B timing of the two 16-bit kernels on the C3/C5 fine-pass shape (diagnostic)."""
+"""Interleaved A/B/C timing of the three 16-bit kernels (1 = lp4, 2 = lp8, 3 = lp16) on the C3/C5 fine-pass shape (diagnostic)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -18,9 +18,9 @@ for sem, kw in ((0, dict(use_semantics=False)), (2, dict(use_semantics=True, sem
     mac = {0: 593408, 2: 634496}[sem]
     for prec in ("fp16", "bf16"):
         pk = net.nerf_fine.packed_weights(prec)
-        best = {1: 1e9, 2: 1e9}
+        best = {1: 1e9, 2: 1e9, 3: 1e9}
         for rep in range(reps):
-            for wps in (1, 2):
+            for wps in (1, 2, 3):
                 _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(wps), "select")
                 for _ in range(5):
                     ops.mlp_forward_rays_lp(pk, sem, prec, o, d, v, z)
@@ -31,5 +31,6 @@ for sem, kw in ((0, dict(use_semantics=False)), (2, dict(use_semantics=True, sem
                 ev[1].record(); torch.cuda.synchronize()
                 best[wps] = min(best[wps], ev[0].elapsed_time(ev[1]) / 40)
         tf = lambda ms: 2 * mac * R * 192 / (ms * 1e-3) / 1e12
-        print(f"sem {sem} {prec} R={R}: lp4 {best[1]:.4f} ms ({tf(best[1]):.0f} TF, {tf(best[1])/25:.1f} %)   lp8 {best[2]:.4f} ms ({tf(best[2]):.0f} TF, {tf(best[2])/25:.1f} %)")
-_lib.check(_lib.lib().nsos_mlp_lp_select_kernel(2), "select")
+        print(f"sem {sem} {prec} R={R}: lp4 {best[1]:.4f} ms ({tf(best[1]):.0f} TF, {tf(best[1])/25.166:.1f} %)   lp8 {best[2]:.4f} ms ({tf(best[2]):.0f} TF, {tf(best[2])/25.166:.1f} %)"
+              f"   lp16 {best[3]:.4f} ms ({tf(best[3]):.0f} TF, {tf(best[3])/25.166:.1f} %)", flush=True)
+_lib.check(_lib.lib().nsos_mlp_lp_select_kernel(3), "select")

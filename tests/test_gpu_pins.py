@@ -197,14 +197,18 @@ def test_free_running_render_at_c2_size(manifest, peaky):
       2. with the port's z_fine handed in, ALL 4096 rays are strictly within 1e-4 on every fine key -- whatever deviates
          in the free-running render comes from the sampler's inputs, not from the fine network or the compositing;
       3. right-bisect index flips (the u = 1 end sample excluded, where both indices give the same position):
-         measured 0.07-0.12 % of rays, asserted <= 0.3 %;
+         measured 2-3 rays of 4096 (0.05-0.07 %), asserted <= 8 rays (0.2 %);
       4. rays whose fine maps leave the 1e-4 band free-running (measured: 1.0 % spiky field, 1.6 % default-init): the
          hierarchical sampler is ill-conditioned wherever the coarse weights are small -- the reference's
          alpha = 1 - exp(-sigma*delta) lives on a 6e-8 grid, so a last-ulp difference in sigma moves an alpha of 1e-4 by
          6e-4 of itself, the cdf by up to 1e-4 and importance samples by up to 1e-2.  The yardstick is the reference's
          OWN rounding error: its coarse network evaluated in fp64 (and rounded to fp32 once) instead of fp32, everything
-         else unchanged, gives N_self rays in which the reference leaves the 1e-4 band around ITSELF.  The HIP path (whose
-         coarse raw is as close to the fp64 values as MKL's) must not exceed 2 N_self + 8."""
+         else unchanged, gives N_self rays in which the reference leaves the 1e-4 band around ITSELF.  "HIP vs reference"
+         carries TWO independent realisations of that rounding noise (the HIP path's and the reference's, each against the
+         exact values), "reference vs fp64" one: sqrt(2) N_self is the expectation for a coarse pass exactly as accurate as
+         the reference's.  Measured (round 4, deterministic: eval mode, fixed seeds): 34 vs N_self 21 (default-init), 43 vs 26
+         (spiky) = 1.62 / 1.65 N_self; asserted <= 1.5 N_self + 8 (round 3 allowed 2 N_self + 8).  bench.py prints the same
+         pair for the headline batch (`parity.*.yardstick`: 41 vs 47 on the dense field, 0 vs 0 on the default-init one)."""
     cfg = tp.PortConfig(n_importance=128, **CFGS["semcoord"])
     sd = ref_state("semcoord", manifest, peaky=peaky)
     rays = tp.synthetic_rays(4096, seed=0)
@@ -238,7 +242,7 @@ def test_free_running_render_at_c2_size(manifest, peaky):
     for k in ("rgb", "depth", "acc", "disp", "semantics", "weights", "raw"):                          # 2
         close(N(pinned[k]), N(ref[k]), what=f"fine {k} at C2 size on the reference's z_fine")
     flip_rays = int((inds_hip != inds_ref)[:, :-1].any(-1).sum())                                     # 3
-    assert flip_rays <= 0.003 * 4096, f"{flip_rays} rays with a flipped bisect index"
+    assert flip_rays <= 8, f"{flip_rays} rays with a flipped bisect index"
 
     def outside(maps):
         o = np.zeros(4096, bool)
@@ -260,6 +264,6 @@ def test_free_running_render_at_c2_size(manifest, peaky):
           f"{e_ref:.2e}, HIP {e_hip:.2e}; rays outside 1e-4 of the reference: HIP {n_hip} ({100 * n_hip / 4096:.2f} %), the reference "
           f"with an fp64 coarse network {n_self} ({100 * n_self / 4096:.2f} %)")
     assert e_hip <= 2.0 * e_ref + 1e-7, "the coarse raw must be as close to the exact values as the reference's own"
-    assert n_hip <= 2 * n_self + 8, f"{n_hip} rays outside 1e-4 vs {n_self} for the reference against its own fp64 coarse pass"
+    assert n_hip <= 1.5 * n_self + 8, f"{n_hip} rays outside 1e-4 vs {n_self} for the reference against its own fp64 coarse pass"
     mse = float(((N(out['rgb']) - N(ref['rgb'])) ** 2).mean())
     assert 10 * np.log10(1.0 / max(mse, 1e-30)) > 75.0, "PSNR of rgb vs the reference path"
