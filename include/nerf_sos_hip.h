@@ -87,6 +87,44 @@ size_t nsos_mlp_packed_bytes(int32_t sem_mode);
 int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
                       void* stream);
 
+/* ---- K2-G: the MLP for any architecture the reference's constructors accept (csrc/mlp_generic.hip) -------------------------
+ * nn.Linear tensors ([out,in] row-major fp32, device memory) of ONE NeRFMLP.mlp, described as the reference builds it
+ * (models/nerf_mlp.py:40-64; NeRFMLP.__init__ :136-166): depth D, width W, the skip set as a bit mask (bit i: "i in skips", the
+ * output of pts_linears.i is concatenated with input_pts, :73-74), multires / multires_views (xyz_freqs / dir_freqs; -1 = no
+ * embedding: the raw 3-vector), use_viewdirs (0: output_linear only, :97-98), the semantic head as its Linear modules in order
+ * (sem_layers of them: 2 for sem_layer <= 2, sem_layer otherwise, :58-63; ReLU between them), sem_with_coord (cat([h,
+ * input_pts]), :79), sem_with_geo (geo[0..1] = geo_map_sem's two Linears on alpha; semantics *= mapping, :60,:81-83).
+ * Exact-fp32 MFMA arithmetic (fmaf chains, bias first), forward only.  raw: [n, 4 + sem_dim] (4 without view directions).
+ * The shipped architecture (8 x 256, skips {4}, 10 / 4 octaves, view directions, two-Linear head) should use nsos_mlp_forward_*:
+ * this path is ~2x slower there.  Limits: depth <= 16, sem_layers <= 8, ceil(W / 32) * 32 * 4 buffers within 160 KiB of LDS
+ * (W <= 256 with the deep head, <= 320 without), 4 + sem_dim (x 2 with sem_with_geo) <= 32; NSOS_ERR_UNSUPPORTED otherwise. */
+#define NSOS_GENERIC_MAX_DEPTH 16
+#define NSOS_GENERIC_MAX_SEM 8
+typedef struct nsos_generic_linear {
+    const float* weight;   /* [out_dim, in_dim] */
+    const float* bias;     /* [out_dim] */
+    int32_t out_dim, in_dim;
+} nsos_generic_linear;
+typedef struct nsos_generic_mlp {
+    int32_t depth, width, skip_mask;
+    int32_t xyz_freqs, dir_freqs;              /* octaves; -1: use_embed = False */
+    int32_t use_viewdirs, use_semantics, sem_dim, sem_with_coord, sem_with_geo, sem_layers;
+    nsos_generic_linear pts[NSOS_GENERIC_MAX_DEPTH];
+    nsos_generic_linear alpha, feature, views, rgb;   /* use_viewdirs */
+    nsos_generic_linear output;                        /* !use_viewdirs */
+    nsos_generic_linear sem[NSOS_GENERIC_MAX_SEM];
+    nsos_generic_linear geo[2];
+} nsos_generic_mlp;
+size_t nsos_mlp_generic_packed_bytes(const nsos_generic_mlp* mlp);      /* 0: unsupported description */
+int32_t nsos_mlp_generic_out_channels(const nsos_generic_mlp* mlp);    /* 0: unsupported description */
+int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream);
+/* `mlp` must describe the same architecture `packed` was packed for (its tensor pointers are not read here). */
+int32_t nsos_mlp_generic_forward_rays(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
+                                      const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                      float* raw, void* stream);
+int32_t nsos_mlp_generic_forward_points(const nsos_generic_mlp* mlp, const void* packed, const float* pts, const float* dirs,
+                                        int64_t n_pts, float* raw, void* stream);
+
 /* ---- K0: pinhole ray generation (SURVEY.md section 8f "next", rank 1) ------------------------------------
  * get_persp_rays (utils/ray.py:12-22; callers data/gen_dataset.py:189,202) for the pixels
  * [pix_begin, pix_end) of an H x W image in row-major order (pixel = j*W + i):

@@ -19,6 +19,24 @@ class MlpTensors(C.Structure):
                 ("rgb_w", _fp), ("rgb_b", _fp), ("sem0_w", _fp), ("sem0_b", _fp), ("sem2_w", _fp), ("sem2_b", _fp)]
 
 
+class GenericLinear(C.Structure):
+    """struct nsos_generic_linear"""
+    _fields_ = [("weight", _fp), ("bias", _fp), ("out_dim", _i32), ("in_dim", _i32)]
+
+
+GENERIC_MAX_DEPTH, GENERIC_MAX_SEM = 16, 8
+
+
+class GenericMlp(C.Structure):
+    """struct nsos_generic_mlp"""
+    _fields_ = [("depth", _i32), ("width", _i32), ("skip_mask", _i32), ("xyz_freqs", _i32), ("dir_freqs", _i32),
+                ("use_viewdirs", _i32), ("use_semantics", _i32), ("sem_dim", _i32), ("sem_with_coord", _i32),
+                ("sem_with_geo", _i32), ("sem_layers", _i32),
+                ("pts", GenericLinear * GENERIC_MAX_DEPTH), ("alpha", GenericLinear), ("feature", GenericLinear),
+                ("views", GenericLinear), ("rgb", GenericLinear), ("output", GenericLinear),
+                ("sem", GenericLinear * GENERIC_MAX_SEM), ("geo", GenericLinear * 2)]
+
+
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks)
 SIGNATURES = {
     "nsos_abi_version": (_i32, []),
@@ -26,6 +44,11 @@ SIGNATURES = {
     "nsos_source_hash": (C.c_char_p, []),
     "nsos_mlp_packed_bytes": (_sz, [_i32]),
     "nsos_mlp_pack": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
+    "nsos_mlp_generic_packed_bytes": (_sz, [C.POINTER(GenericMlp)]),
+    "nsos_mlp_generic_out_channels": (_i32, [C.POINTER(GenericMlp)]),
+    "nsos_mlp_generic_pack": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
+    "nsos_mlp_generic_forward_rays": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "nsos_mlp_generic_forward_points": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _i64, _fp, _fp]),
     "nsos_generate_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, C.POINTER(C.c_float), _i64, _i64, _fp, _fp, _fp]),
     "nsos_patch_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _i32, _fp, _i32, _fp, _i32, C.POINTER(C.c_int32), _fp,
                                 _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -1,0 +1,463 @@
+// K2-G: positional encoding + MLP for ANY architecture the reference's constructors accept (models/nerf_mlp.py:40-64,
+// models/nerf_net.py:22-56): depth, width, skip set, multires / multires_views (or no embedding), use_viewdirs = False
+// (output_linear), the deep semantic head (sem_layer > 2), sem_dim, sem_with_geo.  The shipped architecture (8 x 256, skip 4,
+// multires 10 / 4, view directions, the two-layer head) has its own hand-scheduled kernels (mlp_fused.hip and the 16-bit
+// family); everything else renders through this one, on the same exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32:
+// bitwise an fmaf chain), forward only.
+//
+// Mapping.  A workgroup = 4 waves = one per SIMD = one tile of 32 points.  The network is a PROGRAM of dense ops
+// (nsos_generic_mlp -> build_program below, mirroring MLP.forward line by line); every op reads its inputs from and writes
+// its output to per-tile activation buffers in LDS, [feature][32 points] fp32 (a feature row = 128 B).  An op's output tiles
+// (32 features each) are dealt to the waves round-robin, two at a time per wave (tiles t and t + 4: one B operand feeds both
+// accumulators); the contraction runs over the op's input SEGMENTS (the concatenations of the reference: [input_pts, h] of
+// the skip layer, [h, input_pts] of the semantic head, [feature, input_views]) in groups of 4 k-steps = 8 input rows:
+//   B operand  lane (point j, hi): row 2 ks + hi of the segment, one ds_read_b32 per k-step (conflict-free: 64 consecutive words)
+//   A operand  one global_load_dwordx4 per group and tile from the packed stream [tile][group][lane][4] (L2-resident: the
+//              whole net is 0.3-3 MB), prefetched four groups ahead -- no LDS staging, no barrier inside an op
+//   bias       a leading group whose input is the constant buffer [1, 0, ...]: acc = fma(bias, 1, 0), then the chain
+// One __syncthreads per op.  Small heads (alpha, rgb, logits: one tile) occupy one wave; at 8 x 256 that is ~10 % of a tile's
+// time -- this kernel buys generality, the fast paths keep the shipped configs.
+// Ceiling: 2 x 64-cycle MFMAs per k-step and wave against 16 B/lane of A operand per 4 k-steps: ~8 B/clk/CU from L2.
+#include "mlp_common.h"
+
+using namespace nsos;
+
+namespace {
+
+constexpr int kGenMaxOps = 48, kGenMaxGroups = 56, kGenMaxSeg = 3;
+constexpr int kGenRowFloats = 32;     // one LDS row = one feature of the tile's 32 points = 128 B
+
+enum { kGenDense = 0, kGenMul = 1 };
+struct GenOp {
+    int kind;        // kGenDense / kGenMul
+    int out_off;     // LDS float offset of the op's output row 0
+    int out_dim;     // rows written (dense: out features; mul: rows multiplied)
+    int out_tiles;
+    int relu;        // bit 0: ReLU; bit 1: also write zeros into the pad rows of the last tile (a whole buffer is this op's output)
+    int n_groups;    // groups of 4 k-steps over all segments, the bias group first
+    int w_off;       // float offset of the op's A stream in the packed weights
+    int src_off;     // mul: LDS float offset of the factor rows
+    int grp_off[kGenMaxGroups + 8];   // LDS float offset of the first input row of group g (entries past n_groups: the constant buffer)
+};
+struct GenProgram {              // at the head of the packed buffer (device memory); identical on the host (build_program)
+    int n_ops, lds_floats, n_out, out_off;
+    int x_off, x_rows, x_dim, x_freqs;      // encoded xyz: buffer, padded rows, real rows, octaves (-1: raw coordinates)
+    int v_off, v_rows, v_dim, v_freqs;      // encoded view direction (v_dim = 0 without view directions)
+    int ones_off, w_floats, pad0, pad1;
+    GenOp ops[kGenMaxOps];
+};
+
+struct GenParams {
+    const GenProgram* prog;
+    const float* wts;
+    const float* rays_o; const float* rays_d; const float* viewdirs; const float* z_vals;   // ray mode
+    const float* pts; const float* dirs;                                                      // point mode
+    float* raw;
+    long long n_pts;
+    int n_samples;
+    int n_tiles;
+};
+
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// encoded feature f of a 3-vector (models/embedder.py:34-48): [x y z | sin(2^0 x..z) cos(2^0 x..z) | sin(2^1 ..) ...]
+__device__ __forceinline__ float gen_feature(const float (&x)[3], int f, int dim, int freqs) {
+    if (f >= dim) return 0.0f;
+    if (f < 3 || freqs < 0) return f == 0 ? x[0] : (f == 1 ? x[1] : x[2]);   // (freqs < 0: use_embed = False, dim = 3)
+    const int m = f - 3, k = m / 6, r = m - 6 * k, c = r >= 3 ? r - 3 : r;
+    const float xv = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+    const float a = xv * __builtin_bit_cast(float, (unsigned)(127 + k) << 23);   // 2^k, exact (freq_bands = 2 ** linspace(0, L-1, L))
+    float sn, cs;
+    sincos_pe(a, sn, cs);
+    return r >= 3 ? cs : sn;
+}
+
+typedef const __attribute__((address_space(4))) GenOp& GenOpRef;
+
+template <int OFF>
+__device__ __forceinline__ void gen_ld_off(f32x4& v, unsigned voff, unsigned long long base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "i"(OFF) : "memory");
+}
+__device__ __forceinline__ unsigned long long gen_uniform64(const void* p) {   // the pointer is wave-uniform: say so (see sem_wgrad16.hip)
+    const unsigned long long b = (unsigned long long)p;
+    unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32) |
+                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b);
+    asm volatile("s_nop 4" : "+s"(u));     // readfirstlane -> SGPR base of a vector-memory instruction: five wait states
+    return u;
+}
+
+// The contraction of one op for output tiles t0 (and t0 + 4 if TWO): groups of 4 k-steps, A operands prefetched FOUR groups
+// ahead through a register ring with hand-counted waits (the loads are asm: left to itself hipcc rotates the ring with copies
+// and drains the queue at every group).  n_groups is a multiple of 4 (the packer pads with zero-weight groups on the constant
+// buffer); the ring's last four loads run up to 4 KiB past the tile's stream (into the next tile's, or the buffer's tail pad).
+template <bool TWO>
+__device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const float* lds, int t0, int lane, int pt, int hi,
+                                            f32x16& acc0, f32x16& acc1) {
+    const int ng = op.n_groups;
+    const unsigned long long base0 = gen_uniform64(wts + op.w_off + (size_t)t0 * ng * 256);
+    const unsigned long long base1 = gen_uniform64(wts + op.w_off + (size_t)(t0 + (TWO ? 4 : 0)) * ng * 256);
+    unsigned voff = (unsigned)lane * 16u;
+    f32x4 r0[4], r1[4];
+    gen_ld_off<0>(r0[0], voff, base0);
+    if constexpr (TWO) gen_ld_off<0>(r1[0], voff, base1);
+    gen_ld_off<1024>(r0[1], voff, base0);
+    if constexpr (TWO) gen_ld_off<1024>(r1[1], voff, base1);
+    gen_ld_off<2048>(r0[2], voff, base0);
+    if constexpr (TWO) gen_ld_off<2048>(r1[2], voff, base1);
+    gen_ld_off<3072>(r0[3], voff, base0);
+    if constexpr (TWO) gen_ld_off<3072>(r1[3], voff, base1);
+    voff += 4096u;
+    // B operands one group ahead (LDS latency under the previous group's MFMAs); the last prefetch reads group `ng`: a valid
+    // table entry (the table is padded past kGenMaxGroups) pointing at the constant buffer
+    const float* bp0 = lds + op.grp_off[0] + hi * kGenRowFloats + pt;
+    float bn0 = bp0[0], bn1 = bp0[2 * kGenRowFloats], bn2 = bp0[4 * kGenRowFloats], bn3 = bp0[6 * kGenRowFloats];
+    for (int g = 0; g < ng; g += 4) {
+        static_for<0, 4>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const float b0 = bn0, b1 = bn1, b2 = bn2, b3 = bn3;
+            const float* bp = lds + op.grp_off[g + u + 1] + hi * kGenRowFloats + pt;
+            bn0 = bp[0]; bn1 = bp[2 * kGenRowFloats]; bn2 = bp[4 * kGenRowFloats]; bn3 = bp[6 * kGenRowFloats];
+            // group g + u has landed when at most the loads of the three younger groups are outstanding
+            if constexpr (TWO) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0[u]), "+v"(r1[u]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" : "+v"(r0[u]) : : "memory");
+            acc0 = mfma_f32(r0[u][0], b0, acc0);
+            if constexpr (TWO) acc1 = mfma_f32(r1[u][0], b0, acc1);
+            acc0 = mfma_f32(r0[u][1], b1, acc0);
+            if constexpr (TWO) acc1 = mfma_f32(r1[u][1], b1, acc1);
+            acc0 = mfma_f32(r0[u][2], b2, acc0);
+            if constexpr (TWO) acc1 = mfma_f32(r1[u][2], b2, acc1);
+            acc0 = mfma_f32(r0[u][3], b3, acc0);
+            if constexpr (TWO) acc1 = mfma_f32(r1[u][3], b3, acc1);
+            NSOS_PIN();
+            gen_ld_off<u * 1024>(r0[u], voff, base0);     // group g + u + 4
+            if constexpr (TWO) gen_ld_off<u * 1024>(r1[u], voff, base1);
+            NSOS_PIN();
+        });
+        voff += 4096u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]) : : "memory");   // the overshoot loads: drained, unused
+    if constexpr (TWO) asm volatile("" : "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]));
+}
+
+__global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt = lane & 31, hi = lane >> 5;
+    // the program is read-only and every access is wave-uniform: through the CONSTANT address space the loads are scalar (s_load,
+    // lgkm counter) -- as vector-memory loads they shared the vm counter with the A-operand prefetches, and waiting for a group's
+    // LDS offset drained the whole prefetch queue
+    const __attribute__((address_space(4))) GenProgram& G = *(const __attribute__((address_space(4))) GenProgram*)P.prog;
+    const int n_ops = G.n_ops, n_out = G.n_out, out_off = G.out_off;
+    {   // the constant input [1, 0, 0, ...] (8 rows): the bias group's B operand
+        const int row = tid >> 5, col = tid & 31;
+        lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;
+    }
+    for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        // ---- inputs and encodings: thread (point p, part): features part, part + 8, ...
+        const int p = tid & 31, part = tid >> 5;
+        const long long gp = (long long)tile * 32 + p;
+        const bool valid = gp < P.n_pts;
+        const long long gc = valid ? gp : P.n_pts - 1;
+        float x[3], dv[3] = {0.0f, 0.0f, 0.0f};
+        if (P.pts) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[c] = P.pts[3 * gc + c];
+                if (G.v_dim) dv[c] = P.dirs[3 * gc + c];
+            }
+        } else {
+            const long long ray = gc / P.n_samples;
+            const float z = P.z_vals[gc];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float m = P.rays_d[3 * ray + c] * z;      // models/sampler.py:70,166 (mul, then add)
+                x[c] = P.rays_o[3 * ray + c] + m;
+                if (G.v_dim) dv[c] = P.viewdirs[3 * ray + c];
+            }
+        }
+        // NaN / Inf in a point's inputs must come out as NaN (v_max(0, NaN) = 0 would launder them at the first ReLU)
+        const float poison = ((x[0] - x[0]) + (x[1] - x[1])) + ((x[2] - x[2]) + (dv[0] - dv[0])) + ((dv[1] - dv[1]) + (dv[2] - dv[2]));
+        for (int f = part; f < G.x_rows; f += 8) lds[G.x_off + f * kGenRowFloats + p] = gen_feature(x, f, G.x_dim, G.x_freqs);
+        for (int f = part; f < G.v_rows; f += 8) lds[G.v_off + f * kGenRowFloats + p] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+        for (int r = part; r < 32; r += 8) lds[out_off + r * kGenRowFloats + p] = 0.0f;
+        __syncthreads();
+
+        for (int oi = 0; oi < n_ops; ++oi) {
+            const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
+            if (op.kind == kGenMul) {       // semantics * geo_map_sem(alpha) (models/nerf_mlp.py:81-83)
+                for (int r = part; r < op.out_dim; r += 8) lds[op.out_off + r * kGenRowFloats + p] *= lds[op.src_off + r * kGenRowFloats + p];
+                __syncthreads();
+                continue;
+            }
+            const int out_tiles = op.out_tiles;
+            for (int t0 = wave; t0 < out_tiles; t0 += 8) {
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+                const bool two = t0 + 4 < out_tiles;          // wave-uniform
+                if (two) dense_tiles<true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                else dense_tiles<false>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                // accumulator register r of lane (j, hi) = output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi of point j
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = 32 * t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    // (rows past out_dim have all-zero weights: their accumulators are exactly 0 -- written only where the buffer's pad
+                    //  rows are read by a later op as zero-weighted inputs, never into the shared OUT buffer)
+                    const bool relu = op.relu & 1, pad = op.relu & 2;
+                    if (row0 < op.out_dim || pad) lds[op.out_off + row0 * kGenRowFloats + pt] = relu ? fmaxf(acc0[r], 0.0f) : acc0[r];
+                    if (two && (row0 + 128 < op.out_dim || pad)) lds[op.out_off + (row0 + 128) * kGenRowFloats + pt] = relu ? fmaxf(acc1[r], 0.0f) : acc1[r];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- raw[p, c] = OUT[c][p]   (models/nerf_mlp.py:93-98: cat([rgb, alpha, semantics]) / output_linear)
+        if (valid)
+            for (int c = part; c < n_out; c += 8) P.raw[gp * n_out + c] = poison != poison ? __builtin_nanf("") : lds[out_off + c * kGenRowFloats + p];
+        __syncthreads();
+    }
+}
+
+// one launch per op: the op's A stream [tile][group][lane][4]
+struct GenPackOp {
+    const float* w; const float* bias;
+    int in_dim, out_dim, out_tiles, n_groups, n_seg;
+    int seg_col0[kGenMaxSeg], seg_rows[kGenMaxSeg], seg_groups[kGenMaxSeg];
+    float* out;
+};
+__global__ __launch_bounds__(256) void gen_pack_kernel(const GenPackOp Q) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Q.out_tiles * Q.n_groups * 256;
+    if (gid >= total) return;
+    const int j = (int)(gid & 3), lane = (int)((gid >> 2) & 63);
+    const long long tg = gid >> 8;
+    const int g = (int)(tg % Q.n_groups), t = (int)(tg / Q.n_groups);
+    const int i = lane & 31, hi = lane >> 5, row = 32 * t + i;
+    float v = 0.0f;
+    if (row < Q.out_dim) {
+        if (g == 0) {                                   // bias group: input row 0 is the constant 1
+            if (2 * j + hi == 0) v = Q.bias ? Q.bias[row] : 0.0f;
+        } else {
+            int gl = g - 1, s = 0;
+            while (s < Q.n_seg && gl >= Q.seg_groups[s]) { gl -= Q.seg_groups[s]; ++s; }
+            const int kr = 8 * gl + 2 * j + hi;
+            if (s < Q.n_seg && kr < Q.seg_rows[s]) v = Q.w[(long long)row * Q.in_dim + Q.seg_col0[s] + kr];     // (s == n_seg: a pad group)
+        }
+    }
+    Q.out[gid] = v;
+}
+
+// ---------------------------------------------------------------------------------------------- host: the program
+struct HostSeg { int buf_off, rows, col0; };
+struct HostOp { GenOp op; const float* w; const float* bias; int in_dim; int n_seg; HostSeg seg[kGenMaxSeg]; };
+struct HostProgram { GenProgram prog; HostOp hops[kGenMaxOps]; int32_t err; };
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// Mirrors MLP.__init__ / MLP.forward (models/nerf_mlp.py:40-100) and NeRFMLP.__init__ (:136-166) as a sequence of dense ops over
+// LDS activation buffers.  Pure host arithmetic: pack and every launch rebuild it from the same description.
+void build_program(const nsos_generic_mlp& M, HostProgram& H) {
+    H = HostProgram{};
+    GenProgram& G = H.prog;
+    H.err = NSOS_OK;
+    const int D = M.depth, W = M.width;
+    if (D < 1 || D > NSOS_GENERIC_MAX_DEPTH || W < 1 || M.sem_layers < 0 || M.sem_layers > NSOS_GENERIC_MAX_SEM || M.xyz_freqs > 24 || M.dir_freqs > 24) { H.err = NSOS_ERR_UNSUPPORTED; return; }
+    const int x_dim = M.xyz_freqs < 0 ? 3 : 3 + 6 * M.xyz_freqs;
+    const int v_dim = M.use_viewdirs ? (M.dir_freqs < 0 ? 3 : 3 + 6 * M.dir_freqs) : 0;
+    const int Wp = pad_to(W, 32), Hp = pad_to(W / 2 > 0 ? W / 2 : 1, 32);
+    const bool sem = M.use_viewdirs && M.use_semantics && M.sem_layers > 0;     // without view directions the reference never runs the head (:97-98)
+    const int sem_dim = sem ? M.sem_dim : 0;
+    if (sem && (sem_dim < 1 || 4 + sem_dim * (M.sem_with_geo ? 2 : 1) > 32)) { H.err = NSOS_ERR_UNSUPPORTED; return; }
+    // the skip set: layer i's output is concatenated with the input (i in skips) -- the LAST layer must not be one (the heads
+    // take W inputs: the reference itself fails there)
+    if (D >= 1 && ((M.skip_mask >> (D - 1)) & 1)) { H.err = NSOS_ERR_UNSUPPORTED; return; }
+    // LDS buffers (float offsets): ONES | X | V | HA | HB | SA | SB | OUT
+    int off = 0;
+    auto alloc = [&](int rows) { const int o = off; off += rows * kGenRowFloats; return o; };
+    G.ones_off = alloc(8);
+    G.x_dim = x_dim; G.x_rows = pad_to(x_dim, 8); G.x_freqs = M.xyz_freqs; G.x_off = alloc(G.x_rows);
+    G.v_dim = v_dim; G.v_rows = pad_to(v_dim, 8); G.v_freqs = M.dir_freqs; G.v_off = alloc(G.v_rows > 0 ? G.v_rows : 0);
+    const int HA = alloc(Wp), HB = alloc(Wp);
+    // the head buffers: semantic chain (widths W ... W/2) and the view branch's hidden layer (W/2)
+    const int sw = sem ? (M.sem_layers > 2 ? Wp : Hp) : 0;
+    const int sa_rows = sw > Hp ? sw : (M.use_viewdirs ? Hp : 0), sb_rows = sem && (M.sem_layers > 2 || M.sem_with_geo) ? (sw > Hp ? sw : Hp) : 0;
+    const int SA = alloc(sa_rows), SB = alloc(sb_rows);
+    G.out_off = alloc(32);
+    G.lds_floats = off;
+    G.n_out = M.use_viewdirs ? 4 + sem_dim : 4;
+    int n = 0, w_off = 0;
+    auto dense = [&](const nsos_generic_linear& L, int out_buf, int out_row0, bool relu, int n_seg, const HostSeg* segs) {
+        if (n >= kGenMaxOps || !L.weight || !L.bias) { H.err = H.err ? H.err : (n >= kGenMaxOps ? NSOS_ERR_UNSUPPORTED : NSOS_ERR_NULL_POINTER); return; }
+        HostOp& ho = H.hops[n];
+        GenOp& op = ho.op;
+        op.kind = kGenDense; op.out_off = out_buf + out_row0 * kGenRowFloats; op.out_dim = L.out_dim; op.out_tiles = pad_to(L.out_dim, 32) / 32;
+        op.relu = (relu ? 1 : 0) | (out_buf != G.out_off ? 2 : 0);
+        int g = 0, in_dim = 0;
+        op.grp_off[g++] = G.ones_off;
+        for (int s = 0; s < n_seg; ++s) {
+            ho.seg[s] = segs[s];
+            ho.seg[s].col0 = in_dim;
+            in_dim += segs[s].rows;
+            const int ng = pad_to(segs[s].rows, 8) / 8;
+            for (int k = 0; k < ng; ++k) {
+                if (g >= kGenMaxGroups) { H.err = NSOS_ERR_UNSUPPORTED; return; }
+                op.grp_off[g++] = segs[s].buf_off + 8 * k * kGenRowFloats;
+            }
+        }
+        if (in_dim != L.in_dim) { H.err = NSOS_ERR_BAD_SHAPE; return; }
+        while (g % 4) {                                   // the kernel's loop is unrolled by four groups: pad with zero-weight groups
+            if (g >= kGenMaxGroups) { H.err = NSOS_ERR_UNSUPPORTED; return; }
+            op.grp_off[g++] = G.ones_off;
+        }
+        for (int k = g; k < kGenMaxGroups + 8; ++k) op.grp_off[k] = G.ones_off;
+        op.n_groups = g; op.w_off = w_off;
+        w_off += op.out_tiles * g * 256;
+        ho.w = L.weight; ho.bias = L.bias; ho.in_dim = in_dim; ho.n_seg = n_seg;
+        ++n;
+    };
+    const HostSeg Xs = {G.x_off, x_dim, 0}, Vs = {G.v_off, v_dim, 0};
+    int cur = -1;                                                      // the trunk's current activation buffer
+    for (int i = 0; i < D; ++i) {
+        const int out = (i & 1) ? HB : HA;
+        if (i == 0) dense(M.pts[0], out, 0, true, 1, &Xs);
+        else {
+            const HostSeg hs = {cur, W, 0};
+            if ((M.skip_mask >> (i - 1)) & 1) { const HostSeg two[2] = {Xs, hs}; dense(M.pts[i], out, 0, true, 2, two); }   // cat([input_pts, h]) (:73-74)
+            else dense(M.pts[i], out, 0, true, 1, &hs);
+        }
+        cur = out;
+    }
+    const int other = cur == HA ? HB : HA;
+    const HostSeg hs = {cur, W, 0};
+    if (!M.use_viewdirs) {
+        dense(M.output, G.out_off, 0, false, 1, &hs);                                          // output_linear (:97-98)
+    } else {
+        dense(M.alpha, G.out_off, 3, false, 1, &hs);                                           // alpha = alpha_linear(h) (:77)
+        if (sem) {
+            int src = -1, src_rows = 0;
+            for (int k = 0; k < M.sem_layers; ++k) {                                           // semantic_linear (:58-64, :79-80)
+                const bool last = k == M.sem_layers - 1;
+                const int out = last ? G.out_off : ((k & 1) ? SB : SA);
+                if (k == 0) {
+                    if (M.sem_with_coord) { const HostSeg two[2] = {hs, Xs}; dense(M.sem[0], out, last ? 4 : 0, !last, 2, two); }   // cat([h, input_pts])
+                    else dense(M.sem[0], out, last ? 4 : 0, !last, 1, &hs);
+                } else {
+                    const HostSeg ss = {src, src_rows, 0};
+                    dense(M.sem[k], out, last ? 4 : 0, !last, 1, &ss);
+                }
+                src = out; src_rows = M.sem[k].out_dim;
+            }
+            if (M.sem_with_geo) {                                                              // semantics *= geo_map_sem(alpha) (:60, :81-83)
+                const int gbuf = (M.sem_layers & 1) ? SB : SA;                                 // whichever the chain is done with
+                const HostSeg as = {G.out_off + 3 * kGenRowFloats, 1, 0};
+                dense(M.geo[0], gbuf, 0, true, 1, &as);
+                const HostSeg gs = {gbuf, M.geo[0].out_dim, 0};
+                dense(M.geo[1], G.out_off, 4 + sem_dim, false, 1, &gs);
+                if (n < kGenMaxOps) {
+                    GenOp& op = H.hops[n].op;
+                    op = GenOp{};
+                    op.kind = kGenMul; op.out_off = G.out_off + 4 * kGenRowFloats; op.src_off = G.out_off + (4 + sem_dim) * kGenRowFloats; op.out_dim = sem_dim;
+                    ++n;
+                }
+            }
+        }
+        dense(M.feature, other, 0, false, 1, &hs);                                             // feature = feature_linear(h) (:86)
+        const HostSeg fv[2] = {{other, W, 0}, Vs};
+        dense(M.views, SA, 0, true, 2, fv);                                                    // relu(views_linears.0(cat([feature, input_views]))) (:87-90)
+        const HostSeg vh = {SA, M.views.out_dim, 0};
+        dense(M.rgb, G.out_off, 0, false, 1, &vh);                                             // rgb_linear (:92)
+    }
+    G.n_ops = n;
+    G.w_floats = w_off;
+    for (int i = 0; i < n; ++i) G.ops[i] = H.hops[i].op;
+    if (!H.err && G.lds_floats * 4 > 160 * 1024) H.err = NSOS_ERR_UNSUPPORTED;
+}
+
+constexpr size_t kGenHeaderBytes = (sizeof(GenProgram) + 255) / 256 * 256;
+constexpr size_t kGenTailBytes = 8192;     // the prefetch ring reads up to four groups (4 KiB) past the last tile's stream
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" size_t nsos_mlp_generic_packed_bytes(const nsos_generic_mlp* mlp) {
+    if (!mlp) return 0;
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    if (H.err) return 0;
+    return kGenHeaderBytes + (size_t)H.prog.w_floats * 4 + kGenTailBytes;
+}
+
+extern "C" int32_t nsos_mlp_generic_out_channels(const nsos_generic_mlp* mlp) {
+    if (!mlp) return 0;
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    return H.err ? 0 : H.prog.n_out;
+}
+
+extern "C" int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream) {
+    NSOS_REQUIRE(mlp && packed, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(((uintptr_t)packed & 15) == 0, NSOS_ERR_MISALIGNED);
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    if (H.err) return H.err;
+    NSOS_REQUIRE(packed_bytes >= kGenHeaderBytes + (size_t)H.prog.w_floats * 4 + kGenTailBytes, NSOS_ERR_BUFFER_TOO_SMALL);
+    const hipStream_t st = (hipStream_t)stream;
+    // the program travels with the weights (pageable host memory: the copy is staged by the runtime before the call returns)
+    hipError_t e = hipMemcpyAsync(packed, &H.prog, sizeof(GenProgram), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int32_t)e;
+    float* wts = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + kGenHeaderBytes);
+    for (int i = 0; i < H.prog.n_ops; ++i) {
+        const HostOp& ho = H.hops[i];
+        if (ho.op.kind != kGenDense) continue;
+        GenPackOp Q = {};
+        Q.w = ho.w; Q.bias = ho.bias; Q.in_dim = ho.in_dim; Q.out_dim = ho.op.out_dim; Q.out_tiles = ho.op.out_tiles;
+        Q.n_groups = ho.op.n_groups; Q.n_seg = ho.n_seg;
+        for (int s = 0; s < ho.n_seg; ++s) { Q.seg_col0[s] = ho.seg[s].col0; Q.seg_rows[s] = ho.seg[s].rows; Q.seg_groups[s] = pad_to(ho.seg[s].rows, 8) / 8; }
+        Q.out = wts + ho.op.w_off;
+        const long long total = (long long)Q.out_tiles * Q.n_groups * 256;
+        hipLaunchKernelGGL(gen_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Q);
+    }
+    return nsos_launch_status();
+}
+
+static int32_t generic_launch(const nsos_generic_mlp* mlp, const void* packed, GenParams p, int64_t n_pts, hipStream_t st) {
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    if (H.err) return H.err;
+    NSOS_REQUIRE((n_pts + 31) / 32 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    p.prog = static_cast<const GenProgram*>(packed);
+    p.wts = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + kGenHeaderBytes);
+    p.n_pts = n_pts;
+    p.n_tiles = (int)((n_pts + 31) / 32);
+    const int lds_bytes = H.prog.lds_floats * 4;
+    // (per call: the attribute is a property of the kernel on this device, the size a property of the architecture rendered)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int32_t)e;
+    const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
+    const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
+    hipLaunchKernelGGL(mlp_generic_kernel, dim3(grid), dim3(256), lds_bytes, st, p);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_mlp_generic_forward_rays(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
+                                                 const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                 float* raw, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed && rays_o && rays_d && z_vals && raw, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!mlp->use_viewdirs || viewdirs, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    GenParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals; p.raw = raw; p.n_samples = n_samples;
+    return generic_launch(mlp, packed, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_generic_forward_points(const nsos_generic_mlp* mlp, const void* packed, const float* pts, const float* dirs,
+                                                   int64_t n_pts, float* raw, void* stream) {
+    if (n_pts == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed && pts && raw, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!mlp->use_viewdirs || dirs, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts > 0, NSOS_ERR_BAD_SHAPE);
+    GenParams p = {};
+    p.pts = pts; p.dirs = dirs; p.raw = raw; p.n_samples = 1;
+    return generic_launch(mlp, packed, p, n_pts, (hipStream_t)stream);
+}

@@ -23,9 +23,10 @@ import torch.nn as nn
 
 from . import ops
 
-_SUPPORTED = ("the HIP kernels are specialised for the architecture every shipped NeRF-SOS config uses: "
-              "netdepth=8, netwidth=256, skips=[4], viewdirs=True, use_embed=True, multires=10, multires_views=4, "
-              "conv_embed=False, sem_layer<=2, sem_dim=2, sem_with_geo=False")
+# The architecture every shipped NeRF-SOS config uses (netdepth=8, netwidth=256, skips=[4], viewdirs=True, use_embed=True,
+# multires=10, multires_views=4, sem_layer<=2, sem_dim=2, sem_with_geo=False) has hand-scheduled kernels in three precisions and
+# backward kernels; every other architecture the reference's constructors accept renders through the generic fp32 kernel
+# (MLP.fast below; csrc/mlp_generic.hip), forward only.  conv_embed=True is the one constructor argument refused outright.
 
 
 def _named_params(module: nn.Module):
@@ -45,31 +46,48 @@ def _named_params(module: nn.Module):
     return [(n, m._parameters[a]) for n, m, a in slots if m._parameters.get(a) is not None]
 
 
+def fc_block(in_f, out_f):
+    """models/nerf_mlp.py:18-22 (the deep semantic head's middle layers)."""
+    return nn.Sequential(nn.Linear(in_f, out_f), nn.ReLU())
+
+
 class MLP(nn.Module):
-    """Parameter container of the 8x256 NeRF MLP with the semantic head.  Layers are created in the
-    reference's order (models/nerf_mlp.py:40-64) so a given torch seed yields identical initial weights."""
+    """Parameter container of the NeRF MLP with the semantic head, for every architecture the reference's constructor builds.
+    Layers are created in the reference's order (models/nerf_mlp.py:40-64) so a given torch seed yields identical initial
+    weights, with the reference's module names (state_dict keys).  `fast` marks the architecture every shipped config uses
+    (8 x 256, skips [4], 63 / 27 encoded inputs, view directions, the two-Linear head with sem_dim 2): that one runs on the
+    hand-scheduled kernels (exact fp32, 16-bit, split-fp16; training); everything else renders through the generic fp32
+    kernel (csrc/mlp_generic.hip), forward only."""
 
     def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=(4,), use_viewdirs=True,
                  use_semantics=True, sem_layer=2, sem_dim=2, sem_with_coord=False, sem_with_geo=False):
         super().__init__()
-        if not (D == 8 and W == 256 and tuple(skips) == (4,) and use_viewdirs and input_ch == 63
-                and input_ch_views == 27 and output_ch == 4 and sem_layer <= 2 and sem_dim == 2 and not sem_with_geo):
-            raise NotImplementedError("nerf_sos_amd.MLP: " + _SUPPORTED)
+        if output_ch != 4:
+            raise NotImplementedError("nerf_sos_amd.MLP: output_ch must be 4 (rgb + sigma; NeRFNet never builds anything else, models/nerf_net.py:44-56)")
         self.D, self.W = D, W
         self.input_ch, self.input_ch_views = input_ch, input_ch_views
         self.skips = list(skips)
         self.use_viewdirs, self.use_semantics, self.sem_with_coord = use_viewdirs, use_semantics, sem_with_coord
+        self.fast = (D == 8 and W == 256 and tuple(skips) == (4,) and bool(use_viewdirs) and input_ch == 63 and input_ch_views == 27
+                     and (not use_semantics or (sem_layer <= 2 and sem_dim == 2 and not sem_with_geo)))
         self.pts_linears = nn.ModuleList(
             [nn.Linear(input_ch, W)] +
             [nn.Linear(W + input_ch, W) if i in self.skips else nn.Linear(W, W) for i in range(D - 1)])
-        self.alpha_linear = nn.Linear(W, 1)
-        self.feature_linear = nn.Linear(W, W)
-        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
-        self.rgb_linear = nn.Linear(W // 2, output_ch - 1)
+        if use_viewdirs:
+            self.alpha_linear = nn.Linear(W, 1)
+            self.feature_linear = nn.Linear(W, W)
+            self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+            self.rgb_linear = nn.Linear(W // 2, output_ch - 1)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)                                       # models/nerf_mlp.py:55
         if use_semantics:
             sem_in = W + input_ch if sem_with_coord else W
-            self.semantic_linear = nn.Sequential(nn.Linear(sem_in, W // 2), nn.ReLU(), nn.Linear(W // 2, sem_dim))
-            self.geo_map_sem = None
+            if sem_layer <= 2:
+                self.semantic_linear = nn.Sequential(nn.Linear(sem_in, W // 2), nn.ReLU(), nn.Linear(W // 2, sem_dim))
+            else:                                                                              # models/nerf_mlp.py:63
+                self.semantic_linear = nn.Sequential(nn.Linear(sem_in, W), nn.ReLU(), *[fc_block(W, W) for _ in range(sem_layer - 3)],
+                                                     nn.Linear(W, W // 2), nn.ReLU(), nn.Linear(W // 2, sem_dim))
+            self.geo_map_sem = nn.Sequential(nn.Linear(1, W // 2), nn.ReLU(), nn.Linear(W // 2, sem_dim)) if sem_with_geo else None
 
     @property
     def sem_mode(self) -> int:
@@ -87,13 +105,27 @@ class NeRFMLP(nn.Module):
                  use_embed=True, multires=10, multires_views=4, conv_embed=False, netchunk=1024 * 64,
                  use_semantics=False, sem_layer=2, sem_dim=2, sem_with_coord=False, sem_with_geo=False):
         super().__init__()
-        if not (input_dim == 3 and viewdirs and use_embed and multires == 10 and multires_views == 4
-                and not conv_embed):
-            raise NotImplementedError("nerf_sos_amd.NeRFMLP: " + _SUPPORTED)
-        self.chunk = netchunk  # kept for interface parity; the fused kernel needs no point chunking
-        self.mlp = MLP(net_depth, net_width, skips=skips, input_ch=3 + 6 * multires, output_ch=output_dim,
-                       input_ch_views=3 + 6 * multires_views, use_viewdirs=viewdirs, use_semantics=use_semantics,
+        if input_dim != 3:
+            raise NotImplementedError("nerf_sos_amd.NeRFMLP: input_dim must be 3 (NeRFNet never builds anything else, models/nerf_net.py:44-56)")
+        if conv_embed:
+            # a Conv1d over the SAMPLES of a ray between the encoding and the MLP (models/nerf_mlp.py:152-158,196-209): couples
+            # neighbouring points, no shipped config turns it on
+            raise NotImplementedError("nerf_sos_amd.NeRFMLP: conv_embed=True is not implemented")
+        if viewdirs and not use_embed:
+            # the reference builds this net and then fails in its first forward: `embeddirs` stays None, so the directions are never
+            # appended (models/nerf_mlp.py:142-150,203) while MLP.forward still splits 3 view channels off its input (:68)
+            raise ValueError("nerf_sos_amd.NeRFMLP: use_embed=False needs viewdirs=False (the reference's own forward fails otherwise)")
+        self.chunk = netchunk  # kept for interface parity; the fused kernels need no point chunking
+        self.use_viewdirs = bool(viewdirs)
+        self.multires = int(multires) if use_embed else None
+        self.multires_views = (int(multires_views) if use_embed else None) if viewdirs else None
+        input_ch = 3 + 6 * multires if use_embed else 3                                       # PositionEncoder.out_dim (models/embedder.py:21-32)
+        input_ch_views = (3 + 6 * multires_views if use_embed else 3) if viewdirs else 0
+        self.mlp = MLP(net_depth, net_width, skips=skips, input_ch=input_ch, output_ch=output_dim,
+                       input_ch_views=input_ch_views, use_viewdirs=viewdirs, use_semantics=use_semantics,
                        sem_layer=sem_layer, sem_dim=sem_dim, sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
+        self.fast = self.mlp.fast
+        self._gplan = None     # ops.GenericPlan of the current parameter storages (generic architectures)
         self._packed = {}      # precision -> packed stream
         self._packed_key = {}  # precision -> (data_ptr, version) of every parameter when it was packed
         self._plan = None      # ops.PackPlan of the current parameter storages
@@ -113,6 +145,16 @@ class NeRFMLP(nn.Module):
         frozen net call invalidate_packed()."""
         named = _named_params(self.mlp)
         params = [p for _, p in named]
+        if not self.fast:
+            if precision != "fp32":
+                raise NotImplementedError(f"nerf_sos_amd: mlp_precision {precision!r} exists for the shipped architecture only "
+                                          "(8 x 256, skips [4], multires 10 / 4, view directions, two-Linear head); this net renders in fp32")
+            key = tuple((p.data_ptr(), p._version) for p in params)
+            if self._gplan is None or self._packed_key.get("generic") != key:
+                self._gplan = ops.GenericPlan(self.mlp, self.multires, self.multires_views)
+                self._packed["generic"] = self._gplan.run(self._packed.get("generic"))
+                self._packed_key["generic"] = key
+            return self._packed["generic"]
         ptrs = tuple(p.data_ptr() for p in params)
         if self._plan is None or self._plan.ptrs != ptrs:
             self._plan = ops.PackPlan(dict(named), self.sem_mode)
@@ -125,7 +167,7 @@ class NeRFMLP(nn.Module):
 
     def __getstate__(self):  # copy.deepcopy / pickling: the plan holds raw device pointers, the streams are derived data
         state = self.__dict__.copy()
-        state["_plan"], state["_packed"], state["_packed_key"] = None, {}, {}
+        state["_plan"], state["_packed"], state["_packed_key"], state["_gplan"] = None, {}, {}, None
         return state
 
     def invalidate_packed(self) -> None:
@@ -133,16 +175,26 @@ class NeRFMLP(nn.Module):
         data_ptr nor _version).  Trainable nets never need it."""
         self._packed.clear()
         self._packed_key.clear()
-        self._plan = None
+        self._plan = self._gplan = None
+
+    def query_rays(self, rays_o, rays_d, viewdirs, z_vals):
+        """raw [R,S,C] of a generic-architecture net for the points o + d z (NeRFNet's ray path)."""
+        packed = self.packed_weights()
+        return ops.mlp_generic_forward_rays(self._gplan, packed, rays_o, rays_d, viewdirs if self.use_viewdirs else None, z_vals)
 
     def forward(self, inputs, viewdirs=None):
-        if viewdirs is None:
-            raise NotImplementedError("nerf_sos_amd.NeRFMLP: view directions are required (use_viewdirs=True)")
+        if self.use_viewdirs and viewdirs is None:
+            raise ValueError("nerf_sos_amd.NeRFMLP: this net was built with viewdirs=True: pass the view directions "
+                             "(the reference fails in embeddirs(None) here, models/nerf_mlp.py:203)")
         _no_autograd(self, "NeRFMLP.forward")
         lead = inputs.shape[:-1]
         pts = inputs.reshape(-1, inputs.shape[-1]).float()
-        dirs = viewdirs.expand(inputs.shape).reshape(-1, viewdirs.shape[-1]).float()
-        raw = ops.mlp_forward_points(self.packed_weights(), self.sem_mode, pts, dirs)
+        dirs = viewdirs.expand(inputs.shape).reshape(-1, viewdirs.shape[-1]).float() if self.use_viewdirs else None
+        if self.fast:
+            raw = ops.mlp_forward_points(self.packed_weights(), self.sem_mode, pts, dirs)
+        else:
+            packed = self.packed_weights()
+            raw = ops.mlp_generic_forward_points(self._gplan, packed, pts, dirs)
         return raw.reshape(list(lead) + [raw.shape[-1]])
 
 
@@ -350,8 +402,16 @@ class NeRFNet(nn.Module):
         anything else trainable -> _FullRender (every parameter, fp32)."""
         args = (rays_o, rays_d, near, far, viewdirs, raw_noise_std, retraw, retpts)
         trainable = _trainable(self)
+        generic = not (self.nerf.fast and self.nerf_fine.fast)
+        if generic and self.mlp_precision != "fp32":
+            raise NotImplementedError(f"nerf_sos_amd.NeRFNet: mlp_precision {self.mlp_precision!r} exists for the shipped architecture only; this one renders in fp32")
         if not trainable:
             return self._render_rays_impl(*args, save=False, **kwargs)[0]
+        if generic:
+            raise NotImplementedError(
+                "nerf_sos_amd.NeRFNet: backward kernels exist for the shipped architecture only (netdepth 8, netwidth 256, multires 10 / 4, "
+                "view directions, two-Linear semantic head); this architecture renders forward-only -- wrap the call in torch.no_grad() "
+                "or freeze every parameter.  There is no autograd fallback on purpose.")
         other = [n for n in trainable if "semantic_linear" not in n]
         if other:
             # any backbone parameter trainable (e.g. configs/flower_full.txt trains everything): full backward
@@ -380,6 +440,8 @@ class NeRFNet(nn.Module):
         saved = {}
 
         def query(net, z, tag):
+            if not net.fast:     # any other architecture: the generic fp32 kernel (forward only; render_rays refused training above)
+                return net.query_rays(rays_o, rays_d, viewdirs, z)
             if not save:
                 if self.mlp_precision != "fp32":
                     return ops.mlp_forward_rays_lp(net.packed_weights(self.mlp_precision), net.sem_mode,
@@ -412,13 +474,16 @@ class NeRFNet(nn.Module):
         raw = query(self.nerf, z_vals, "coarse")
         noise = (pre[1] if pre else torch.randn((R, n_samples), device=dev)) if raw_noise_std > 0. else None   # renderer.py:47
         sampled = None
-        if fine and 2 <= n_samples <= 64 and R > 0:
+        if fine and 2 <= n_samples <= 64 and R > 0 and raw.shape[-1] <= 6:
             # coarse compositing and hierarchical resampling in ONE launch (the draws keep the reference's order:
             # sigma noise of the coarse pass, then the importance u -- renderer.py:47, sampler.py:103)
             u = (pre[2] if pre else torch.rand((R, self.N_importance), device=dev)) if perturb != 0.0 else None
             ret, *sampled = ops.composite_importance(raw, z_vals, rays_d, self.N_importance, noise, raw_noise_std, self.white_bkgd, u)
         else:
             ret = ops.composite(raw, z_vals, rays_d, noise, raw_noise_std, self.white_bkgd)
+        if self.use_semantics and "semantics" not in ret:
+            # viewdirs=False: output_linear has no semantic channels; the reference's renderer still returns sum(w * raw[..., 4:]) = [R, 0]
+            ret["semantics"] = raw.new_zeros((R, 0))
         if save:
             saved["coarse"]["weights"] = ret['weights']
             saved["coarse"]["noise"] = noise
@@ -442,6 +507,8 @@ class NeRFNet(nn.Module):
             raw = query(self.nerf_fine, z_fine, "fine")
             noise = (pre[3] if pre else torch.randn((R, n_samples + N), device=dev)) if raw_noise_std > 0. else None
             ret = ops.composite(raw, z_fine, rays_d, noise, raw_noise_std, self.white_bkgd)
+            if self.use_semantics and "semantics" not in ret:
+                ret["semantics"] = raw.new_zeros((R, 0))
             if save:
                 saved["fine"]["weights"] = ret['weights']
                 saved["fine"]["noise"] = noise

@@ -187,6 +187,89 @@ class PackPlan:
         return out
 
 
+class GenericPlan:
+    """One NeRFMLP.mlp of ANY architecture the reference's constructors accept, described for the generic kernel
+    (nsos_generic_mlp, csrc/mlp_generic.hip): the Linear modules in the reference's forward order with their device pointers.
+    `mlp` is the nerf_net.MLP parameter container; `multires` / `multires_views` are octave counts or None (use_embed=False)."""
+
+    def __init__(self, mlp, multires, multires_views):
+        keep = []
+
+        def lin(dst, module):
+            w, b = _dev(module.weight.detach(), "weight"), _dev(module.bias.detach(), "bias")
+            keep.extend((w, b))
+            dst.weight, dst.bias = w.data_ptr(), b.data_ptr()
+            dst.out_dim, dst.in_dim = int(w.shape[0]), int(w.shape[1])
+
+        G = _lib.GenericMlp()
+        G.depth, G.width = int(mlp.D), int(mlp.W)
+        if G.depth > _lib.GENERIC_MAX_DEPTH:
+            raise NotImplementedError(f"nerf_sos_amd: netdepth {G.depth} > {_lib.GENERIC_MAX_DEPTH}")
+        G.skip_mask = sum(1 << int(i) for i in mlp.skips if 0 <= int(i) < G.depth)
+        G.xyz_freqs = -1 if multires is None else int(multires)
+        G.dir_freqs = -1 if multires_views is None else int(multires_views)
+        G.use_viewdirs, G.use_semantics = int(bool(mlp.use_viewdirs)), int(bool(mlp.use_semantics))
+        G.sem_with_coord = int(bool(mlp.sem_with_coord))
+        for i, m in enumerate(mlp.pts_linears):
+            lin(G.pts[i], m)
+        if mlp.use_viewdirs:
+            lin(G.alpha, mlp.alpha_linear), lin(G.feature, mlp.feature_linear), lin(G.views, mlp.views_linears[0]), lin(G.rgb, mlp.rgb_linear)
+        else:
+            lin(G.output, mlp.output_linear)
+        G.sem_layers = G.sem_dim = G.sem_with_geo = 0
+        if mlp.use_semantics:
+            linears = [m for m in mlp.semantic_linear.modules() if isinstance(m, torch.nn.Linear)]   # Sequential order = forward order
+            if len(linears) > _lib.GENERIC_MAX_SEM:
+                raise NotImplementedError(f"nerf_sos_amd: a semantic head of {len(linears)} Linear layers (> {_lib.GENERIC_MAX_SEM})")
+            for k, m in enumerate(linears):
+                lin(G.sem[k], m)
+            G.sem_layers, G.sem_dim = len(linears), int(linears[-1].weight.shape[0])
+            if getattr(mlp, "geo_map_sem", None) is not None:
+                G.sem_with_geo = 1
+                lin(G.geo[0], mlp.geo_map_sem[0]), lin(G.geo[1], mlp.geo_map_sem[2])
+        self.desc, self.keep, self.device = G, keep, keep[0].device
+        self.ptrs = tuple(t.data_ptr() for t in keep)
+        self.nbytes = int(_lib.lib().nsos_mlp_generic_packed_bytes(C.byref(G)))
+        self.out_channels = int(_lib.lib().nsos_mlp_generic_out_channels(C.byref(G)))
+        if self.nbytes == 0 or self.out_channels == 0:
+            raise NotImplementedError(
+                "nerf_sos_amd: this architecture is outside the generic kernel's limits (include/nerf_sos_hip.h: depth <= 16, "
+                "activation buffers of ceil(W/32)*32 rows within 160 KiB of LDS -- W <= 256 with the deep semantic head --, "
+                "4 + sem_dim (x2 with sem_with_geo) <= 32 output rows, a skip on the last layer is the reference's own shape error)")
+
+    def run(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None or out.numel() * 4 < self.nbytes or out.device != self.device:
+            out = torch.empty((self.nbytes + 3) // 4, device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nsos_mlp_generic_pack(C.byref(self.desc), _p(out), self.nbytes, _stream()), "nsos_mlp_generic_pack")
+        return out
+
+
+def mlp_generic_forward_rays(plan: GenericPlan, packed: torch.Tensor, rays_o: torch.Tensor, rays_d: torch.Tensor,
+                             viewdirs: Optional[torch.Tensor], z_vals: torch.Tensor) -> torch.Tensor:
+    """raw [R,S,C] for the points o + d*z of each ray through the generic-architecture kernel (models/nerf_mlp.py:67-100,179-215)."""
+    rays_o, rays_d, z_vals = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d"), _dev(z_vals, "z_vals")
+    if viewdirs is not None:
+        viewdirs = _dev(viewdirs, "viewdirs")
+    R, S = z_vals.shape
+    raw = torch.empty((R, S, plan.out_channels), device=z_vals.device, dtype=torch.float32)
+    ev = _ev_begin()
+    _lib.check(_lib.lib().nsos_mlp_generic_forward_rays(C.byref(plan.desc), _p(packed), _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
+                                                        R, S, _p(raw), _stream()), "nsos_mlp_generic_forward_rays")
+    _ev_end(ev, R * S)
+    return raw
+
+
+def mlp_generic_forward_points(plan: GenericPlan, packed: torch.Tensor, pts: torch.Tensor, dirs: Optional[torch.Tensor]) -> torch.Tensor:
+    """raw [P,C] for explicit points (and per-point view directions, if the net takes them)."""
+    pts = _dev(pts, "pts")
+    if dirs is not None:
+        dirs = _dev(dirs, "dirs")
+    raw = torch.empty((pts.shape[0], plan.out_channels), device=pts.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_generic_forward_points(C.byref(plan.desc), _p(packed), _p(pts), _p(dirs), pts.shape[0], _p(raw), _stream()),
+               "nsos_mlp_generic_forward_points")
+    return raw
+
+
 def pack_mlp(params: Dict[str, torch.Tensor], sem_mode: int, out: Optional[torch.Tensor] = None,
              precision: str = "fp32") -> torch.Tensor:
     """Gather one net's state-dict tensors (keys relative to `<net>.mlp.`) into the MFMA-order stream
@@ -421,6 +504,16 @@ def composite(raw: torch.Tensor, z_vals: torch.Tensor, rays_d: torch.Tensor, noi
     """VolumetricRenderer.forward (models/renderer.py:35-85); returns the reference's dict."""
     raw, z_vals, rays_d = _dev(raw, "raw"), _dev(z_vals, "z_vals"), _dev(rays_d, "rays_d")
     R, S, Cn = raw.shape
+    if Cn > 6:
+        # sem_dim > 2 (generic architectures only): the kernel composites two semantic channels per launch -- the same weights
+        # every time, the extra maps two channels at a time (device-side copies of the channel slices; no shipped config comes here)
+        ret = composite(raw[..., :6].contiguous(), z_vals, rays_d, noise, noise_std, white_bkgd)
+        sems = [ret["semantics"]]
+        for c in range(6, Cn, 2):
+            sub = torch.cat([raw[..., :4], raw[..., c:min(c + 2, Cn)]], -1)
+            sems.append(composite(sub, z_vals, rays_d, noise, noise_std, white_bkgd)["semantics"])
+        ret["semantics"] = torch.cat(sems, -1)
+        return ret
     if noise is not None:
         noise = _dev(noise, "noise")
         if tuple(noise.shape) != (R, S):

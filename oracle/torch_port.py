@@ -49,17 +49,24 @@ class PortConfig:
     use_semantics: bool = False
     sem_dim: int = 2
     sem_with_coord: bool = False
+    # the constructor arguments no shipped config changes (round 4: the generic-architecture kernel)
+    use_viewdirs: bool = True     # models/nerf_net.py:23 `viewdirs`
+    use_embed: bool = True
+    sem_layer: int = 2
+    sem_with_geo: bool = False
     white_bkgd: bool = False
     ray_chunk: int = 1024 * 32
     pts_chunk: int = 1024 * 64
 
     @property
     def xyz_dim(self) -> int:
-        return 3 + 6 * self.multires
+        return 3 + 6 * self.multires if self.use_embed else 3
 
     @property
     def dir_dim(self) -> int:
-        return 3 + 6 * self.multires_views
+        if not self.use_viewdirs:
+            return 0
+        return 3 + 6 * self.multires_views if self.use_embed else 3
 
 
 # --------------------------------------------------------------------------- weights
@@ -70,15 +77,34 @@ def _linear_shapes(cfg: PortConfig):
     for i in range(cfg.net_depth):
         fan_in = X if i == 0 else (W + X if i == cfg.skip + 1 else W)
         out.append((f"pts_linears.{i}", W, fan_in))
-    out.append(("alpha_linear", 1, W))
-    out.append(("feature_linear", W, W))
-    out.append(("views_linears.0", W // 2, V + W))
-    out.append(("rgb_linear", 3, W // 2))
+    if cfg.use_viewdirs:
+        out.append(("alpha_linear", 1, W))
+        out.append(("feature_linear", W, W))
+        out.append(("views_linears.0", W // 2, V + W))
+        out.append(("rgb_linear", 3, W // 2))
+    else:
+        out.append(("output_linear", 4, W))
     if cfg.use_semantics:
         sem_in = W + X if cfg.sem_with_coord else W
-        out.append(("semantic_linear.0", W // 2, sem_in))
-        out.append(("semantic_linear.2", cfg.sem_dim, W // 2))
+        if cfg.sem_layer <= 2:
+            out.append(("semantic_linear.0", W // 2, sem_in))
+            out.append(("semantic_linear.2", cfg.sem_dim, W // 2))
+        else:     # Sequential(Linear, ReLU, *fc_block(W, W) x (sem_layer - 3), Linear(W, W/2), ReLU, Linear(W/2, sem_dim)): nerf_mlp.py:63
+            out.append(("semantic_linear.0", W, sem_in))
+            n = cfg.sem_layer - 3
+            for k in range(n):
+                out.append((f"semantic_linear.{2 + k}.0", W, W))
+            out.append((f"semantic_linear.{2 + n}", W // 2, W))
+            out.append((f"semantic_linear.{4 + n}", cfg.sem_dim, W // 2))
+        if cfg.sem_with_geo:
+            out.append(("geo_map_sem.0", W // 2, 1))
+            out.append(("geo_map_sem.2", cfg.sem_dim, W // 2))
     return out
+
+
+def _sem_chain(cfg: PortConfig):
+    """Names of the semantic head's Linear modules in forward order."""
+    return [n for n, _, _ in _linear_shapes(cfg) if n.startswith("semantic_linear.")]
 
 
 def init_state_dict(cfg: PortConfig, seed: Optional[int] = 0) -> "OrderedDict[str, Tensor]":
@@ -161,14 +187,23 @@ def mlp_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, cfg: PortConfig,
             tap(f"h{i}", h)
         if i == cfg.skip:
             h = torch.cat([input_pts, h], -1)
+    if not cfg.use_viewdirs:
+        return lin("output_linear", h)                               # :97-98
     alpha = lin("alpha_linear", h)
     sem = None
     if cfg.use_semantics:
-        sem_in = torch.cat([h, input_pts], dim=-1) if cfg.sem_with_coord else h
-        s = F.relu(lin("semantic_linear.0", sem_in))
-        if tap:
-            tap("sem_hidden", s)
-        sem = lin("semantic_linear.2", s)
+        s = torch.cat([h, input_pts], dim=-1) if cfg.sem_with_coord else h
+        chain = _sem_chain(cfg)
+        for k, name in enumerate(chain):
+            s = lin(name, s)
+            if k < len(chain) - 1:
+                s = F.relu(s)
+                if tap and k == 0:
+                    tap("sem_hidden", s)
+        sem = s
+        if cfg.sem_with_geo:                                         # :81-83
+            mapping = lin("geo_map_sem.2", F.relu(lin("geo_map_sem.0", alpha)))
+            sem = sem * mapping
     feature = lin("feature_linear", h)
     if tap:
         tap("feature", feature)
@@ -179,14 +214,17 @@ def mlp_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, cfg: PortConfig,
     return torch.cat([rgb, alpha] + ([sem] if sem is not None else []), -1)
 
 
-def point_query(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Tensor, cfg: PortConfig) -> Tensor:
-    """models/nerf_mlp.py:179-215: flatten, chunk, encode both inputs, run the MLP."""
+def point_query(sd: Dict[str, Tensor], prefix: str, pts: Tensor, viewdirs: Optional[Tensor], cfg: PortConfig) -> Tensor:
+    """models/nerf_mlp.py:179-215: flatten, chunk, encode both inputs (unless use_embed is off), run the MLP."""
     flat = pts.reshape(-1, pts.shape[-1])
-    dirs = viewdirs.reshape(-1, viewdirs.shape[-1])
+    dirs = viewdirs.reshape(-1, viewdirs.shape[-1]) if cfg.use_viewdirs else None
+    enc_x = (lambda t: posenc(t, cfg.multires)) if cfg.use_embed else (lambda t: t)
+    enc_v = (lambda t: posenc(t, cfg.multires_views)) if cfg.use_embed else (lambda t: t)
     outs = []
     for i in range(0, flat.shape[0], cfg.pts_chunk):
-        e = torch.cat([posenc(flat[i:i + cfg.pts_chunk], cfg.multires),
-                       posenc(dirs[i:i + cfg.pts_chunk], cfg.multires_views)], -1)
+        e = enc_x(flat[i:i + cfg.pts_chunk])
+        if dirs is not None:
+            e = torch.cat([e, enc_v(dirs[i:i + cfg.pts_chunk])], -1)
         outs.append(mlp_forward(sd, prefix, e, cfg))
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
@@ -331,7 +369,7 @@ def render_rays(sd, cfg: PortConfig, rays_o, rays_d, near, far, viewdirs, raw_no
     draws = draws or Draws()
     z = stratified_z(near, far, cfg.n_samples, draws.t_rand)
     pts = ray_points(rays_o, rays_d, z)
-    raw = point_query(sd, "nerf", pts, viewdirs[..., None, :].expand(pts.shape), cfg)
+    raw = point_query(sd, "nerf", pts, viewdirs[..., None, :].expand(pts.shape) if cfg.use_viewdirs else None, cfg)
     n0 = draws.noise0 * raw_noise_std if (raw_noise_std > 0 and draws.noise0 is not None) else None
     ret = composite(raw, z, rays_d, n0, cfg)
     if retraw:
@@ -342,7 +380,7 @@ def render_rays(sd, cfg: PortConfig, rays_o, rays_d, near, far, viewdirs, raw_no
         ret0 = ret
         z_fine, z_samples = importance_z(z, ret0["weights"], cfg.n_importance, draws.u)
         pts = ray_points(rays_o, rays_d, z_fine)
-        raw = point_query(sd, "nerf_fine", pts, viewdirs[..., None, :].expand(pts.shape), cfg)
+        raw = point_query(sd, "nerf_fine", pts, viewdirs[..., None, :].expand(pts.shape) if cfg.use_viewdirs else None, cfg)
         n1 = draws.noise1 * raw_noise_std if (raw_noise_std > 0 and draws.noise1 is not None) else None
         ret = composite(raw, z_fine, rays_d, n1, cfg)
         if retraw:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: per-phase cycle attribution of the reduced-precision MLP kernel (nsos_mlp_profile_rays_lp stamps).
-usage: phase_profile_lp.py [sem_mode 0|1|2] [fp16|bf16] [waves_per_simd 2|1]"""
+usage: phase_profile_lp.py [sem_mode 0|1|2] [fp16|bf16] [kernel 3|2|1] [--save]     (3 = mlp_lp16_kernel, the default; 2 = mlp_lp8_kernel; 1 = mlp_lp_kernel)"""
 import ctypes as C
 import os
 import sys
@@ -13,8 +13,8 @@ from nerf_sos_amd import synthetic as syn
 
 sem = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp16"
-wps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 2      # 2: mlp_lp8_kernel (8 waves x 32 points), 1: mlp_lp_kernel (4 x 64)
-NW, COLS = (8, 1) if wps == 2 else (4, 2)
+wps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 3      # 3: mlp_lp16_kernel, 2: mlp_lp8_kernel (both 8 waves x 32 points), 1: mlp_lp_kernel (4 x 64)
+NW, COLS = (8, 1) if wps >= 2 else (4, 2)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=sem > 0, sem_with_coord=sem == 2).to(dev).eval()
@@ -52,18 +52,33 @@ torch.cuda.synchronize()
 launch_ms = ev[0].elapsed_time(ev[1]) / 10 if not SAVE else float('nan')
 st = stamps.cpu().view(16, 64).numpy()
 M = 32  # cycles of one 32x32x16 MFMA
-names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * COLS * M}
-for l in range(1, 9):
-    names += [f"L{l} mfma", f"L{l} act"]
-    ideal[f"L{l} mfma"] = (136 + (32 if l == 5 else 0)) * COLS * M
-    if l == 7:
-        names.append("sigma+sem heads")
-        ideal["sigma+sem heads"] = {0: 0, 1: 68, 2: 84}[sem] * COLS * M
-names += ["view mfma", "dir enc", "dir mfma", "rgb head + store"]
-ideal["view mfma"] = 68 * COLS * M
-ideal["dir mfma"] = 8 * COLS * M
-print(f"# {'mlp_lp8_kernel: 8 waves x 32 points (two per SIMD: waves w and w+4 share one matrix pipe)' if wps == 2 else 'mlp_lp_kernel: 4 waves x 64 points'}"
-      f", sem_mode {sem}, {prec}; cycles per phase of one 256-point tile, per wave; ideal = this wave's MFMAs x 32")
+if wps == 3:
+    # mlp_lp16_kernel: 16-cycle MFMAs (16x16x32), two per A operand; no bias MFMAs; heads on the matrix pipe
+    M = 16
+    names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 64 * M}
+    for l in range(1, 9):
+        names += [f"L{l} mfma", f"L{l} act"]
+        ideal[f"L{l} mfma"] = (320 if l == 5 else 256) * M
+        if l == 7:
+            names.append("sigma+sem heads")
+            ideal["sigma+sem heads"] = {0: 16, 1: 128 + 16 + 16 + 8, 2: 160 + 16 + 8}[sem] * M
+    names += ["dir enc", "view mfma", "rgb mfma", "stores"]
+    ideal["view mfma"] = 144 * M
+    ideal["rgb mfma"] = 8 * M
+    title = "mlp_lp16_kernel: 8 waves x 32 points (two per SIMD) on v_mfma_f32_16x16x32"
+else:
+    names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * COLS * M}
+    for l in range(1, 9):
+        names += [f"L{l} mfma", f"L{l} act"]
+        ideal[f"L{l} mfma"] = (136 + (32 if l == 5 else 0)) * COLS * M
+        if l == 7:
+            names.append("sigma+sem heads")
+            ideal["sigma+sem heads"] = {0: 0, 1: 68, 2: 84}[sem] * COLS * M
+    names += ["view mfma", "dir enc", "dir mfma", "rgb head + store"]
+    ideal["view mfma"] = 68 * COLS * M
+    ideal["dir mfma"] = 8 * COLS * M
+    title = 'mlp_lp8_kernel: 8 waves x 32 points (two per SIMD: waves w and w+4 share one matrix pipe)' if wps == 2 else 'mlp_lp_kernel: 4 waves x 64 points'
+print(f"# {title}, sem_mode {sem}, {prec}{', training (SAVE) variant' if SAVE else ''}; cycles per phase of one 256-point tile, per wave; ideal = this wave's MFMA cycles")
 print(f"{'phase':18s}" + "".join(f" w{w:<8d}" for w in range(NW)) + "   ideal_mfma")
 tot = [0] * NW
 for k in range(1, len(names)):
@@ -72,9 +87,9 @@ for k in range(1, len(names)):
         tot[w] += d[w]
     print(f"{names[k]:18s}" + "".join(f" {x:<9d}" for x in d) + f"   {ideal.get(names[k], 0)}")
 print(f"{'total':18s}" + "".join(f" {x:<9d}" for x in tot) + f"   {sum(ideal.values())}")
-print(f"matrix-pipe time of the tile per SIMD (both waves' MFMAs): {sum(ideal.values()) * (2 if wps == 2 else 1)}; "
-      f"wall per tile (wave 0): {tot[0]}  -> pipe busy {sum(ideal.values()) * (2 if wps == 2 else 1) / tot[0]:.3f}")
-if wps == 2:
+print(f"matrix-pipe time of the tile per SIMD (both waves' MFMAs): {sum(ideal.values()) * (2 if wps >= 2 else 1)}; "
+      f"wall per tile (wave 0): {tot[0]}  -> pipe busy {sum(ideal.values()) * (2 if wps >= 2 else 1) / tot[0]:.3f}")
+if wps >= 2:
     whole = int(st[0, 63] - st[0, 62])
     print(f"whole kernel, block 0 wave 0: {whole} shader cycles for {R * 192 // 256 // 256} tiles = {whole / (R * 192 / 256 / 256):.0f} per tile; launch {launch_ms:.4f} ms "
           f"-> effective shader clock {whole / launch_ms / 1e6:.3f} GHz")

@@ -686,8 +686,11 @@ def test_lp_training_variant(golden, manifest, precision, tol, lp_kernel):
     assert torch.equal(raw16, raw16_inf)
     rows16 = ops.sem_in_rows(sem_in16, R * 64).float()
     assert sem_in16.dtype == dt and (rows16[:, 319] == 1).all() and (rows16[:, :256] >= 0).all()
-    assert torch.equal(rows16[:, 256:], sem_in[:, 256:]), "the encoding columns are the same 16-bit values in every kernel"
     fmt = 2.0 ** -10 if precision == "fp16" else 2.0 ** -7
+    # the encoding columns: the same features rounded to the same format; the lp16 encoder forms cos as sin(2 pi (frac + 1/4)),
+    # which can land on the neighbouring 16-bit value
+    enc_diff = (rows16[:, 256:] - sem_in[:, 256:]).abs()
+    assert float(enc_diff.max()) <= fmt * (1 + float(sem_in[:, 256:].abs().max())) and float((enc_diff > 0).float().mean()) < 0.02
     assert (rows16[:, :256] - sem_in[:, :256]).abs().max() <= 8 * fmt * (1 + sem_in[:, :256].abs().max())
     hid16 = torch.relu(rows16[:, :W1.shape[1]].double() @ W1.T + b1).float()
     assert (hid16.to(dt).float() - sem_hid16.float()).abs().max() <= 2 * fmt * (1 + hid16.abs().max())
