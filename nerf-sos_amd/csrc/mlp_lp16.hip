@@ -26,13 +26,17 @@
 //
 // What else changed against mlp_lp8_kernel:
 //   * NO bias MFMAs.  There a bias was an A operand multiplied by a B of ones: 2 of a chunk's 34 MFMAs (5.9 % of the matrix
-//     pipe's time; with 16-row tiles it would be 11 %).  Here a tile's bias is a 1 KiB group of the stream holding, per lane,
-//     the four fp32 values bias[16 t + 4 q + r] -- read through the ring like an A operand and used as the C operand of the
-//     tile's first two MFMAs.  Its ring slot is re-loaded one group late (after those MFMAs): Sched below counts the waits
-//     for that schedule.  Layers with an encoding input (0, 5, sem+coord head, view branch) carry the bias in the encoding's
-//     pad column (input 1.0) instead.
-//   * Hidden layers are tile-QUAD-major (chunk c = output tiles 4c..4c+3 over all 8 slices: 4 bias groups + 32 A operands =
-//     one full 36 KiB slot, 64 MFMAs), with the previous quad's activation riding behind the MFMAs exactly as the tile
+//     pipe's time; with 16-row tiles it would be 11 %).  Here a hidden layer's chunk carries its four tiles' biases as a 256-byte
+//     block behind its 32 A operands (lane (n, q) of tile t: the four fp32 values bias[16 t + 4 q + r]); the PREVIOUS chunk
+//     reads them straight into the accumulators' block-0 registers (read_bias / quad_layer) once the riding activation is done
+//     with those registers, and the tile's first two MFMAs take them as their C operand.  (First version: the bias as a ring
+//     group of its own in front of each tile's first A operand -- the four MFMA-less groups at the head of every chunk halved
+//     the ring's look-ahead there: 10.26 k cycles per layer against 9.79 k now, profiles/r04.)  The raw tile's bias (heads)
+//     still travels through the ring as a group whose slot is the next group's C operand (Sched's BIAS mask: its slot is
+//     re-loaded one group late).  Layers with an encoding input (0, 5, sem+coord head, view branch) carry the bias in the
+//     encoding's pad column (input 1.0) instead.
+//   * Hidden layers are tile-QUAD-major (chunk c = output tiles 4c..4c+3 over all 8 slices: 32 A operands + the bias block,
+//     64 MFMAs), with the previous quad's activation riding behind the MFMAs exactly as the tile
 //     pairs did (same register counts: a quad buffer is 32 registers, a quad's activation 16 packed words).
 //   * The sigma, rgb and semantic-logit heads are MFMAs into ONE 16-row "raw" tile R[c] (rows 0..2 rgb, 3 sigma, 4..5
 //     semantics): 8 + 4 + 4 A operands, 32 MFMAs per wave and tile instead of ~5 k cycles of v_dot2c / fp32 FMA chains on
@@ -52,6 +56,12 @@ namespace {
 
 constexpr int kRing16 = 4, kMid16 = 2, kDma16 = 5;
 
+// NFILL (pipeline16x): how many 1 KiB pieces the chunk TWO AHEAD holds -- the DMA issued during a chunk fetches that one, and
+// copies only those pieces (the slot stride stays 36 KiB).  Copying every slot whole was 40 pieces per chunk (8 waves x 5, four
+// of them redundant) = 1.6 MB per 256-point tile from L2 against the 1.28 MB the kernel reads; the weight stream is the
+// largest single cost around the MFMAs (profiles/r04: a build without it runs 12 % fewer cycles per tile).  Static per call
+// site (the chunk order of a tile is fixed); where a call site serves several positions, the largest count among them.
+
 // ---- the chunk's LDS read schedule --------------------------------------------------------------------------------
 // Groups 0..NG-1 (NG a multiple of 4: the ring slot of group g is g % 4 at every call site); bit g of BIAS marks a bias
 // group: no MFMA of its own, its ring slot is the C operand of the NEXT group's MFMAs.  Reads are issued in target order:
@@ -59,12 +69,13 @@ constexpr int kRing16 = 4, kMid16 = 2, kDma16 = 5;
 // nothing -- its slot is still needed).  Targets NWORK..NG-1 (padding) are never read; targets >= NG are the next chunk's
 // first groups (always read: resident, proven by this chunk's barrier).  LDS returns in order, so "lgkmcnt(n)" with n =
 // the number of reads issued after R(g) means group g (and the bias group in front of it) has landed.
-template <int NG, int NWORK, unsigned long long BIAS>
+template <int NG, int NWORK, unsigned long long BIAS, unsigned long long EXTRA = 0ull>
 struct Sched {
     static_assert(NG % 4 == 0 && NG >= kRing16 + kMid16 + 2 && NG <= 36, "chunk length");
     static_assert(NWORK >= kRing16 && NWORK <= NG, "the first four groups were read by the previous chunk");
     static_assert((BIAS >> (NWORK - 1)) == 0 && (BIAS & (BIAS >> 1)) == 0, "a bias group is followed by a work group");
     static constexpr bool is_bias(int g) { return g >= 0 && g < NG && ((BIAS >> g) & 1ull); }
+    static constexpr bool has_extra(int g) { return g >= 0 && g < NG && ((EXTRA >> g) & 1ull); }   // one more LDS read issued after group g's ring reads
     static constexpr bool issued(int x) { return x < NWORK || x >= NG; }
     static constexpr int top_before(int g) {            // highest target whose read was issued before the work of group g
         int top = kRing16 - 1;
@@ -72,17 +83,27 @@ struct Sched {
             if (!is_bias(h)) top = h + kRing16;
         return top;
     }
+    static constexpr int issuer_of(int x) {             // the group after whose work target x is read (-1: the previous chunk)
+        for (int h = 0; h < NG; ++h)
+            if (!is_bias(h) && top_before(h) < x && x <= h + kRing16) return h;
+        return -1;
+    }
     static constexpr int younger(int g) {
         int n = 0;
         for (int x = g + 1; x <= top_before(g); ++x) n += issued(x) ? 1 : 0;
+        // extra reads issued after R(g) and before the work of group g: after the work of groups issuer_of(g) .. g - 1 (an extra
+        // follows its group's ring reads, so the issuer's own extra is younger than R(g) too)
+        const int from = issuer_of(g);
+        for (int h = from < 0 ? 0 : from; h < g; ++h) n += has_extra(h) ? 1 : 0;
         return n;
     }
 };
 
-// work(g, cur, prev): ring slots of group g and of group g-1 (the bias operand when g-1 is a bias group)
-template <int NG, int NWORK, unsigned long long BIAS, class M, class B, class TL, class S>
-__device__ __forceinline__ void pipeline16(f32x4 (&ring)[kRing16], const ChunkCtx ctx, M&& work, B&& mid, TL&& tail, S&& side) {
-    using SC = Sched<NG, NWORK, BIAS>;
+// work(g, cur, prev): ring slots of group g and of group g-1 (the bias operand when g-1 is a bias group); extra(g): the EXTRA reads
+template <int NG, int NWORK, unsigned long long BIAS, unsigned long long EXTRA, class M, class B, class TL, class S, class X>
+__device__ __forceinline__ void pipeline16x(f32x4 (&ring)[kRing16], const ChunkCtx ctx, M&& work, B&& mid, TL&& tail, S&& side, X&& extra,
+                                            const int nfill) {
+    using SC = Sched<NG, NWORK, BIAS, EXTRA>;
     static_for<0, NG>([&](auto ic) {
         constexpr int g = decltype(ic)::value;
         if constexpr (g == kMid16) {
@@ -104,13 +125,49 @@ __device__ __forceinline__ void pipeline16(f32x4 (&ring)[kRing16], const ChunkCt
                 }
             });
         }
-        dma_slot<g - kMid16, kDma16>(side);
+        if constexpr (SC::has_extra(g)) {
+            NSOS_PIN();
+            extra(ic);
+            NSOS_PIN();
+        }
+#if defined(NSOS_LP16_NODMA)        // (A/B builds only, scripts/diag/build_variant.sh: timing without the weight stream; wrong results)
+#elif defined(NSOS_LP16_DMA_STAGGER)   // (A/B: the two waves of a SIMD issue their pieces ten groups apart)
+        side(std::integral_constant<int, g - kMid16>{}, std::integral_constant<int, g - kMid16 - 10>{});
+#else
+#ifdef NSOS_LP16_DMA_BURST            // (A/B: all five pieces back to back behind the barrier)
+        if constexpr (g == kMid16) {
+            NSOS_PIN();
+            for (int i = 0; i < kDma16; ++i) side(i, nfill);
+            NSOS_PIN();
+        }
+#elif defined(NSOS_LP16_DMA_LATE)     // (A/B: the pieces in the MFMA-dense middle of the chunk, two groups apart)
+        if constexpr (g >= 8 && g < 8 + 2 * kDma16 && (g & 1) == 0) {
+            NSOS_PIN();
+            side((g - 8) >> 1, nfill);
+            NSOS_PIN();
+        }
+#else
+        if constexpr (g >= kMid16 && g < kMid16 + kDma16) {
+            NSOS_PIN();
+#ifdef NSOS_LP16_FULL_DMA   // (A/B builds only: every slot copied whole)
+            side(g - kMid16, 36);
+#else
+            side(g - kMid16, nfill);
+#endif
+            NSOS_PIN();
+        }
+#endif
+#endif
         if constexpr (g == NG - 3) {
             NSOS_PIN();
             tail();
             NSOS_PIN();
         }
     });
+}
+template <int NG, int NWORK, unsigned long long BIAS, class M, class B, class TL, class S>
+__device__ __forceinline__ void pipeline16(f32x4 (&ring)[kRing16], const ChunkCtx ctx, M&& work, B&& mid, TL&& tail, S&& side, const int nfill) {
+    pipeline16x<NG, NWORK, BIAS, 0ull>(ring, ctx, work, mid, tail, side, [](auto) {}, nfill);
 }
 
 #define NSOS_RELU_WORD16(W, FLOOR) do { unsigned w_ = (W); asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(w_) : "s"(FLOOR)); (W) = w_; } while (0)
@@ -209,12 +266,41 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(dst_slot + poff(i));
         dma_1k(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo), dst, voff);
     };
-    unsigned fill_lo = 0, fill_hi = 0, fill_dst = 0, fill_w = 0, fill_wlast = 0;
-    auto side = [&](int i) {
-        const unsigned off = i < 4 ? fill_w + 8192u * (unsigned)i : fill_wlast;
-        const unsigned long long sp = (((unsigned long long)fill_hi << 32) | fill_lo) + off;
-        dma_1k(reinterpret_cast<const void*>(sp), fill_dst + off, voff);
+#ifdef NSOS_LP16_DMA_STAGGER
+    unsigned fill_wlast = 0;
+#endif
+    unsigned fill_lo = 0, fill_hi = 0, fill_dst = 0, fill_w = 0;
+#ifdef NSOS_LP16_DMA_STAGGER
+    auto side = [&](auto early_c, auto late_c) {
+        constexpr int EARLY = decltype(early_c)::value, LATE = decltype(late_c)::value;
+        auto piece = [&](int i) {
+            const unsigned off = i < 4 ? fill_w + 8192u * (unsigned)i : fill_wlast;
+            const unsigned long long sp = (((unsigned long long)fill_hi << 32) | fill_lo) + off;
+            dma_1k(reinterpret_cast<const void*>(sp), fill_dst + off, voff);
+        };
+        if constexpr (EARLY >= 0 && EARLY < kDma16) { if (wave_s < 4) { NSOS_PIN(); piece(EARLY); NSOS_PIN(); } }
+        if constexpr (LATE >= 0 && LATE < kDma16) { if (wave_s >= 4) { NSOS_PIN(); piece(LATE); NSOS_PIN(); } }
     };
+#else
+    auto side = [&](int i, int nfill) {
+        // this wave's i-th piece of the chunk being fetched: piece wave + 8 i -- if the chunk holds it.  The test is wave-uniform, but
+        // a BRANCH around the copy cuts the chunk's straight-line code into basic blocks and the register allocator then spills
+        // across them (8-38 scratch instructions per tile): where the test does not fold at compile time the piece is issued with
+        // EXEC cleared instead -- a no-op that costs an issue slot -- inside one asm statement.
+        const unsigned off = fill_w + 8192u * (unsigned)i;
+        const unsigned long long sp = (((unsigned long long)fill_hi << 32) | fill_lo) + off;
+        if (__builtin_constant_p(nfill) && 8 * i + 7 < nfill) {
+            dma_1k(reinterpret_cast<const void*>(sp), fill_dst + off, voff);
+        } else {
+            unsigned keep;
+            unsigned long long saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_mov_b64 %1, exec\n\ts_cmp_lt_i32 %5, %6\n\ts_cselect_b64 exec, %1, 0\n\ts_nop 2\n\t"
+                         "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep), "=&s"(saved) : "s"(fill_dst + off), "v"(voff), "s"(reinterpret_cast<const void*>(sp)), "s"(wave_s + 8 * i), "s"(nfill)
+                         : "memory", "scc");
+        }
+    };
+#endif
     auto mid = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -223,7 +309,9 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         fill_hi = __builtin_amdgcn_readfirstlane((unsigned)(sp >> 32));
         fill_dst = __builtin_amdgcn_readfirstlane(d2);
         fill_w = __builtin_amdgcn_readfirstlane(woff);
+#ifdef NSOS_LP16_DMA_STAGGER
         fill_wlast = __builtin_amdgcn_readfirstlane(wlast);
+#endif
     };
     auto tail = [&]() {
         const unsigned tc = c0, td = d0;
@@ -346,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
 
         // ---- generic chunk runners ----------------------------------------------------------------------------
         // slice-major chunk over NT tiles: group g = (slice S0 + g / NT, tile g % NT); acc[t][c] (+)= A x B(slice)[c]; ZF: slice S0 starts the sum
-        auto slice_chunk = [&](auto nt_c, auto nsl_c, auto zf_c, auto& acc, auto&& bsel, auto&& ride) {
+        auto slice_chunk = [&](auto nt_c, auto nsl_c, auto zf_c, auto& acc, auto&& bsel, auto&& ride, const int nfill) {
             constexpr int NT = decltype(nt_c)::value, NSL = decltype(nsl_c)::value;
             constexpr bool ZF = decltype(zf_c)::value != 0;
             pipeline16<NT * NSL, NT * NSL, 0ull>(ring, ctx(), [&](auto ic, const f32x4& a32, const f32x4&) {
@@ -360,30 +448,38 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                     acc[t][1] = T::mfma_k32(aop, bsel(IC(sl), IC(1)), acc[t][1]);
                 }
                 ride(ic);
-            }, mid, tail, side);
+            }, mid, tail, side, nfill);
 #pragma unroll
             for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]));   // (keeps LLVM from sinking the chunk: see mlp_lp8.hip)
         };
-        // tile-quad chunk of a hidden layer: groups [b0, A(0,0), b1, A(0,1), b2, A(0,2), b3, A(0,3), A(1,0..3), ..., A(7,0..3)]
-        auto quad_chunk = [&](auto& zq, auto&& ride) {
-            pipeline16<36, 36, 0x55ull>(ring, ctx(), [&](auto ic, const f32x4& a32, const f32x4& prev) {
-                constexpr int g = decltype(ic)::value;
+        // tile-quad chunk of a hidden layer: 32 A operands, group g = (slice g >> 2, tile g & 3); zq[t][0] holds the tile's bias when the
+        // chunk starts (read from LDS by the PREVIOUS chunk -- bias_next below -- or by bias_now): the C operand of both first MFMAs.
+        // EXTRA / extra: this chunk's own reads of the NEXT quad chunk's bias (its counted part; see quad_layer)
+        auto quad_chunk = [&](auto extra_c, auto& zq, auto&& ride, auto&& extra, const int nfill) {
+            constexpr unsigned long long EXTRA = (unsigned long long)decltype(extra_c)::value;
+            pipeline16x<32, 32, 0ull, EXTRA>(ring, ctx(), [&](auto ic, const f32x4& a32, const f32x4&) {
+                constexpr int g = decltype(ic)::value, s = g >> 2, t = g & 3;
                 const u32x4 aop = __builtin_bit_cast(u32x4, a32);
-                if constexpr (g < 8) {
-                    if constexpr (g & 1) {          // first slice: C = the tile's bias
-                        constexpr int t = g >> 1;
-                        zq[t][0] = T::mfma_k32(aop, H[0][0], prev);
-                        zq[t][1] = T::mfma_k32(aop, H[0][1], prev);
-                    }
+                if constexpr (s == 0) {             // block 1 first: zq[t][0] is still the bias
+                    zq[t][1] = T::mfma_k32(aop, H[0][1], zq[t][0]);
+                    zq[t][0] = T::mfma_k32(aop, H[0][0], zq[t][0]);
                 } else {
-                    constexpr int s = 1 + ((g - 8) >> 2), t = (g - 8) & 3;
                     zq[t][0] = T::mfma_k32(aop, H[s][0], zq[t][0]);
                     zq[t][1] = T::mfma_k32(aop, H[s][1], zq[t][1]);
                 }
+#ifndef NSOS_LP16_NORIDE              // (A/B builds only: timing without the riding activation; wrong results)
                 ride(ic);
-            }, mid, tail, side);
+#endif
+            }, mid, tail, side, extra, nfill);
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(zq[t][0]), "+v"(zq[t][1]));
+        };
+        // the bias block of a quad chunk: group 32 of its slot, [tile][q][4 x fp32]; tile t of lane (n, q) at byte 32768 + 64 t + 16 q.
+        // slot_lane = the lane's A-operand address in that slot (slot + 16 lane).
+        auto read_bias = [&](auto tc, f32x4& dst, unsigned slot_lane) {
+            constexpr int t = decltype(tc)::value;
+            const unsigned addr = slot_lane - (unsigned)(lane * 16) + (unsigned)(q * 16);
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(32768 + 64 * t) : "memory");
         };
         auto no_ride = [](auto) {};
         // packed word w (0..3) of local slice ls (0..1), block c of a finished quad zq: tiles 2 ls, 2 ls + 1
@@ -419,41 +515,50 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
             slice_chunk(IC(16), IC(2), IC(1), Z, from_ex, [&](auto gc_) {
                 constexpr int g = decltype(gc_)::value;     // SAVE: the four stores of the encoding slices
                 if constexpr (SAVE && SEM != 0 && g >= 3 && g < 15 && g % 3 == 0) store_ex_k(IC(g / 3 - 1));
-            });
+            }, 33);     // (fetches the chunk two ahead: layer 1's second quad)
             stamp();  // 2: L0 MFMAs
             activate_all(Z);
             stamp();  // 3: L0 activation
         }
-        auto quad_layer = [&](const int l, const bool tail_pending, const bool leave_tail) {
+        auto quad_layer = [&](const int l, const bool tail_pending, const bool leave_tail, const bool bias_now, const bool next_quad) {
             // chunk c accumulates output tiles 4c..4c+3 over all 8 input slices into Zq[c & 1]; the activation of the PREVIOUS quad
             // rides behind this chunk's MFMAs.  The layer's input H stays live until its last chunk: finished slices 0..3 wait in
             // Ho and move into H behind the last chunk's MFMAs, each right after its final use there; quad 2 is activated straight
             // into H[4..5] once those are dead; quad 3 is the tail (rides in the next layer's first chunk, or one exposed pass).
+            // Biases: chunk c reads the NEXT chunk's four bias vectors into Zq[(c + 1) & 1][t][0] once the riding activation is done
+            // with those registers (groups 24..27; the last chunk: 22, 24, 26, 28, and only when a quad layer follows directly --
+            // `next_quad`, a runtime flag: those four reads are not in the counted waits, which makes the waits behind them stricter,
+            // never looser).  `bias_now`: the layer's first chunk follows some other kind of chunk: read and wait here.
             const unsigned floor = l < 8 ? 0u : 0x80008000u;     // feature_linear (l == 8) has no activation
             u32x4 Ho[4][2];
-            auto ride_tail = [&](auto gc_) {     // the previous layer's quad 3 (Zq[1]) -> H[6..7] (always a ReLU layer): input slices 6, 7 are read from group 28 on
+            if (bias_now) {
+                static_for<0, 4>([&](auto tc) { read_bias(tc, Zq[0][decltype(tc)::value][0], c0); });
+                lgkm_wait<0>();
+                asm volatile("" : "+v"(Zq[0][0][0]), "+v"(Zq[0][1][0]), "+v"(Zq[0][2][0]), "+v"(Zq[0][3][0]));
+            }
+            auto ride_tail = [&](auto gc_) {     // the previous layer's quad 3 (Zq[1]) -> H[6..7] (always a ReLU layer): input slices 6, 7 are read from group 24 on
                 constexpr int g = decltype(gc_)::value;
-                if constexpr (g >= 8 && g <= 24) {
+                if constexpr (g >= 4 && g <= 20) {
                     if (tail_pending) {
-                        if constexpr (g >= 9) {
-                            constexpr int k = g - 9;
+                        if constexpr (g >= 5) {
+                            constexpr int k = g - 5;
                             NSOS_RELU_WORD16(H[6 + (k >> 3)][(k >> 2) & 1][k & 3], 0u);
                         }
-                        if constexpr (g < 24) {
-                            constexpr int k = g - 8;
+                        if constexpr (g < 20) {
+                            constexpr int k = g - 4;
                             H[6 + (k >> 3)][(k >> 2) & 1][k & 3] = quad_word(Zq[1], k >> 3, (k >> 2) & 1, k & 3);
                         }
                     }
                 }
             };
-            auto ride_act = [&](auto gc_, auto src_c, auto base_c) {   // 16 words of quad buffer src -> Ho[base .. base+1]: convert in groups 8..23, clamp one group later
+            auto ride_act = [&](auto gc_, auto src_c, auto base_c) {   // 16 words of quad buffer src -> Ho[base .. base+1]: convert in groups 4..19, clamp one group later
                 constexpr int g = decltype(gc_)::value, SRC = decltype(src_c)::value, BASE = decltype(base_c)::value;
-                if constexpr (g >= 9 && g <= 24) {
-                    constexpr int k = g - 9;
+                if constexpr (g >= 5 && g <= 20) {
+                    constexpr int k = g - 5;
                     NSOS_RELU_WORD16(Ho[BASE + (k >> 3)][(k >> 2) & 1][k & 3], floor);
                 }
-                if constexpr (g >= 8 && g < 24) {
-                    constexpr int k = g - 8;
+                if constexpr (g >= 4 && g < 20) {
+                    constexpr int k = g - 4;
                     Ho[BASE + (k >> 3)][(k >> 2) & 1][k & 3] = quad_word(Zq[SRC], k >> 3, (k >> 2) & 1, k & 3);
                 }
             };
@@ -463,19 +568,31 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                 if constexpr (SAVE && SEM != 0 && g >= 3 && (g - 3) % 6 == 0 && (g - 3) / 6 < (CH == 2 ? 2 : 3))
                     if (l == 8) store_h7_k(IC(8 + 3 * CH + (g - 3) / 6));
             };
-            quad_chunk(Zq[0], [&](auto gc_) { ride_tail(gc_); ride_save(gc_, IC(0)); });
-            quad_chunk(Zq[1], [&](auto gc_) { ride_act(gc_, IC(0), IC(0)); ride_save(gc_, IC(1)); });
-            quad_chunk(Zq[0], [&](auto gc_) { ride_act(gc_, IC(1), IC(2)); ride_save(gc_, IC(2)); });
-            quad_chunk(Zq[1], [&](auto gc_) {
+            constexpr unsigned long long kBiasAt = 0xFull << 24;          // groups 24..27: one bias vector each (c1 = the next chunk's slot: tail() rotates the names at group 29)
+            quad_chunk(std::integral_constant<unsigned long long, kBiasAt>{}, Zq[0], [&](auto gc_) { ride_tail(gc_); ride_save(gc_, IC(0)); },
+                       [&](auto gc_) { read_bias(IC(decltype(gc_)::value - 24), Zq[1][decltype(gc_)::value - 24][0], c1); }, 33);
+            quad_chunk(std::integral_constant<unsigned long long, kBiasAt>{}, Zq[1], [&](auto gc_) { ride_act(gc_, IC(0), IC(0)); ride_save(gc_, IC(1)); },
+                       [&](auto gc_) { read_bias(IC(decltype(gc_)::value - 24), Zq[0][decltype(gc_)::value - 24][0], c1); }, 33);
+            // (the last two chunks fetch the NEXT part's first two chunks: quads / slice chunks / the heads' chunks (<= 33 pieces) --
+            //  or, behind feature_linear, the view branch's full slots)
+            const int nfill_next = l == 8 ? 36 : 33;
+            quad_chunk(std::integral_constant<unsigned long long, kBiasAt>{}, Zq[0], [&](auto gc_) { ride_act(gc_, IC(1), IC(2)); ride_save(gc_, IC(2)); },
+                       [&](auto gc_) { read_bias(IC(decltype(gc_)::value - 24), Zq[1][decltype(gc_)::value - 24][0], c1); }, nfill_next);
+            quad_chunk(std::integral_constant<unsigned long long, 0ull>{}, Zq[1], [&](auto gc_) {
                 constexpr int g = decltype(gc_)::value;
-                // input slice s was last used by group 7 (s = 0) / 11 + 4 (s - 1): Ho[s] -> H[s], one block per group
-                if constexpr (g >= 8 && g <= 21 && ((g - 8) & 3) < 2) mov_slice16(H[(g - 8) >> 2][(g - 8) & 1], Ho[(g - 8) >> 2][(g - 8) & 1]);
-                // quad 2 (Zq[0]) -> H[4] (dead from group 24: 8 words in groups 24..31) and H[5] (dead from group 28: groups 28..35)
-                if constexpr (g >= 25 && g <= 32) { constexpr int k = g - 25; NSOS_RELU_WORD16(H[4][k >> 2][k & 3], floor); }
-                if constexpr (g >= 29) { constexpr int k = g - 29; NSOS_RELU_WORD16(H[5][k >> 2][k & 3], floor); }
-                if constexpr (g >= 24 && g <= 31) { constexpr int k = g - 24; H[4][k >> 2][k & 3] = quad_word(Zq[0], 0, k >> 2, k & 3); }
-                if constexpr (g >= 28) { constexpr int k = g - 28; H[5][k >> 2][k & 3] = quad_word(Zq[0], 1, k >> 2, k & 3); }
-            });
+                // input slice s was last used by group 4 s + 3: Ho[s] -> H[s], one block per group
+                if constexpr (g >= 4 && g <= 17 && ((g - 4) & 3) < 2) mov_slice16(H[(g - 4) >> 2][(g - 4) & 1], Ho[(g - 4) >> 2][(g - 4) & 1]);
+                // quad 2 (Zq[0]) -> H[4] (dead from group 20: 8 words in groups 20..27) and H[5] (dead from group 24: groups 24..31)
+                if constexpr (g >= 21 && g <= 28) { constexpr int k = g - 21; NSOS_RELU_WORD16(H[4][k >> 2][k & 3], floor); }
+                if constexpr (g >= 25) { constexpr int k = g - 25; NSOS_RELU_WORD16(H[5][k >> 2][k & 3], floor); }
+                if constexpr (g >= 20 && g <= 27) { constexpr int k = g - 20; H[4][k >> 2][k & 3] = quad_word(Zq[0], 0, k >> 2, k & 3); }
+                if constexpr (g >= 24) { constexpr int k = g - 24; H[5][k >> 2][k & 3] = quad_word(Zq[0], 1, k >> 2, k & 3); }
+                // the next layer's first bias vectors into Zq[0][t][0], each once its register's last word has been converted
+                // (tile 0: group 21, tile 1: 23, tile 2: 25, tile 3: 27); uncounted (see above)
+                if constexpr (g == 22 || g == 24 || g == 26 || g == 28) {
+                    if (next_quad) { NSOS_PIN(); read_bias(IC((g - 22) >> 1), Zq[0][(g - 22) >> 1][0], c1); NSOS_PIN(); }
+                }
+            }, [](auto) {}, nfill_next);
             NSOS_RELU_WORD16(H[5][1][3], floor);     // the word converted in the chunk's last group
             stamp();  // 2 + 2l: MFMAs of layer l (with the riding activation of quads 0..2)
             if (!leave_tail) {
@@ -489,7 +606,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         };
         dead();
 #pragma unroll 1
-        for (int l = 1; l <= 4; ++l) quad_layer(l, l != 1, l != 4);
+        for (int l = 1; l <= 4; ++l) quad_layer(l, l != 1, l != 4, l == 1, l != 4);
         dead();
         {   // ---- layer 5 (skip): h part slice-major over all 16 tiles (4 chunks of 2 slices), then the x63 part (bias in its pad column)
             f32x4 Z[16][2];
@@ -497,11 +614,11 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
             auto from_H23 = [&](auto sc, auto cc) { return H[2 + decltype(sc)::value][decltype(cc)::value]; };
             auto from_H45 = [&](auto sc, auto cc) { return H[4 + decltype(sc)::value][decltype(cc)::value]; };
             auto from_H67 = [&](auto sc, auto cc) { return H[6 + decltype(sc)::value][decltype(cc)::value]; };
-            slice_chunk(IC(16), IC(2), IC(1), Z, from_H01, no_ride);
-            slice_chunk(IC(16), IC(2), IC(0), Z, from_H23, no_ride);
-            slice_chunk(IC(16), IC(2), IC(0), Z, from_H45, no_ride);
-            slice_chunk(IC(16), IC(2), IC(0), Z, from_H67, no_ride);
-            slice_chunk(IC(16), IC(2), IC(0), Z, from_ex, no_ride);
+            slice_chunk(IC(16), IC(2), IC(1), Z, from_H01, no_ride, 32);
+            slice_chunk(IC(16), IC(2), IC(0), Z, from_H23, no_ride, 32);
+            slice_chunk(IC(16), IC(2), IC(0), Z, from_H45, no_ride, 32);
+            slice_chunk(IC(16), IC(2), IC(0), Z, from_H67, no_ride, 33);     // (layer 6's first quad)
+            slice_chunk(IC(16), IC(2), IC(0), Z, from_ex, no_ride, 33);
             stamp();  // 12: MFMAs of layer 5
             activate_all(Z);
             stamp();  // 13: activation pass
@@ -509,7 +626,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         dead();
 #pragma unroll 1
         for (int l = 6; l <= 8; ++l) {
-            quad_layer(l, l == 7, l == 6);
+            quad_layer(l, l == 7, l == 6, l != 7, l == 6);
             if (l == 7) {
                 dead();
                 // ---- H = relu(h7): sigma head (models/nerf_mlp.py:77) and the semantic head (:79-80), all on the matrix pipe
@@ -525,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                             R[0] = T::mfma_k32(aop, H[g - 1][0], R[0]);
                             R[1] = T::mfma_k32(aop, H[g - 1][1], R[1]);
                         }
-                    }, mid, tail, side);
+                    }, mid, tail, side, 33);
                     asm volatile("" : "+v"(R[0]), "+v"(R[1]));
                 } else {
                     f32x4 S8[8][2];
@@ -537,8 +654,8 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                         constexpr int g = decltype(gc_)::value, CH = decltype(ch_c)::value;
                         if constexpr (SAVE && g >= 3 && (g - 3) % 6 == 0 && (g - 3) / 6 < (CH == 2 ? 2 : 3)) store_h7_k(IC(3 * CH + (g - 3) / 6));
                     };
-                    slice_chunk(IC(8), IC(4), IC(1), S8, from_Hlo, [&](auto gc_) { ride_sem(gc_, IC(0)); });
-                    slice_chunk(IC(8), IC(4), IC(0), S8, from_Hhi, [&](auto gc_) { ride_sem(gc_, IC(1)); });
+                    slice_chunk(IC(8), IC(4), IC(1), S8, from_Hlo, [&](auto gc_) { ride_sem(gc_, IC(0)); }, SEM == 2 ? 29 : 21);   // (the head's tail chunk)
+                    slice_chunk(IC(8), IC(4), IC(0), S8, from_Hhi, [&](auto gc_) { ride_sem(gc_, IC(1)); }, 33);
                     // the head's hidden activations -> Sp (one exposed pass, inside the tail chunk below, before the logit MFMAs)
                     auto activate_sem = [&]() {
                         asm volatile("s_nop 7" ::: "memory");
@@ -593,7 +710,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                                 R[1] = T::mfma_k32(aop, Sp[g - 25][1], R[1]);
                             }
                             ride_sem(ic, IC(2));
-                        }, mid, tail, side);
+                        }, mid, tail, side, 33);
                     } else {
                         // [bias of semantic_linear.0 as a constant K-slice: 8 tiles][bias of the raw tile][8 x sigma][4 x logits]
                         const unsigned one_w = q == 0 ? (unsigned)(T::kOnes & 0xffffu) : 0u;     // B = e_0: k position (q 0, e 0) is 1.0
@@ -616,7 +733,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                                 R[1] = T::mfma_k32(aop, Sp[g - 17][1], R[1]);
                             }
                             ride_sem(ic, IC(2));
-                        }, mid, tail, side);
+                        }, mid, tail, side, 33);
                     }
                     asm volatile("" : "+v"(R[0]), "+v"(R[1]));
                 }
@@ -642,7 +759,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         }
         stamp();  // direction encoding
         u32x4 Vp[4][2];
-        auto view_chunk = [&](auto& zq, auto&& ride) {
+        auto view_chunk = [&](auto& zq, auto&& ride, const int nfill) {
             pipeline16<36, 36, 0ull>(ring, ctx(), [&](auto ic, const f32x4& a32, const f32x4&) {
                 constexpr int g = decltype(ic)::value, s = g >> 2, t = g & 3;
                 const u32x4 aop = __builtin_bit_cast(u32x4, a32);
@@ -657,16 +774,16 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                     zq[t][1] = T::mfma_k32(aop, ed[1], zq[t][1]);
                 }
                 ride(ic);
-            }, mid, tail, side);
+            }, mid, tail, side, nfill);
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(zq[t][0]), "+v"(zq[t][1]));
         };
-        view_chunk(Zq[0], no_ride);
+        view_chunk(Zq[0], no_ride, 4);       // (fetches the rgb chunk)
         view_chunk(Zq[1], [&](auto gc_) {
             constexpr int g = decltype(gc_)::value;
             if constexpr (g >= 9 && g <= 24) { constexpr int k = g - 9; NSOS_RELU_WORD16(Vp[k >> 3][(k >> 2) & 1][k & 3], 0u); }
             if constexpr (g >= 8 && g < 24) { constexpr int k = g - 8; Vp[k >> 3][(k >> 2) & 1][k & 3] = quad_word(Zq[0], k >> 3, (k >> 2) & 1, k & 3); }
-        });
+        }, 32);                              // (the next tile's layer 0)
         stamp();  // view-branch MFMAs
         {
             asm volatile("s_nop 7" ::: "memory");
@@ -700,7 +817,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                 R[0] = T::mfma_k32(aop, Vp[g][0], R[0]);
                 R[1] = T::mfma_k32(aop, Vp[g][1], R[1]);
             }
-        }, mid, tail, side);
+        }, mid, tail, side, 33);             // (the next tile's layer 1, first quad)
         asm volatile("" : "+v"(R[0]), "+v"(R[1]));
         stamp();  // rgb MFMAs
         {
@@ -789,11 +906,11 @@ int32_t launch16(const LpParams& p, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------ packing
 // One descriptor per chunk of the stream (36 groups of 1 KiB = 512 16-bit elements; lane (i = lane & 15, q = lane >> 4), element e):
-//   an A operand of (tile t, slice s) holds W[row0 + 16 t + i][col(s, q, e)], col by the input's kind:
+//   an A operand of (tile t, slice s) holds W[16 t + i][col(s, q, e)], col by the input's kind:
 //     hidden input (an accumulator-layout H):  col_base + 32 s + 16 (e >> 2) + 4 q + (e & 3)
 //     encoding input (natural order):          col_base + 32 s + 8 q + e;  past n_enc features: the bias if this is the pad column, else 0
 //   a bias group holds, as fp32, bias[16 t + 4 q + r] in the lane's four words.
-enum Kind16 { kQ16 = 0,      // tile quad a0 of a hidden layer: [b, A(0,t)] x 4, then A(s, t) slice-major, s = 1..7
+enum Kind16 { kQ16 = 0,      // tile quad a0 of a hidden layer: 32 A operands, g = 4 s + t, then the bias block (group 32: [t][q][4 x fp32])
               kSlice16 = 1,  // slice-major: g = (s - s0) * nt + t; hidden input
               kEnc16 = 2,    // slice-major over encoding slices s0..: g = (s - s0) * nt + t; bias in the pad column (f == pad_at)
               kView16 = 3,   // quad a0 of the view branch: g = s * 4 + t, s < 8 hidden (feature), s == 8 the direction slice (bias at f == 27)
@@ -828,10 +945,6 @@ __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
     // a group is either 512 16-bit operand elements or 256 fp32 bias values (two 16-bit halves each)
     bool is_bias = false;
     float v = 0.0f;
-    auto bias_val = [&](const float* b, int t) {     // element pair (e >> 1) of the lane = fp32 word r = e >> 1
-        is_bias = true;
-        v = b ? b[16 * t + 4 * q + (e >> 1)] : 0.0f;
-    };
     auto raw_bias = [&]() {                          // the raw tile: rows 0..2 rgb, 3 sigma, 4..5 semantics
         is_bias = true;
         const int row = 4 * q + (e >> 1);
@@ -841,13 +954,15 @@ __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
     auto logits_a = [&](int s) { v = (i == 4 || i == 5) ? P.sem2_w[(i - 4) * (W / 2) + hid_col(s, q, e)] : 0.0f; };
     switch (ck.kind) {
         case kQ16: {
-            if (g < 8) {
-                const int t = 4 * ck.a0 + (g >> 1);
-                if (g & 1) v = ck.w[(long long)(16 * t + i) * ck.in_dim + ck.col_base + hid_col(0, q, e)];
-                else bias_val(ck.bias, t);
-            } else {
-                const int s = 1 + ((g - 8) >> 2), t = 4 * ck.a0 + ((g - 8) & 3);
-                v = ck.w[(long long)(16 * t + i) * ck.in_dim + ck.col_base + hid_col(s, q, e)];
+            if (g < 32) {
+                const int sl = g >> 2, t = 4 * ck.a0 + (g & 3);
+                v = ck.w[(long long)(16 * t + i) * ck.in_dim + ck.col_base + hid_col(sl, q, e)];
+            } else if (g == 32) {     // the bias block: [tile 0..3][q][4 x fp32] = the first 128 16-bit elements of the group
+                const int word = (lane * 8 + e) >> 1;            // fp32 index inside the group
+                if (word < 64) {
+                    is_bias = true;
+                    v = ck.bias ? ck.bias[16 * (4 * ck.a0 + (word >> 4)) + (word & 15)] : 0.0f;    // word = 16 t + 4 q + r = feature within the quad
+                }
             }
         } break;
         case kSlice16: {

@@ -7,6 +7,7 @@ from nerf_sos_amd import _lib, ops, synthetic as syn
 dev = "cuda:0"
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+KERNELS = tuple(int(c) for c in sys.argv[3]) if len(sys.argv) > 3 else (1, 2, 3)      # e.g. "3": mlp_lp16_kernel only (A/B libraries)
 for sem, kw in ((0, dict(use_semantics=False)), (2, dict(use_semantics=True, sem_with_coord=True))):
     torch.manual_seed(0)
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **kw).to(dev).eval()
@@ -20,7 +21,7 @@ for sem, kw in ((0, dict(use_semantics=False)), (2, dict(use_semantics=True, sem
         pk = net.nerf_fine.packed_weights(prec)
         best = {1: 1e9, 2: 1e9, 3: 1e9}
         for rep in range(reps):
-            for wps in (1, 2, 3):
+            for wps in KERNELS:
                 _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(wps), "select")
                 for _ in range(5):
                     ops.mlp_forward_rays_lp(pk, sem, prec, o, d, v, z)
@@ -31,6 +32,6 @@ for sem, kw in ((0, dict(use_semantics=False)), (2, dict(use_semantics=True, sem
                 ev[1].record(); torch.cuda.synchronize()
                 best[wps] = min(best[wps], ev[0].elapsed_time(ev[1]) / 40)
         tf = lambda ms: 2 * mac * R * 192 / (ms * 1e-3) / 1e12
-        print(f"sem {sem} {prec} R={R}: lp4 {best[1]:.4f} ms ({tf(best[1]):.0f} TF, {tf(best[1])/25.166:.1f} %)   lp8 {best[2]:.4f} ms ({tf(best[2]):.0f} TF, {tf(best[2])/25.166:.1f} %)"
-              f"   lp16 {best[3]:.4f} ms ({tf(best[3]):.0f} TF, {tf(best[3])/25.166:.1f} %)", flush=True)
+        print(f"sem {sem} {prec} R={R}: " + "   ".join(f"{ {1: 'lp4', 2: 'lp8', 3: 'lp16'}[k]} {best[k]:.4f} ms ({tf(best[k]):.0f} TF, {tf(best[k])/25.166:.1f} %)"
+                                                         for k in KERNELS), flush=True)
 _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(3), "select")

@@ -96,7 +96,8 @@ def test_lds_ring_protocol_holds_in_the_built_code():
     spec.loader.exec_module(chk)
     if not os.path.exists(chk.OBJDUMP):
         pytest.skip("llvm-objdump not found")
-    kernels = {k: v for k, v in chk.disassemble(_lib.LIB_PATH).items() if "mlp_" in k and "pack" not in k}
+    # (mlp_generic_kernel waits for its LDS reads through the compiler's own counters: nothing hand-counted there)
+    kernels = {k: v for k, v in chk.disassemble(_lib.LIB_PATH).items() if "mlp_" in k and "pack" not in k and "mlp_generic" not in k}
     assert len(kernels) >= 32, sorted(kernels)
     for name, ins in kernels.items():
         bad, n_reads, n_scratch = chk.check_kernel(ins)
@@ -117,6 +118,14 @@ def test_lds_ring_protocol_holds_in_the_built_code():
                 limit = 80
             elif "ELi2ELb1ELb0EEE" in name:     # sem+coord, SAVE
                 limit = 56
+        if "mlp_lp16_kernel" in name:  # ...ELi<SEM>ELb<SAVE>ELb<PROF>E...  every inference instantiation scratch-free; the training
+            # variants keep a few dwords around their stores and ~100 spill instructions inside the never-taken ocml sincosf blocks
+            # (arguments >= 2^15) of the four encoder instances
+            limit = 0
+            if "ELb1EEE" in name:               # PROF: diagnostics builds
+                limit = 40
+            if "ELb1ELb" in name:               # SAVE
+                limit = 130
         if "mlp_x3_kernel" in name and "ELi0EEE" not in name:   # ...ELi<SEM>ELi<SAVE>E...: the training variants may park a
             limit = 64                                            # few row pointers / unpacked words in scratch around their stores
         assert n_scratch <= limit, (name, n_scratch)

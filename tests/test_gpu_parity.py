@@ -299,11 +299,17 @@ def test_end_to_end_vs_reference(golden, manifest, monkeypatch, name, peaky, whi
         got = N(out[k])
         assert got.shape == want.shape, f"{k}: {got.shape} vs {want.shape}"
         if k in ("weights", "raw", "z_std") and n_imp:
+            # the fine pass's per-sample tensors follow the importance samples: where a last-ulp difference of the coarse weights
+            # flips a bisect index, a sample moves.  Counted per RAY (measured, round 4, 16 rays per case: weights at most 1 ray,
+            # z_std none); `raw` is per SAMPLE POSITION -- any moved sample puts its ray outside -- so it keeps an element share
+            # (measured <= 3.1e-3).  With the reference's z_fine pinned every key is strictly inside (tests/test_gpu_pins.py).
             err = np.abs(got.astype(np.float64) - want)
             tol = 1e-4 + 1e-4 * np.abs(want)
             rays_out = int((err > tol).reshape(err.shape[0], -1).any(-1).sum())
-            print(f"PARITYCOUNT end_to_end {tag} {k}: {rays_out} of {err.shape[0]} rays, {(err > tol).mean():.5f} of elements outside tol")
-            assert (err > tol).mean() < 5e-3, f"{tag} {k}: {(err > tol).mean():.4f} outside tol"
+            if k == "raw":
+                assert (err > tol).mean() < 4e-3, f"{tag} {k}: {(err > tol).mean():.4f} of elements outside tol"
+            else:
+                assert rays_out <= 1, f"{tag} {k}: {rays_out} of {err.shape[0]} rays outside tol"
         else:
             close(got, want, what=f"{tag} {k}")
 
@@ -773,8 +779,7 @@ def test_per_call_sample_count_override(manifest, n_coarse):
         close(N(out[k]), ref[k].numpy(), atol=1e-4, rtol=1e-4, what=k)
     for k in ("rgb", "acc", "semantics"):   # fine pass: bulk agreement (index flips)
         bad = (np.abs(N(out[k]) - ref[k].numpy()) > 1e-4 * (1 + np.abs(ref[k].numpy()))).any(-1).mean()
-        print(f"PARITYCOUNT sample_count_override {n_coarse} {k}: {int(round(bad * 40))} of 40 rays outside")
-        assert bad <= 0.05, (k, bad)
+        assert bad * 40 <= 1.5, (k, bad)       # measured (round 4): at most 1 of the 40 rays (an index flip)
     net.train()                              # train mode: jitter + noise draws at the overridden count
     tr = net(rays.to(DEV), (tp.NEAR, tp.FAR), N_samples=n_coarse, raw_noise_std=1.0)
     assert tr["weights"].shape == (40, M) and bool(torch.isfinite(tr["rgb"]).all())
@@ -1026,9 +1031,9 @@ def test_fuzz_shapes_module_vs_port(case):
     if N_ > 0:
         for k in ("rgb", "acc"):
             a, b = N(out[k]).reshape(R, -1), ref[k].numpy().reshape(R, -1)
-            bad = (np.abs(a - b) > 2e-4 * (1 + np.abs(b))).any(-1).mean()
-            print(f"PARITYCOUNT fuzz case {case} {k}: {int(round(bad * R))} of {R} rays outside 2e-4; at 1e-4: {int((np.abs(a - b) > 1e-4 * (1 + np.abs(b))).any(-1).sum())}")
-            assert bad <= max(0.05, 1.5 / R), (case, k, bad, dict(R=R, S=S, N=N_, name=name, white=white, peaky=peaky))
+            n_bad = int((np.abs(a - b) > 1e-4 * (1 + np.abs(b))).any(-1).sum())
+            # measured (round 4): no ray of any of the 16 cases outside 1e-4; one index flip may move one ray
+            assert n_bad <= 1, (case, k, bad, dict(R=R, S=S, N=N_, name=name, white=white, peaky=peaky))
 
 
 @pytest.mark.parametrize("case", range(12))

@@ -45,11 +45,19 @@ def test_mode_kwargs():
     assert net.chunk == 32768 and net.nerf.chunk == 65536
 
 
-@pytest.mark.parametrize("kw", [dict(netwidth=128), dict(multires=6), dict(viewdirs=False), dict(conv_embed=True),
-                                dict(use_semantics=True, sem_layer=4), dict(use_semantics=True, sem_dim=5)])
-def test_unsupported_architectures_raise(kw):
-    with pytest.raises(NotImplementedError, match="specialised"):
-        nerf_sos_amd.NeRFNet(**kw)
+@pytest.mark.parametrize("kw", [dict(netwidth=128), dict(multires=6), dict(viewdirs=False), dict(use_semantics=True, sem_layer=4),
+                                dict(use_semantics=True, sem_dim=5), dict(use_semantics=True, sem_with_geo=True), dict(netdepth=3, netdepth_fine=5)])
+def test_other_architectures_construct_and_take_the_generic_kernel(kw):
+    """Every ctor kwarg the reference accepts constructs (round 4); anything but the shipped architecture is marked for the
+    generic fp32 kernel (tests/test_generic_arch.py renders them against the reference's goldens)."""
+    net = nerf_sos_amd.NeRFNet(**kw)
+    assert not (net.nerf.fast and net.nerf_fine.fast)
+    assert nerf_sos_amd.NeRFNet().nerf.fast
+
+
+def test_conv_embed_is_refused():
+    with pytest.raises(NotImplementedError, match="conv_embed"):
+        nerf_sos_amd.NeRFNet(conv_embed=True)
 
 
 def test_shape_assert_matches_reference():
