@@ -27,8 +27,9 @@ extern "C" {
 #endif
 
 /* bumped whenever an existing entry point's arguments or buffer formats change (2: 16-bit / tile-major saved operands of
- * nsos_mlp_forward_rays_save16_lp and nsos_sem_head_wgrad_x3; 3: pose_rows in nsos_patch_batch / nsos_pixel_batch) */
-#define NSOS_ABI_VERSION 3
+ * nsos_mlp_forward_rays_save16_lp and nsos_sem_head_wgrad_x3; 3: pose_rows in nsos_patch_batch / nsos_pixel_batch; 4: the tile-major
+ * sem_hid16 of the default 16-bit kernel, nsos_mlp_save16_layout's NSOS_SEM_HID_TILED bit) */
+#define NSOS_ABI_VERSION 4
 
 enum {
     NSOS_OK = 0,
@@ -282,8 +283,13 @@ int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem_mode, int3
  *     different rows per instruction: groups of 32 consecutive points, [group][K 0..19][kg 0..1][point 0..31][8 channels] --
  *     channel 16 K + 8 kg + c of point 32 g + i is element ((g * 20 + K) * 64 + kg * 32 + i) * 8 + c.  The buffer must hold
  *     ceil(P / 32) * 32 rows of 320 elements; rows past P are not written.
- * OR the layout value into nsos_sem_head_wgrad_x3's sem_in_dtype.  sem_hid16 is row-major in both. */
-enum { NSOS_SEM_IN_ROWS = 0, NSOS_SEM_IN_TILED = 16 };
+ * OR the layout value into nsos_sem_head_wgrad_x3's sem_in_dtype.
+ * sem_hid16: [P, 128] row-major, or -- NSOS_SEM_HID_TILED (32) set in the layout value: the 16x16x32 kernel, the default since
+ * round 4 -- tile-major like sem_in: [group of 32 points][octet 0..15][point][8 channels] (8 KiB per group; rows past P of the
+ * last group are never written): every store instruction of the kernel then writes four runs of 256 contiguous bytes instead of
+ * 64 pieces of 16 bytes in as many 256-byte rows (partial-line writes are filled from memory first: the training variant's
+ * excess read traffic of round 3). */
+enum { NSOS_SEM_IN_ROWS = 0, NSOS_SEM_IN_TILED = 16, NSOS_SEM_HID_TILED = 32 };
 int32_t nsos_mlp_save16_layout(int64_t n_points);
 int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                         const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,

@@ -431,8 +431,8 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
                                           const void* sem_hid, const void* sem_in, int32_t sem_in_dtype, int64_t n_rays,
                                           int32_t n_samples, const float* scale, float* gw1_aug, float* gw2, float* gb2,
                                           void* workspace, size_t workspace_bytes, void* stream) {
-    const int32_t tiled = sem_in_dtype & NSOS_SEM_IN_TILED;
-    sem_in_dtype &= ~NSOS_SEM_IN_TILED;
+    const int32_t tiled = sem_in_dtype & (NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED);
+    sem_in_dtype &= ~(NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED);
     NSOS_REQUIRE(sem_in_dtype >= 0 && sem_in_dtype <= 2 && !(tiled && sem_in_dtype == 0), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(gw1_aug && gw2 && gb2, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);

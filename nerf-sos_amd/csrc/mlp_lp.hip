@@ -633,7 +633,8 @@ extern "C" int32_t nsos_mlp_forward_rays_save_lp(const void* packed, int32_t sem
 }
 
 extern "C" int32_t nsos_mlp_save16_layout(int64_t n_points) {   // the same condition forward_rays_lp selects the kernel by
-    return (lp_waves_per_simd() >= 2 && n_points < (1ll << 31)) ? NSOS_SEM_IN_TILED : NSOS_SEM_IN_ROWS;
+    if (!(lp_waves_per_simd() >= 2 && n_points < (1ll << 31))) return NSOS_SEM_IN_ROWS;
+    return lp_waves_per_simd() == 3 ? (NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED) : NSOS_SEM_IN_TILED;
 }
 
 extern "C" int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         auto save_store = [&save_grp](auto boff_c, unsigned off, const u32x4& v) {
             constexpr int BOFF = decltype(boff_c)::value;
             unsigned long long b = save_grp + (unsigned long long)(BOFF & ~4095);
-            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" : : "v"(off), "v"(v), "s"(b), "i"(BOFF & 4095) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(b), "i"(BOFF & 4095) : "memory");   // (s_nop: see the hidden-activation stores)
         };
         if constexpr (SAVE) {
             // TILE-MAJOR sem_in (include/nerf_sos_hip.h): [group of 32 points][octet 0..39][point][8 channels] -- store K, half kg of
@@ -421,7 +421,9 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
             if constexpr (SAVE) {
                 const auto r0 = __builtin_amdgcn_permlane16_swap(H[s][c][0], H[s][c][2], false, false);
                 const auto r1 = __builtin_amdgcn_permlane16_swap(H[s][c][1], H[s][c][3], false, false);
+#ifndef NSOS_LP16_SKIP_IN    // (A/B builds only: scripts/diag/build_variant.sh)
                 if (save_ok[c]) save_store(IC(s * 2048 + c * 256), save_off, u32x4{r0[0], r1[0], r0[1], r1[1]});
+#endif
             }
         };
         // the k-th of the 16 stores of relu(h7) (k = 2 s + c) / of the 4 stores of the encoding slices
@@ -672,20 +674,26 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) NSOS_RELU_WORD16(Sp[s][c][w], 0u);
                         if constexpr (SAVE) {
-                            // the hidden activations as the logit MFMAs consume them: [P,128] 16-bit, row-major; a lane holds channels
-                            // 16 t + 4 q + {0..3} of tile t: one v_permlane16_swap per word pair -> 8 consecutive channels per lane
+                            // the hidden activations as the logit MFMAs consume them, 16-bit, TILE-MAJOR like sem_in ([group of 32 points][octet
+                            // 0..15][point][8 channels], include/nerf_sos_hip.h): a lane holds channels 16 t + 4 q + {0..3} of tile t; one
+                            // v_permlane16_swap per word pair -> 8 consecutive channels per lane = octet 4 s + 2 (q & 1) + (q >> 1) of its point:
+                            // the lane offset of the relu(h7) stores serves these too, and a store writes four runs of 256 contiguous bytes
+                            const unsigned long long hid_grp = reinterpret_cast<unsigned long long>(P.sem_hid16 + (long long)(wave_first >> 5) * 2048);
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
 #pragma unroll
                                 for (int c = 0; c < 2; ++c) {
                                     const auto r0 = __builtin_amdgcn_permlane16_swap(Sp[s][c][0], Sp[s][c][2], false, false);
                                     const auto r1 = __builtin_amdgcn_permlane16_swap(Sp[s][c][1], Sp[s][c][3], false, false);
-                                    if (save_ok[c]) {
-                                        unsigned* hrow16 = P.sem_hid16 + (long long)(wave_first + 16 * c + n) * 64;
-                                        // even groups: channels 32 s + 4 q + {0..7}; odd groups: 32 s + 16 + 4 (q - 1) + {0..7}
-                                        const int ch0 = 32 * s + ((q & 1) ? 16 + 4 * (q - 1) : 4 * q);
-                                        *reinterpret_cast<u32x4*>(hrow16 + (ch0 >> 1)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
-                                    }
+                                    const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+#ifndef NSOS_LP16_SKIP_HID   // (A/B builds only)
+                                    if (save_ok[c])
+                                        // (s_nop: a store of more than 8 bytes followed by a write of its data registers needs wait states, and the
+                                        //  hazard recognizer does not look inside asm -- eight stores back to back all got v[184:187] and stored each
+                                        //  other's words)
+                                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(save_off), "v"(v), "s"(hid_grp + (unsigned long long)((s * 2048 + c * 256) & ~4095)),
+                                                     "i"((s * 2048 + c * 256) & 4095) : "memory");
+#endif
                                 }
                         }
                     };

@@ -155,7 +155,7 @@ __device__ __forceinline__ u32x2 lds_read_tr(unsigned addr) {
     return v;
 }
 
-template <int XFMT, bool TILED>   // XFMT 1: fp16, 2: bf16; TILED: sem_in in the tile-major layout of nsos_mlp_forward_rays_save16_lp
+template <int XFMT, bool TILED, bool HTILED>   // XFMT 1: fp16, 2: bf16; TILED / HTILED: sem_in / hid in the tile-major layouts of nsos_mlp_forward_rays_save16_lp
 __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* __restrict__ weights, const float* __restrict__ g_sem,
                                                                   const float* __restrict__ w2, const unsigned short* __restrict__ hid,
                                                                   const unsigned short* __restrict__ sem_in,
@@ -174,8 +174,9 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     const long long s1 = s0 + per < n_full ? s0 + per : n_full;
     const int nf = __builtin_amdgcn_readfirstlane((int)(s1 > s0 ? s1 - s0 : 0));
     const float scale = *scale_p;
-    // g-kind lane: point pl of the step, features 8 fo .. 8 fo + 7
-    const int pl = 4 * gt + (lane >> 4), fo = lane & 15;
+    // g-kind lane: point pl of the step, features 8 fo .. 8 fo + 7.  Row-major hid: a wave takes 4 points x all 16 octets (four
+    // 256-byte rows); tile-major hid ([group][octet][point][8]): 16 points x 4 octets (four 256-byte runs)
+    const int pl = HTILED ? (lane & 15) : 4 * gt + (lane >> 4), fo = HTILED ? 4 * gt + (lane >> 4) : (lane & 15);
     f32x2 w2a[4], w2b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                                                    // scale is a power of two: exact
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < 4; ++q) gw2[0][q] = gw2[1][q] = f32x2{0.0f, 0.0f};
 
-    const unsigned off_w = 4u * (unsigned)pl, off_h = ((unsigned)pl * 128u + 8u * (unsigned)fo) * 2u;   // hid: 16-bit like sem_in
+    const unsigned off_w = 4u * (unsigned)pl, off_h = HTILED ? (unsigned)fo * 512u + (unsigned)pl * 16u : ((unsigned)pl * 128u + 8u * (unsigned)fo) * 2u;   // hid: 16-bit like sem_in
     auto widen = [](unsigned w) { return XFMT == 1 ? (float)__builtin_bit_cast(_Float16, (unsigned short)w) : __builtin_bit_cast(float, w << 16); };
     const unsigned long long g_base = uniform64(g_sem);
     // the ray of the lane's point, kept by increments: point s0 * 16 + pl now, + 16 per fetched step (n_samples >= 8: two wraps at most)
@@ -227,16 +228,24 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     // re-derived per fetch from the step index was two v_readfirstlane + s_nop 4 + 64-bit multiplies: 316 of the 2 000 cycles
     // a step took on the g-kind waves.)
     // (tile-major sem_in: step s is half (s & 1) of group s >> 1: + 256 B into the group's second half, then on to the next group)
-    unsigned long long wb_run = uniform64(weights + s0 * 16), hb_run = uniform64(hid + s0 * 16 * 128),
+    unsigned long long wb_run = uniform64(weights + s0 * 16), hb_run = uniform64(HTILED ? hid + (s0 >> 1) * (32 * 128) + (s0 & 1) * (16 * 8) : hid + s0 * 16 * 128),
                        xb_run = uniform64(TILED ? sem_in + (s0 >> 1) * (32 * 320) + (s0 & 1) * (16 * 8) : sem_in + s0 * 16 * 320);
     int x_half = __builtin_amdgcn_readfirstlane((int)(s0 & 1));
+    int h_half = x_half;
     auto fetch_g = [&](bool advance, SetG& s) {
         s.wt = ld_f32<0>(off_w, wb_run);
         s.g = ld_f32x2(ray_q * 8u, g_base);
         s.h = ld_u32x4(off_h, hb_run);
         if (advance) {
             wb_run += 16 * 4;
-            hb_run += 16 * 128 * 2;
+            if constexpr (HTILED) {       // step s is half (s & 1) of group s >> 1: + 256 B into the second half, then on to the next group
+                unsigned inc = h_half ? 32u * 128u * 2u - 256u : 256u;
+                asm volatile("" : "+s"(inc), "+s"(h_half));
+                hb_run += inc;
+                h_half ^= 1;
+                asm volatile("" : "+s"(hb_run));
+            }
+            else hb_run += 16 * 128 * 2;
             ray_r += 16u;
             if (ray_r >= (unsigned)S) { ray_r -= (unsigned)S; ++ray_q; }
             if (ray_r >= (unsigned)S) { ray_r -= (unsigned)S; ++ray_q; }
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
             SetG t;
             t.wt = valid ? weights[pc] : 0.0f;
             t.g = f32x2{g_sem[2ull * r], g_sem[2ull * r + 1]};
-            t.h = *reinterpret_cast<const u32x4*>(hid + (unsigned long long)pc * 128 + 8 * fo);
+            t.h = *reinterpret_cast<const u32x4*>(HTILED ? hid + (((unsigned long long)(pc >> 5) * 16 + fo) * 32 + (pc & 31)) * 8 : hid + (unsigned long long)pc * 128 + 8 * fo);
             stage_g(t, 0);
         } else {
 #pragma unroll
@@ -485,12 +494,13 @@ int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_seman
     const long long n_pts = (long long)n_rays * n_samples;
     const unsigned short* x = static_cast<const unsigned short*>(sem_in);
     const unsigned short* h = static_cast<const unsigned short*>(sem_hid);
-    const bool tiled = (sem_in_dtype & NSOS_SEM_IN_TILED) != 0;
-    const int fmt = sem_in_dtype & ~NSOS_SEM_IN_TILED;
-#define NSOS_WG16_LAUNCH(F, T) hipLaunchKernelGGL((sem_head_wgrad16_kernel<F, T>), dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x, \
-                                                  scale, n_pts, (long long)n_rays, (int)n_samples, partial)
-    if (fmt == 1) { if (tiled) NSOS_WG16_LAUNCH(1, true); else NSOS_WG16_LAUNCH(1, false); }
-    else { if (tiled) NSOS_WG16_LAUNCH(2, true); else NSOS_WG16_LAUNCH(2, false); }
+    const bool tiled = (sem_in_dtype & NSOS_SEM_IN_TILED) != 0, htiled = (sem_in_dtype & NSOS_SEM_HID_TILED) != 0;
+    const int fmt = sem_in_dtype & ~(NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED);
+    if (htiled && !tiled) return NSOS_ERR_UNSUPPORTED;       // (the kernels store either sem_in alone or both matrices tile-major)
+#define NSOS_WG16_LAUNCH(F, T, H) hipLaunchKernelGGL((sem_head_wgrad16_kernel<F, T, H>), dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x, \
+                                                     scale, n_pts, (long long)n_rays, (int)n_samples, partial)
+    if (fmt == 1) { if (htiled) NSOS_WG16_LAUNCH(1, true, true); else if (tiled) NSOS_WG16_LAUNCH(1, true, false); else NSOS_WG16_LAUNCH(1, false, false); }
+    else { if (htiled) NSOS_WG16_LAUNCH(2, true, true); else if (tiled) NSOS_WG16_LAUNCH(2, true, false); else NSOS_WG16_LAUNCH(2, false, false); }
 #undef NSOS_WG16_LAUNCH
     return nsos_launch_status();
 }

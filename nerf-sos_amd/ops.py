@@ -341,14 +341,19 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
     dev = z_vals.device
     raw = torch.empty((R, S, 6), device=dev, dtype=torch.float32)
     compact = compact and precision in ("fp16", "bf16")
-    if compact and _lib.lib().nsos_mlp_save16_layout(R * S) == SEM_IN_TILED:
+    layout = int(_lib.lib().nsos_mlp_save16_layout(R * S)) if compact else 0
+    if layout & SEM_IN_TILED:
         # tile-major (what the two-waves-per-SIMD kernel stores contiguously): [group of 32 points][K][kg * 32 + point][8 channels];
         # sem_head_wgrad recognises it by its four dimensions, sem_in_rows() turns it into [P,320]
         sem_in = torch.empty(((R * S + 31) // 32, 20, 64, 8), device=dev, dtype=torch.float16 if precision == "fp16" else torch.bfloat16)
     else:
         sem_in = torch.empty((R * S, 320), device=dev,
                              dtype=(torch.float16 if precision == "fp16" else torch.bfloat16) if compact else torch.float32)
-    sem_hid = torch.empty((R * S, 128), device=dev, dtype=sem_in.dtype if compact else torch.float32)
+    if layout & SEM_HID_TILED:
+        # tile-major like sem_in (the default 16-bit kernel): [group of 32 points][octet 0..15][point][8 channels]; sem_hid_rows() -> [P,128]
+        sem_hid = torch.empty(((R * S + 31) // 32, 16, 32, 8), device=dev, dtype=sem_in.dtype)
+    else:
+        sem_hid = torch.empty((R * S, 128), device=dev, dtype=sem_in.dtype if compact else torch.float32)
     ev = _ev_begin()
     if precision == "fp32":
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
@@ -373,6 +378,16 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
 
 
 SEM_IN_TILED = 16   # NSOS_SEM_IN_TILED (include/nerf_sos_hip.h)
+SEM_HID_TILED = 32  # NSOS_SEM_HID_TILED
+
+
+def sem_hid_rows(sem_hid: torch.Tensor, n_points: int) -> torch.Tensor:
+    """[P,128] row-major from the tile-major sem_hid [ceil(P/32), 16, 32, 8] of mlp_forward_rays_save(compact=True) with the
+    default 16-bit kernel (channel 8 o + c of point 32 g + i at [g, o, i, c]); a row-major tensor is returned as it is."""
+    if sem_hid.dim() != 4:
+        return sem_hid
+    G = sem_hid.shape[0]
+    return sem_hid.permute(0, 2, 1, 3).reshape(G * 32, 128)[:n_points]
 
 
 def sem_in_rows(sem_in: torch.Tensor, n_points: int) -> torch.Tensor:
@@ -430,7 +445,10 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     tiled = sem_in.dim() == 4                      # the tile-major layout of mlp_forward_rays_save(compact=True), see sem_in_rows
     if tiled and x_dtype == 0:
         raise TypeError("sem_head_wgrad: the tile-major sem_in layout is a 16-bit one")
-    if (tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (R * S, 128) or tuple(sem2_w.shape) != (2, 128)
+    htiled = sem_hid.dim() == 4                    # tile-major hidden activations (the default 16-bit kernel), see sem_hid_rows
+    if htiled and not tiled:
+        raise TypeError("sem_head_wgrad: a tile-major sem_hid comes with a tile-major sem_in")
+    if (tuple(g_semantics.shape) != (R, 2) or tuple(sem_hid.shape) != (((R * S + 31) // 32, 16, 32, 8) if htiled else (R * S, 128)) or tuple(sem2_w.shape) != (2, 128)
             or tuple(sem_in.shape) != (((R * S + 31) // 32, 20, 64, 8) if tiled else (R * S, 320))):
         raise ValueError("sem_head_wgrad: inconsistent shapes")
     dev = weights.device
@@ -443,13 +461,14 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     use_split = split_fp16 and S >= 8 and R * S < 2 ** 31
     if not use_split and x_dtype != 0:
         sem_in, x_dtype, tiled = sem_in_rows(sem_in, R * S).float(), 0, False          # the exact kernel reads fp32 rows
+        sem_hid, htiled = sem_hid_rows(sem_hid, R * S), False
     if x_dtype == 0:
         sem_hid = sem_hid.float()                    # fp32 sem_in: fp32 hid (the 16-bit kernel reads both matrices in one format)
     elif sem_hid.dtype != sem_in.dtype:
         sem_hid = sem_hid.to(sem_in.dtype)
     if use_split:   # the power of two that keeps g_hid in fp16 range is derived (and divided out again) on the device
         _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in),
-                                                     x_dtype | (SEM_IN_TILED if tiled else 0),
+                                                     x_dtype | (SEM_IN_TILED if tiled else 0) | (SEM_HID_TILED if htiled else 0),
                                                      R, S, None, _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
                                                      _stream()),
                    "nsos_sem_head_wgrad_x3")

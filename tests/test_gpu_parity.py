@@ -699,6 +699,8 @@ def test_lp_training_variant(golden, manifest, precision, tol, lp_kernel):
     assert float(enc_diff.max()) <= fmt * (1 + float(sem_in[:, 256:].abs().max())) and float((enc_diff > 0).float().mean()) < 0.02
     assert (rows16[:, :256] - sem_in[:, :256]).abs().max() <= 8 * fmt * (1 + sem_in[:, :256].abs().max())
     hid16 = torch.relu(rows16[:, :W1.shape[1]].double() @ W1.T + b1).float()
+    assert sem_hid16.dim() == 4, "the default kernel stores the hidden activations tile-major"
+    sem_hid16 = ops.sem_hid_rows(sem_hid16, R * 64)
     assert (hid16.to(dt).float() - sem_hid16.float()).abs().max() <= 2 * fmt * (1 + hid16.abs().max())
     W2 = mlp.semantic_linear[2].weight.detach().to(dt).double()
     logits = sem_hid16.double() @ W2.T + mlp.semantic_linear[2].bias.detach().double()
@@ -879,7 +881,8 @@ def test_lp16_ragged_counts_and_agreement_with_lp8(manifest, name, precision, lp
             sv = ops.mlp_forward_rays_save(pk, mlp.sem_mode, o, d, v, z, precision, compact=True)
             assert torch.equal(sv[0], out), "the training variant renders bit-identically to inference"
             rows = ops.sem_in_rows(sv[1], R * S).float()
-            assert bool((rows[:, 319] == 1).all()) and bool((rows[:, :256] >= 0).all()) and bool(torch.isfinite(sv[2].float()).all())
+            hid_rows = ops.sem_hid_rows(sv[2], R * S).float()        # (rows past the last point of the last group are never written)
+            assert bool((rows[:, 319] == 1).all()) and bool((rows[:, :256] >= 0).all()) and bool(torch.isfinite(hid_rows).all()) and bool((hid_rows >= 0).all())
 
 
 # ------------------------------------------------------------------------------------------ K2-LP8 (two waves per SIMD)
