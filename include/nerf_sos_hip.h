@@ -236,11 +236,13 @@ int32_t nsos_sem_head_backward(const float* weights, const float* g_semantics, c
  * above fused into the weight-gradient reductions, on the exact-fp32 MFMA.  Out: gw1_aug [128,320] =
  * [d semantic_linear.0.weight (first in_dim columns) | unused | d semantic_linear.0.bias (column 319)],
  * gw2 [2,128] = d semantic_linear.2.weight, gb2 [2] = d semantic_linear.2.bias.  g_hid / g_logits are never
- * materialised.  workspace: nsos_sem_head_wgrad_workspace_bytes() bytes.  Deterministic (block-ordered reduction). */
+ * materialised.  workspace: nsos_sem_head_wgrad_workspace_bytes() bytes.  Deterministic (block-ordered reduction).
+ * gb1 != NULL (round 4): the first output is written as the CONTIGUOUS [128, in_dim] weight gradient instead (in_dim = 256 or
+ * 319: semantic_linear.0's fan-in) and the bias gradient goes to gb1 [128] -- the tensors autograd takes, without slicing copies. */
 size_t nsos_sem_head_wgrad_workspace_bytes(void);
 int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w, const float* sem_hid,
                             const float* sem_in, int64_t n_rays, int32_t n_samples, float* gw1_aug, float* gw2,
-                            float* gb2, void* workspace, size_t workspace_bytes, void* stream);
+                            float* gb2, void* workspace, size_t workspace_bytes, float* gb1, int32_t in_dim, void* stream);
 /* The same on the 16-bit matrix pipe with split-fp16 operands (fp32 accumulate): HBM-bound instead of MFMA-bound.
  * g_hid = (g_logits @ W_sem2) * mask is brought into fp16 range by a power of two and gw1_aug divided by it again on
  * the way out: `scale` = that power of two as a device scalar, or NULL to have it derived on the device from
@@ -253,7 +255,7 @@ int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, cons
 int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                                const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
                                const float* scale, float* gw1_aug, float* gw2, float* gb2, void* workspace,
-                               size_t workspace_bytes, void* stream);
+                               size_t workspace_bytes, float* gb1, int32_t in_dim, void* stream);
 
 /* ---- K2-LP: the same fused network with 16-bit MFMA inputs and fp32 accumulation (reduced-precision configs) ----
  * For BASELINE configs C3 (bf16) and C5 (fp16, eval-only).  NOT bit/1e-4-comparable with the reference's fp32
@@ -263,6 +265,11 @@ enum { NSOS_DTYPE_F32 = 0, NSOS_DTYPE_F16 = 1, NSOS_DTYPE_BF16 = 2 };
 size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode);
 int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* tensors, int32_t sem_mode, int32_t dtype, void* packed,
                          size_t packed_bytes, void* stream);
+/* Re-pack only what depends on semantic_linear.* (the head's chunks of every stream + the vector-ALU heads' block) into a buffer
+ * that already holds a full nsos_mlp_pack_lp of the same trunk: the shipped recipe trains the semantic heads alone
+ * (run_nerf.py:307-318), so a training step re-packs 3 chunks per stream instead of 37-40.  sem_mode PLAIN / COORD only. */
+int32_t nsos_mlp_pack_lp_heads(const nsos_mlp_tensors* tensors, int32_t sem_mode, int32_t dtype, void* packed,
+                               size_t packed_bytes, void* stream);
 int32_t nsos_mlp_forward_rays_lp(const void* packed, int32_t sem_mode, int32_t dtype, const float* rays_o,
                                  const float* rays_d, const float* viewdirs, const float* z_vals, int64_t n_rays,
                                  int32_t n_samples, float* raw, void* stream);

@@ -67,10 +67,11 @@ SIGNATURES = {
     "nsos_relu_mask": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _fp]),
     "nsos_sem_head_backward": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_sem_head_wgrad_workspace_bytes": (_sz, []),
-    "nsos_sem_head_wgrad": (_i32, [_fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
-    "nsos_sem_head_wgrad_x3": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "nsos_sem_head_wgrad": (_i32, [_fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp, _sz, _fp, _i32, _fp]),
+    "nsos_sem_head_wgrad_x3": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i64, _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp, _i32, _fp]),
     "nsos_mlp_packed_bytes_lp": (_sz, [_i32]),
     "nsos_mlp_pack_lp": (_i32, [C.POINTER(MlpTensors), _i32, _i32, _fp, _sz, _fp]),
+    "nsos_mlp_pack_lp_heads": (_i32, [C.POINTER(MlpTensors), _i32, _i32, _fp, _sz, _fp]),
     "nsos_mlp_forward_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays_save_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
     "nsos_mlp_forward_rays_save16_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),

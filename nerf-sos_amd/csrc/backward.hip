@@ -338,9 +338,12 @@ __global__ __launch_bounds__(256, 1) void sem_head_wgrad_x3_kernel(const float* 
 // 64 outputs x 4 slabs of partials per workgroup, two independent fp64 chains per thread, slabs folded in order through LDS
 // (a single thread walking all the partials of its output was 256 dependent loads: 63 us per call)
 // gw1 is divided by *scale_p (a power of two; nullptr: 1) on the way out
+// gb1 != nullptr: gw1 is written as the contiguous [128, in_dim] weight gradient and the bias gradient (column 319 of the
+// augmented matrix) to gb1 [128] -- what autograd wants, without the two slicing copies per net and step
 __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks,
                                                                     const float* __restrict__ scale_p, float* __restrict__ gw1,
-                                                                    float* __restrict__ gw2, float* __restrict__ gb2) {
+                                                                    float* __restrict__ gw2, float* __restrict__ gb2,
+                                                                    float* __restrict__ gb1, int in_dim) {
     __shared__ double fold[3][64];
     const int el = threadIdx.x & 63, slab = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -361,7 +364,15 @@ __global__ __launch_bounds__(256) void sem_head_wgrad_reduce_kernel(const float*
     s += fold[0][el];
     s += fold[1][el];
     s += fold[2][el];
-    if (e < 128 * 320) gw1[e] = (float)s * (scale_p ? 1.0f / *scale_p : 1.0f);
+    if (e < 128 * 320) {
+        const float v = (float)s * (scale_p ? 1.0f / *scale_p : 1.0f);
+        if (!gb1) gw1[e] = v;
+        else {
+            const int row = e / 320, col = e - 320 * row;
+            if (col < in_dim) gw1[row * in_dim + col] = v;
+            else if (col == 319) gb1[row] = v;
+        }
+    }
     else if (e < 128 * 320 + 256) gw2[e - 128 * 320] = (float)s;
     else gb2[e - 128 * 320 - 256] = (float)s;
 }
@@ -375,8 +386,9 @@ extern "C" size_t nsos_sem_head_wgrad_workspace_bytes(void) { return (size_t)102
 extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_semantics, const float* sem2_w,
                                        const float* sem_hid, const float* sem_in, int64_t n_rays, int32_t n_samples,
                                        float* gw1_aug, float* gw2, float* gb2, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       float* gb1, int32_t in_dim, void* stream) {
     NSOS_REQUIRE(gw1_aug && gw2 && gb2, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!gb1 || (in_dim >= 1 && in_dim <= 319), NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_rays == 0 || (weights && g_semantics && sem2_w && sem_hid && sem_in && workspace), NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(workspace_bytes >= nsos_sem_head_wgrad_workspace_bytes(), NSOS_ERR_BUFFER_TOO_SMALL);
@@ -389,7 +401,7 @@ extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_sema
     hipLaunchKernelGGL(sem_head_wgrad_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, sem_hid, sem_in,
                        n_pts, (int)n_samples, static_cast<float*>(workspace));
     hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,
-                       static_cast<const float*>(workspace), blocks, (const float*)nullptr, gw1_aug, gw2, gb2);
+                       static_cast<const float*>(workspace), blocks, (const float*)nullptr, gw1_aug, gw2, gb2, gb1, (int)in_dim);
     return nsos_launch_status();
 }
 
@@ -430,7 +442,8 @@ __global__ __launch_bounds__(1024) void sem_head_scale_kernel(const float* __res
 extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_semantics, const float* sem2_w,
                                           const void* sem_hid, const void* sem_in, int32_t sem_in_dtype, int64_t n_rays,
                                           int32_t n_samples, const float* scale, float* gw1_aug, float* gw2, float* gb2,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
+                                          void* workspace, size_t workspace_bytes, float* gb1, int32_t in_dim, void* stream) {
+    NSOS_REQUIRE(!gb1 || (in_dim >= 1 && in_dim <= 319), NSOS_ERR_BAD_SHAPE);
     const int32_t tiled = sem_in_dtype & (NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED);
     sem_in_dtype &= ~(NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED);
     NSOS_REQUIRE(sem_in_dtype >= 0 && sem_in_dtype <= 2 && !(tiled && sem_in_dtype == 0), NSOS_ERR_UNSUPPORTED);
@@ -459,6 +472,6 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
         }
     }
     hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,
-                       static_cast<const float*>(workspace), blocks, scale, gw1_aug, gw2, gb2);
+                       static_cast<const float*>(workspace), blocks, scale, gw1_aug, gw2, gb2, gb1, (int)in_dim);
     return nsos_launch_status();
 }

@@ -207,7 +207,7 @@ __host__ __device__ constexpr int lp16_chunks(int sem) {
     return 1 + 28 + 5 + (sem ? 3 : 1) + 3;
 }
 int32_t launch_lp16(const LpParams& p, int32_t sem_mode, bool is_f16, bool save, hipStream_t stream);
-int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned char* chunks, hipStream_t stream);
+int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned char* chunks, hipStream_t stream, bool heads_only = false);
 
 }  // namespace lp
 }  // namespace nsos

@@ -373,6 +373,7 @@ struct LpChunk {
 struct LpPackParams {
     LpChunk ch[40];
     int n_chunks;
+    int first, count;     // the chunks [first, first + count) are written (all of them, or the semantic head's: nsos_mlp_pack_lp_heads)
     const float* alpha_w; const float* alpha_b;
     const float* rgb_w; const float* rgb_b;
     const float* sem2_w; const float* sem2_b;
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams P) {
         P.aux[a] = v;
     }
     const long long per_chunk = kSlotBytes / 2;  // 16-bit elements per slot
-    if (gid >= (long long)P.n_chunks * per_chunk) return;
-    const LpChunk ck = P.ch[gid / per_chunk];
+    if (gid >= (long long)P.count * per_chunk) return;
+    const LpChunk ck = P.ch[P.first + gid / per_chunk];
     const int within = (int)(gid % per_chunk);
     const int g = within >> 9, lane = (within >> 3) & 63, e = within & 7;  // 512 elements per A operand
     const int i = lane & 31, kgl = lane >> 5, m = 8 * kgl + e;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void lp_pack_kernel(const LpPackParams P) {
             else if (f == -2) v = ck.bias[32 * t + i];  // layer-0 bias rides in the encoding's pad slot (input 1.0)
         }
     }
-    P.chunks[gid] = T::bits(v);
+    P.chunks[(long long)P.first * per_chunk + gid] = T::bits(v);
 }
 
 
@@ -468,8 +469,22 @@ extern "C" size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode) {
     return (size_t)kAuxWords * 4 + (2 * (size_t)lp_chunks(sem_mode) + (size_t)lp16_chunks(sem_mode)) * kSlotBytes;
 }
 
+static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed, size_t packed_bytes, void* stream,
+                            bool heads_only);
 extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
                                     size_t packed_bytes, void* stream) {
+    return pack_lp_impl(T_, sem_mode, dtype, packed, packed_bytes, stream, false);
+}
+// Only what depends on semantic_linear.*: the head's chunks of all three streams (chunks 30.. of each: the trunk's 30 chunks come
+// first in every layout) and the aux block.  For the shipped training recipe (--fix_backbone: only the semantic heads train,
+// run_nerf.py:307-318) a step re-packs 3 chunks per stream instead of 37-40.  `packed` must hold a full pack of the same trunk.
+extern "C" int32_t nsos_mlp_pack_lp_heads(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
+                                          size_t packed_bytes, void* stream) {
+    NSOS_REQUIRE(sem_mode == NSOS_SEM_PLAIN || sem_mode == NSOS_SEM_COORD, NSOS_ERR_UNSUPPORTED);
+    return pack_lp_impl(T_, sem_mode, dtype, packed, packed_bytes, stream, true);
+}
+static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed, size_t packed_bytes, void* stream,
+                            bool heads_only) {
     NSOS_REQUIRE(T_ && packed, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(sem_mode >= 0 && sem_mode <= 2 && (dtype == NSOS_DTYPE_F16 || dtype == NSOS_DTYPE_BF16), NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE(packed_bytes >= nsos_mlp_packed_bytes_lp(sem_mode), NSOS_ERR_BUFFER_TOO_SMALL);
@@ -509,13 +524,15 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
         add(T_->views_w, nullptr, W + NSOS_DIR_DIM, W, kDir4, 0, 8);
         NSOS_REQUIRE(n == lp_chunks(sem_mode), NSOS_ERR_UNSUPPORTED);
         P.n_chunks = n;
+        P.first = heads_only ? 30 : 0;                       // L0 (1) + L1-4 (16) + L5 (5) + L6-7 (8) chunks precede the head's
+        P.count = heads_only ? (sem_mode == NSOS_SEM_COORD ? 3 : 2) : n;
         P.alpha_w = T_->alpha_w; P.alpha_b = T_->alpha_b;
         P.rgb_w = T_->rgb_w; P.rgb_b = T_->rgb_b;
         P.sem2_w = sem_mode ? T_->sem2_w : nullptr;
         P.sem2_b = sem_mode ? T_->sem2_b : nullptr;
         P.aux = static_cast<unsigned*>(packed);
         P.chunks = reinterpret_cast<unsigned short*>(P.aux + kAuxWords) + (size_t)layout * n * (kSlotBytes / 2);
-        const long long total = (long long)n * (kSlotBytes / 2);
+        const long long total = (long long)P.count * (kSlotBytes / 2);
         const dim3 grid((unsigned)((total + 255) / 256)), block(256);
         if (dtype == NSOS_DTYPE_F16) hipLaunchKernelGGL(lp_pack_kernel<F16>, grid, block, 0, (hipStream_t)stream, P);
         else hipLaunchKernelGGL(lp_pack_kernel<BF16>, grid, block, 0, (hipStream_t)stream, P);
@@ -523,7 +540,7 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
     const int32_t rc = nsos_launch_status();
     if (rc != NSOS_OK) return rc;
     unsigned char* stream16 = reinterpret_cast<unsigned char*>(static_cast<unsigned*>(packed) + kAuxWords) + 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes;
-    return pack_lp16(T_, sem_mode, dtype == NSOS_DTYPE_F16, stream16, (hipStream_t)stream);
+    return pack_lp16(T_, sem_mode, dtype == NSOS_DTYPE_F16, stream16, (hipStream_t)stream, heads_only);
 }
 
 // which kernel serves the 16-bit path: 3 = mlp_lp16_kernel (round 4: two waves per SIMD on v_mfma_f32_16x16x32; default),

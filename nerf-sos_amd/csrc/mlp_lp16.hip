@@ -931,6 +931,7 @@ struct Chunk16 {
 struct Pack16Params {
     Chunk16 ch[48];
     int n_chunks;
+    int first, count;     // the chunks [first, first + count) are written
     const float* alpha_w; const float* alpha_b;
     const float* rgb_w; const float* rgb_b;
     const float* sem0_w; const float* sem0_b;
@@ -944,8 +945,8 @@ template <class T>
 __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_chunk = kSlotBytes / 2;  // 16-bit elements per slot
-    if (gid >= (long long)P.n_chunks * per_chunk) return;
-    const Chunk16 ck = P.ch[gid / per_chunk];
+    if (gid >= (long long)P.count * per_chunk) return;
+    const Chunk16 ck = P.ch[P.first + gid / per_chunk];
     const int within = (int)(gid % per_chunk);
     const int g = within >> 9, lane = (within >> 3) & 63, e = within & 7;  // 512 elements per group
     const int i = lane & 15, q = lane >> 4;
@@ -1018,11 +1019,12 @@ __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
             if (g < 4) v = i < 3 ? P.rgb_w[i * (W / 2) + hid_col(g, q, e)] : 0.0f;
         } break;
     }
+    const long long at = (long long)P.first * per_chunk + gid;
     if (is_bias) {
         const unsigned u = __builtin_bit_cast(unsigned, v);
-        P.chunks[gid] = (e & 1) ? (unsigned short)(u >> 16) : (unsigned short)(u & 0xffffu);
+        P.chunks[at] = (e & 1) ? (unsigned short)(u >> 16) : (unsigned short)(u & 0xffffu);
     } else {
-        P.chunks[gid] = T::bits(v);
+        P.chunks[at] = T::bits(v);
     }
 }
 
@@ -1031,7 +1033,7 @@ __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
 namespace nsos {
 namespace lp {
 
-int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned char* chunks, hipStream_t stream) {
+int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned char* chunks, hipStream_t stream, bool heads_only) {
     const nsos_mlp_tensors* T_ = static_cast<const nsos_mlp_tensors*>(tensors);
     const int X = NSOS_XYZ_DIM, W = NSOS_NET_WIDTH;
     Pack16Params P = {};
@@ -1060,12 +1062,14 @@ int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned c
     add(nullptr, nullptr, 0, 0, kRgb16, 0, 0);
     if (n != lp16_chunks(sem_mode)) return NSOS_ERR_UNSUPPORTED;
     P.n_chunks = n;
+    P.first = heads_only ? 30 : 0;                // the head's chunks: two slice chunks + the tail (sigma, raw bias, logits)
+    P.count = heads_only ? 3 : n;
     P.alpha_w = T_->alpha_w; P.alpha_b = T_->alpha_b;
     P.rgb_w = T_->rgb_w; P.rgb_b = T_->rgb_b;
     P.sem0_w = sem_mode ? T_->sem0_w : nullptr; P.sem0_b = sem_mode ? T_->sem0_b : nullptr;
     P.sem2_w = sem_mode ? T_->sem2_w : nullptr; P.sem2_b = sem_mode ? T_->sem2_b : nullptr;
     P.chunks = reinterpret_cast<unsigned short*>(chunks);
-    const long long total = (long long)n * (kSlotBytes / 2);
+    const long long total = (long long)P.count * (kSlotBytes / 2);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (is_f16) hipLaunchKernelGGL(lp16_pack_kernel<F16>, grid, block, 0, stream, P);
     else hipLaunchKernelGGL(lp16_pack_kernel<BF16>, grid, block, 0, stream, P);

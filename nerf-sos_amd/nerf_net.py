@@ -126,6 +126,7 @@ class NeRFMLP(nn.Module):
                        sem_layer=sem_layer, sem_dim=sem_dim, sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
         self.fast = self.mlp.fast
         self._gplan = None     # ops.GenericPlan of the current parameter storages (generic architectures)
+        self._frozen_key = {}  # precision -> keys of the frozen (non-head) parameters the packed stream was built from
         self._packed = {}      # precision -> packed stream
         self._packed_key = {}  # precision -> (data_ptr, version) of every parameter when it was packed
         self._plan = None      # ops.PackPlan of the current parameter storages
@@ -161,13 +162,21 @@ class NeRFMLP(nn.Module):
         trainable = any(p.requires_grad for p in params)
         key = None if trainable else tuple((p.data_ptr(), p._version) for p in params)
         if trainable or precision not in self._packed or key != self._packed_key.get(precision):
-            self._packed[precision] = self._plan.run(self._packed.get(precision), precision)
+            # the shipped recipe trains the semantic heads alone (run_nerf.py:307-318): with the 16-bit streams, re-pack only their
+            # chunks while the frozen trunk's (data_ptr, _version) keys stand (3 chunks per stream instead of 37-40 per step and net)
+            heads_only = False
+            if trainable and precision in ("fp16", "bf16") and self.sem_mode != ops.SEM_NONE:
+                frozen = tuple((p.data_ptr(), p._version) for n, p in named if "semantic_linear" not in n)
+                only_heads = all(("semantic_linear" in n) or not p.requires_grad for n, p in named)
+                heads_only = only_heads and precision in self._packed and self._frozen_key.get(precision) == frozen
+                self._frozen_key[precision] = frozen if only_heads else None
+            self._packed[precision] = self._plan.run(self._packed.get(precision), precision, heads_only=heads_only)
             self._packed_key[precision] = key
         return self._packed[precision]
 
     def __getstate__(self):  # copy.deepcopy / pickling: the plan holds raw device pointers, the streams are derived data
         state = self.__dict__.copy()
-        state["_plan"], state["_packed"], state["_packed_key"], state["_gplan"] = None, {}, {}, None
+        state["_plan"], state["_packed"], state["_packed_key"], state["_gplan"], state["_frozen_key"] = None, {}, {}, None, {}
         return state
 
     def invalidate_packed(self) -> None:
@@ -175,6 +184,7 @@ class NeRFMLP(nn.Module):
         data_ptr nor _version).  Trainable nets never need it."""
         self._packed.clear()
         self._packed_key.clear()
+        self._frozen_key.clear()
         self._plan = self._gplan = None
 
     def query_rays(self, rays_o, rays_d, viewdirs, z_vals):
@@ -256,11 +266,11 @@ class _FrozenBackboneRender(torch.autograd.Function):
                 grads += [None] * 4
                 continue
             w2 = mlp.mlp.semantic_linear[2].weight.detach()
-            gw1_aug, gw2, gb2 = ops.sem_head_wgrad(sv["weights"], gs.reshape(-1, 2).contiguous(), w2, sv["sem_hid"],
-                                                   sv["sem_in"],           # [128,320] = [dW1 | (pad) | db1]
-                                                   split_fp16=net.mlp_precision != "fp32")   # exact MFMA only on the exact path
             in_dim = mlp.mlp.semantic_linear[0].weight.shape[1]
-            grads += [gw1_aug[:, :in_dim].contiguous(), gw1_aug[:, 319].contiguous(), gw2, gb2]
+            gw1, gb1, gw2, gb2 = ops.sem_head_wgrad(sv["weights"], gs.reshape(-1, 2).contiguous(), w2, sv["sem_hid"],
+                                                    sv["sem_in"], split_fp16=net.mlp_precision != "fp32",   # exact MFMA only on the exact path
+                                                    in_dim=in_dim)     # dW1 / db1 as their own contiguous tensors: no slicing copies
+            grads += [gw1, gb1, gw2, gb2]
         ctx.saved = None   # release the saved operands now: the node itself lives as long as the caller keeps the loss
         return (None, None, None) + tuple(grads)
 

@@ -167,7 +167,9 @@ class PackPlan:
         self.ptrs = tuple(t.data_ptr() for t in keep)
         self.nbytes = {}
 
-    def run(self, out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
+    def run(self, out: Optional[torch.Tensor] = None, precision: str = "fp32", heads_only: bool = False) -> torch.Tensor:
+        """Pack into `out` (allocated if None / too small).  heads_only (fp16 / bf16 with a semantic head): `out` already holds a
+        full pack of the same trunk -- re-pack only what depends on semantic_linear.* (nsos_mlp_pack_lp_heads)."""
         if precision not in DTYPES:
             raise ValueError(f"precision must be one of {list(DTYPES)}, got {precision!r}")
         nbytes = self.nbytes.get(precision)
@@ -182,6 +184,8 @@ class PackPlan:
             _lib.check(L.nsos_mlp_pack_x3(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_pack_x3")
         elif precision == "fp16x3_bwd":
             _lib.check(L.nsos_mlp_bwd_pack_x3(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_bwd_pack_x3")
+        elif heads_only and self.sem_mode != SEM_NONE:
+            _lib.check(L.nsos_mlp_pack_lp_heads(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp_heads")
         else:
             _lib.check(L.nsos_mlp_pack_lp(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp")
         return out
@@ -428,9 +432,10 @@ _WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
 
 
 def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: torch.Tensor, sem_hid: torch.Tensor,
-                   sem_in: torch.Tensor, split_fp16: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                   sem_in: torch.Tensor, split_fp16: bool = False, in_dim: Optional[int] = None):
     """Backward of the semantic head in one pass (nsos_sem_head_wgrad): returns
-    (gw1_aug [128,320] = [dW1 | . | db1 in column 319], dW2 [2,128], db2 [2]).
+    (gw1_aug [128,320] = [dW1 | . | db1 in column 319], dW2 [2,128], db2 [2]) -- or, with `in_dim` (semantic_linear.0's fan-in:
+    256 or 319), (dW1 [128,in_dim], db1 [128], dW2, db2) as contiguous tensors straight from the reduction.
     split_fp16: the big reduction on the 16-bit matrix pipe with split operands (nsos_sem_head_wgrad_x3; needs S >= 8 and
     fewer than 2^31 points, else the exact kernel runs)."""
     weights, g_semantics = _dev(weights, "weights"), _dev(g_semantics, "g_semantics")
@@ -455,9 +460,11 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
     if dev not in _WGRAD_WS:
         _WGRAD_WS[dev] = torch.empty(_lib.lib().nsos_sem_head_wgrad_workspace_bytes() // 4, device=dev, dtype=torch.float32)
     ws = _WGRAD_WS[dev]
-    gw1 = torch.empty((128, 320), device=dev, dtype=torch.float32)
+    gw1 = torch.empty((128, 320 if in_dim is None else int(in_dim)), device=dev, dtype=torch.float32)
+    gb1 = None if in_dim is None else torch.empty((128,), device=dev, dtype=torch.float32)
     gw2 = torch.empty((2, 128), device=dev, dtype=torch.float32)
     gb2 = torch.empty((2,), device=dev, dtype=torch.float32)
+    out = (gw1, gw2, gb2) if in_dim is None else (gw1, gb1, gw2, gb2)
     use_split = split_fp16 and S >= 8 and R * S < 2 ** 31
     if not use_split and x_dtype != 0:
         sem_in, x_dtype, tiled = sem_in_rows(sem_in, R * S).float(), 0, False          # the exact kernel reads fp32 rows
@@ -470,13 +477,14 @@ def sem_head_wgrad(weights: torch.Tensor, g_semantics: torch.Tensor, sem2_w: tor
         _lib.check(_lib.lib().nsos_sem_head_wgrad_x3(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in),
                                                      x_dtype | (SEM_IN_TILED if tiled else 0) | (SEM_HID_TILED if htiled else 0),
                                                      R, S, None, _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
-                                                     _stream()),
+                                                     _p(gb1), 0 if in_dim is None else int(in_dim), _stream()),
                    "nsos_sem_head_wgrad_x3")
-        return gw1, gw2, gb2
+        return out
     _lib.check(_lib.lib().nsos_sem_head_wgrad(_p(weights), _p(g_semantics), _p(sem2_w), _p(sem_hid), _p(sem_in), R, S,
-                                              _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4, _stream()),
+                                              _p(gw1), _p(gw2), _p(gb2), _p(ws), ws.numel() * 4,
+                                              _p(gb1), 0 if in_dim is None else int(in_dim), _stream()),
                "nsos_sem_head_wgrad")
-    return gw1, gw2, gb2
+    return out
 
 
 def mlp_forward_points(packed: torch.Tensor, sem_mode: int, pts: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:

@@ -171,10 +171,10 @@ def test_split_fp16_entry_points_validate_without_a_gpu():
     assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, None, 0, p, p, None) == 0
     assert lib.nsos_mlp_input_grads_x3(p, 0, p, p, None, 5, None, p, None) == -1
     assert lib.nsos_mlp_bwd_pack_x3(None, 0, p, 1 << 30, None) == -1
-    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 0, 4, 4, p, p, p, p, p, 1 << 30, None) == -3     # fewer than 8 samples per ray
-    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, None, 0, 4, 64, None, p, p, p, p, 1 << 30, None) == -1   # sem_in NULL (scale may be)
-    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 0, 4, 64, None, p, p, p, p, 1 << 20, None) == -4      # workspace too small
-    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 3, 4, 64, p, p, p, p, p, 1 << 30, None) == -3      # unknown sem_in dtype
+    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 0, 4, 4, p, p, p, p, p, 1 << 30, None, 0, None) == -3     # fewer than 8 samples per ray
+    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, None, 0, 4, 64, None, p, p, p, p, 1 << 30, None, 0, None) == -1   # sem_in NULL (scale may be)
+    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 0, 4, 64, None, p, p, p, p, 1 << 20, None, 0, None) == -4      # workspace too small
+    assert lib.nsos_sem_head_wgrad_x3(p, p, p, p, p, 3, 4, 64, p, p, p, p, p, 1 << 30, None, 0, None) == -3      # unknown sem_in dtype
     assert lib.nsos_mlp_forward_rays_save16_lp(p, 2, 2, p, p, p, p, 4, 64, p, None, p, None) == -1       # sem_in16 NULL
     assert lib.nsos_wgrad_x3(p, 256, p, 256, 64, None, 256, None, p, 1 << 30, None) == -1          # dW NULL
     assert lib.nsos_wgrad_x3(p, 255, p, 256, 64, p, 256, None, p, 1 << 30, None) == -2             # row stride < 256

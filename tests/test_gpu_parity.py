@@ -847,6 +847,37 @@ def test_phase_profile_entries_stamp_monotonically_and_leave_results_alone(manif
     assert (seq[1:] >= seq[:-1]).all()
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", ["sem", "semcoord"])
+def test_heads_only_repack_equals_a_full_pack(manifest, name, precision):
+    """nsos_mlp_pack_lp_heads (what a frozen-backbone training step re-packs: the semantic head's chunks of every stream + the
+    vector-ALU heads' block) into a buffer holding a full pack of OLD head weights == a fresh full pack of the new ones, byte for
+    byte -- and NeRFMLP.packed_weights takes that path exactly when only semantic_linear.* is trainable."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS[name]).to(DEV)
+    net.load_state_dict(ref_state(name, manifest, peaky=True))
+    mlp = net.nerf_fine
+    params = dict(mlp.mlp.named_parameters())
+    plan = ops.PackPlan({k: v for k, v in params.items()}, mlp.sem_mode)
+    old = plan.run(None, precision).clone()
+    with torch.no_grad():
+        for k, v in params.items():
+            if "semantic_linear" in k:
+                v.add_(torch.randn_like(v) * 0.05)
+    fresh = plan.run(None, precision)
+    part = plan.run(old, precision, heads_only=True)
+    assert part.data_ptr() == old.data_ptr()
+    assert torch.equal(part.view(torch.int32), fresh.view(torch.int32)), "heads-only re-pack != full pack"
+    # the module: frozen trunk, trainable heads -> first call full, later calls heads-only; results follow in-place updates
+    for n_, p_ in net.named_parameters():
+        p_.requires_grad = "semantic_linear" in n_
+    a = mlp.packed_weights(precision).clone()
+    with torch.no_grad():
+        params["semantic_linear.2.bias"].add_(1.0)
+    b = mlp.packed_weights(precision)
+    assert not torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.equal(b.view(torch.int32), plan.run(None, precision).view(torch.int32))
+
+
 # ------------------------------------------------------------------------------------------ K2-LP16 (16x16x32 tiles; the default)
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 @pytest.mark.parametrize("name", ["nosem", "sem", "semcoord"])

@@ -133,8 +133,11 @@ class _FakePlan:
     def __init__(self, params, sem_mode):
         self.ptrs = tuple(p.data_ptr() for p in params.values())
 
-    def run(self, out, precision):
+    heads = 0
+
+    def run(self, out, precision, heads_only=False):
         _FakePlan.runs += 1
+        _FakePlan.heads += int(heads_only)
         return torch.zeros(1) if out is None else out
 
 
@@ -166,6 +169,20 @@ def test_packed_weights_policy(monkeypatch):
     assert clone._plan is None and clone._packed == {}
     clone.packed_weights()
     assert _FakePlan.runs == 6
+    # the shipped recipe (only semantic_linear.* trainable), 16-bit streams: a full pack first, then the heads' chunks only --
+    # until a frozen parameter changes
+    _FakePlan.runs = _FakePlan.heads = 0
+    sem = nerf_sos_amd.NeRFMLP(use_semantics=True, sem_with_coord=True)
+    for n, p in sem.mlp.named_parameters():
+        p.requires_grad_("semantic_linear" in n)
+    sem.packed_weights("bf16"); sem.packed_weights("bf16"); sem.packed_weights("bf16")
+    assert (_FakePlan.runs, _FakePlan.heads) == (3, 2)
+    with torch.no_grad():
+        sem.mlp.pts_linears[0].weight.mul_(2.0)
+    sem.packed_weights("bf16"); sem.packed_weights("bf16")
+    assert (_FakePlan.runs, _FakePlan.heads) == (5, 3)
+    sem.packed_weights("fp32")                                   # the fp32 stream has no partial pack
+    assert (_FakePlan.runs, _FakePlan.heads) == (6, 3)
 
 
 def test_fused_adam_does_not_bump_versions():
