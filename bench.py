@@ -149,6 +149,19 @@ def cpu_baseline(gpu=None, n_rays: int = 4096, dense=None):
     res["train_fwd_bwd"] = dict(train, cores=best_threads, sample=f"{n_tr} rays of the same batch, train mode (perturb=1, raw_noise_std=1), "
                                 "MSE on rgb + rgb0, every parameter trainable; the reference turns autograd anomaly mode on process-wide "
                                 "(models/sampler.py:2)")
+    # the per-GPU workload of configs[3] (8192 rays), eval forward: 1 warm-up + 2 timed
+    rays8k = tp.synthetic_rays(8192, seed=1)
+    torch.set_num_threads(best_threads)
+    ts = []
+    with torch.no_grad():
+        for k in range(3):
+            t0 = time.perf_counter()
+            tp.render(sd, cfg, rays8k, (tp.NEAR, tp.FAR), retraw=True)
+            if k >= 1:
+                ts.append(time.perf_counter() - t0)
+    res["eval_8192_rays"] = {"value": round(8192 / min(ts), 1), "unit": "rays/s", "cores": best_threads, "runs": len(ts), "warmups": 1,
+                             "sample": "8192 rays (the per-GPU batch of BASELINE configs[3]) of the same camera, same weights, eval-mode forward"}
+    res["frozen_recipe_train_step"] = cpu_frozen_recipe_step(tp, best_threads)
     res["cpu_seconds_spent"] = round(time.perf_counter() - t_all, 1)
     parity = None
     if gpu is not None:
@@ -165,6 +178,52 @@ def cpu_baseline(gpu=None, n_rays: int = 4096, dense=None):
                                                   what="seed-0 weights, sigma head x gain + shift (bench.make_dense_field)")
             parity["psnr_db"] = parity["dense_field"]["psnr_db"]
     return res, parity
+
+
+def cpu_frozen_recipe_step(tp, threads: int):
+    """The training step BASELINE configs[2] names, on the CPU port: one 64x64 patch (stride 6) = 4096 rays through the sem+coord
+    net in train mode (the reference's four random tensors), appearance + 0.01 x geometric correlation losses on semantics0 and
+    semantics (oracle/losses_port.py), backward with only the semantic head trainable (run_nerf.py:307-318, --fix_backbone),
+    Adam.  1 warm-up + 2 timed steps; autograd anomaly mode OFF (the kinder of the two settings the full-backward timing shows)."""
+    import torch
+    from oracle import losses_port as lp
+    torch.set_num_threads(threads)
+    cfg = tp.PortConfig(n_samples=N_COARSE, n_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True, ray_chunk=1 << 20, pts_chunk=1024 * 256)
+    sd = tp.init_state_dict(cfg, seed=0)
+    params = {k: v.clone().requires_grad_("semantic_linear" in k) for k, v in sd.items()}
+    opt = torch.optim.Adam([p_ for p_ in params.values() if p_.requires_grad], lr=5e-4)
+    H, W, focal = 756, 1008, 850.0
+    ar = torch.arange(PATCH, dtype=torch.float32) * PATCH_STRIDE
+    jj, ii = torch.meshgrid(100.0 + ar, 200.0 + ar, indexing="ij")
+    d = torch.stack([(ii - W * 0.5) / focal, -(jj - H * 0.5) / focal, -torch.ones_like(ii)], -1)[None]     # [1, P, P, 3]
+    rays = torch.stack([torch.zeros_like(d), d], 0)
+    n = PATCH * PATCH
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(1, 384, 14, 14, generator=g)
+    neg = torch.zeros(1, dtype=torch.long)                       # one patch: its own negative (argmin of a 1x1 similarity matrix)
+    pa = lp.CorrParams(self_shift=0.18, self_weight=1.0, neg_shift=0.46, neg_weight=1.0)
+    pg = lp.CorrParams(self_shift=0.5, self_weight=1.0, neg_shift=3.0, neg_weight=1.0)
+    ts, loss = [], None
+    for k in range(3):
+        draws = [tp.Draws(t_rand=torch.rand((n, N_COARSE), generator=g), noise0=torch.randn((n, N_COARSE), generator=g),
+                          u=torch.rand((n, N_IMPORTANCE), generator=g), noise1=torch.randn((n, N_FINE), generator=g))]
+        c = [torch.rand([1, 11, 11, 2], generator=g) * 2 - 1 for _ in range(4)]
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        ret = tp.render(params, cfg, rays, (tp.NEAR, tp.FAR), raw_noise_std=1.0, draws_per_chunk=draws, retraw=False)
+        s0, s1 = ret["semantics0"].permute(0, 3, 1, 2), ret["semantics"].permute(0, 3, 1, 2)
+        depth = ret["depth"].detach().reshape(1, PATCH, PATCH, 1).permute(0, 3, 1, 2).contiguous()
+        ro, rd = rays[0].permute(0, 3, 1, 2), rays[1].permute(0, 3, 1, 2)
+        loss = lp.correlation_loss(feat, s0, neg, c[0], c[1], pa) + lp.correlation_loss(feat, s1, neg, c[2], c[3], pa)
+        loss = loss + 0.01 * (lp.geo_correlation_loss(depth.clone(), s0, ro, rd, neg, pg) + lp.geo_correlation_loss(depth.clone(), s1, ro, rd, neg, pg))
+        loss.backward()
+        opt.step()
+        if k >= 1:
+            ts.append(time.perf_counter() - t0)
+    return {"value": round(n / min(ts), 1), "unit": "rays/s", "ms_per_step": round(1e3 * min(ts), 1), "cores": threads, "runs": len(ts), "warmups": 1,
+            "loss": round(float(loss.detach()), 6),
+            "sample": "BASELINE configs[2]'s step on the port: one 64x64 patch = 4096 rays, sem+coord net, train mode, appearance + 0.01 x geometric "
+                      "correlation losses, backward into the semantic head only (--fix_backbone), Adam; anomaly mode off"}
 
 
 def make_dense_field(net, rays, bounds, gain: float = 40.0):
@@ -303,20 +362,20 @@ def gpu_bisect_indices(torch, out, rays, n_coarse, n_importance, near, far):
 KERNEL_SOURCES = {   # traffic.json key -> the files whose content decides the dominant kernel's memory traffic
     "c2_fp32": ("mlp_fused.hip", "mlp_common.h"),
     "c2_fp16x3": ("mlp_x3.hip", "x3_common.h", "mlp_common.h"),
-    "lp8": ("mlp_lp8.hip", "lp_common.h", "mlp_common.h"),
+    "lp16": ("mlp_lp16.hip", "lp_common.h", "mlp_common.h"),
 }
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "traffic.json")
 
 
 def kernel_source_hash(key: str = "c2_fp32") -> str:
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES.get(key, KERNEL_SOURCES["lp8"]):
+    for f in KERNEL_SOURCES.get(key, KERNEL_SOURCES["lp16"]):
         h.update(open(os.path.join(ROOT, "nerf-sos_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def add_traffic(roof, key: str):
-    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r03/traffic.json: FETCH_SIZE
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r04/traffic.json: FETCH_SIZE
     and WRITE_SIZE collected in separate rocprofv3 --pmc runs and corrected as MI355X_MICROARCH.md prescribes), reported only
     while the kernel's sources still hash to the build the passes were measured on."""
     if roof is None or not os.path.exists(TRAFFIC_JSON):
@@ -329,10 +388,10 @@ def add_traffic(roof, key: str):
         roof["traffic_detail"] = {"fetch_size_kb": t["fetch_size_kb"], "write_size_kb": t["write_size_kb"],
                                   "algorithmic_bytes_per_launch_without_weights": t["algorithmic_bytes_per_launch_without_weights"],
                                   "ratio_to_algorithmic": t["ratio"], "scratch_bytes": t.get("scratch_bytes"),
-                                  "source": "profiles/r03/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                  "source": "profiles/r04/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                             "2 x FETCH_SIZE + WRITE_SIZE)"}
     else:
-        roof["traffic_note"] = "profiles/r03/traffic.json was measured on a different build of this kernel: not reported"
+        roof["traffic_note"] = "profiles/r04/traffic.json was measured on a different build of this kernel: not reported"
     return roof
 
 
@@ -481,6 +540,14 @@ def lp_kernel_clock_ghz(torch, dev, precision: str, R: int):
     return _LP_CLOCK[(precision, R)]
 
 
+def lp_kernel_name() -> str:
+    """The 16-bit MLP kernel the library dispatches to (NSOS_LP_KERNEL / nsos_mlp_lp_select_kernel; default: mlp_lp16_kernel)."""
+    k = os.environ.get("NSOS_LP_KERNEL", "")
+    if os.environ.get("NSOS_LP_WAVES", "") == "4" or k == "lp4":
+        return "mlp_lp_kernel"
+    return "mlp_lp8_kernel" if k == "lp8" else "mlp_lp16_kernel"
+
+
 def add_power_note(roof, precision, ctx=None, rays=4096):
     if roof and precision in MEASURED_PIPE_CEILING_TFLOPS:
         c = MEASURED_PIPE_CEILING_TFLOPS[precision]
@@ -500,6 +567,22 @@ def add_power_note(roof, precision, ctx=None, rays=4096):
     return roof
 
 
+def timed_blocks(ctx, step, warmup: int, steps: int, blocks: int):
+    """`blocks` timed regions of `steps` steps each (the variants' protocol: the power-limited 16-bit paths move by a few per
+    cent from block to block, one block of 2-20 steps is thin for three digits): returns the MEDIAN block's (dt, per_rank), the
+    kernel events of all blocks, and the per-block ms per step."""
+    runs, events = [], []
+    for b in range(blocks):
+        dt, per_rank, ev = timed(ctx, step, warmup if b == 0 else 0, steps)
+        runs.append((dt, per_rank))
+        events += ev
+    order = sorted(range(blocks), key=lambda i: runs[i][0])
+    dt, per_rank = runs[order[blocks // 2]]
+    ms = sorted(round(1e3 * r[0] / steps, 4) for r in runs)
+    return dt, per_rank, events, {"blocks": blocks, "steps_per_block": steps, "ms_per_step_min": ms[0], "ms_per_step_median": ms[blocks // 2],
+                                  "ms_per_step_max": ms[-1], "reported": "median block"}
+
+
 def speed_fields(ctx, rays_per_rank_step: int, steps: int, dt: float, per_rank):
     rates = [rays_per_rank_step * steps / t for t in per_rank]
     return {"value": round(ctx.world * rays_per_rank_step * steps / dt, 1), "unit": "rays/s",
@@ -509,7 +592,7 @@ def speed_fields(ctx, rays_per_rank_step: int, steps: int, dt: float, per_rank):
 
 
 # ------------------------------------------------------------------------------------------------------------------ c2
-def run_c2(ctx, args, precision="fp32", steps=None, warmup=None):
+def run_c2(ctx, args, precision="fp32", steps=None, warmup=None, blocks=1):
     import nerf_sos_amd
     from nerf_sos_amd import synthetic as syn
     torch = ctx.torch
@@ -525,10 +608,12 @@ def run_c2(ctx, args, precision="fp32", steps=None, warmup=None):
         with torch.no_grad():
             out["ret"] = net(rays, (syn.NEAR, syn.FAR))
 
-    dt, per_rank, events = timed(ctx, step, args.warmup if warmup is None else warmup, args.steps if steps is None else steps)
-    assert out["ret"]["rgb"].shape == (n_rays, 3)
     k = steps or args.steps
+    dt, per_rank, events, blk = timed_blocks(ctx, step, args.warmup if warmup is None else warmup, k, blocks)
+    assert out["ret"]["rgb"].shape == (n_rays, 3)
     res = speed_fields(ctx, n_rays, k, dt, per_rank)
+    if blocks > 1:
+        res["timing_blocks"] = blk
     flop_per_ray = 2 * MAC_NOSEM * EVALS_PER_RAY
     if precision == "fp32":
         roof = kernel_roofline(events, n_rays * N_FINE, MAC_NOSEM, PEAK_FP32_MFMA_TFLOPS,
@@ -544,6 +629,61 @@ def run_c2(ctx, args, precision="fp32", steps=None, warmup=None):
     return res
 
 
+# ------------------------------------------------------------------------------------------------------------------ c1
+def run_c1(ctx, args):
+    """BASELINE configs[0]: the reference's own CPU-runnable case at its shape -- 1024 rays x 64 samples, coarse-only (N_importance
+    = 0), no semantic head, eval-mode forward, fp32 -- on the GPU path; main() times the CPU port at the same shape beside it."""
+    import nerf_sos_amd
+    from nerf_sos_amd import synthetic as syn
+    torch = ctx.torch
+    n_rays = 1024
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=0, use_semantics=False, perturb=1.0, raw_noise_std=1.0).to(ctx.dev).eval()
+    rays = syn.synthetic_rays(n_rays, seed=ctx.rank, device=ctx.dev)
+    out = {}
+
+    def step(i):
+        with torch.no_grad():
+            out["ret"] = net(rays, (syn.NEAR, syn.FAR))
+
+    dt, per_rank, events = timed(ctx, step, args.warmup, args.steps)
+    assert out["ret"]["rgb"].shape == (n_rays, 3) and "rgb0" not in out["ret"]
+    res = speed_fields(ctx, n_rays, args.steps, dt, per_rank)
+    roof = kernel_roofline(events, n_rays * N_COARSE, MAC_NOSEM, PEAK_FP32_MFMA_TFLOPS, "mlp_fused_kernel<0,true> (the only pass: 65536 points = 512 tiles on 256 CUs)")
+    if roof:
+        roof["whole_path_frac"] = round(res["value"] / ctx.world * 2 * MAC_NOSEM * N_COARSE / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+    res.update(roofline=roof, flop_per_ray=2 * MAC_NOSEM * N_COARSE, rays_per_gpu=n_rays, out=out["ret"], net=net, rays=rays)
+    return res
+
+
+def cpu_baseline_c1(gpu):
+    """The CPU port at BASELINE configs[0]'s own shape (1024 rays x 64 samples, coarse-only): 2 warm-ups, best of 5 at the thread
+    count where torch's CPU kernels peak; the GPU render of the same rays / weights compared key by key."""
+    import torch
+    from oracle import torch_port as tp            # test infrastructure: the CPU baseline / checker, never the product path
+    ncpu, phys = os.cpu_count() or 1, physical_cores()
+    cfg = tp.PortConfig(n_samples=N_COARSE, n_importance=0, use_semantics=False, pts_chunk=1024 * 256)
+    sd = {k: v.detach().cpu() for k, v in gpu[0].items()}
+    rays = gpu[1].detach().cpu()
+    threads = min(32, ncpu)
+    torch.set_num_threads(threads)
+    times = []
+    with torch.no_grad():
+        for k in range(7):
+            t0 = time.perf_counter()
+            ref = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR), retraw=True)
+            if k >= 2:
+                times.append(time.perf_counter() - t0)
+    n = rays.shape[1]
+    res = {"value": round(n / min(times), 1), "unit": "rays/s", "cores": threads, "kind": "port", "physical_cores": phys, "logical_cpus": ncpu,
+           "runs": len(times), "warmups": 2, "median_rays_per_s": round(n / sorted(times)[len(times) // 2], 1),
+           "sample": f"the full {n}-ray batch of BASELINE configs[0] (1024 rays x 64 samples, coarse-only; same rays and weights as the GPU step), "
+                     f"eval-mode forward, fp32, best of {len(times)} after 2 warm-ups at {threads} threads, torch {torch.__version__} CPU ops"}
+    par = render_parity(gpu[2], ref)
+    par["vs"] = "oracle/torch_port.py on the host (bit-identical to the reference on CPU), same rays, same weights"
+    return res, par
+
+
 # ------------------------------------------------------------------------------------------------------------- c3 / c4
 def _loss_args():
     import types
@@ -552,7 +692,7 @@ def _loss_args():
                                  app_corr_params=["0.18", "1", "0.46", "1"], geo_corr_params=["0.5", "1", "3", "1"])
 
 
-def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: int, warmup: int):
+def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: int, warmup: int, blocks: int = 1):
     """c3 (1 patch, 1 GPU) and c4 (2 patches per GPU, sharded): frozen-backbone training step on 64x64 patches."""
     import nerf_sos_amd
     from nerf_sos_amd import sharding, synthetic as syn
@@ -596,12 +736,14 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
         step(i)
     state["timed"] = True
     sharding.reset_collective_counts()
-    dt, per_rank, events = timed(ctx, step, 0, steps)
-    per_step = {k: round(v / steps, 3) for k, v in sorted(sharding.reset_collective_counts().items())}
+    dt, per_rank, events, blk = timed_blocks(ctx, step, 0, steps, blocks)
+    per_step = {k: round(v / (steps * blocks), 3) for k, v in sorted(sharding.reset_collective_counts().items())}
     n_rays = len(own) * PATCH * PATCH
     res = speed_fields(ctx, n_rays, steps, dt, per_rank)
+    if blocks > 1:
+        res["timing_blocks"] = blk
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
-    kname = {"fp32": "mlp_fused_kernel<2,true,1>", "fp16x3": "mlp_x3_kernel<2,1>"}.get(precision, f"mlp_lp8_kernel<{precision},2,SAVE>")
+    kname = {"fp32": "mlp_fused_kernel<2,true,1>", "fp16x3": "mlp_x3_kernel<2,1>"}.get(precision, f"{lp_kernel_name()}<{precision},2,SAVE>")
     roof = add_power_note(kernel_roofline(events, n_rays * N_FINE, MAC_SEMCOORD, peak, f"{kname} (fine pass of the rank's {n_rays} rays, {n_rays * N_FINE} points)"), precision, ctx, n_rays)
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
@@ -650,7 +792,7 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
 
 
 # ------------------------------------------------------------------------------------------------------------------ c5
-def run_c5(ctx, args, precision: str, steps: int, warmup: int):
+def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1):
     """Full-image eval: every rank renders its contiguous block of the 762 048 rays in 65 536-ray chunks (rays generated
     on device from the pose, `raw` never materialised) and post-processes its rows on device."""
     import nerf_sos_amd
@@ -671,15 +813,17 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int):
             state["post"] = ops.eval_postprocess(semantics=ret["semantics"])
             state["rgb"] = ret["rgb"]
 
-    dt, per_rank, events = timed(ctx, step, warmup, steps)
+    dt, per_rank, events, blk = timed_blocks(ctx, step, warmup, steps, blocks)
     n_rays = e - s
     res = speed_fields(ctx, n_rays, steps, dt, per_rank)
+    if blocks > 1:
+        res["timing_blocks"] = blk
     # the total over ranks is the image, not world x the first rank's block
     res["value"] = round(syn.H * syn.W * steps / dt, 1)
     peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
     full_chunk = min(chunk, n_rays)
     roof = add_power_note(kernel_roofline(events, full_chunk * N_FINE, MAC_SEMCOORD, peak,
-                                          f"mlp_lp8_kernel<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)"), precision, ctx, full_chunk)
+                                          f"{lp_kernel_name()}<{precision},2> (fine pass of a {full_chunk}-ray chunk, {full_chunk * N_FINE} points)"), precision, ctx, full_chunk)
     flop_per_ray = 2 * MAC_SEMCOORD * EVALS_PER_RAY
     if roof:
         roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
@@ -717,8 +861,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2",
-                    help="BASELINE.json configs[1..4]; c2 is the headline the metric is quoted on")
+    ap.add_argument("--config", choices=("c1", "c2", "c3", "c4", "c5"), default="c2",
+                    help="BASELINE.json configs[0..4]; c2 is the headline the metric is quoted on")
     ap.add_argument("--precision", choices=("fp32", "fp16x3", "bf16", "fp16"), default=None,
                     help="MLP arithmetic; default: fp32 for c2 (the reference's), bf16 for c3/c4, fp16 for c5 (BASELINE's dtypes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -729,14 +873,25 @@ def main():
     ctx = Ctx(args)
     torch = ctx.torch
     seen = ctx.ranks_seen()
-    prec = args.precision or {"c2": "fp32", "c3": "bf16", "c4": "bf16", "c5": "fp16"}[args.config]
+    prec = args.precision or {"c1": "fp32", "c2": "fp32", "c3": "bf16", "c4": "bf16", "c5": "fp16"}[args.config]
     dist_info = {"backend": ctx.backend, "ranks_seen_by_collective": seen}
 
     line = {"metric": "rays/sec (coarse+fine, 64+128 samples)", "unit": "rays/s", "n_gpus": ctx.world, "steps": args.steps,
             "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     variants = {}
 
-    if args.config == "c2":
+    if args.config == "c1":
+        if prec != "fp32":
+            raise SystemExit("bench.py: c1 is the reference's own fp32 CPU case: --precision fp32")
+        res = run_c1(ctx, args)
+        line.update({k: res[k] for k in ("value", "ms_per_step", "host_enqueue_ms_per_step", "per_rank_rays_per_s")})
+        line["metric"] = "rays/sec (coarse only, 64 samples)"
+        line["dtype"] = "f32"
+        line["config"] = {"workload": "BASELINE configs[0]: LLFF flower shape, 1024 rays/GPU x 64 samples, coarse-only MLP (N_importance = 0), eval-mode "
+                                      "NeRFNet.forward, fp32 exact-MFMA, no semantic head, random-init weights (seed 0), pinhole rays 1008x756 f=850",
+                          "rays_per_gpu": res["rays_per_gpu"], "parallelism": f"ray-sharded x{ctx.world}, no collective in the path", "flop_per_ray": res["flop_per_ray"]}
+        line["roofline"] = res["roofline"]
+    elif args.config == "c2":
         if prec not in ("fp32", "fp16x3"):
             raise SystemExit("bench.py: c2 is the fp32 configuration: --precision fp32 (exact) or fp16x3 (split-fp16, fp32-grade)")
         res = run_c2(ctx, args, prec)
@@ -755,23 +910,23 @@ def main():
             vsteps = max(3, min(args.steps, 20))      # the variants ride along briefly, outside the headline's timed region
             if ctx.world == 1 and prec == "fp32":
                 exact_c = res["out"]["rgb0"]
-                alt = run_c2(ctx, args, "fp16x3", steps=vsteps, warmup=3)
+                alt = run_c2(ctx, args, "fp16x3", steps=vsteps, warmup=3, blocks=5)
                 v = _strip(alt)
                 v["what"] = "the c2 step with the MLP on the 16-bit matrix pipe, split-fp16 operands (3 MFMAs per product, fp32 accumulate)"
                 v["max_abs_rgb0_vs_exact_fp32"] = float((alt["out"]["rgb0"] - exact_c).abs().max())
                 v["parity"] = "same tests and bars as the exact kernel (2e-5 vs the reference goldens)"
                 add_traffic(v.get("roofline"), "c2_fp16x3")
                 variants["c2_fp16x3"] = v
-                v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 6))
+                v = _strip(run_patch_training(ctx, args, 1, "bf16", vsteps, 6, blocks=5))
                 v["what"] = "BASELINE configs[2]: one 64x64 patch = 4096 rays, sem+coord head, bf16 MFMA: train-mode render + appearance & geometric correlation losses + semantic-head backward + Adam"
                 add_traffic(v.get("roofline"), "c3_bf16")
                 variants["c3_bf16"] = v
-            v = _strip(run_c5(ctx, args, "fp16", 2 if ctx.world == 1 else 4, 1))
+            v = _strip(run_c5(ctx, args, "fp16", 2 if ctx.world == 1 else 4, 1, blocks=5))
             v["what"] = ("BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device "
                          "softmax/argmax; row blocks sharded over the GPUs (strong scaling, no collective); a step = one image")
             add_traffic(v.get("roofline"), "c5_fp16")
             variants["c5_fp16"] = v
-            v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 6))
+            v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 6, blocks=5))
             v["what"] = ("BASELINE configs[3]: 8192 rays/GPU (2 patches of 64x64 per GPU), the c3 step sharded over the GPUs: one flat "
                          "all-gather of semantics0/semantics/depth/feat/cls_/ray_o/ray_d, one flat gradient all-reduce")
             add_traffic(v.get("roofline"), "c4_bf16")
@@ -811,6 +966,11 @@ def main():
     if variants:
         line["variants"] = variants
     if ctx.rank == 0:
+        if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c1":
+            net = res["net"]
+            line["cpu_baseline"], line["parity"] = cpu_baseline_c1(({k: v.detach().clone() for k, v in net.state_dict().items()}, res["rays"], res["out"]))
+            for k in ("net", "rays", "out"):
+                res.pop(k, None)
         if ctx.world == 1 and not args.no_cpu_baseline and args.config == "c2":
             gpu = dense = None
             if prec in ("fp32", "fp16x3"):

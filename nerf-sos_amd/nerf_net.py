@@ -125,6 +125,8 @@ class NeRFMLP(nn.Module):
                        input_ch_views=input_ch_views, use_viewdirs=viewdirs, use_semantics=use_semantics,
                        sem_layer=sem_layer, sem_dim=sem_dim, sem_with_coord=sem_with_coord, sem_with_geo=sem_with_geo)
         self.fast = self.mlp.fast
+        # arithmetic of point queries (forward): "fp32" exact MFMA; "fp16x3" / "fp16" / "bf16" as NeRFNet.mlp_precision, which sets it
+        self.mlp_precision = "fp32"
         self._gplan = None     # ops.GenericPlan of the current parameter storages (generic architectures)
         self._frozen_key = {}  # precision -> keys of the frozen (non-head) parameters the packed stream was built from
         self._packed = {}      # precision -> packed stream
@@ -200,7 +202,12 @@ class NeRFMLP(nn.Module):
         lead = inputs.shape[:-1]
         pts = inputs.reshape(-1, inputs.shape[-1]).float()
         dirs = viewdirs.expand(inputs.shape).reshape(-1, viewdirs.shape[-1]).float() if self.use_viewdirs else None
-        if self.fast:
+        if self.fast and self.mlp_precision != "fp32":
+            # the 16-bit / split-fp16 kernels take rays: every point is a ray of one sample with o = the point, d = 0, z = 0
+            # (o + 0 * 0 is the point, bit for bit), its direction the ray's view direction
+            raw = ops.mlp_forward_rays_lp(self.packed_weights(self.mlp_precision), self.sem_mode, self.mlp_precision, pts.contiguous(),
+                                          torch.zeros_like(pts), dirs.contiguous(), pts.new_zeros((pts.shape[0], 1)))[:, 0]
+        elif self.fast:
             raw = ops.mlp_forward_points(self.packed_weights(), self.sem_mode, pts, dirs)
         else:
             packed = self.packed_weights()
@@ -357,6 +364,7 @@ class NeRFNet(nn.Module):
         self.render_kwargs_test = dict(self.render_kwargs_train, perturb=0., raw_noise_std=0.)
         # Not in the reference (which is fp32 only): "fp32" = exact-fp32 MFMA (parity path, default);
         # "fp16" / "bf16" = 16-bit MFMA inputs with fp32 accumulation (BASELINE configs C5 / C3), inference only.
+        # Point queries (NeRFMLP.forward, forward_pts, export_density) follow it: the setter hands it to both nets.
         self.mlp_precision = "fp32"
         # Full backward (every parameter trainable), mlp_precision == "fp32": the 256x256 weight-gradient reductions run on the
         # exact-fp32 MFMA -- the precision whose name promises the reference's arithmetic gets it in the backward too
@@ -402,6 +410,19 @@ class NeRFNet(nn.Module):
         if self.nerf_fine is not self.nerf:
             nets.append(("fine", self.nerf_fine))
         return nets
+
+    @property
+    def mlp_precision(self) -> str:
+        return self._mlp_precision
+
+    @mlp_precision.setter
+    def mlp_precision(self, value: str) -> None:
+        if value not in ("fp32", "fp16x3", "fp16", "bf16"):
+            raise ValueError(f"NeRFNet.mlp_precision must be 'fp32', 'fp16x3', 'fp16' or 'bf16', got {value!r}")
+        self._mlp_precision = value
+        for net in (self.nerf, self.nerf_fine):
+            if net.fast:                  # generic architectures render in fp32 (render_rays refuses anything else)
+                net.mlp_precision = value
 
     def render_rays(self, rays_o, rays_d, near, far, viewdirs=None, raw_noise_std=0., verbose=False,
                     retraw=False, retpts=False, pytest=False, **kwargs) -> Dict[str, torch.Tensor]:
@@ -590,3 +611,23 @@ class NeRFNet(nn.Module):
                 NeRFNet._BOUNDS.move_to_end(key)
             return t
         return b.to(device=rays_d.device, dtype=torch.float32).reshape(-1).contiguous()
+
+
+def export_density(model: NeRFNet, extents=(2.0, 2.0, 2.0), voxel_size: float = 2. / 256., device=None, slab: int = 64) -> torch.Tensor:
+    """sigma [W/v, H/v, D/v] of the fine net on the reference's export grid (engines/eval.py:285-300: linspace grid x 14, ZERO view
+    directions, `model.nerf_fine(pts, viewdirs=0)`, sigma = max(raw[..., -1], 0)) -- the one caller of the point-query entry.
+    Returned on the device (the reference's .cpu().numpy() and its mrc / ply writers are the harness's business).  The grid is
+    queried `slab` x-planes at a time: 256^3 points x (3 + 3 + C) floats at once is 0.7-0.8 GB for nothing."""
+    model.eval()
+    dev = torch.device(device) if device is not None else next(model.parameters()).device
+    h, w, d = extents
+    with torch.no_grad():
+        xs = torch.linspace(-w / 2, w / 2, int(w / voxel_size), device=dev)
+        ys = torch.linspace(-h / 2, h / 2, int(h / voxel_size), device=dev)
+        zs = torch.linspace(-d / 2, d / 2, int(d / voxel_size), device=dev)
+        out = torch.empty((xs.numel(), ys.numel(), zs.numel()), device=dev, dtype=torch.float32)
+        for i in range(0, xs.numel(), slab):
+            pts = torch.stack(torch.meshgrid(xs[i:i + slab], ys, zs, indexing="ij"), dim=-1).float() * 14
+            raw = model.nerf_fine(pts, viewdirs=torch.zeros_like(pts))
+            out[i:i + slab] = raw[..., -1].clamp_min(0)
+    return out

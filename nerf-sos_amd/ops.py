@@ -404,6 +404,15 @@ def sem_in_rows(sem_in: torch.Tensor, n_points: int) -> torch.Tensor:
     return sem_in.view(G, 20, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(G * 32, 320)[:n_points]
 
 
+def sem_hid_tiled(rows: torch.Tensor) -> torch.Tensor:
+    """The inverse of sem_hid_rows: a [P,128] 16-bit matrix in the tile-major layout (zero rows up to a multiple of 32)."""
+    P = rows.shape[0]
+    G = (P + 31) // 32
+    pad = torch.zeros((G * 32, 128), device=rows.device, dtype=rows.dtype)
+    pad[:P] = rows
+    return pad.view(G, 32, 16, 8).permute(0, 2, 1, 3).contiguous()
+
+
 def sem_in_tiled(rows: torch.Tensor) -> torch.Tensor:
     """The inverse of sem_in_rows: a [P,320] 16-bit matrix in the tile-major layout (zero rows up to a multiple of 32)."""
     P = rows.shape[0]

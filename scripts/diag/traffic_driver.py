@@ -30,13 +30,13 @@ for _ in range(REPS):
 net, o, d, v, z = setup(65536, True)
 pk = net.nerf_fine.packed_weights("fp16")
 for _ in range(REPS):
-    ops.mlp_forward_rays_lp(pk, 2, "fp16", o, d, v, z)                                         # mlp_lp8_kernel<F16,2,false>, c5 chunk
+    ops.mlp_forward_rays_lp(pk, 2, "fp16", o, d, v, z)                                         # mlp_lp16_kernel<F16,2,false>, c5 chunk
 for R in (4096, 8192):
     net, o, d, v, z = setup(R, True)
     pk = net.nerf_fine.packed_weights("bf16")
     for _ in range(REPS):
-        ops.mlp_forward_rays_save(pk, 2, o, d, v, z, "bf16", compact=True)                     # mlp_lp8_kernel<BF16,2,true>, c3 / c4
+        ops.mlp_forward_rays_save(pk, 2, o, d, v, z, "bf16", compact=True)                     # mlp_lp16_kernel<BF16,2,true>, c3 / c4
     for _ in range(REPS):
-        ops.mlp_forward_rays_lp(pk, 2, "bf16", o, d, v, z)                                     # mlp_lp8_kernel<BF16,2,false>
+        ops.mlp_forward_rays_lp(pk, 2, "bf16", o, d, v, z)                                     # mlp_lp16_kernel<BF16,2,false>
 torch.cuda.synchronize()
 print("traffic driver done")

@@ -5,7 +5,7 @@ per kernel x launch shape the median counter values, the HBM bytes per launch af
 algorithmic bytes next to them, and the hash of the kernel sources the passes were measured on (bench.py reports
 `roofline.traffic` for a variant only while that hash still holds).
 
-usage: make_traffic_json.py gpurun_out/traffic_<tag> profiles/r03/traffic.json [<summary text file to write>]
+usage: make_traffic_json.py gpurun_out/traffic_<tag> profiles/r04/traffic.json [<summary text file to write>]
 """
 import csv
 import json
@@ -27,11 +27,11 @@ S = 192
 LAUNCHES = [
     ("c2_fp32", lambda n: "mlp_fused_kernel<0, true, 0>" in n, 0, 4096, 4, 0, 0),
     ("c2_fp16x3", lambda n: "mlp_x3_kernel<0, 0>" in n, 0, 4096, 4, 0, 0),
-    ("c5_fp16", lambda n: "mlp_lp8_kernel" in n and "F16, 2, false" in n and "BF16" not in n, 0, 65536, 6, 0, 2),
-    ("c3_bf16", lambda n: "mlp_lp8_kernel" in n and "BF16, 2, true" in n, 0, 4096, 6, 896, 2),
-    ("c4_bf16", lambda n: "mlp_lp8_kernel" in n and "BF16, 2, true" in n, 1, 8192, 6, 896, 2),
-    ("bf16_inference_4096", lambda n: "mlp_lp8_kernel" in n and "BF16, 2, false" in n, 0, 4096, 6, 0, 2),
-    ("bf16_inference_8192", lambda n: "mlp_lp8_kernel" in n and "BF16, 2, false" in n, 1, 8192, 6, 0, 2),
+    ("c5_fp16", lambda n: "mlp_lp16_kernel" in n and "F16, 2, false" in n and "BF16" not in n, 0, 65536, 6, 0, 2),
+    ("c3_bf16", lambda n: "mlp_lp16_kernel" in n and "BF16, 2, true" in n, 0, 4096, 6, 896, 2),
+    ("c4_bf16", lambda n: "mlp_lp16_kernel" in n and "BF16, 2, true" in n, 1, 8192, 6, 896, 2),
+    ("bf16_inference_4096", lambda n: "mlp_lp16_kernel" in n and "BF16, 2, false" in n, 0, 4096, 6, 0, 2),
+    ("bf16_inference_8192", lambda n: "mlp_lp16_kernel" in n and "BF16, 2, false" in n, 1, 8192, 6, 0, 2),
 ]
 PACKED_BYTES = {("fp32", 0): 4096 + 73 * 36864, ("x3", 0): None, ("lp", 2): None}
 
@@ -56,6 +56,9 @@ doc["source"] = (f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate pas
 doc["correction"] = ("MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B / lane) coalesced reads "
                      "-> x2; WRITE_SIZE calibrates exactly on these kernels (c2: 12288 KB = 786432 points x 16 B; c5: 294912 KB = "
                      "12582912 points x 24 B).  hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE")
+doc["isolated_launch_median_us"] = ("duration of the driver's back-to-back launches of ONE kernel under the profiler -- NOT bench.py's kernel_ms, which is the "
+                                    "HIP-event time of the same kernel inside a whole step (cold L2 weights, a different clock state): the short 16-bit launches "
+                                    "differ by 5-10 % between the two; the counters are per launch and do not depend on it")
 doc["kernels"] = OrderedDict()
 lines = []
 for key, match, idx, rays, C, save, sem in LAUNCHES:
@@ -75,7 +78,7 @@ for key, match, idx, rays, C, save, sem in LAUNCHES:
     e = OrderedDict(kernel=short, rays=rays, points=pts, fetch_size_kb=round(f_kb, 1), write_size_kb=round(w_kb, 1),
                     hbm_bytes_per_launch=int(round((2 * f_kb + w_kb) * 1024)), algorithmic_bytes_per_launch_without_weights=int(algo),
                     ratio=round((2 * f_kb + w_kb) * 1024 / algo, 3),
-                    kernel_source_sha16=bench.kernel_source_hash(key), median_us=dur,
+                    kernel_source_sha16=bench.kernel_source_hash(key), isolated_launch_median_us=dur,
                     vgpr=tr[0].get("VGPR_Count") if tr else None, agpr=tr[0].get("Accum_VGPR_Count") if tr else None,
                     scratch_bytes=tr[0].get("Scratch_Size") if tr else None, lds_bytes=tr[0].get("LDS_Block_Size") if tr else None)
     doc["kernels"][key] = e

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): HBM traffic of the fine-pass MLP kernels of every precision path, as MI355X_MICROARCH.md's
 # HBM section prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (no trace domains combined with --pmc) -- plus a
 # kernel-trace pass of the same driver for durations / register / scratch columns.  Outputs: gpurun_out/traffic_<tag>/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -255,3 +255,46 @@ def test_device_rng_counter_draws_equal_host_counter_draws():
         b = ops.render_draws(77, cnt, 300, 64, 128, DEV)
         assert all(torch.equal(x, y) for x, y in zip(a, b)) and int(cnt.item()) == call
     assert not torch.equal(ops.render_draws(77, 1, 300, 64, 128, DEV)[0], ops.render_draws(77, 2, 300, 64, 128, DEV)[0])
+
+
+@pytest.mark.parametrize("cfg", ["nosem", "semcoord"])
+def test_density_export_grid(manifest, cfg):
+    """SURVEY 3.3 / engines/eval.py:285-300 at its own size: 256^3 grid points x 14, zero view directions, through the fine net's
+    point-query entry.  A seeded sample of the grid against the CPU port's point query (fp32 band of the parity tests), the
+    slab loop against one direct call, and the 16-bit precisions through the same entry (they used to fall back to fp32)."""
+    from oracle import torch_port as tp
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS[cfg]).to(DEV).eval()
+    sd = ref_state(cfg, manifest, peaky=False)
+    net.load_state_dict(sd)
+    sigma = nerf_sos_amd.export_density(net)
+    assert sigma.shape == (256, 256, 256) and torch.isfinite(sigma).all() and float(sigma.min()) >= 0 and float(sigma.max()) > 0
+    lin = torch.linspace(-1, 1, 256)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, 256, (8192, 3), generator=g)
+    idx[:8] = torch.tensor([[0, 0, 0], [255, 255, 255], [0, 255, 0], [255, 0, 0], [0, 0, 255], [63, 64, 65], [64, 0, 0], [127, 128, 255]])
+    pts = torch.stack([lin[idx[:, 0]], lin[idx[:, 1]], lin[idx[:, 2]]], -1) * 14
+    pcfg = tp.PortConfig(use_semantics=CFGS[cfg]["use_semantics"], sem_with_coord=CFGS[cfg].get("sem_with_coord", False))
+    with torch.no_grad():
+        raw_ref = tp.point_query({k: v.cpu() for k, v in sd.items()}, "nerf_fine", pts[:, None, :], torch.zeros_like(pts)[:, None, :], pcfg)[:, 0]
+        raw = net.nerf_fine(pts.to(DEV), viewdirs=torch.zeros(8192, 3, device=DEV))
+    assert raw.shape == raw_ref.shape
+    scale = 1 + raw_ref.abs()
+    assert float(((raw.cpu() - raw_ref).abs() / scale).max()) <= 2e-5
+    got = sigma[idx[:, 0].to(DEV), idx[:, 1].to(DEV), idx[:, 2].to(DEV)]
+    assert torch.equal(got, raw[:, -1].clamp_min(0))            # the slab loop = one direct call of the same points
+    for prec, tol in (("fp16x3", 2e-5), ("fp16", 2e-2), ("bf16", 1e-1)):
+        net.mlp_precision = prec
+        assert net.nerf_fine.mlp_precision == prec
+        with torch.no_grad():
+            lp = net.nerf_fine(pts.to(DEV), viewdirs=torch.zeros(8192, 3, device=DEV))
+            z = torch.zeros(8192, 1, device=DEV)
+            direct = ops.mlp_forward_rays_lp(net.nerf_fine.packed_weights(prec), net.nerf_fine.sem_mode, prec, pts.to(DEV),
+                                             torch.zeros(8192, 3, device=DEV), torch.zeros(8192, 3, device=DEV), z)[:, 0]
+        assert torch.equal(lp, direct)
+        err = float(((lp - raw).abs() / (1 + raw.abs())).max())
+        assert err <= tol, (prec, err)
+        if prec != "fp16x3":
+            assert not torch.equal(lp, raw)                     # it IS the 16-bit kernel now
+    net.mlp_precision = "fp32"
+    with pytest.raises(ValueError):
+        net.mlp_precision = "fp8"
