@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         auto save_store = [&save_grp](auto boff_c, unsigned off, const u32x4& v) {
             constexpr int BOFF = decltype(boff_c)::value;
             unsigned long long b = save_grp + (unsigned long long)(BOFF & ~4095);
-            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(v), "s"(b), "i"(BOFF & 4095) : "memory");   // (s_nop: see the hidden-activation stores)
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(b), "i"(BOFF & 4095) : "memory");   // (s_nop: see the hidden-activation stores)
         };
         if constexpr (SAVE) {
             // TILE-MAJOR sem_in (include/nerf_sos_hip.h): [group of 32 points][octet 0..39][point][8 channels] -- store K, half kg of
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
                                         // (s_nop: a store of more than 8 bytes followed by a write of its data registers needs wait states, and the
                                         //  hazard recognizer does not look inside asm -- eight stores back to back all got v[184:187] and stored each
                                         //  other's words)
-                                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(save_off), "v"(v), "s"(hid_grp + (unsigned long long)((s * 2048 + c * 256) & ~4095)),
+                                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(save_off), "v"(v), "s"(hid_grp + (unsigned long long)((s * 2048 + c * 256) & ~4095)),
                                                      "i"((s * 2048 + c * 256) & 4095) : "memory");
 #endif
                                 }
