@@ -776,7 +776,31 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
                      "what": "the whole step (render, losses, backward, Adam) captured once and replayed: GraphedPatchStep"}
         except Exception as e:   # the eager numbers above stand on their own
             graph = {"error": repr(e)[:300]}
+    # diagnostics, outside the timed regions: three more eager steps with every collective bracketed by HIP events and host clocks
+    # (sharding.COLLECTIVE_EVENTS) and the optimizer bracketed here -- what the first real multi-GPU run needs to be read from one line
+    sharding.COLLECTIVE_EVENTS = {}
+    diag_t, opt_ev = {}, []
+    for i in range(3):
+        opt.zero_grad(set_to_none=True)
+        sharding.sharded_patch_step(net, rays, (syn.NEAR, syn.FAR), B, feat, cls_, corr, geo, correlation_w=1.0, geo_w=0.01, step=10_000 + i,
+                                    seed=0, timings=diag_t, contrast_loss=contrast, contrast_w=0.01)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        opt.step()
+        e1.record()
+        opt_ev.append((e0, e1))
+    torch.cuda.synchronize()
+    coll_ev, sharding.COLLECTIVE_EVENTS = sharding.COLLECTIVE_EVENTS, None
+    sharding.reset_collective_counts()
+    by_kind = {k: {"gpu_ms": round(sum(a.elapsed_time(b) for a, b, _ in v) / len(v), 4), "host_ms": round(1e3 * sum(h for _, _, h in v) / len(v), 4),
+                   "calls": len(v) // 3} for k, v in sorted(coll_ev.items())}
+    breakdown = {k: mean_ms(diag_t.get(k, [])) for k in ("render", "gather", "losses_backward", "allreduce")}
+    breakdown["optimizer"] = mean_ms(opt_ev)
     st = timings.get("stats", {})
+    res.update(step_breakdown_ms=dict(breakdown, what="HIP-event spans on rank 0's stream, mean of 3 eager steps outside the timed regions: train-mode "
+                                                      "render of the own patches | flat patch all-gather | losses + backward (N > 1: with the two loss "
+                                                      "reductions inside) | flat gradient all-reduce | fused Adam"),
+               collective_ms_by_kind=by_kind)
     res.update(roofline=roof, whole_step_graph=graph, rays_per_gpu=n_rays, patches=B, loss=round(float(state["loss"]), 6), precision=precision,
                contrastive_loss=("NeRFContrastive on the batch's class tokens, weight 0.01" if contrast is not None else
                                  "not evaluated: one patch has no off-diagonal similarity (the reference's argmin fails on B = 1)"),
@@ -785,7 +809,7 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
                             "gathered_bytes_per_patch": st.get("bytes_per_patch"),
                             "gathered_keys": list(sharding.PATCH_KEYS), "all_gathers_per_step": st.get("collectives", 0 if ctx.world == 1 else None),
                             # every collective this rank issued in the timed steps, by kind (sharding.collective counts them): the
-                            # flat patch gather, the geometric loss's three phase reductions + its role-sum reduction, the gradient all-reduce
+                            # flat patch gather, the row-partitioned losses' two reductions (means, sums), the gradient all-reduce
                             "calls_per_step_by_kind": per_step, "calls_per_step": round(sum(per_step.values()), 3),
                             "all_reduce_floats": sum(p.numel() for p in net.parameters() if p.requires_grad)})
     return res
@@ -946,6 +970,8 @@ def main():
                           "flop_per_ray_forward": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
         line["roofline"] = add_traffic(res["roofline"], "c3_bf16" if args.config == "c3" else "c4_bf16") if prec == "bf16" else res["roofline"]
         line["collectives"] = res["collectives"]
+        dist_info.update(collective_ms_by_kind=res.get("collective_ms_by_kind"), step_breakdown_ms=res.get("step_breakdown_ms"),
+                         calls_per_step_by_kind=res["collectives"]["calls_per_step_by_kind"])
         line["loss"] = res["loss"]
         line["whole_step_graph"] = res.get("whole_step_graph")
         line["contrastive_loss"] = res.get("contrastive_loss")

@@ -448,21 +448,27 @@ int32_t nsos_eval_postprocess(const float* semantics, const float* rgb, const fl
  * engines/trainer.py:159-160): every rank holds the WHOLE batch's depth / code / rays (sharding.all_gather_patches) but
  * evaluates the O(P^4) pair sets only for ITS OWN row patches `rows[0..n_rows)` (device int32, global patch ids).  The patches
  * are coupled through four global sums (mean(fd), mean(fd1) per pair set, utils/image.py:316-319) and through the gradient a
- * patch receives as the NEGATIVE of another rank's patch, so the call is split into phases with a sum-all-reduce of workspace
- * slots in between (offsets from nsos_corr_workspace_slots; the workspace is nsos_corr_workspace_bytes(1, ...)):
- *   phase 0: prep + pass 1            -> all-reduce scal[0..1]   (2 doubles at scal_offset_bytes)
- *   phase 1: pass 2                   -> all-reduce scal[2..3]
- *   phase 2: passes 3, 4 + role sums  -> all-reduce scal[4..5] and gsum (gsum_floats fp32 at gsum_offset_bytes)
- *   phase 3: loss (the batch-wide value, identical on every rank) and grad_code [B,C,H,W] for every patch.
- *   phase 4: phases 0..3 in one call, for a single process (nothing to reduce in between): fewer, merged finishing launches.
- * With rows = all patches and no reductions the four phases equal nsos_geo_correlation_loss up to summation order. */
+ * patch receives as the NEGATIVE of another rank's patch, so the call is split into phases with TWO sum-all-reduces in between:
+ *   phase 0: prep + pass 1 + the row-mean residual of the own rows   -> all-reduce means[0..3]  (4 doubles)
+ *   phase 1: passes 3, 4 + role sums of the gradient + the loss sums -> all-reduce sums (fp32: batch * n_points * 4 role sums, then the
+ *            two loss sums as three fp32 terms each -- an exact split of the rank's fp64 partial -- + 2 spare: nsos_corr_exchange_floats)
+ *   phase 2: loss (the batch-wide value, identical on every rank) and grad_code [B,C,H,W] for every patch.
+ *   phase 3: phases 0..2 in one call, for a single process (nothing to reduce in between): fewer, merged finishing launches.
+ * `means` / `sums` are the workspace's own slots (offsets from nsos_corr_workspace_slots; the workspace is
+ * nsos_corr_workspace_bytes(1, ...)) unless exchange_means (8 doubles, 8-byte aligned; all 8 may be reduced) / exchange_sums
+ * (nsos_corr_exchange_floats(batch, n_points) floats) are given: a training step hands every loss evaluation of the step a slice
+ * of ONE buffer per reduction and issues one all-reduce per phase for all of them (sharding._losses_direct).
+ * With rows = all patches and no reductions the phases equal nsos_geo_correlation_loss up to summation order (the loss sums'
+ * split is exact; summed over ranks it carries fp32 rounding of each term, <= 1e-7 of the fp32 loss value). */
+int64_t nsos_corr_exchange_floats(int32_t batch, int32_t n_points);
 int32_t nsos_corr_workspace_slots(int32_t batch, int32_t n_points, int64_t* scal_offset_bytes, int64_t* gsum_offset_bytes,
                                   int64_t* gsum_floats);
 int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, const float* code, const float* ray_o, const float* ray_d,
                                        const int64_t* neg_indx, const int32_t* rows, int32_t n_rows, int32_t batch,
                                        int32_t code_dim, int32_t height, int32_t width, float self_shift, float self_weight,
                                        float neg_shift, float neg_weight, float max_depth, int32_t filter_in_place, float* loss,
-                                       float* grad_code, void* workspace, size_t workspace_bytes, void* stream);
+                                       float* grad_code, void* workspace, size_t workspace_bytes, double* exchange_means,
+                                       float* exchange_sums, void* stream);
 /* The training step's form of the row-partitioned call (engines/trainer.py:147-166 scores the coarse AND the fine semantic map
  * against the same geometry): TWO codes over ONE set of `batch` geometry patches, evaluated as the stacked batch of 2 * batch
  * patches [code0; code1] -- every term of the loss is a mean over the batch and the batch-wide quantities it subtracts depend
@@ -476,7 +482,19 @@ int32_t nsos_geo_correlation_loss_pair(int32_t phase, const float* depth, const 
                                        int32_t n_rows, int32_t batch, int32_t channel_last, int32_t code_dim, int32_t height,
                                        int32_t width, float self_shift, float self_weight, float neg_shift, float neg_weight,
                                        float max_depth, float* loss, float* grad_code0, float* grad_code1, void* workspace,
-                                       size_t workspace_bytes, void* stream);
+                                       size_t workspace_bytes, double* exchange_means, float* exchange_sums, void* stream);
+/* CorrelationLoss (utils/image.py:335-370) row-partitioned the same way: phases 0..2 and the two reductions of
+ * nsos_geo_correlation_loss_rows (one process: nsos_app_correlation_loss[_nhwc]).  A row patch needs only its own samples (coords1
+ * of n, coords2 of neg[n]); its column gradient lands in patch neg[n], which another rank may own: `sums` carries that gradient for
+ * every row (batch * S*S * 4 floats + the split loss sums), and phase 2 writes grad_code for the patches in `rows` only (zeros for
+ * the others -- no rank needs them).  channel_last as nsos_app_correlation_loss_nhwc.  workspace: nsos_corr_workspace_bytes(0, ...);
+ * rand1 / rand2 must hold the same draws on every rank. */
+int32_t nsos_app_correlation_loss_rows(int32_t phase, const float* feats, const float* code, const int64_t* neg_indx,
+                                       const float* rand1, const float* rand2, const int32_t* rows, int32_t n_rows, int32_t batch,
+                                       int32_t channel_last, int32_t feat_dim, int32_t feat_h, int32_t feat_w, int32_t code_dim,
+                                       int32_t code_h, int32_t code_w, int32_t feature_samples, float self_shift, float self_weight,
+                                       float neg_shift, float neg_weight, float* loss, float* grad_code, void* workspace,
+                                       size_t workspace_bytes, double* exchange_means, float* exchange_sums, void* stream);
 
 /* ---- contrastive loss on the batch's class tokens (BASELINE configs[2]: "contrastive loss") ---------------
  * NeRFContrastive.forward with min_max_contrast=True (utils/image.py:192-218; call site engines/trainer.py:168-170,

@@ -103,12 +103,15 @@ SIGNATURES = {
     "nsos_app_correlation_loss_nhwc": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                               _f32, _f32, _f32, _f32, _fp, _fp, _fp, _sz, _fp]),
     "nsos_geo_correlation_loss_pair": (_i32, [_i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
-                                              _f32, _f32, _f32, _fp, _fp, _fp, _fp, _sz, _fp]),
+                                              _f32, _f32, _f32, _fp, _fp, _fp, _fp, _sz, _fp, _fp, _fp]),
+    "nsos_app_correlation_loss_rows": (_i32, [_i32, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                              _f32, _f32, _f32, _f32, _fp, _fp, _fp, _sz, _fp, _fp, _fp]),
+    "nsos_corr_exchange_floats": (_i64, [_i32, _i32]),
     "nsos_geo_correlation_loss": (_i32, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32,
                                          _i32, _fp, _fp, _fp, _sz, _fp]),
     "nsos_corr_workspace_slots": (_i32, [_i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "nsos_geo_correlation_loss_rows": (_i32, [_i32, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32,
-                                              _f32, _i32, _fp, _fp, _fp, _sz, _fp]),
+                                              _f32, _i32, _fp, _fp, _fp, _sz, _fp, _fp, _fp]),
     "nsos_render_draws": (_i32, [C.c_uint64, C.c_uint64, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
     "nsos_render_draws_counted": (_i32, [C.c_uint64, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp]),
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),

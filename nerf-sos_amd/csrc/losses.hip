@@ -27,6 +27,8 @@ namespace {
 constexpr int kMaxC = 4;        // semantic code channels supported (sem_dim; the shipped recipes use 2)
 constexpr int kRedBlocks = 8192;  // upper bound on partial sums per reduction (64 row blocks x 128 patches)
 
+constexpr int kSumTail = 8;     // floats behind the exchanged gradient sums: 2 loss sums x 3 fp32 terms (+ 2 spare)
+
 struct CorrParams {
     float self_shift, self_weight, neg_shift, neg_weight;
 };
@@ -45,7 +47,9 @@ struct Ws {
     float* gcol;       // [2][B][N][kMaxC] gradient w.r.t. normalised column codes
     float* fdmat;      // app only: [2][B][N][N]
     float* fn;         // app only: normalised sampled features [2][B][N][Cf]  (0: coords1 of n, 1: coords2 of neg[n])
-    float* gsum;       // geo only: [B][N][kMaxC] gradient w.r.t. the normalised codes, summed over roles (row-partitioned call)
+    float* gsum;       // row-partitioned calls, the slot the ranks sum: geo [B][N][kMaxC] gradient w.r.t. the normalised codes, summed
+                       // over roles; app [B][N][kMaxC] gradient w.r.t. the coords2 samples of neg[n] (row n's);  + kSumTail floats:
+                       // the two loss sums as three fp32 terms each (exact split of the fp64 partials)
     float* gcolp;      // geo only: [2][B][ceil(N / 64)][kMaxC][N] column-code gradient partials, one per block of 64 rows (fused pass 3)
 };
 
@@ -66,7 +70,7 @@ inline size_t ws_layout(Ws* w, void* base, int B, int N, int Cf, bool app) {
     float* gcol = (float*)take(sizeof(float) * 2 * B * N * kMaxC);
     float* fdmat = (float*)take(app ? sizeof(float) * 2 * B * N * N : 0);
     float* fn = (float*)take(app ? sizeof(float) * 2 * B * N * Cf : 0);
-    float* gsum = (float*)take(app ? 0 : sizeof(float) * B * N * kMaxC);
+    float* gsum = (float*)take(sizeof(float) * ((size_t)B * N * kMaxC + kSumTail));
     float* gcolp = (float*)take(app ? 0 : sizeof(float) * 2 * B * ((N + 63) / 64) * kMaxC * N);
     if (w) *w = Ws{rowsum, partial, scal, pts, cn, cn2, dinv, dinv2, grow, gcol, fdmat, fn, gsum, gcolp};
     return off;
@@ -655,16 +659,38 @@ __global__ void loss_finish_kernel(const double* __restrict__ scal, double cnt, 
     loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
     if (geo && scal[7] != 0.0) loss[0] = __builtin_nanf("");                      // NaN inputs (geo_prep_kernel)
 }
+// Row-partitioned calls: the loss sums travel with the fp32 gradient sums (ONE all-reduce for both) as three fp32 terms each --
+// an exact split of the rank's fp64 partial (3 x 24 bits >= 53); the sum over the ranks then carries fp32 rounding of each term
+// (<= 1e-7 of the loss, whose value is fp32 anyway).  With nothing to add (one rank) the round trip is exact.
+__device__ __forceinline__ void split_sum(double v, float* out) {
+    const float a = (float)v;
+    const float b = (float)(v - (double)a);
+    out[0] = a;
+    out[1] = b;
+    out[2] = (float)(v - (double)a - (double)b);
+}
+__global__ void split_sums_kernel(const double* __restrict__ scal, float* __restrict__ tail) {
+    split_sum(scal[4], tail);
+    split_sum(scal[5], tail + 3);
+    tail[6] = tail[7] = 0.0f;
+}
+__global__ void loss_finish_split_kernel(const float* __restrict__ tail, const double* __restrict__ flags, double cnt, CorrParams prm,
+                                         float* __restrict__ loss, int geo) {
+    const double s0 = (double)tail[0] + (double)tail[1] + (double)tail[2], s1 = (double)tail[3] + (double)tail[4] + (double)tail[5];
+    const float l_neg = (float)(s0 / cnt), l_self = (float)(s1 / cnt);
+    loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
+    if (geo && flags[7] != 0.0) loss[0] = __builtin_nanf("");
+}
 // single-process call: pair_finish_kernel(slot 4) for both sets + loss_finish_kernel in one launch of 64 threads
 __global__ void pass3_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal, double cnt, CorrParams prm,
-                                    float* __restrict__ loss, int geo) {
+                                    float* __restrict__ loss, int geo, const double* __restrict__ flags) {
     const double s0 = partial_sum(partial, nb, 0), s1 = partial_sum(partial, nb, 1);
     if (threadIdx.x != 0) return;
     scal[4] = s0;
     scal[5] = s1;
     const float l_neg = (float)(s0 / cnt), l_self = (float)(s1 / cnt);
     loss[0] = prm.neg_weight * l_neg + prm.self_weight * l_self;
-    if (geo && scal[7] != 0.0) loss[0] = __builtin_nanf("");
+    if (geo && flags[7] != 0.0) loss[0] = __builtin_nanf("");
 }
 
 // backward of F.normalize for one point: g_v = (g - y (g.y)) / d  if ||v|| >= eps, else g / eps
@@ -756,9 +782,9 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
                                                          const float* __restrict__ rnd2, int B, int Cf, int Hf, int Wf, int Hc,
                                                          int Wc, int S, float* __restrict__ fn, float* __restrict__ cn,
                                                          float* __restrict__ cn2, float* __restrict__ dinv, float* __restrict__ dinv2,
-                                                         int channel_last) {
+                                                         int channel_last, const int* __restrict__ rows) {
     __shared__ double red[2];
-    const int p = blockIdx.x, n = blockIdx.y, side = blockIdx.z, N = S * S;
+    const int p = blockIdx.x, n = rows ? rows[blockIdx.y] : (int)blockIdx.y, side = blockIdx.z, N = S * S;
     const int src = side == 0 ? n : (int)neg[n];
     float gx, gy;
     sample_coord(side == 0 ? rnd1 : rnd2, n, p, S, gx, gy);
@@ -798,8 +824,9 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
 // One workgroup per row point p; a wave takes four column points at a time, lanes across channels (coalesced), so four
 // independent row fetches are in flight per lane (one column per iteration was a chain of dependent L2 round trips: 63 us
 // for 14 MFLOP).  Products are rounded to fp32 and summed in fp64, as before.
-__global__ __launch_bounds__(1024) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat) {
-    const int set = blockIdx.z, n = blockIdx.y, p = blockIdx.x;
+__global__ __launch_bounds__(1024) void app_fd_kernel(const float* __restrict__ fn, int B, int N, int Cf, float* __restrict__ fdmat,
+                                                      const int* __restrict__ rows) {
+    const int set = blockIdx.z, n = rows ? rows[blockIdx.y] : (int)blockIdx.y, p = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const float* a = fn + (((size_t)0 * B + n) * N + p) * Cf;
     const float* bb = fn + (((size_t)(set == 0 ? 1 : 0) * B + n) * N) * Cf;
@@ -826,9 +853,11 @@ template <int C>
 __global__ __launch_bounds__(128) void app_point_grad_kernel(int B, int N, const float* __restrict__ cn, const float* __restrict__ cn2,
                                                              const float* __restrict__ dinv, const float* __restrict__ dinv2,
                                                              const float* __restrict__ grow, const float* __restrict__ gcol,
-                                                             float* __restrict__ g1, float* __restrict__ g2) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)B * N) return;
+                                                             float* __restrict__ g1, float* __restrict__ g2,
+                                                             const int* __restrict__ rows, int n_rows) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)(rows ? n_rows : B) * N) return;
+    if (rows) i = (long long)rows[i / N] * N + i % N;          // the row patches of this call; every index below is patch-major
     float gy[C], gv[C];
 #pragma unroll
     for (int c = 0; c < C; ++c)   // rows of both sets + columns of the self set all are code(coords1) of patch n
@@ -851,22 +880,27 @@ template <int C>
 __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, int Hc, int Wc, const long long* __restrict__ neg,
                                                           const float* __restrict__ rnd1, const float* __restrict__ rnd2,
                                                           const float* __restrict__ g1, const float* __restrict__ g2,
-                                                          float* __restrict__ grad_code, int channel_last) {
+                                                          float* __restrict__ grad_code, int channel_last,
+                                                          const int* __restrict__ rows, int n_rows) {
     constexpr int kMaxSamples = 1024;
     __shared__ __attribute__((aligned(16))) int corner[kMaxSamples];          // x0 | y0 << 16
     __shared__ float weight[kMaxSamples][4];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long px = (long long)Hc * Wc;
     // a workgroup's pixels may straddle two patches when Hc*Wc is not a multiple of 256: geometry is staged per patch below
-    const bool live = i < (long long)B * px;
-    const int m = live ? (int)(i / px) : -1, y = live ? (int)((i / Wc) % Hc) : 0, x = live ? (int)(i % Wc) : 0;
-    const int m_first = (int)(((long long)blockIdx.x * blockDim.x) / px);
+    // `rows`: the patches whose gradient this call forms (the rank's own in the sharded step); pixel index i runs over THEIR slots
+    const int n_out = rows ? n_rows : B;
+    const bool live = i < (long long)n_out * px;
+    const int slot = live ? (int)(i / px) : -1, y = live ? (int)((i / Wc) % Hc) : 0, x = live ? (int)(i % Wc) : 0;
+    const int m = !live ? -1 : rows ? rows[slot] : slot;
+    const int s_first = (int)(((long long)blockIdx.x * blockDim.x) / px);
     const long long last_i = (long long)blockIdx.x * blockDim.x + blockDim.x - 1;
-    const int m_last = (int)((last_i < (long long)B * px ? last_i : (long long)B * px - 1) / px);
+    const int s_last = (int)((last_i < (long long)n_out * px ? last_i : (long long)n_out * px - 1) / px);
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
-    for (int mm = m_first; mm <= m_last; ++mm)
+    for (int ss = s_first; ss <= s_last; ++ss) {
+        const int mm = rows ? rows[ss] : ss;
         for (int side = 0; side < 2; ++side)
             for (int n = 0; n < B; ++n) {
                 if (side == 0 ? n != mm : (int)neg[n] != mm) continue;        // workgroup-uniform
@@ -901,6 +935,7 @@ __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, i
                     }
                 }
             }
+    }
     if (!live) return;
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -909,7 +944,7 @@ __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, i
 
 // ------------------------------------------------------------------------------------------ host side
 template <bool GEO, int C, bool NARROW>
-int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases) {
+int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases, const double* flags) {
     const int N = A.N, B = A.B;
     const int tb = PairShape<GEO, NARROW>::kThreads, rows_per_block = PairShape<GEO, NARROW>::kRows;
     const dim3 grid((N + rows_per_block - 1) / rows_per_block, A.rows ? A.n_rows : B, 2);
@@ -954,7 +989,7 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
             if (fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW, true>), grid, dim3(tb), lds_rows3, st, A);
         }
         if (!fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
-        if (loss) hipLaunchKernelGGL(pass3_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0);
+        if (loss) hipLaunchKernelGGL(pass3_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0, flags ? flags : A.scal);
         else hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
         if constexpr (kCanFuse) {
             if (fuse) hipLaunchKernelGGL((pair_cols_fold_kernel<C>), dim3((N + 63) / 64, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
@@ -965,13 +1000,13 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
 }
 
 template <bool GEO, int C>
-int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases = 7) {
+int32_t run_pair_passes(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases = 7, const double* flags = nullptr) {
     if constexpr (GEO) {
         const int cus = nsos_device_cus();
         const long long wide = (long long)((A.N + 63) / 64) * (A.rows ? A.n_rows : A.B) * 2;   // workgroups at 64 rows each
-        if (wide < cus && !nsos_env_flag("NSOS_GEO_FORCE_WIDE")) return run_pair_passes_shape<true, C, true>(A, want_grad, loss, st, phases);
+        if (wide < cus && !nsos_env_flag("NSOS_GEO_FORCE_WIDE")) return run_pair_passes_shape<true, C, true>(A, want_grad, loss, st, phases, flags);
     }
-    return run_pair_passes_shape<GEO, C, false>(A, want_grad, loss, st, phases);
+    return run_pair_passes_shape<GEO, C, false>(A, want_grad, loss, st, phases, flags);
 }
 
 template <int C>
@@ -1044,20 +1079,26 @@ __global__ __launch_bounds__(256) void geo_finish_kernel(int B, int N, const flo
     for (int c = 0; c < C; ++c) grad_code[in.code_at(m % in.Bg, c, p, C, N)] = gv[c];
 }
 
-// phase 0: depth filter + points + normalised codes of the WHOLE batch (cheap, every rank), pass 1 over own rows -> scal[0..1]
-// phase 1: (scal[0..1] all-reduced) pass 2 -> scal[2..3]
-// phase 2: (scal[2..3] all-reduced) passes 3 and 4 over own rows -> scal[4..5] (loss sums), gsum
-// phase 3: (scal[4..5], gsum all-reduced) loss value and d loss / d code for every patch of the batch
+// Row-partitioned evaluation (multi-GPU: each rank evaluates the pair sets of ITS OWN row patches), two reductions per call:
+// phase 0: depth filter + points + normalised codes of the WHOLE batch (cheap, every rank), pass 1 over own rows and the row-mean
+//          residual of those rows -> means[0..3]                                   [means[0..3] summed over the ranks]
+// phase 1: passes 3 and 4 over own rows -> sums = the role sums of the gradient + the split loss sums    [sums summed over the ranks]
+// phase 2: loss value and d loss / d code for every patch of the batch
+// phase 3: all of it in one call (single process: nothing to reduce)
+// `means` (8 doubles) / `sums` (B N kMaxC + kSumTail floats) default to the workspace's own slots; the sharded training step passes
+// slices of ONE buffer per reduction shared by all of its loss evaluations, so that a step issues one all-reduce per phase.
 template <int C>
 int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long long* neg,
                       const int* rows, int n_rows, int B, int N, CorrParams prm, float max_depth, int write_back, float* loss,
-                      void* workspace, hipStream_t st) {
+                      void* workspace, double* xmeans, float* xsums, hipStream_t st) {
     Ws w;
     ws_layout(&w, workspace, B, N, 0, false);
     const long long tot = (long long)B * N;
     const unsigned gb = (unsigned)((tot + 255) / 256);
-    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, rows, n_rows, w.gcolp, in.Bg};
-    if (phase == 0 || phase == 4) {
+    double* means = xmeans ? xmeans : w.scal;       // [0..5]; the depth maximum and the NaN flag ([6], [7]) stay in the workspace
+    float* sums = xsums ? xsums : w.gsum;
+    PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, means, w.grow, w.gcol, max_depth, prm, rows, n_rows, w.gcolp, in.Bg};
+    if (phase == 0 || phase == 3) {
         const long long tot_geo = (long long)in.Bg * N;                            // depth: one map per GEOMETRY patch
         const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
         hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial);
@@ -1065,36 +1106,40 @@ int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long lo
         hipLaunchKernelGGL((geo_prep_kernel<C>), dim3(gb), dim3(256), 0, st, depth, in, B, N, max_depth, write_back,
                            w.scal, w.pts, w.cn, w.dinv);
     }
-    if (phase == 4) {   // single process: nothing to reduce between the phases -- every launch of the loss from one call
+    if (phase == 3) {   // single process: nothing to reduce between the phases -- every launch of the loss from one call
         if (n_rows == 0) {
-            hipError_t e = hipMemsetAsync(w.scal, 0, 6 * sizeof(double), st);
-            if (e == hipSuccess) e = hipMemsetAsync(w.gsum, 0, sizeof(float) * tot * kMaxC, st);
+            hipError_t e = hipMemsetAsync(means, 0, 6 * sizeof(double), st);
+            if (e == hipSuccess) e = hipMemsetAsync(sums, 0, sizeof(float) * (tot * kMaxC + kSumTail), st);
             if (e != hipSuccess) return (int32_t)e;
-            hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss, 1);
+            hipLaunchKernelGGL(loss_finish_split_kernel, dim3(1), dim3(1), 0, st, sums + tot * kMaxC, w.scal, (double)B * N * N, prm, loss, 1);
         } else {
             const bool want_grad = in.grad[0] || in.grad[1];
-            const int32_t rc = run_pair_passes<true, C>(A, want_grad, loss, st, 7);
+            const int32_t rc = run_pair_passes<true, C>(A, want_grad, loss, st, 7, w.scal);
             if (rc != NSOS_OK) return rc;
-            if (want_grad) hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, w.gsum);
+            if (want_grad) hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, sums);
         }
-        if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, in);
+        if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, sums, in);
         return nsos_launch_status();
     }
-    if (phase <= 2) {
-        const int slot = phase * 2;
-        if (n_rows == 0) {   // a rank without patches contributes zeros
-            hipError_t e = hipMemsetAsync(w.scal + slot, 0, 2 * sizeof(double), st);
-            if (e == hipSuccess && phase == 2) e = hipMemsetAsync(w.gsum, 0, sizeof(float) * tot * kMaxC, st);
+    if (phase == 0) {
+        hipError_t e = hipMemsetAsync(means, 0, (xmeans ? 8 : 6) * sizeof(double), st);   // a rank without patches contributes zeros
+        if (e != hipSuccess) return (int32_t)e;
+        if (n_rows == 0) return nsos_launch_status();
+        return run_pair_passes<true, C>(A, true, nullptr, st, 3, w.scal);
+    }
+    if (phase == 1) {
+        if (n_rows == 0) {
+            const hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * (tot * kMaxC + kSumTail), st);
             return e == hipSuccess ? nsos_launch_status() : (int32_t)e;
         }
-        const int32_t rc = run_pair_passes<true, C>(A, true, nullptr, st, 1 << phase);
+        const int32_t rc = run_pair_passes<true, C>(A, true, nullptr, st, 4, w.scal);
         if (rc != NSOS_OK) return rc;
-        if (phase == 2)
-            hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, w.gsum);
+        hipLaunchKernelGGL((geo_gsum_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, neg, rows, n_rows, w.grow, w.gcol, sums);
+        hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(1), 0, st, means, sums + tot * kMaxC);
         return nsos_launch_status();
     }
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, w.scal, (double)B * N * N, prm, loss, 1);
-    if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, w.gsum, in);
+    hipLaunchKernelGGL(loss_finish_split_kernel, dim3(1), dim3(1), 0, st, sums + tot * kMaxC, w.scal, (double)B * N * N, prm, loss, 1);
+    if (in.grad[0] || in.grad[1]) hipLaunchKernelGGL((geo_finish_kernel<C>), dim3(gb), dim3(256), 0, st, B, N, w.cn, w.dinv, sums, in);
     return nsos_launch_status();
 }
 
@@ -1106,8 +1151,8 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
     Ws w;
     ws_layout(&w, workspace, B, N, Cf, true);
     hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, B, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
-                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last);
-    hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(1024), 0, st, w.fn, B, N, Cf, w.fdmat);   // 16 waves x 2 column quads each: a short dependent chain
+                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last, nullptr);
+    hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(1024), 0, st, w.fn, B, N, Cf, w.fdmat, nullptr);   // 16 waves x 2 column quads each: a short dependent chain
     PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm, nullptr, 0, nullptr, 0};
     const int32_t rc = run_pair_passes<false, C>(A, grad_code != nullptr, loss, st);
     if (rc != NSOS_OK) return rc;
@@ -1117,10 +1162,59 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
         float* g2 = w.fn + (size_t)B * N * kMaxC;
         const long long tot = (long long)B * N;
         hipLaunchKernelGGL((app_point_grad_kernel<C>), dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, st, B, N, w.cn, w.cn2, w.dinv,
-                           w.dinv2, w.grow, w.gcol, g1, g2);
+                           w.dinv2, w.grow, w.gcol, g1, g2, nullptr, 0);
         const long long px = (long long)B * Hc * Wc;
         hipLaunchKernelGGL((app_scatter_kernel<C>), dim3((unsigned)((px + 63) / 64)), dim3(64), 0, st, B, N, S, Hc, Wc, neg, rnd1, rnd2,   // one wave per workgroup: 64 CUs busy per patch instead of 16
-                           g1, g2, grad_code, channel_last);
+                           g1, g2, grad_code, channel_last, nullptr, 0);
+    }
+    return nsos_launch_status();
+}
+
+// Row-partitioned appearance loss: the phases and the two reductions of geo_rows_impl.  Everything a row patch n needs is its own
+// (the coords1 samples of n, the coords2 samples of neg[n], both fd matrices), except where its column gradient lands: g2[n] is
+// scattered into patch neg[n], which another rank may own -- `sums` carries g2 of every row (zeros for rows of other ranks), so
+// after the reduction each rank scatters into ITS patches (grad_code of the others: zeros; no rank needs them).
+template <int C>
+int32_t app_rows_impl(int phase, const float* feats, const float* code, const long long* neg, const float* rnd1, const float* rnd2,
+                      const int* rows, int n_rows, int B, int Cf, int Hf, int Wf, int Hc, int Wc, int S, CorrParams prm, float* loss,
+                      float* grad_code, void* workspace, double* xmeans, float* xsums, hipStream_t st, int channel_last) {
+    const int N = S * S;
+    Ws w;
+    ws_layout(&w, workspace, B, N, Cf, true);
+    const long long tot = (long long)B * N;
+    double* means = xmeans ? xmeans : w.scal;
+    float* sums = xsums ? xsums : w.gsum;
+    PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, means, w.grow, w.gcol, 0.0f, prm, rows, n_rows, nullptr, 0};
+    if (phase == 0) {
+        hipError_t e = hipMemsetAsync(means, 0, (xmeans ? 8 : 6) * sizeof(double), st);
+        if (e != hipSuccess) return (int32_t)e;
+        if (n_rows == 0) return nsos_launch_status();
+        hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, n_rows, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
+                           w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last, rows);
+        hipLaunchKernelGGL(app_fd_kernel, dim3(N, n_rows, 2), dim3(1024), 0, st, w.fn, B, N, Cf, w.fdmat, rows);
+        return run_pair_passes<false, C>(A, true, nullptr, st, 3);
+    }
+    if (phase == 1) {
+        hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * (tot * kMaxC + kSumTail), st);
+        if (e != hipSuccess) return (int32_t)e;
+        if (n_rows == 0) return nsos_launch_status();
+        const int32_t rc = run_pair_passes<false, C>(A, true, nullptr, st, 4);
+        if (rc != NSOS_OK) return rc;
+        hipLaunchKernelGGL((app_point_grad_kernel<C>), dim3((unsigned)(((long long)n_rows * N + 127) / 128)), dim3(128), 0, st, B, N, w.cn, w.cn2,
+                           w.dinv, w.dinv2, w.grow, w.gcol, w.fn, sums, rows, n_rows);       // g1 -> the (consumed) feature buffer
+        hipLaunchKernelGGL(split_sums_kernel, dim3(1), dim3(1), 0, st, means, sums + tot * kMaxC);
+        return nsos_launch_status();
+    }
+    hipLaunchKernelGGL(loss_finish_split_kernel, dim3(1), dim3(1), 0, st, sums + tot * kMaxC, w.scal, (double)B * N * N, prm, loss, 0);
+    if (grad_code) {
+        const long long px_all = (long long)B * Hc * Wc;
+        hipError_t e = hipMemsetAsync(grad_code, 0, sizeof(float) * px_all * C, st);
+        if (e != hipSuccess) return (int32_t)e;
+        if (n_rows > 0) {
+            const long long px = (long long)n_rows * Hc * Wc;
+            hipLaunchKernelGGL((app_scatter_kernel<C>), dim3((unsigned)((px + 63) / 64)), dim3(64), 0, st, B, N, S, Hc, Wc, neg, rnd1, rnd2,
+                               w.fn, sums, grad_code, channel_last, rows, n_rows);
+        }
     }
     return nsos_launch_status();
 }
@@ -1166,19 +1260,24 @@ extern "C" int32_t nsos_corr_workspace_slots(int32_t batch, int32_t n_points, in
     ws_layout(&w, reinterpret_cast<void*>((uintptr_t)4096), batch, n_points, 0, false);   // offsets relative to a fake base
     *scal_offset_bytes = (int64_t)((uintptr_t)w.scal - 4096);
     *gsum_offset_bytes = (int64_t)((uintptr_t)w.gsum - 4096);
-    *gsum_floats = (int64_t)batch * n_points * kMaxC;
+    *gsum_floats = (int64_t)batch * n_points * kMaxC + kSumTail;
     return NSOS_OK;
+}
+
+extern "C" int64_t nsos_corr_exchange_floats(int32_t batch, int32_t n_points) {
+    return batch > 0 && n_points > 0 ? (int64_t)batch * n_points * kMaxC + kSumTail : 0;
 }
 
 static int32_t geo_rows_entry(int32_t phase, float* depth, const GeoInputs in, const int64_t* neg_indx, const int32_t* rows, int32_t n_rows,
                               int32_t code_dim, int32_t height, int32_t width, float self_shift, float self_weight, float neg_shift,
                               float neg_weight, float max_depth, int32_t filter_in_place, float* loss, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              size_t workspace_bytes, double* xmeans, float* xsums, void* stream) {
     const int batch = in.Bg * in.n_codes;
-    NSOS_REQUIRE(phase >= 0 && phase <= 4, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(phase >= 0 && phase <= 3, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE((((uintptr_t)xmeans) & 7) == 0 && (((uintptr_t)xsums) & 3) == 0, NSOS_ERR_MISALIGNED);
     NSOS_REQUIRE(depth && in.code[0] && (in.n_codes == 1 || in.code[1]) && in.ray_o && in.ray_d && neg_indx && workspace && (n_rows == 0 || rows),
                  NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(phase < 3 || loss, NSOS_ERR_NULL_POINTER);   // phases 3 and 4 write the loss
+    NSOS_REQUIRE(phase < 2 || loss, NSOS_ERR_NULL_POINTER);   // phases 2 and 3 write the loss
     NSOS_REQUIRE(batch > 0 && height > 0 && width > 0 && n_rows >= 0 && n_rows <= batch, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
     const long long N = (long long)height * width;
@@ -1189,10 +1288,10 @@ static int32_t geo_rows_entry(int32_t phase, float* depth, const GeoInputs in, c
     const long long* neg = reinterpret_cast<const long long*>(neg_indx);
     const hipStream_t st = (hipStream_t)stream;
     switch (code_dim) {
-        case 1: return geo_rows_impl<1>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
-        case 2: return geo_rows_impl<2>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
-        case 3: return geo_rows_impl<3>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
-        default: return geo_rows_impl<4>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, st);
+        case 1: return geo_rows_impl<1>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, xmeans, xsums, st);
+        case 2: return geo_rows_impl<2>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, xmeans, xsums, st);
+        case 3: return geo_rows_impl<3>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, xmeans, xsums, st);
+        default: return geo_rows_impl<4>(phase, depth, in, neg, rows, n_rows, batch, (int)N, prm, max_depth, filter_in_place, loss, workspace, xmeans, xsums, st);
     }
 }
 
@@ -1201,11 +1300,12 @@ extern "C" int32_t nsos_geo_correlation_loss_rows(int32_t phase, float* depth, c
                                                   int32_t batch, int32_t code_dim, int32_t height, int32_t width,
                                                   float self_shift, float self_weight, float neg_shift, float neg_weight,
                                                   float max_depth, int32_t filter_in_place, float* loss, float* grad_code,
-                                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                                  void* workspace, size_t workspace_bytes, double* exchange_means,
+                                                  float* exchange_sums, void* stream) {
     if (batch == 0) return NSOS_OK;
     const GeoInputs in = {{code, nullptr}, {grad_code, nullptr}, ray_o, ray_d, batch, 1, 0};
     return geo_rows_entry(phase, depth, in, neg_indx, rows, n_rows, code_dim, height, width, self_shift, self_weight, neg_shift,
-                          neg_weight, max_depth, filter_in_place, loss, workspace, workspace_bytes, stream);
+                          neg_weight, max_depth, filter_in_place, loss, workspace, workspace_bytes, exchange_means, exchange_sums, stream);
 }
 
 extern "C" int32_t nsos_geo_correlation_loss_pair(int32_t phase, const float* depth, const float* code0, const float* code1,
@@ -1214,13 +1314,13 @@ extern "C" int32_t nsos_geo_correlation_loss_pair(int32_t phase, const float* de
                                                   int32_t code_dim, int32_t height, int32_t width, float self_shift,
                                                   float self_weight, float neg_shift, float neg_weight, float max_depth, float* loss,
                                                   float* grad_code0, float* grad_code1, void* workspace, size_t workspace_bytes,
-                                                  void* stream) {
+                                                  double* exchange_means, float* exchange_sums, void* stream) {
     if (batch == 0) return NSOS_OK;
     NSOS_REQUIRE(batch > 0, NSOS_ERR_BAD_SHAPE);
     const GeoInputs in = {{code0, code1}, {grad_code0, grad_code1}, ray_o, ray_d, batch, 2, channel_last != 0};
     // the depth filter (values > max_depth -> the largest value below it) is applied on the fly, never written back
     return geo_rows_entry(phase, const_cast<float*>(depth), in, neg_indx, rows, n_rows, code_dim, height, width, self_shift, self_weight,
-                          neg_shift, neg_weight, max_depth, 0, loss, workspace, workspace_bytes, stream);
+                          neg_shift, neg_weight, max_depth, 0, loss, workspace, workspace_bytes, exchange_means, exchange_sums, stream);
 }
 
 static int32_t app_entry(const float* feats, const float* code, const int64_t* neg_indx, const float* rand1, const float* rand2,
@@ -1265,4 +1365,36 @@ extern "C" int32_t nsos_app_correlation_loss_nhwc(const float* feats, const floa
                                                   float* grad_code, void* workspace, size_t workspace_bytes, void* stream) {
     return app_entry(feats, code, neg_indx, rand1, rand2, batch, feat_dim, feat_h, feat_w, code_dim, code_h, code_w, feature_samples,
                      self_shift, self_weight, neg_shift, neg_weight, loss, grad_code, workspace, workspace_bytes, stream, 1);
+}
+
+extern "C" int32_t nsos_app_correlation_loss_rows(int32_t phase, const float* feats, const float* code, const int64_t* neg_indx,
+                                                  const float* rand1, const float* rand2, const int32_t* rows, int32_t n_rows,
+                                                  int32_t batch, int32_t channel_last, int32_t feat_dim, int32_t feat_h, int32_t feat_w,
+                                                  int32_t code_dim, int32_t code_h, int32_t code_w, int32_t feature_samples,
+                                                  float self_shift, float self_weight, float neg_shift, float neg_weight, float* loss,
+                                                  float* grad_code, void* workspace, size_t workspace_bytes, double* exchange_means,
+                                                  float* exchange_sums, void* stream) {
+    if (batch == 0) return NSOS_OK;
+    NSOS_REQUIRE(phase >= 0 && phase <= 2, NSOS_ERR_UNSUPPORTED);      // (one process: nsos_app_correlation_loss[_nhwc])
+    NSOS_REQUIRE(feats && code && neg_indx && rand1 && rand2 && workspace && (n_rows == 0 || rows) && (phase < 2 || loss), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(batch > 0 && feat_dim > 0 && feat_h > 0 && feat_w > 0 && code_h > 0 && code_w > 0 && feature_samples > 0 && n_rows >= 0 &&
+                 n_rows <= batch, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(code_dim >= 1 && code_dim <= kMaxC, NSOS_ERR_UNSUPPORTED);
+    const int N = feature_samples * feature_samples;
+    NSOS_REQUIRE(N <= 1024, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(((uintptr_t)workspace & 15) == 0 && (((uintptr_t)exchange_means) & 7) == 0 && (((uintptr_t)exchange_sums) & 3) == 0, NSOS_ERR_MISALIGNED);
+    NSOS_REQUIRE(workspace_bytes >= nsos_corr_workspace_bytes(0, batch, N, feat_dim), NSOS_ERR_BUFFER_TOO_SMALL);
+    const CorrParams prm = {self_shift, self_weight, neg_shift, neg_weight};
+    const long long* neg = reinterpret_cast<const long long*>(neg_indx);
+    const hipStream_t st = (hipStream_t)stream;
+#define NSOS_APP_ROWS(CC)                                                                                                                    \
+    return app_rows_impl<CC>(phase, feats, code, neg, rand1, rand2, rows, n_rows, batch, feat_dim, feat_h, feat_w, code_h, code_w, feature_samples, \
+                             prm, loss, grad_code, workspace, exchange_means, exchange_sums, st, channel_last != 0)
+    switch (code_dim) {
+        case 1: NSOS_APP_ROWS(1);
+        case 2: NSOS_APP_ROWS(2);
+        case 3: NSOS_APP_ROWS(3);
+        default: NSOS_APP_ROWS(4);
+    }
+#undef NSOS_APP_ROWS
 }

@@ -23,6 +23,32 @@ def _params_of(values: Sequence, defaults):
     return tuple(vals)
 
 
+def exchange_floats(batch: int, n_points: int) -> int:
+    """fp32 elements one row-partitioned loss evaluation contributes to the step's `sums` reduction."""
+    return int(_lib.lib().nsos_corr_exchange_floats(int(batch), int(n_points)))
+
+
+def _run_phases(run, ws: torch.Tensor, batch: int, n_points: int, group) -> None:
+    """A row-partitioned geometric evaluation on its own: phase 3 (everything in one call) without a process group; with one,
+    phases 0..2 and the two sum-all-reduces of its workspace slots in between.  Every rank issues both reductions (a rank that
+    owns no patch contributes zeros): the sequence of collectives does not depend on the data."""
+    import ctypes as C_
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        run(3)
+        return
+    from .sharding import collective
+    so, go, gn = C_.c_int64(), C_.c_int64(), C_.c_int64()
+    _lib.check(_lib.lib().nsos_corr_workspace_slots(batch, n_points, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
+    means = ws[so.value // 8: so.value // 8 + 4]
+    sums = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
+    run(0)
+    collective("loss_means_all_reduce", lambda async_op: dist.all_reduce(means, group=group, async_op=async_op), group)
+    run(1)
+    collective("loss_sums_all_reduce", lambda async_op: dist.all_reduce(sums, group=group, async_op=async_op), group)
+    run(2)
+
+
 def _is_channel_last_view(t: torch.Tensor) -> bool:
     """[B,C,H,W] that is a permuted view of a dense [B,H,W,C] tensor (what `ret['semantics'].permute(0,3,1,2)` is)."""
     return t.dim() == 4 and t.shape[1] > 1 and not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous()
@@ -143,6 +169,47 @@ class CorrelationLoss(nn.Module):
 
         return launch
 
+    def rows_phased(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor], rows: Sequence[int],
+                    exchange, weight: float = 1.0, neg: Optional[torch.Tensor] = None):
+        """The row-partitioned evaluation for the patch-sharded step (`nsos_app_correlation_loss_rows`): every rank passes the
+        whole batch and ITS patches `rows`, draws the same coordinates (a generator seeded alike on every rank), and runs
+        phase 0 -> [sum `means` over the ranks] -> phase 1 -> [sum `sums`] -> phase 2.  Returns (run(phase), (loss, grad)):
+        after phase 2 `loss` is the batch-wide value on every rank and `grad` [B,C,P,P] holds weight * d loss / d code for the
+        patches in `rows` (zeros elsewhere).  exchange = (means [8] fp64, sums [exchange_floats(B, S S)] fp32): slices of the two
+        buffers the step reduces once per phase for all of its evaluations."""
+        feats = _dev(orig_feats.detach(), "orig_feats")
+        B, Cf, Hf, Wf = feats.shape
+        Bc, C, Hc, Wc = orig_code.shape
+        if Bc != B:
+            raise ValueError(f"orig_feats has {B} patches, orig_code {Bc}")
+        S = self.feature_samples
+        dev = feats.device
+        rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :343
+        rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :344
+        if neg is None:
+            neg = self._neg_index(sim_matrix, B, dev)
+        lib = _lib.lib()
+        w = float(weight)
+        prm = (self.self_shift, self.self_weight * w, self.neg_shift, self.neg_weight * w)
+        code = orig_code.detach()
+        nhwc = _is_channel_last_view(code)
+        code = _dev(code.permute(0, 2, 3, 1), "orig_code") if nhwc else _dev(code, "orig_code")
+        grad = torch.empty_like(code)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        nbytes = lib.nsos_corr_workspace_bytes(0, B, S * S, Cf)
+        ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
+        from .sharding import device_index
+        rows_t = device_index(rows, torch.int32, dev)
+        xm, xs = exchange
+
+        def run(phase):
+            _lib.check(lib.nsos_app_correlation_loss_rows(phase, _p(feats), _p(code), neg.data_ptr(), _p(rand1), _p(rand2),
+                                                          rows_t.data_ptr() if len(rows) else None, len(rows), B, 1 if nhwc else 0, Cf, Hf, Wf,
+                                                          C, Hc, Wc, S, *prm, _p(loss), _p(grad), ws.data_ptr(), ws.numel() * 8,
+                                                          _p(xm), _p(xs), _stream()), "nsos_app_correlation_loss_rows")
+
+        return run, (loss, grad.permute(0, 3, 1, 2) if nhwc else grad)
+
     def forward(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor]):
         return _CorrFn.apply(orig_code, self._launcher(orig_feats, orig_code.shape, sim_matrix))
 
@@ -204,28 +271,16 @@ class GeoCorrelationLoss(CorrelationLoss):
                                                          float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
                                                          ws.numel() * 8, _stream()), "nsos_geo_correlation_loss")
                 return loss, grad
-            import ctypes as C_
-            import torch.distributed as dist
-            so, go, gn = C_.c_int64(), C_.c_int64(), C_.c_int64()
-            _lib.check(lib.nsos_corr_workspace_slots(B, H * W, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
-            scal = ws[so.value // 8: so.value // 8 + 6]
-            gsum = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
             from .sharding import device_index
             rows_t = device_index(rows, torch.int32, dev)     # uploaded once (a fresh torch.tensor(..., device=) synchronises)
-            reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-            for phase in (range(4) if reduce else (4,)):      # single process: every launch from one call (phase 4)
+
+            def run(phase):
                 _lib.check(lib.nsos_geo_correlation_loss_rows(phase, dbuf.data_ptr(), _p(code), _p(ro), _p(rd), neg.data_ptr(),
                                                               rows_t.data_ptr() if len(rows) else None, len(rows), B, C, H, W, *prm,
                                                               float(self.max_depth), 1, _p(loss), _p(grad), ws.data_ptr(),
-                                                              ws.numel() * 8, _stream()), "nsos_geo_correlation_loss_rows")
-                if reduce and phase < 3:
-                    from .sharding import collective
-                    part = scal[2 * phase: 2 * phase + 2]
-                    collective("geo_loss_phase_all_reduce", lambda async_op: dist.all_reduce(part, group=group, async_op=async_op), group)
-                    # every rank or none: a rank that owns no patch has a code without gradient (want_grad False) but must not
-                    # skip a collective its peers issue -- the group-wide condition is the grad mode the loss was called in
-                    if phase == 2 and grad_mode:
-                        collective("geo_loss_role_sum_all_reduce", lambda async_op: dist.all_reduce(gsum, group=group, async_op=async_op), group)
+                                                              ws.numel() * 8, None, None, _stream()), "nsos_geo_correlation_loss_rows")
+
+            _run_phases(run, ws, B, H * W, group)
             return loss, grad
 
         out = _CorrFn.apply(orig_code, launch)
@@ -259,32 +314,28 @@ class GeoCorrelationLoss(CorrelationLoss):
         if grad_mode is None:
             grad_mode = torch.is_grad_enabled()
 
-        def launch(c0, c1, want_grad):
-            import ctypes as C_
-            import torch.distributed as dist
-            from .sharding import collective, device_index
+        def launch(c0, c1, want_grad, exchange=None):
+            """exchange = (means, sums): slices of the step's two reduction buffers -- returns the phase runner instead of running
+            (the caller interleaves the phases of several evaluations with ONE all-reduce per phase: sharding._losses_direct)."""
+            from .sharding import device_index
             c0, c1 = _dev(c0.detach(), "code0"), _dev(c1.detach(), "code1")
             nbytes = lib.nsos_corr_workspace_bytes(1, 2 * B, H * W, 0)
             ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
             loss = torch.empty((), device=dev, dtype=torch.float32)
             g0 = torch.empty_like(c0) if want_grad else None
             g1 = torch.empty_like(c1) if want_grad else None
-            so, go, gn = C_.c_int64(), C_.c_int64(), C_.c_int64()
-            _lib.check(lib.nsos_corr_workspace_slots(2 * B, H * W, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
-            scal = ws[so.value // 8: so.value // 8 + 6]
-            gsum = ws.view(torch.float32)[go.value // 4: go.value // 4 + gn.value]
             rows_t = device_index(rows2, torch.int32, dev)
-            reduce = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-            for phase in (range(4) if reduce else (4,)):      # single process: every launch from one call (phase 4)
+            xm, xs = exchange if exchange is not None else (None, None)
+
+            def run(phase):
                 _lib.check(lib.nsos_geo_correlation_loss_pair(phase, _p(d), _p(c0), _p(c1), _p(ro), _p(rd), neg2.data_ptr(),
                                                               rows_t.data_ptr() if len(rows2) else None, len(rows2), B, 1, C, H, W, *prm,
                                                               float(self.max_depth), _p(loss), _p(g0), _p(g1), ws.data_ptr(),
-                                                              ws.numel() * 8, _stream()), "nsos_geo_correlation_loss_pair")
-                if reduce and phase < 3:
-                    part = scal[2 * phase: 2 * phase + 2]
-                    collective("geo_loss_phase_all_reduce", lambda async_op: dist.all_reduce(part, group=group, async_op=async_op), group)
-                    if phase == 2 and grad_mode:
-                        collective("geo_loss_role_sum_all_reduce", lambda async_op: dist.all_reduce(gsum, group=group, async_op=async_op), group)
+                                                              ws.numel() * 8, _p(xm), _p(xs), _stream()), "nsos_geo_correlation_loss_pair")
+
+            if exchange is not None:
+                return run, (loss, g0, g1)
+            _run_phases(run, ws, 2 * B, H * W, group)
             return loss, g0, g1
 
         return launch
@@ -309,6 +360,13 @@ class GeoCorrelationLoss(CorrelationLoss):
         launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, 2.0 * float(weight), neg, grad_mode)
         want = torch.is_grad_enabled() if grad_mode is None else bool(grad_mode)
         return launch(code0, code1, want)
+
+    def pair_phased(self, depth, code0, code1, ray_o, ray_d, sim_matrix, rows, exchange, weight: float = 1.0,
+                    neg: Optional[torch.Tensor] = None):
+        """pair_value_and_grads split at its two reductions: (run(phase), (loss, grad0, grad1)) with the reduced slots in
+        `exchange` = (means [8] fp64, sums [exchange_floats(2 B, P P)] fp32) -- see rows_phased."""
+        launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, None, 2.0 * float(weight), neg, True)
+        return launch(code0, code1, True, exchange)
 
 
 def similarity_negatives(cls_tokens: torch.Tensor, copies: int = 1, want_similarity: bool = False):

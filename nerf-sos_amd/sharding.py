@@ -51,6 +51,10 @@ def local_patches(n_patches: int, rank: int, world: int) -> List[int]:
 # orders streams, and the process group's own timeout -- set it at init_process_group -- aborts the job through its watchdog).
 COLLECTIVE_TIMEOUT_S: Optional[float] = float(os.environ.get("NSOS_COLLECTIVE_TIMEOUT_S", "0")) or None
 COLLECTIVE_COUNTS: Dict[str, int] = {}
+# diagnostics (bench.py): a dict here makes every collective record (HIP event before, HIP event after, host seconds) under its
+# kind -- the events on the CURRENT stream (the RCCL work is joined to it by wait()), so that one bench line of the first real
+# multi-GPU run says where a step's time went
+COLLECTIVE_EVENTS: Optional[Dict[str, list]] = None
 
 
 def reset_collective_counts() -> Dict[str, int]:
@@ -63,6 +67,21 @@ def reset_collective_counts() -> Dict[str, int]:
 def collective(kind: str, launch: Callable[..., "dist.Work"], group=None):
     """Run `launch(async_op=True)` (a torch.distributed collective) under the watchdog and count it under `kind`."""
     COLLECTIVE_COUNTS[kind] = COLLECTIVE_COUNTS.get(kind, 0) + 1
+    if COLLECTIVE_EVENTS is not None and torch.cuda.is_available():
+        import time
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        t0 = time.perf_counter()
+        try:
+            _collective(kind, launch, group)
+        finally:
+            ev[1].record()
+            COLLECTIVE_EVENTS.setdefault(kind, []).append((ev[0], ev[1], time.perf_counter() - t0))
+        return
+    _collective(kind, launch, group)
+
+
+def _collective(kind: str, launch: Callable[..., "dist.Work"], group=None):
     work = launch(async_op=True)
     if work is None:
         return
@@ -296,7 +315,33 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             n_ = corr_loss._neg_index(similarity_matrix(full["cls_"]) if sim is None else sim, B, dev)
             neg2 = torch.cat([n_, n_ + B])
         neg = neg2[:B]
-        if side is not None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # N > 1: all three evaluations row-partitioned (each rank the pair sets of its own patches), their phases interleaved
+            # so that the step issues ONE all-reduce per phase for all of them: the means (3 x 8 doubles) and the sums (the
+            # gradients' role sums + the split loss sums, fp32)
+            from .losses import exchange_floats
+            P2 = full["depth"].shape[1] * full["depth"].shape[2]
+            S2 = corr_loss.feature_samples ** 2
+            sizes = [exchange_floats(2 * B, P2), exchange_floats(B, S2), exchange_floats(B, S2)]
+            means = torch.zeros(24, device=dev, dtype=torch.float64)
+            sums = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            xs = torch.split(sums, sizes)
+            run_a0, (la0, ga0) = corr_loss.rows_phased(f, s0, sim, own, (means[0:8], xs[1]), correlation_w, neg)
+            run_a1, (la1, ga1) = corr_loss.rows_phased(f, s1, sim, own, (means[8:16], xs[2]), correlation_w, neg)
+            run_g, (lg, gg0, gg1) = geo_loss.pair_phased(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
+                                                        sim, own, (means[16:24], xs[0]), geo_w, neg2)
+            runs = (run_g, run_a0, run_a1)
+            for r_ in runs:
+                r_(0)
+            collective("loss_means_all_reduce", lambda async_op: dist.all_reduce(means, group=group, async_op=async_op), group)
+            for r_ in runs:
+                r_(1)
+            collective("loss_sums_all_reduce", lambda async_op: dist.all_reduce(sums, group=group, async_op=async_op), group)
+            for r_ in runs:
+                r_(2)
+            side = None
+        elif side is not None:
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -307,8 +352,9 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
         else:
             la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
             la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
-        lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
-                                                      sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
+                                                          sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
             for t in (la0, la1, ga0, ga1):
@@ -417,13 +463,17 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     reference (single process only: ranks would draw different coordinates).  `generator`, if given, is used INSTEAD (a
     persistent generator the caller advances step after step -- what a captured graph of this step needs, graphs.py:
     a fresh per-step generator cannot be registered with a graph).
-    `timings`, if a dict, receives HIP event pairs under 'gather' and 'allreduce' (recorded on the current stream;
+    `timings`, if a dict, receives HIP event pairs under 'render', 'gather', 'losses_backward' and 'allreduce' (recorded on the current stream;
     RCCL's own stream is joined by the non-async collectives before the second event) and the gather `stats`."""
     rank, world = _world(group)
     own = local_patches(n_patches, rank, world)
     if rays.shape[1] != len(own):
         raise ValueError(f"sharded_patch_step: rank {rank} owns {len(own)} of {n_patches} patches, got rays for {rays.shape[1]}")
     dev = rays.device
+    ev_r = None
+    if timings is not None and dev.type == "cuda":
+        ev_r = torch.cuda.Event(enable_timing=True)
+        ev_r.record()
     if len(own):
         ret = net(rays, bounds, retraw=False)
     else:   # more ranks than patches: this rank renders nothing but still takes part in every collective
@@ -461,7 +511,9 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     all_reduce_grads(net.parameters(), group)
     if ev:
         ev[3].record()
+        timings.setdefault("render", []).append((ev_r, ev[0]))
         timings.setdefault("gather", []).append((ev[0], ev[1]))
+        timings.setdefault("losses_backward", []).append((ev[1], ev[2]))      # (with their own two reductions when N > 1)
         timings.setdefault("allreduce", []).append((ev[2], ev[3]))
         timings["stats"] = stats
     return loss.detach()

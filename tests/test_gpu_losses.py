@@ -162,41 +162,102 @@ def test_geo_correlation_loss_row_partitioned_equals_golden(tag):
     def call(phase, k):
         _lib.check(lib.nsos_geo_correlation_loss_rows(phase, P_(dbs[k]), P_(cd), P_(ray_o), P_(ray_d.contiguous()), P_(neg),
                                                       P_(rws[k]) if halves[k] else None, len(halves[k]), B, Cn, P, P, *prm, 15.0, 1,
-                                                      P_(out_loss[k]), P_(out_grad[k]), P_(wss[k]), wss[k].numel() * 8, None), "rows")
+                                                      P_(out_loss[k]), P_(out_grad[k]), P_(wss[k]), wss[k].numel() * 8, None, None, None), "rows")
 
-    for phase in range(4):
+    assert gn.value == lib.nsos_corr_exchange_floats(B, P * P) == B * P * P * 4 + 8
+    for phase in range(3):                       # phase 0 -> [means summed] -> phase 1 -> [sums summed] -> phase 2
         for k in range(2):
             call(phase, k)
         torch.cuda.synchronize()
-        if phase < 3:
-            sl = slice(so.value // 8 + 2 * phase, so.value // 8 + 2 * phase + 2)
+        if phase == 0:
+            sl = slice(so.value // 8, so.value // 8 + 4)
             tot = wss[0][sl] + wss[1][sl]
             wss[0][sl] = tot
             wss[1][sl] = tot
-            if phase == 2:
-                gl = slice(go.value // 4, go.value // 4 + gn.value)
-                g = wss[0].view(torch.float32)[gl] + wss[1].view(torch.float32)[gl]
-                wss[0].view(torch.float32)[gl] = g
-                wss[1].view(torch.float32)[gl] = g
+        if phase == 1:
+            gl = slice(go.value // 4, go.value // 4 + gn.value)
+            g = wss[0].view(torch.float32)[gl] + wss[1].view(torch.float32)[gl]
+            wss[0].view(torch.float32)[gl] = g
+            wss[1].view(torch.float32)[gl] = g
     for k in range(2):
         assert abs(out_loss[k].item() - want) < 1e-4 * (1 + abs(want))
         assert rel(out_grad[k], GOLD[f"{tag}_grad"]) < 1e-4
     assert torch.equal(out_grad[0], out_grad[1]) and torch.equal(out_loss[0], out_loss[1])
-    # phase 4 = the four phases in one call (what a single process uses: merged finishing launches), rows = every patch, against the
-    # four separate phases over the same rows: the same kernels on the same partial sums -- loss and gradient bit for bit
+    # phase 3 = the three phases in one call (what a single process uses: merged finishing launches), rows = every patch, against the
+    # separate phases over the same rows: the same kernels on the same partial sums (the loss sums' fp32 split is exact when nothing
+    # is added) -- loss and gradient bit for bit; and with the reduced slots handed in from outside (exchange buffers)
     all_rows = torch.arange(B, dtype=torch.int32, device=DEV)
     res = {}
-    for name, phases in (("one call", (4,)), ("four phases", (0, 1, 2, 3))):
+    for name, phases, ext in (("one call", (3,), False), ("phases", (0, 1, 2), False), ("phases, external slots", (0, 1, 2), True)):
         ws = torch.zeros((nbytes + 15) // 16 * 2, device=DEV, dtype=torch.float64)
         db = T(GOLD[f"{tag}_depth"]).contiguous()
         lo, gr = torch.empty((), device=DEV), torch.empty_like(cd)
+        xm = torch.full((8,), float("nan"), device=DEV, dtype=torch.float64) if ext else None
+        xs = torch.full((gn.value,), float("nan"), device=DEV) if ext else None
         for ph in phases:
             _lib.check(lib.nsos_geo_correlation_loss_rows(ph, P_(db), P_(cd), P_(ray_o), P_(ray_d.contiguous()), P_(neg), P_(all_rows), B, B, Cn,
-                                                          P, P, *prm, 15.0, 1, P_(lo), P_(gr), P_(ws), ws.numel() * 8, None), "rows")
+                                                          P, P, *prm, 15.0, 1, P_(lo), P_(gr), P_(ws), ws.numel() * 8,
+                                                          P_(xm) if ext else None, P_(xs) if ext else None, None), "rows")
         torch.cuda.synchronize()
         res[name] = (lo.clone(), gr.clone())
-    assert torch.equal(res["one call"][0], res["four phases"][0]) and torch.equal(res["one call"][1], res["four phases"][1])
+        if ext:
+            assert torch.isfinite(xm).all() and torch.isfinite(xs).all()
+    for name in ("phases", "phases, external slots"):
+        assert torch.equal(res["one call"][0], res[name][0]) and torch.equal(res["one call"][1], res[name][1]), name
     assert torch.equal(res["one call"][0], loss.detach())
+
+
+@pytest.mark.parametrize("tag", ["app_small", "app_full"])
+def test_correlation_loss_row_partitioned_equals_golden(tag):
+    """CorrelationLoss row-partitioned (nsos_app_correlation_loss_rows: what each rank of the patch-sharded step calls for its own
+    patches): two "ranks" in one process -- both halves' phases, the two reduced buffers added by hand the way the all-reduces do
+    -- give the golden loss on both, and each rank's gradient equals the golden gradient on ITS patches (zeros elsewhere);
+    with one rank owning everything the result equals the single-call entry bit for bit."""
+    mod = nerf_sos_amd.CorrelationLoss(ref_args())
+    feats, sim = T(GOLD[f"{tag}_feats"]), T(GOLD[f"{tag}_sim"])
+    code = T(GOLD[f"{tag}_code"])
+    B = code.shape[0]
+    want, want_grad = GOLD[f"{tag}_loss"][0], torch.from_numpy(np.asarray(GOLD[f"{tag}_grad"]))
+    from nerf_sos_amd.losses import exchange_floats
+    nx = exchange_floats(B, mod.feature_samples ** 2)
+    assert nx == B * mod.feature_samples ** 2 * 4 + 8
+    for split in ([list(range(B))], [list(range(0, B, 2)), list(range(1, B, 2))], [[], list(range(B))]):
+        evals = []
+        for rows in split:
+            xm, xs = torch.zeros(8, device=DEV, dtype=torch.float64), torch.full((nx,), float("nan"), device=DEV)
+            with InjectRand(GOLD[f"{tag}_rand1"], GOLD[f"{tag}_rand2"]):
+                run, (lo, gr) = mod.rows_phased(feats, code, sim, rows, (xm, xs))
+            evals.append((run, lo, gr, xm, xs, rows))
+        for phase in range(3):
+            for e in evals:
+                e[0](phase)
+            torch.cuda.synchronize()
+            if phase < 2:
+                bufs = [e[3 + phase] for e in evals]
+                tot = torch.stack(bufs).sum(0)
+                for b_ in bufs:
+                    b_.copy_(tot)
+        for run, lo, gr, xm, xs, rows in evals:
+            assert abs(lo.item() - want) < 1e-4 * (1 + abs(want)), (split, lo.item(), want)
+            own = torch.zeros(B, dtype=torch.bool)
+            own[rows] = True
+            if rows:
+                assert rel(gr.cpu()[own], want_grad[own].numpy()) < 1e-4
+            assert (not (~own).any()) or float(gr.cpu()[~own].abs().max()) == 0.0
+        assert all(torch.equal(e[1], evals[0][1]) for e in evals)
+        if len(split) == 1:
+            with InjectRand(GOLD[f"{tag}_rand1"], GOLD[f"{tag}_rand2"]):
+                l1, g1 = mod.value_and_grad(feats, code, sim)
+            assert torch.equal(l1, evals[0][1]) and torch.equal(g1, evals[0][2])
+    # the renderer's channel-last maps through the same entry
+    code_cl = code.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    xm, xs = torch.zeros(8, device=DEV, dtype=torch.float64), torch.zeros(nx, device=DEV)
+    with InjectRand(GOLD[f"{tag}_rand1"], GOLD[f"{tag}_rand2"]):
+        run, (lo, gr) = mod.rows_phased(feats, code_cl, sim, list(range(B)), (xm, xs))
+    for phase in range(3):
+        run(phase)
+    assert torch.equal(lo, evals[0][1]) if len(split) == 1 else abs(lo.item() - want) < 1e-4 * (1 + abs(want))
+    assert rel(gr, want_grad.numpy()) < 1e-4 and gr.permute(0, 2, 3, 1).is_contiguous()
 
 
 def test_losses_on_rendered_patches_train_the_semantic_head():

@@ -187,10 +187,12 @@ def test_bench_eight_ranks_smoke(config, steps):
         c = j["collectives"]
         assert j["config"]["patches"] == 16 and j["config"]["rays_per_gpu"] == 8192
         assert c["all_gathers_per_step"] == 1 and c["gathered_bytes_per_patch"] == 482816
-        # per step and rank: ONE flat patch gather, the stacked geometric loss's three phase reductions + its role-sum
-        # reduction, ONE flat gradient all-reduce -- counted by sharding.collective, nothing hidden
-        assert c["calls_per_step_by_kind"] == {"all_gather": 1.0, "geo_loss_phase_all_reduce": 3.0,
-                                                "geo_loss_role_sum_all_reduce": 1.0, "grad_all_reduce": 1.0}, c
+        # per step and rank FOUR collectives: ONE flat patch gather, the row-partitioned losses' two reductions (the means and the
+        # sums of the geometric AND both appearance evaluations, one buffer each), ONE flat gradient all-reduce -- counted by
+        # sharding.collective, nothing hidden
+        assert c["calls_per_step_by_kind"] == {"all_gather": 1.0, "loss_means_all_reduce": 1.0, "loss_sums_all_reduce": 1.0,
+                                                "grad_all_reduce": 1.0}, c
+        assert c["calls_per_step"] == 4.0
         assert c["all_reduce_floats"] == 2 * 41218 and abs(j["loss"]) < 10
     if config == "c5":
         assert j["scaling"] == "strong" and j["config"]["rays_per_gpu"] == 95256 and j["finite"] is True
