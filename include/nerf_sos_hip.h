@@ -370,6 +370,7 @@ int32_t nsos_mlp_lp_set_stamp_buffer(uint64_t* stamps);
  * each (mlp_lp8.hip); 1 = the round-1 kernel, one 512-register wave per SIMD with 64 points (mlp_lp.hip).  Same packed
  * stream, bit-identical results; exists for A/B measurements (models/nerf_mlp.py:67-100 is what both replace). */
 int32_t nsos_mlp_lp_select_kernel(int32_t waves_per_simd);
+int32_t nsos_mlp_lp_selected_kernel(void);   /* 3 = mlp_lp16_kernel (default), 2 = mlp_lp8_kernel, 1 = mlp_lp_kernel */
 
 /* ... and for the split-fp16 kernel (128-point tiles: more than 2 x 128 x (CU count) points).  scripts/phase_profile_x3.py. */
 int32_t nsos_mlp_profile_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "nsos_mlp_input_grads_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _i64, _fp, _fp, _fp]),
     "nsos_mlp_profile_rays_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_lp_select_kernel": (_i32, [_i32]),
+    "nsos_mlp_lp_selected_kernel": (_i32, []),
     "nsos_mlp_lp_set_stamp_buffer": (_i32, [_fp]),
     "nsos_mlp_profile_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),

@@ -471,13 +471,16 @@ extern "C" size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode) {
 
 static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed, size_t packed_bytes, void* stream,
                             bool heads_only);
+static int lp_waves_per_simd();
 extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
                                     size_t packed_bytes, void* stream) {
     return pack_lp_impl(T_, sem_mode, dtype, packed, packed_bytes, stream, false);
 }
 // Only what depends on semantic_linear.*: the head's chunks of all three streams (chunks 30.. of each: the trunk's 30 chunks come
 // first in every layout) and the aux block.  For the shipped training recipe (--fix_backbone: only the semantic heads train,
-// run_nerf.py:307-318) a step re-packs 3 chunks per stream instead of 37-40.  `packed` must hold a full pack of the same trunk.
+// run_nerf.py:307-318) a step re-packs 3 chunks instead of 37-40 -- and only in the stream of the kernel that is selected NOW
+// (nsos_mlp_lp_selected_kernel: one launch per net and step instead of three); `packed` must hold a full pack of the same trunk,
+// and after nsos_mlp_lp_select_kernel the next pack must be a full one (the other streams' heads are stale).
 extern "C" int32_t nsos_mlp_pack_lp_heads(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
                                           size_t packed_bytes, void* stream) {
     NSOS_REQUIRE(sem_mode == NSOS_SEM_PLAIN || sem_mode == NSOS_SEM_COORD, NSOS_ERR_UNSUPPORTED);
@@ -495,7 +498,9 @@ static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_
     if (sem_mode) NSOS_REQUIRE(T_->sem0_w && T_->sem0_b && T_->sem2_w && T_->sem2_b, NSOS_ERR_NULL_POINTER);
 
     const int X = NSOS_XYZ_DIM, W = NSOS_NET_WIDTH;
+    const int selected = lp_waves_per_simd();
     for (int layout = 0; layout < 2; ++layout) {   // 0: slice-major hidden layers (mlp_lp_kernel), 1: tile-pair-major (mlp_lp8_kernel)
+        if (heads_only && selected != layout + 1) continue;
         LpPackParams P = {};
         int n = 0;
         auto add = [&](const float* w, const float* bias, int in_dim, int col, int kind, int a0, int ng) {
@@ -540,6 +545,7 @@ static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_
     const int32_t rc = nsos_launch_status();
     if (rc != NSOS_OK) return rc;
     unsigned char* stream16 = reinterpret_cast<unsigned char*>(static_cast<unsigned*>(packed) + kAuxWords) + 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes;
+    if (heads_only && selected != 3) return NSOS_OK;
     return pack_lp16(T_, sem_mode, dtype == NSOS_DTYPE_F16, stream16, (hipStream_t)stream, heads_only);
 }
 
@@ -567,6 +573,8 @@ extern "C" int32_t nsos_mlp_lp_set_stamp_buffer(uint64_t* stamps) {
     g_lp_stamps = reinterpret_cast<unsigned long long*>(stamps);
     return NSOS_OK;
 }
+
+extern "C" int32_t nsos_mlp_lp_selected_kernel(void) { return lp_waves_per_simd(); }
 
 extern "C" int32_t nsos_mlp_lp_select_kernel(int32_t waves_per_simd) {
     NSOS_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 3, NSOS_ERR_UNSUPPORTED);

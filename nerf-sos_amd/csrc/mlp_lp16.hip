@@ -54,7 +54,16 @@ using namespace nsos::lp;
 
 namespace {
 
-constexpr int kRing16 = 4, kMid16 = 2, kDma16 = 5;
+#ifndef NSOS_LP16_WAVES
+#define NSOS_LP16_WAVES 8
+#endif
+// waves per workgroup (= per CU): 8 = two per SIMD; 16 = four per SIMD (the kernel needs <= 128 registers then): one weight slot then
+// serves 512 points, so the DMA's LDS writes, the barrier and the DMA issue slots per chunk are paid once per 2 x the MFMA work
+constexpr int kW16 = NSOS_LP16_WAVES;
+static_assert(kW16 == 8 || kW16 == 16, "8 or 16 waves per workgroup");
+constexpr int kTile16 = 32 * kW16;                                  // points per tile (= per pass over the weight stream)
+constexpr int kFull16 = kSlotGroups / kW16;                         // pieces every wave fetches of a full 36-piece chunk (4 | 2) ...
+constexpr int kRing16 = 4, kMid16 = 2, kDma16 = kFull16 + 1;        // ... + one more for the first waves (pieces 32..35)
 
 // NFILL (pipeline16x): how many 1 KiB pieces the chunk TWO AHEAD holds -- the DMA issued during a chunk fetches that one, and
 // copies only those pieces (the slot stride stays 36 KiB).  Copying every slot whole was 40 pieces per chunk (8 waves x 5, four
@@ -240,7 +249,7 @@ __device__ __forceinline__ void encode16(u32x4 (&out)[NS], const float (&x)[3], 
 }
 
 template <class T, int SEM, bool SAVE = false, bool PROF = false>
-__global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
+__global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB tables + 6 KiB output stage
     const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NCH = lp16_chunks(SEM);
@@ -254,10 +263,10 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
     auto slot_addr = [&](int b) { return lds_base + (unsigned)(b * kSlotBytes); };
     unsigned c0 = lane_addr(0), c1 = lane_addr(1), c2 = lane_addr(2), c3 = lane_addr(3);
     unsigned d0 = slot_addr(0), d1 = slot_addr(1), d2 = slot_addr(2), d3 = slot_addr(3);
-    // byte offset of this wave's i-th piece inside a chunk / slot: piece wave + 8 i (the surplus ones re-copy piece 35)
+    // byte offset of this wave's i-th piece inside a chunk / slot: piece wave + kW16 i (the surplus ones re-copy piece 35)
     const unsigned woff = (unsigned)wave_s * 1024u;
-    const unsigned wlast = wave_s + 32 < kSlotGroups ? woff + 32768u : (unsigned)(kSlotGroups - 1) * 1024u;
-    auto poff = [&](int i) { return i < 4 ? woff + 8192u * (unsigned)i : wlast; };
+    const unsigned wlast = wave_s + kW16 * kFull16 < kSlotGroups ? woff + (unsigned)(kW16 * kFull16) * 1024u : (unsigned)(kSlotGroups - 1) * 1024u;
+    auto poff = [&](int i) { return i < kFull16 ? woff + (unsigned)(kW16 * 1024) * (unsigned)i : wlast; };
     const unsigned char* const src_end = P.chunks + (size_t)NCH * kSlotBytes;
     const unsigned char* srcf = P.chunks + (size_t)(2 % NCH) * kSlotBytes;
     auto dma_piece = [&](const unsigned char* src_chunk, unsigned dst_slot, int i) {
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
     auto side = [&](auto early_c, auto late_c) {
         constexpr int EARLY = decltype(early_c)::value, LATE = decltype(late_c)::value;
         auto piece = [&](int i) {
-            const unsigned off = i < 4 ? fill_w + 8192u * (unsigned)i : fill_wlast;
+            const unsigned off = i < kFull16 ? fill_w + (unsigned)(kW16 * 1024) * (unsigned)i : fill_wlast;
             const unsigned long long sp = (((unsigned long long)fill_hi << 32) | fill_lo) + off;
             dma_1k(reinterpret_cast<const void*>(sp), fill_dst + off, voff);
         };
@@ -283,20 +292,20 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
     };
 #else
     auto side = [&](int i, int nfill) {
-        // this wave's i-th piece of the chunk being fetched: piece wave + 8 i -- if the chunk holds it.  The test is wave-uniform, but
+        // this wave's i-th piece of the chunk being fetched: piece wave + kW16 i -- if the chunk holds it.  The test is wave-uniform, but
         // a BRANCH around the copy cuts the chunk's straight-line code into basic blocks and the register allocator then spills
         // across them (8-38 scratch instructions per tile): where the test does not fold at compile time the piece is issued with
         // EXEC cleared instead -- a no-op that costs an issue slot -- inside one asm statement.
-        const unsigned off = fill_w + 8192u * (unsigned)i;
+        const unsigned off = fill_w + (unsigned)(kW16 * 1024) * (unsigned)i;
         const unsigned long long sp = (((unsigned long long)fill_hi << 32) | fill_lo) + off;
-        if (__builtin_constant_p(nfill) && 8 * i + 7 < nfill) {
+        if (__builtin_constant_p(nfill) && kW16 * i + kW16 - 1 < nfill) {
             dma_1k(reinterpret_cast<const void*>(sp), fill_dst + off, voff);
         } else {
             unsigned keep;
             unsigned long long saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_mov_b64 %1, exec\n\ts_cmp_lt_i32 %5, %6\n\ts_cselect_b64 exec, %1, 0\n\ts_nop 2\n\t"
                          "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep), "=&s"(saved) : "s"(fill_dst + off), "v"(voff), "s"(reinterpret_cast<const void*>(sp)), "s"(wave_s + 8 * i), "s"(nfill)
+                         : "=&s"(keep), "=&s"(saved) : "s"(fill_dst + off), "v"(voff), "s"(reinterpret_cast<const void*>(sp)), "s"(wave_s + kW16 * i), "s"(nfill)
                          : "memory", "scc");
         }
     };
@@ -322,6 +331,9 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
     };
     auto ctx = [&]() { return ChunkCtx{c0, c1}; };
 
+#ifdef NSOS_LP16_PRIO   // (A/B: static priority for the second-dispatched half of the workgroup, MI355X_MICROARCH.md "two waves per SIMD" item 4)
+    if (wave_s >= 4) __builtin_amdgcn_s_setprio(NSOS_LP16_PRIO);
+#endif
     f32x4 ring[kRing16];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
     if constexpr (PROF)
-        if (P.prof && blockIdx.x < 2 && lane0 == 0) P.prof[(blockIdx.x * 8 + wave_s) * kProfSlots + kProfSlots - 2] = __builtin_readcyclecounter();
+        if (P.prof && blockIdx.x < 2 && lane0 == 0 && wave_s < 8) P.prof[(blockIdx.x * 8 + wave_s) * kProfSlots + kProfSlots - 2] = __builtin_readcyclecounter();
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         // (lane-dependent loop invariants are re-derived per tile instead of living -- in scratch -- across every chunk: see mlp_lp8.hip)
         int lane = lane0;
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
             if constexpr (PROF) {
                 if (P.prof && tile == (int)(blockIdx.x + gridDim.x) && blockIdx.x < 2) {
                     const unsigned long long t = __builtin_readcyclecounter();
-                    if (lane == 0 && stamp_k < kProfSlots) P.prof[(blockIdx.x * 8 + wave_s) * kProfSlots + stamp_k] = t;
+                    if (lane == 0 && stamp_k < kProfSlots && wave_s < 8) P.prof[(blockIdx.x * 8 + wave_s) * kProfSlots + stamp_k] = t;
                 }
                 ++stamp_k;
             }
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
         stamp();  // 0: tile start
         // ---- this lane's two points: tile*256 + wave*32 + 16 c + n
         const int n_pts = (int)P.n_pts;
-        const int wave_first = tile * kTilePts + wave_s * 32;
+        const int wave_first = tile * kTile16 + wave_s * 32;
         const int n_here = n_pts - wave_first >= 32 ? 32 : (n_pts - wave_first < 0 ? 0 : n_pts - wave_first);
         int* const park = reinterpret_cast<int*>(lds + kSlots * kSlotBytes + kAuxWords * 4) + wave_s * 192 + lane;   // [2][64] ints of the wave's output stage
         bool save_ok[2] = {false, false};
@@ -881,12 +893,12 @@ __global__ __launch_bounds__(512, 1) void mlp_lp16_kernel(const LpParams P) {
     }
 #undef IC
     if constexpr (PROF)
-        if (P.prof && blockIdx.x < 2 && lane0 == 0) P.prof[(blockIdx.x * 8 + wave_s) * kProfSlots + kProfSlots - 1] = __builtin_readcyclecounter();
+        if (P.prof && blockIdx.x < 2 && lane0 == 0 && wave_s < 8) P.prof[(blockIdx.x * 8 + wave_s) * kProfSlots + kProfSlots - 1] = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
-constexpr int kLdsBytes16 = kSlots * kSlotBytes + kAuxWords * 4 + 8 * 768;   // 4 weight slots + encoding tables + the output stage (768 B per wave)
+constexpr int kLdsBytes16 = kSlots * kSlotBytes + kAuxWords * 4 + kW16 * 768;   // 4 weight slots + encoding tables + the output stage (768 B per wave)
 
 template <class T, int SEM, bool SAVE, bool PROF>
 int32_t launch16p(const LpParams& p, hipStream_t stream) {
@@ -899,8 +911,10 @@ int32_t launch16p(const LpParams& p, hipStream_t stream) {
         configured = true;
     }
     const int cus = nsos_device_cus();
-    const int grid = p.n_tiles < cus ? p.n_tiles : cus;
-    hipLaunchKernelGGL((mlp_lp16_kernel<T, SEM, SAVE, PROF>), dim3(grid), dim3(512), kLdsBytes16, stream, p);
+    LpParams q = p;
+    q.n_tiles = (int)((p.n_pts + kTile16 - 1) / kTile16);
+    const int grid = q.n_tiles < cus ? q.n_tiles : cus;
+    hipLaunchKernelGGL((mlp_lp16_kernel<T, SEM, SAVE, PROF>), dim3(grid), dim3(64 * kW16), kLdsBytes16, stream, q);
     return nsos_launch_status();
 }
 template <class T, int SEM, bool SAVE>

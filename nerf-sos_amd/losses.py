@@ -127,8 +127,14 @@ class CorrelationLoss(nn.Module):
             neg = torch.randperm(sim_matrix.shape[0], device=device, dtype=torch.long, generator=self.generator)   # :357
         return neg.to(device=device, dtype=torch.int64).contiguous()
 
+    def draw_coords(self, n_calls: int, B: int, device) -> torch.Tensor:
+        """[n_calls, 2, B, S, S, 2]: the sample coordinates of `n_calls` evaluations in ONE launch of the module's generator (a
+        training step scores two maps: four torch.rand launches otherwise); pass [i] as `coords` to value_and_grad / rows_phased."""
+        S = self.feature_samples
+        return torch.rand([n_calls, 2, B, S, S, 2], device=device, generator=self.generator)
+
     def _launcher(self, orig_feats: torch.Tensor, code_shape, sim_matrix: Optional[torch.Tensor], weight: float = 1.0,
-                  neg: Optional[torch.Tensor] = None):
+                  neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None):
         """Draws the sample coordinates and the negatives (the reference's order: rand1, rand2, negatives) and returns
         launch(code, want_grad) -> (weight * loss, weight * d loss / d code or None).  `weight` rides on the kernel's own
         self / negative weights (no extra launch); `neg`: negatives computed by the caller (one argmin per step, not per call)."""
@@ -139,8 +145,11 @@ class CorrelationLoss(nn.Module):
             raise ValueError(f"orig_feats has {B} patches, orig_code {Bc}")
         S = self.feature_samples
         dev = feats.device
-        rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :343 (the kernel applies *2-1)
-        rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :344
+        if coords is not None:                                                                           # drawn by the caller (draw_coords)
+            rand1, rand2 = _dev(coords[0], "coords"), _dev(coords[1], "coords")
+        else:
+            rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                       # :343 (the kernel applies *2-1)
+            rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                       # :344
         if neg is None:
             neg = self._neg_index(sim_matrix, B, dev)
         lib = _lib.lib()
@@ -170,7 +179,7 @@ class CorrelationLoss(nn.Module):
         return launch
 
     def rows_phased(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor], rows: Sequence[int],
-                    exchange, weight: float = 1.0, neg: Optional[torch.Tensor] = None):
+                    exchange, weight: float = 1.0, neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None):
         """The row-partitioned evaluation for the patch-sharded step (`nsos_app_correlation_loss_rows`): every rank passes the
         whole batch and ITS patches `rows`, draws the same coordinates (a generator seeded alike on every rank), and runs
         phase 0 -> [sum `means` over the ranks] -> phase 1 -> [sum `sums`] -> phase 2.  Returns (run(phase), (loss, grad)):
@@ -184,8 +193,11 @@ class CorrelationLoss(nn.Module):
             raise ValueError(f"orig_feats has {B} patches, orig_code {Bc}")
         S = self.feature_samples
         dev = feats.device
-        rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :343
-        rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                           # :344
+        if coords is not None:
+            rand1, rand2 = _dev(coords[0], "coords"), _dev(coords[1], "coords")
+        else:
+            rand1 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                       # :343
+            rand2 = torch.rand([B, S, S, 2], device=dev, generator=self.generator)                       # :344
         if neg is None:
             neg = self._neg_index(sim_matrix, B, dev)
         lib = _lib.lib()
@@ -214,10 +226,11 @@ class CorrelationLoss(nn.Module):
         return _CorrFn.apply(orig_code, self._launcher(orig_feats, orig_code.shape, sim_matrix))
 
     def value_and_grad(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor],
-                       weight: float = 1.0, neg: Optional[torch.Tensor] = None, want_grad: bool = True):
+                       weight: float = 1.0, neg: Optional[torch.Tensor] = None, want_grad: bool = True,
+                       coords: Optional[torch.Tensor] = None):
         """(weight * loss, weight * d loss / d orig_code) straight from the launch, outside autograd -- for a training step that
         sums the gradients of several losses itself and enters autograd once (sharding._losses_and_backward)."""
-        return self._launcher(orig_feats, orig_code.shape, sim_matrix, weight, neg)(orig_code, want_grad)
+        return self._launcher(orig_feats, orig_code.shape, sim_matrix, weight, neg, coords)(orig_code, want_grad)
 
 
 class GeoCorrelationLoss(CorrelationLoss):

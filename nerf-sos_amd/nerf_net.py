@@ -168,7 +168,8 @@ class NeRFMLP(nn.Module):
             # chunks while the frozen trunk's (data_ptr, _version) keys stand (3 chunks per stream instead of 37-40 per step and net)
             heads_only = False
             if trainable and precision in ("fp16", "bf16") and self.sem_mode != ops.SEM_NONE:
-                frozen = tuple((p.data_ptr(), p._version) for n, p in named if "semantic_linear" not in n)
+                # (+ the kernel selection: a heads-only re-pack touches the selected kernel's stream only)
+                frozen = (ops.lp_selected_kernel(),) + tuple((p.data_ptr(), p._version) for n, p in named if "semantic_linear" not in n)
                 only_heads = all(("semantic_linear" in n) or not p.requires_grad for n, p in named)
                 heads_only = only_heads and precision in self._packed and self._frozen_key.get(precision) == frozen
                 self._frozen_key[precision] = frozen if only_heads else None

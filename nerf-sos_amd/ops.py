@@ -303,6 +303,11 @@ def mlp_forward_rays(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, 
     return raw
 
 
+def lp_selected_kernel() -> int:
+    """3 = mlp_lp16_kernel (default), 2 = mlp_lp8_kernel, 1 = mlp_lp_kernel (NSOS_LP_KERNEL / nsos_mlp_lp_select_kernel)."""
+    return int(_lib.lib().nsos_mlp_lp_selected_kernel())
+
+
 def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, rays_o: torch.Tensor,
                         rays_d: torch.Tensor, viewdirs: torch.Tensor, z_vals: torch.Tensor) -> torch.Tensor:
     """K2 on the 16-bit matrix pipe: raw [R,S,C] fp32.  precision "fp16" / "bf16": reduced-precision MFMA inputs with

@@ -315,6 +315,7 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             n_ = corr_loss._neg_index(similarity_matrix(full["cls_"]) if sim is None else sim, B, dev)
             neg2 = torch.cat([n_, n_ + B])
         neg = neg2[:B]
+        xy = corr_loss.draw_coords(2, B, dev)      # both evaluations' coordinates in one launch (rand1, rand2 of s0, then of s1)
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # N > 1: all three evaluations row-partitioned (each rank the pair sets of its own patches), their phases interleaved
@@ -327,8 +328,8 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             means = torch.zeros(24, device=dev, dtype=torch.float64)
             sums = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
             xs = torch.split(sums, sizes)
-            run_a0, (la0, ga0) = corr_loss.rows_phased(f, s0, sim, own, (means[0:8], xs[1]), correlation_w, neg)
-            run_a1, (la1, ga1) = corr_loss.rows_phased(f, s1, sim, own, (means[8:16], xs[2]), correlation_w, neg)
+            run_a0, (la0, ga0) = corr_loss.rows_phased(f, s0, sim, own, (means[0:8], xs[1]), correlation_w, neg, xy[0])
+            run_a1, (la1, ga1) = corr_loss.rows_phased(f, s1, sim, own, (means[8:16], xs[2]), correlation_w, neg, xy[1])
             run_g, (lg, gg0, gg1) = geo_loss.pair_phased(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
                                                         sim, own, (means[16:24], xs[0]), geo_w, neg2)
             runs = (run_g, run_a0, run_a1)
@@ -347,11 +348,12 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             with torch.cuda.stream(side):
                 for t in (f, s0, s1, neg2):
                     t.record_stream(side)
-                la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
-                la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
+                xy.record_stream(side)
+                la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0])
+                la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1])
         else:
-            la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg)
-            la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg)
+            la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0])
+            la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1])
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
             lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
                                                           sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True)

@@ -116,7 +116,7 @@ def test_c4_per_gpu_workload_fp32_vs_port_losses(manifest):
         ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
     gen = sharding.loss_generator(torch.device(DEV), 3, 11)
     S = 11
-    draws = [torch.rand([2, S, S, 2], device=DEV, generator=gen).cpu() for _ in range(4)]   # corr(s0): 2 draws, corr(s1): 2 draws
+    draws = list(torch.rand([2, 2, 2, S, S, 2], device=DEV, generator=gen).cpu().reshape(4, 2, S, S, 2))   # one launch: corr(s0) rand1, rand2, corr(s1) rand1, rand2
     sim = sharding.similarity_matrix(cls_).cpu()
     s0, s1 = ret["semantics0"].permute(0, 3, 1, 2).cpu(), ret["semantics"].permute(0, 3, 1, 2).cpu()
     depth = ret["depth"].permute(0, 3, 1, 2).cpu().contiguous()

@@ -864,9 +864,25 @@ def test_heads_only_repack_equals_a_full_pack(manifest, name, precision):
             if "semantic_linear" in k:
                 v.add_(torch.randn_like(v) * 0.05)
     fresh = plan.run(None, precision)
-    part = plan.run(old, precision, heads_only=True)
-    assert part.data_ptr() == old.data_ptr()
-    assert torch.equal(part.view(torch.int32), fresh.view(torch.int32)), "heads-only re-pack != full pack"
+    # the re-pack touches the stream of the SELECTED kernel only: per kernel, a render from the partly re-packed buffer equals the
+    # render from a fresh full pack, and after all three selections the buffer is the fresh pack byte for byte
+    rays = tp.synthetic_rays(64, seed=3).to(DEV)
+    o, d = rays[0].contiguous(), rays[1].contiguous()
+    z, v = ops.ray_setup(d, torch.full((64,), tp.NEAR, device=DEV), torch.full((64,), tp.FAR, device=DEV), 48, None)
+    part = old
+    try:
+        for k in (1, 2, 3):
+            _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(k), "select")
+            assert ops.lp_selected_kernel() == k
+            part = plan.run(part, precision, heads_only=True)
+            assert part.data_ptr() == old.data_ptr()
+            assert torch.equal(ops.mlp_forward_rays_lp(part, mlp.sem_mode, precision, o, d, v, z),
+                               ops.mlp_forward_rays_lp(fresh, mlp.sem_mode, precision, o, d, v, z)), f"kernel {k}: heads-only re-pack != full pack"
+            if k < 3:
+                assert not torch.equal(part.view(torch.int32), fresh.view(torch.int32))     # the other streams still hold the old heads
+    finally:
+        _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(3), "select")
+    assert torch.equal(part.view(torch.int32), fresh.view(torch.int32)), "heads-only re-packs of all three streams != full pack"
     # the module: frozen trunk, trainable heads -> first call full, later calls heads-only; results follow in-place updates
     for n_, p_ in net.named_parameters():
         p_.requires_grad = "semantic_linear" in n_
@@ -875,7 +891,18 @@ def test_heads_only_repack_equals_a_full_pack(manifest, name, precision):
         params["semantic_linear.2.bias"].add_(1.0)
     b = mlp.packed_weights(precision)
     assert not torch.equal(a.view(torch.int32), b.view(torch.int32))
-    assert torch.equal(b.view(torch.int32), plan.run(None, precision).view(torch.int32))
+    full = plan.run(None, precision)
+    assert not torch.equal(b.view(torch.int32), full.view(torch.int32))        # (the streams of the kernels not selected keep the old heads)
+    assert torch.equal(ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z), ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
+    # a change of the kernel selection forces a full pack (the other streams' heads would be stale)
+    try:
+        _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(2), "select")
+        with torch.no_grad():
+            params["semantic_linear.2.bias"].add_(1.0)
+        c = mlp.packed_weights(precision)
+        assert torch.equal(c.view(torch.int32), plan.run(None, precision).view(torch.int32))
+    finally:
+        _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(3), "select")
 
 
 # ------------------------------------------------------------------------------------------ K2-LP16 (16x16x32 tiles; the default)
