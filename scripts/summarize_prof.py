@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+DRIVER = "--driver" in sys.argv or os.environ.get("PROFILE_CMD", "").endswith("traffic_driver.py")   # the profiled command was the kernel driver
 
 
 def find(pat):
@@ -44,7 +45,13 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_tcc"):
         seen = defaultdict(dict)
         for r in sorted(rows, key=lambda r: int(r.get("Dispatch_Id", 0))):
             name = short(r["Kernel_Name"])
-            if "mlp_fused" in name or "mlp_lp_kernel" in name:
+            if DRIVER and ("mlp_lp" in name or "mlp_x3" in name or "mlp_fused" in name):
+                # scripts/diag/traffic_driver.py: REPS launches per kernel and shape, in a fixed order
+                d = seen[name]
+                if r["Dispatch_Id"] not in d:
+                    d[r["Dispatch_Id"]] = len(d)
+                name += f" [launch set {d[r['Dispatch_Id']] // 6}]"
+            elif "mlp_fused" in name or "mlp_lp_kernel" in name:
                 d = seen[name]
                 if r["Dispatch_Id"] not in d:
                     d[r["Dispatch_Id"]] = len(d)
@@ -52,6 +59,6 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write", "pmc_tcc"):
             agg[(name, r.get("Grid_Size", ""))][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"== pmc pass: mean counter value per dispatch")
         for k, cs in sorted(agg.items(), key=lambda kv: -len(kv[1]))[:40]:
-            if not any(t in k[0] for t in ("mlp_fused", "mlp_lp_kernel", "composite", "importance", "wgrad", "pair_")):
+            if not any(t in k[0] for t in ("mlp_", "composite", "importance", "wgrad", "pair_")):
                 continue
             print(f"  {k[0]:60s} grid {k[1]:>8s} " + "  ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(cs.items())))
