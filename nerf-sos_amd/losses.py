@@ -133,8 +133,15 @@ class CorrelationLoss(nn.Module):
         S = self.feature_samples
         return torch.rand([n_calls, 2, B, S, S, 2], device=device, generator=self.generator)
 
+    def queue_coords(self, coords) -> None:
+        """Sample coordinates for the NEXT len(coords) evaluations (each item [2, B, S, S, 2] from draw_coords), consumed in order by
+        forward / value_and_grad calls that are not handed `coords` themselves."""
+        self._queued = list(coords)
+
     def _launcher(self, orig_feats: torch.Tensor, code_shape, sim_matrix: Optional[torch.Tensor], weight: float = 1.0,
                   neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None):
+        if coords is None and getattr(self, "_queued", None):
+            coords = self._queued.pop(0)
         """Draws the sample coordinates and the negatives (the reference's order: rand1, rand2, negatives) and returns
         launch(code, want_grad) -> (weight * loss, weight * d loss / d code or None).  `weight` rides on the kernel's own
         self / negative weights (no extra launch); `neg`: negatives computed by the caller (one argmin per step, not per call)."""

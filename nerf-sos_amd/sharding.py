@@ -397,11 +397,14 @@ def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, 
         if gen is not None:
             corr_loss.generator = gen
         f = full["feat"]
+        if hasattr(corr_loss, "queue_coords"):     # the same one-launch draw as the direct path: both formulations see the same samples
+            xy = corr_loss.draw_coords(2, s0.shape[0], dev)
+            corr_loss.queue_coords([xy[0], xy[1]])
         if side is not None:
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for t in (f, s0, s1, sim):
+                for t in (f, s0, s1, sim) + ((xy,) if hasattr(corr_loss, "queue_coords") else ()):
                     t.record_stream(side)
                 app = correlation_w * (corr_loss(f, s0, sim) + corr_loss(f, s1, sim))
         else:
