@@ -408,7 +408,7 @@ extern "C" int32_t nsos_sem_head_wgrad(const float* weights, const float* g_sema
 namespace nsos_detail {
 int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                          const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples, const float* scale,
-                         float* partial, int blocks, hipStream_t st);   // sem_wgrad16.hip
+                         float* partial, int blocks, hipStream_t st, float* scale_out);   // sem_wgrad16.hip
 }
 
 namespace {
@@ -459,16 +459,18 @@ extern "C" int32_t nsos_sem_head_wgrad_x3(const float* weights, const float* g_s
     if (steps < blocks) blocks = (int)(steps > 0 ? steps : 1);
     const hipStream_t st = (hipStream_t)stream;
     float* ws = static_cast<float*>(workspace);
-    if (!scale) {
-        float* derived = ws + (size_t)1024 * kWgradOut;
+    float* const derived = ws + (size_t)1024 * kWgradOut;
+    const bool in_kernel = !scale && sem_in_dtype != 0;      // the 16-bit kernel derives the scale itself (one launch less per call)
+    if (!scale && !in_kernel) {
         hipLaunchKernelGGL(sem_head_scale_kernel, dim3(1), dim3(1024), 0, st, g_semantics, 2ll * n_rays, sem2_w, derived);
         scale = derived;
     }
     switch (sem_in_dtype) {
         case 0: hipLaunchKernelGGL(sem_head_wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, weights, g_semantics, sem2_w, static_cast<const float*>(sem_hid), static_cast<const float*>(sem_in), scale, n_pts, (int)n_samples, ws); break;
         default: {
-            const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype | tiled, n_rays, n_samples, scale, ws, blocks, st);
+            const int32_t rc = nsos_detail::sem_head_wgrad16(weights, g_semantics, sem2_w, sem_hid, sem_in, sem_in_dtype | tiled, n_rays, n_samples, scale, ws, blocks, st, derived);
             if (rc != NSOS_OK) return rc;
+            if (in_kernel) scale = derived;
         }
     }
     hipLaunchKernelGGL(sem_head_wgrad_reduce_kernel, dim3((kWgradOut + 63) / 64), dim3(256), 0, st,

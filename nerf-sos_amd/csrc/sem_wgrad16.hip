@@ -35,7 +35,7 @@
 namespace nsos_detail {
 int32_t sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                          const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples, const float* scale,
-                         float* partial, int blocks, hipStream_t st);
+                         float* partial, int blocks, hipStream_t st, float* scale_out);
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -160,7 +160,8 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
                                                                   const float* __restrict__ w2, const unsigned short* __restrict__ hid,
                                                                   const unsigned short* __restrict__ sem_in,
                                                                   const float* __restrict__ scale_p, long long n_pts,
-                                                                  long long n_rays, int S, float* __restrict__ partial) {
+                                                                  long long n_rays, int S, float* __restrict__ partial,
+                                                                  float* __restrict__ scale_out) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kBufBytes];
     const int lane = threadIdx.x & 63, i = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,7 +174,30 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     const long long s0 = (long long)blockIdx.x * per;
     const long long s1 = s0 + per < n_full ? s0 + per : n_full;
     const int nf = __builtin_amdgcn_readfirstlane((int)(s1 > s0 ? s1 - s0 : 0));
-    const float scale = *scale_p;
+    // The power of two that brings g_hid into the 16-bit range: handed in, or (scale_p == NULL) derived here by EVERY workgroup
+    // from the same 2 n_rays + 256 values -- what sem_head_scale_kernel computes (backward.hip), without its launch: a maximum
+    // does not depend on the order, so all workgroups agree bit for bit; workgroup 0 publishes it for the reduction kernel.
+    float scale;
+    if (scale_p) scale = *scale_p;
+    else {
+        float* const red = reinterpret_cast<float*>(lds);
+        float m = 0.0f;
+        for (long long j = threadIdx.x; j < 2 * n_rays; j += 512) m = fmaxf(m, fabsf(g_sem[j]));
+        float c = threadIdx.x < 128 ? fabsf(w2[threadIdx.x]) + fabsf(w2[128 + threadIdx.x]) : 0.0f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            m = fmaxf(m, __shfl_xor(m, off, 64));
+            c = fmaxf(c, __shfl_xor(c, off, 64));
+        }
+        if (lane == 0) { red[wave] = m; red[8 + wave] = c; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { m = fmaxf(m, red[k]); c = fmaxf(c, red[8 + k]); }
+        const float bound = fmaxf(m * c, 1e-30f);
+        scale = exp2f(fminf(fmaxf(floorf(log2f(256.0f / bound)), -60.0f), 60.0f));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
+        __syncthreads();                               // the staging images reuse this LDS
+    }
     // g-kind lane: point pl of the step, features 8 fo .. 8 fo + 7.  Row-major hid: a wave takes 4 points x all 16 octets (four
     // 256-byte rows); tile-major hid ([group][octet][point][8]): 16 points x 4 octets (four 256-byte runs)
     const int pl = HTILED ? (lane & 15) : 4 * gt + (lane >> 4), fo = HTILED ? 4 * gt + (lane >> 4) : (lane & 15);
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
 
 int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_semantics, const float* sem2_w, const void* sem_hid,
                                       const void* sem_in, int32_t sem_in_dtype, int64_t n_rays, int32_t n_samples,
-                                      const float* scale, float* partial, int blocks, hipStream_t st) {
+                                      const float* scale, float* partial, int blocks, hipStream_t st, float* scale_out) {
     const long long n_pts = (long long)n_rays * n_samples;
     const unsigned short* x = static_cast<const unsigned short*>(sem_in);
     const unsigned short* h = static_cast<const unsigned short*>(sem_hid);
@@ -498,7 +522,7 @@ int32_t nsos_detail::sem_head_wgrad16(const float* weights, const float* g_seman
     const int fmt = sem_in_dtype & ~(NSOS_SEM_IN_TILED | NSOS_SEM_HID_TILED);
     if (htiled && !tiled) return NSOS_ERR_UNSUPPORTED;       // (the kernels store either sem_in alone or both matrices tile-major)
 #define NSOS_WG16_LAUNCH(F, T, H) hipLaunchKernelGGL((sem_head_wgrad16_kernel<F, T, H>), dim3(blocks), dim3(512), 0, st, weights, g_semantics, sem2_w, h, x, \
-                                                     scale, n_pts, (long long)n_rays, (int)n_samples, partial)
+                                                     scale, n_pts, (long long)n_rays, (int)n_samples, partial, scale_out)
     if (fmt == 1) { if (htiled) NSOS_WG16_LAUNCH(1, true, true); else if (tiled) NSOS_WG16_LAUNCH(1, true, false); else NSOS_WG16_LAUNCH(1, false, false); }
     else { if (htiled) NSOS_WG16_LAUNCH(2, true, true); else if (tiled) NSOS_WG16_LAUNCH(2, true, false); else NSOS_WG16_LAUNCH(2, false, false); }
 #undef NSOS_WG16_LAUNCH

@@ -332,7 +332,7 @@ class _FullRender(torch.autograd.Function):
             # trunk masks from the saved fp32 activations, "fp16x3": split-fp16 reductions and the forward's bit masks
             by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
                                    mlp.packed_weights("fp16x3_bwd"), sv["masks"],
-                                   split_wgrad=net.mlp_precision == "fp16x3" or net.exact_weight_gradients is False)
+                                   split_wgrad=net.mlp_precision != "fp32" or net.exact_weight_gradients is False)
             grads += [by_name.get(n) for n in names]
         ctx.saved = None   # release 10 KB/point of activations now (the node lives as long as the caller keeps the loss)
         return (None, None, None) + tuple(grads)
@@ -341,6 +341,8 @@ class _FullRender(torch.autograd.Function):
 class NeRFNet(nn.Module):
     """Coarse + fine volumetric renderer with the reference's constructor and call contract
     (models/nerf_net.py:22-195).  Note the reference's spelling ``pts_chuck``."""
+
+    _warned_full_16bit = False
 
     def __init__(self, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, N_samples=64, N_importance=64,
                  viewdirs=True, use_embed=True, multires=10, multires_views=4, conv_embed=False,
@@ -447,9 +449,14 @@ class NeRFNet(nn.Module):
         other = [n for n in trainable if "semantic_linear" not in n]
         if other:
             # any backbone parameter trainable (e.g. configs/flower_full.txt trains everything): full backward
-            if self.mlp_precision not in ("fp32", "fp16x3"):
-                raise NotImplementedError("NeRFNet: the full backward needs fp32-accurate activations; set "
-                                          "mlp_precision = 'fp32' or 'fp16x3', or freeze the backbone (run_nerf.py:307-318)")
+            if self.mlp_precision not in ("fp32", "fp16x3") and not NeRFNet._warned_full_16bit:
+                # there is no 16-bit full backward (the reference has no 16-bit path at all): a trainable backbone under
+                # "fp16" / "bf16" trains on the split-fp16 kernels -- 16-bit matrix pipe, fp32-grade values, the same gradient
+                # tests as "fp16x3" -- instead of raising; inference and frozen-backbone steps keep the 16-bit kernels
+                import warnings
+                warnings.warn(f"nerf_sos_amd.NeRFNet: mlp_precision={self.mlp_precision!r} with a trainable backbone runs the "
+                              "split-fp16 ('fp16x3') forward and backward kernels: there is no 16-bit full backward", stacklevel=2)
+                NeRFNet._warned_full_16bit = True
             params = [p_ for _, m in self._sem_nets() for _, p_ in _named_params(m.mlp)]
             outs = _FullRender.apply(self, args, kwargs, *params)
             return dict(zip(self._last_keys, outs))
@@ -480,8 +487,8 @@ class NeRFNet(nn.Module):
                                                    self.mlp_precision, rays_o, rays_d, viewdirs, z)
                 return ops.mlp_forward_rays(net.packed_weights(), net.sem_mode, rays_o, rays_d, viewdirs, z)
             if save == "all":   # full backward (K7): every layer's activations (exact-fp32 or split-fp16 kernel)
-                raw, acts, masks = ops.mlp_forward_rays_save_all(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,
-                                                                 rays_d, viewdirs, z, self.mlp_precision)
+                prec = self.mlp_precision if self.mlp_precision in ("fp32", "fp16x3") else "fp16x3"    # (see render_rays)
+                raw, acts, masks = ops.mlp_forward_rays_save_all(net.packed_weights(prec), net.sem_mode, rays_o, rays_d, viewdirs, z, prec)
                 saved[tag] = dict(acts=acts, raw=raw, z=z, masks=masks)
                 return raw
             raw, sem_in, sem_hid = ops.mlp_forward_rays_save(net.packed_weights(self.mlp_precision), net.sem_mode, rays_o,

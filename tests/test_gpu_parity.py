@@ -408,9 +408,10 @@ def test_training_variant_matches_inference_and_optimizer_step(manifest):
     assert c["semantics"].square().mean() < a["semantics"].square().mean()
 
 
-def test_unfrozen_backbone_trains_in_fp32_and_raises_at_16_bit():
-    """Everything trainable (configs/*_full.txt): the full backward runs on the fp32 path; there is no 16-bit full
-    backward and no autograd fallback, so that combination raises.  Backward twice through one render raises too."""
+def test_unfrozen_backbone_trains_in_fp32_and_on_the_split_kernels_at_16_bit():
+    """Everything trainable (configs/*_full.txt): the full backward runs on the fp32 path; there is no 16-bit full backward, so a
+    16-bit mlp_precision with a trainable backbone trains on the split-fp16 kernels (a warning says so; the gradients are the
+    "fp16x3" ones bit for bit).  Backward twice through one render raises."""
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True).to(DEV)
     rays = tp.synthetic_rays(8).to(DEV)
     ret = net(rays, (tp.NEAR, tp.FAR))
@@ -420,9 +421,25 @@ def test_unfrozen_backbone_trains_in_fp32_and_raises_at_16_bit():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     with pytest.raises(RuntimeError):
         loss.backward()
-    net.mlp_precision = "bf16"
-    with pytest.raises(NotImplementedError, match="fp32"):
-        net(rays, (tp.NEAR, tp.FAR))
+    grads = {}
+    for prec in ("fp16x3", "bf16"):
+        net.mlp_precision = prec
+        net.zero_grad(set_to_none=True)
+        nerf_sos_amd.NeRFNet._warned_full_16bit = False
+        torch.manual_seed(3)
+        if prec == "bf16":
+            with pytest.warns(UserWarning, match="split-fp16"):
+                ret = net(rays, (tp.NEAR, tp.FAR))
+        else:
+            ret = net(rays, (tp.NEAR, tp.FAR))
+        (ret["rgb"].sum() + ret["rgb0"].sum()).backward()
+        grads[prec] = {n: p.grad.clone() for n, p in net.named_parameters()}
+    assert all(torch.equal(grads["bf16"][n], grads["fp16x3"][n]) for n in grads["bf16"])
+    with torch.no_grad():                                    # inference under "bf16" stays on the 16-bit kernel
+        net.mlp_precision = "bf16"
+        a = net(rays, (tp.NEAR, tp.FAR))["rgb"]
+        net.mlp_precision = "fp16x3"
+        assert not torch.equal(a, net(rays, (tp.NEAR, tp.FAR))["rgb"])
 
 
 # ------------------------------------------------------------------------------------------ K0 (section 8f)
