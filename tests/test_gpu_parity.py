@@ -437,9 +437,9 @@ def test_unfrozen_backbone_trains_in_fp32_and_on_the_split_kernels_at_16_bit():
     assert all(torch.equal(grads["bf16"][n], grads["fp16x3"][n]) for n in grads["bf16"])
     with torch.no_grad():                                    # inference under "bf16" stays on the 16-bit kernel
         net.mlp_precision = "bf16"
-        a = net(rays, (tp.NEAR, tp.FAR))["rgb"]
+        a = net(rays, (tp.NEAR, tp.FAR))["raw"]
         net.mlp_precision = "fp16x3"
-        assert not torch.equal(a, net(rays, (tp.NEAR, tp.FAR))["rgb"])
+        assert not torch.equal(a, net(rays, (tp.NEAR, tp.FAR))["raw"])
 
 
 # ------------------------------------------------------------------------------------------ K0 (section 8f)
