@@ -47,8 +47,9 @@ def local_patches(n_patches: int, rank: int, world: int) -> List[int]:
 # per step, the geometric loss's phase reductions included) and puts a watchdog on each one.  A rank that skips a
 # collective its peers issue (a mismatch of the call sequences -- e.g. a rank that owns no patch taking a short cut) is a
 # hang, not an error, in torch.distributed: with COLLECTIVE_TIMEOUT_S set, the host waits on the work handle for at most that
-# long and then raises with the name of the collective and the rank (gloo honours the wait timeout; with RCCL the wait only
-# orders streams, and the process group's own timeout -- set it at init_process_group -- aborts the job through its watchdog).
+# long and then raises with the name of the collective and the rank (gloo only: with RCCL a timed wait would block the host on
+# every collective, so there the wait only orders streams and the process group's own timeout -- set it at init_process_group --
+# aborts the job through its watchdog).
 COLLECTIVE_TIMEOUT_S: Optional[float] = float(os.environ.get("NSOS_COLLECTIVE_TIMEOUT_S", "0")) or None
 COLLECTIVE_COUNTS: Dict[str, int] = {}
 # diagnostics (bench.py): a dict here makes every collective record (HIP event before, HIP event after, host seconds) under its
@@ -85,7 +86,11 @@ def _collective(kind: str, launch: Callable[..., "dist.Work"], group=None):
     work = launch(async_op=True)
     if work is None:
         return
-    if COLLECTIVE_TIMEOUT_S is None:
+    # RCCL: wait() without a timeout only makes the current stream wait for the collective's stream -- the host runs on.  A wait
+    # WITH a timeout blocks the host thread until the collective has completed (ProcessGroupNCCL::WorkNCCL::wait): four host
+    # synchronisations per training step.  There the process group's own timeout (init_process_group(timeout=...)) and its
+    # watchdog abort a diverged job; the per-collective host wait is for gloo (CPU tests, ranks sharing one GPU).
+    if COLLECTIVE_TIMEOUT_S is None or dist.get_backend(group) == "nccl":
         work.wait()
         return
     import datetime
