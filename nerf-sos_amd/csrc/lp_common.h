@@ -203,9 +203,13 @@ int32_t launch_lp8(const LpParams& p, int32_t sem_mode, bool is_f16, bool save, 
 
 // mlp_lp16.hip: the same workgroup shape on v_mfma_f32_16x16x32 (its own packed stream: p.chunks points at it)
 __host__ __device__ constexpr int lp16_chunks(int sem) {
-    // L0 (1) + 7 quad layers x 4 + L5 h (4) + L5 x63 (1) + [sem0 h (2) + tail (1) | sigma (1)] + views (2) + rgb (1)
-    return 1 + 28 + 5 + (sem ? 3 : 1) + 3;
+    // L0 (1) + 7 quad layers x 4 + L5 h (4) + L5 x63 (1) + [sem0 h (2) + tail (1) | sigma (1)] + views (2)
+    return 1 + 28 + 5 + (sem ? 3 : 1) + 2;
 }
+// behind the chunks: the four A operands of rgb_linear (rows 0..2 of the raw tile x 4 slices of the view branch's hidden
+// activations), which the kernel keeps resident in LDS instead of streaming them as a chunk of their own
+constexpr int kLp16TailBytes = 4096;
+__host__ __device__ constexpr size_t lp16_stream_bytes(int sem) { return (size_t)lp16_chunks(sem) * kSlotBytes + kLp16TailBytes; }
 int32_t launch_lp16(const LpParams& p, int32_t sem_mode, bool is_f16, bool save, hipStream_t stream);
 int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned char* chunks, hipStream_t stream, bool heads_only = false);
 

@@ -466,7 +466,7 @@ extern "C" size_t nsos_mlp_packed_bytes_lp(int32_t sem_mode) {
     if (sem_mode < 0 || sem_mode > 2) return 0;
     // aux + the slice-major stream of mlp_lp_kernel + the stream of mlp_lp8_kernel (tile-pair-major hidden layers) + the stream
     // of mlp_lp16_kernel (16x16x32 tiles, tile-quad-major hidden layers)
-    return (size_t)kAuxWords * 4 + (2 * (size_t)lp_chunks(sem_mode) + (size_t)lp16_chunks(sem_mode)) * kSlotBytes;
+    return (size_t)kAuxWords * 4 + 2 * (size_t)lp_chunks(sem_mode) * kSlotBytes + lp16_stream_bytes(sem_mode);
 }
 
 static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed, size_t packed_bytes, void* stream,

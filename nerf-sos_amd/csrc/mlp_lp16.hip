@@ -43,6 +43,10 @@
 //     the vector ALU.  rgb and semantics therefore see the hidden activations and their weights rounded to 16 bits (the
 //     sigma head always did); the tests hold this to an emulation with exactly these roundings (tests/test_gpu_parity.py).  Lane
 //     (n, 0) ends up with [r, g, b, sigma] of its point: the C = 4 output is one 16-byte store per point.
+//     rgb_linear's four A operands (4 KiB behind the stream's chunks) are fetched once per workgroup and stay in LDS: its 8 MFMAs
+//     run right behind the view branch's activation (a chunk of their own -- barrier, ring restart, DMA pieces -- cost 2.6 k
+//     cycles per tile for 8 MFMAs; folding them into the next tile's layer-0 chunk instead made hipcc keep the 32 registers of
+//     the pending activations in scratch across the tile boundary: +15 % cycles, profiles/r04).
 //   * The encodings are evaluated for the lane's 2 x 16 feature slots from a per-(q, slot) table in LDS (octave scale per
 //     coordinate + phase: sin(2 pi (frac + 1/4)) = cos), the same two-term revolution arithmetic as Enc::evaluate_hw.
 // Results are NOT bit-identical to mlp_lp_kernel / mlp_lp8_kernel (other contraction order inside the MFMAs, 16-bit heads):
@@ -190,6 +194,7 @@ __device__ __forceinline__ void mov_slice16(u32x4& dst, const u32x4& src) {   //
 // Slot j = 8 s + e of lane group q carries encoded feature f = 32 s + 8 q + e.  Table entry (q, j) = {sx, sy, sz, phase}:
 // the feature's octave scale 2^k on its coordinate (0 on the other two) and phase 0 (sin) / 0.25 revolutions (cos); all
 // zero for the raw coordinates (f < 3) and the pad slots, whose values are selected separately.
+constexpr int kRgbLds = kSlots * kSlotBytes + kAuxWords * 4 + kW16 * 768;   // LDS offset of rgb_linear's four resident A operands
 constexpr int kTabXyz = 0;            // [4 q][16 slots] f32x4 = 1 KiB, in the (otherwise unused) aux region of LDS
 constexpr int kTabDir = 1024;         // [4 q][8 slots] f32x4 = 512 B
 __device__ __forceinline__ f32x4 enc_table_entry(int f, int n_freqs) {
@@ -340,6 +345,14 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P
 #pragma unroll
         for (int i = 0; i < kDma16; ++i)
             dma_piece(P.chunks + (size_t)(k % NCH) * kSlotBytes, k == 0 ? d0 : (k == 1 ? d1 : d2), i);
+    // rgb_linear's four A operands stay resident in LDS (kRgbLds): its 8 MFMAs per wave and tile run right behind the view branch's
+    // activation instead of in a chunk of their own (a barrier, a ring restart and five DMA pieces for 8 MFMAs: 2.6 k cycles per tile)
+    if (wave_s < 4) {
+        const unsigned long long sp = (unsigned long long)(P.chunks + (size_t)NCH * kSlotBytes + (size_t)wave_s * 1024);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sp), hi = __builtin_amdgcn_readfirstlane((unsigned)(sp >> 32));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(kRgbLds + wave_s * 1024));
+        dma_1k(reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo), dst, voff);
+    }
     unsigned char* const tabs = lds + kSlots * kSlotBytes;
     if (threadIdx.x < 64) {            // xyz table: entry (q, j) of feature 32 (j >> 3) + 8 q + (j & 7)
         const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
@@ -798,12 +811,12 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(zq[t][0]), "+v"(zq[t][1]));
         };
-        view_chunk(Zq[0], no_ride, 4);       // (fetches the rgb chunk)
+        view_chunk(Zq[0], no_ride, 32);      // (fetches the next tile's layer 0)
         view_chunk(Zq[1], [&](auto gc_) {
             constexpr int g = decltype(gc_)::value;
             if constexpr (g >= 9 && g <= 24) { constexpr int k = g - 9; NSOS_RELU_WORD16(Vp[k >> 3][(k >> 2) & 1][k & 3], 0u); }
             if constexpr (g >= 8 && g < 24) { constexpr int k = g - 8; Vp[k >> 3][(k >> 2) & 1][k & 3] = quad_word(Zq[0], k >> 3, (k >> 2) & 1, k & 3); }
-        }, 32);                              // (the next tile's layer 0)
+        }, 33);                              // (the next tile's layer 1, first quad)
         stamp();  // view-branch MFMAs
         {
             asm volatile("s_nop 7" ::: "memory");
@@ -829,15 +842,20 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P
             }
             chk[c] = acc;
         }
-        // rgb_linear: rows 0..2 of the raw tile, 4 slices of the view branch's hidden activations
-        pipeline16<8, 4, 0ull>(ring, ctx(), [&](auto ic, const f32x4& a32, const f32x4&) {
-            constexpr int g = decltype(ic)::value;
-            if constexpr (g < 4) {
-                const u32x4 aop = __builtin_bit_cast(u32x4, a32);
-                R[0] = T::mfma_k32(aop, Vp[g][0], R[0]);
-                R[1] = T::mfma_k32(aop, Vp[g][1], R[1]);
+        // rgb_linear: rows 0..2 of the raw tile += W_rgb x the view branch's hidden activations (4 slices), operands from LDS
+        {
+            f32x4 ra[4];
+            const unsigned ra_addr = lds_base + (unsigned)kRgbLds + (unsigned)(lane * 16);
+            static_for<0, 4>([&](auto kc) { lds_read_a<decltype(kc)::value * 1024>(ra[decltype(kc)::value], ra_addr); });
+            // (drains the ring's look-ahead reads of the next chunk too: its counted waits then pass at once)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 aop = __builtin_bit_cast(u32x4, ra[k]);
+                R[0] = T::mfma_k32(aop, Vp[k][0], R[0]);
+                R[1] = T::mfma_k32(aop, Vp[k][1], R[1]);
             }
-        }, mid, tail, side, 33);             // (the next tile's layer 1, first quad)
+        }
         asm volatile("" : "+v"(R[0]), "+v"(R[1]));
         stamp();  // rgb MFMAs
         {
@@ -898,7 +916,8 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P
     __syncthreads();
 }
 
-constexpr int kLdsBytes16 = kSlots * kSlotBytes + kAuxWords * 4 + kW16 * 768;   // 4 weight slots + encoding tables + the output stage (768 B per wave)
+constexpr int kLdsBytes16 = kRgbLds + kLp16TailBytes;   // 4 weight slots + encoding tables + the output stage (768 B per wave) + rgb_linear's operands
+static_assert(kLdsBytes16 <= 160 * 1024, "LDS");
 
 template <class T, int SEM, bool SAVE, bool PROF>
 int32_t launch16p(const LpParams& p, hipStream_t stream) {
@@ -946,6 +965,7 @@ struct Pack16Params {
     Chunk16 ch[48];
     int n_chunks;
     int first, count;     // the chunks [first, first + count) are written
+    int tail;             // != 0: also the four rgb_linear operands behind the last chunk
     const float* alpha_w; const float* alpha_b;
     const float* rgb_w; const float* rgb_b;
     const float* sem0_w; const float* sem0_b;
@@ -959,9 +979,11 @@ template <class T>
 __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_chunk = kSlotBytes / 2;  // 16-bit elements per slot
-    if (gid >= (long long)P.count * per_chunk) return;
-    const Chunk16 ck = P.ch[P.first + gid / per_chunk];
-    const int within = (int)(gid % per_chunk);
+    const long long body = (long long)P.count * per_chunk;
+    if (gid >= body + (P.tail ? kLp16TailBytes / 2 : 0)) return;
+    const bool in_tail = gid >= body;
+    const Chunk16 ck = in_tail ? Chunk16{nullptr, nullptr, 0, 0, kRgb16, 0, 0} : P.ch[P.first + gid / per_chunk];
+    const int within = in_tail ? (int)(gid - body) : (int)(gid % per_chunk);
     const int g = within >> 9, lane = (within >> 3) & 63, e = within & 7;  // 512 elements per group
     const int i = lane & 15, q = lane >> 4;
     const int W = NSOS_NET_WIDTH, X = NSOS_XYZ_DIM;
@@ -1033,7 +1055,7 @@ __global__ __launch_bounds__(256) void lp16_pack_kernel(const Pack16Params P) {
             if (g < 4) v = i < 3 ? P.rgb_w[i * (W / 2) + hid_col(g, q, e)] : 0.0f;
         } break;
     }
-    const long long at = (long long)P.first * per_chunk + gid;
+    const long long at = in_tail ? (long long)P.n_chunks * per_chunk + within : (long long)P.first * per_chunk + gid;
     if (is_bias) {
         const unsigned u = __builtin_bit_cast(unsigned, v);
         P.chunks[at] = (e & 1) ? (unsigned short)(u >> 16) : (unsigned short)(u & 0xffffu);
@@ -1073,7 +1095,6 @@ int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned c
     }
     quads(T_->feature_w, T_->feature_b);
     for (int j = 0; j < 2; ++j) add(T_->views_w, T_->views_b, W + NSOS_DIR_DIM, 0, kView16, j, 4);
-    add(nullptr, nullptr, 0, 0, kRgb16, 0, 0);
     if (n != lp16_chunks(sem_mode)) return NSOS_ERR_UNSUPPORTED;
     P.n_chunks = n;
     P.first = heads_only ? 30 : 0;                // the head's chunks: two slice chunks + the tail (sigma, raw bias, logits)
@@ -1083,7 +1104,8 @@ int32_t pack_lp16(const void* tensors, int32_t sem_mode, bool is_f16, unsigned c
     P.sem0_w = sem_mode ? T_->sem0_w : nullptr; P.sem0_b = sem_mode ? T_->sem0_b : nullptr;
     P.sem2_w = sem_mode ? T_->sem2_w : nullptr; P.sem2_b = sem_mode ? T_->sem2_b : nullptr;
     P.chunks = reinterpret_cast<unsigned short*>(chunks);
-    const long long total = (long long)P.count * (kSlotBytes / 2);
+    P.tail = heads_only ? 0 : 1;                  // rgb_linear's operands behind the chunks (kLp16TailBytes)
+    const long long total = (long long)P.count * (kSlotBytes / 2) + (P.tail ? kLp16TailBytes / 2 : 0);
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (is_f16) hipLaunchKernelGGL(lp16_pack_kernel<F16>, grid, block, 0, stream, P);
     else hipLaunchKernelGGL(lp16_pack_kernel<BF16>, grid, block, 0, stream, P);

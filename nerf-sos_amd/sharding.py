@@ -236,11 +236,12 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: 
     collective("grad_all_reduce", lambda async_op: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op), group)
     if average:
         flat /= dist.get_world_size(group)
-    off = 0
+    views, off = [], 0
     for p in ps:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        views.append(flat[off:off + n].view_as(p.grad))
         off += n
+    torch._foreach_copy_([p.grad for p in ps], views)        # one launch for all tensors
 
 
 _SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}

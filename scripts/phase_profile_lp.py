@@ -64,7 +64,7 @@ if wps == 3:
             ideal["sigma+sem heads"] = {0: 16, 1: 128 + 16 + 16 + 8, 2: 160 + 16 + 8}[sem] * M
     names += ["dir enc", "view mfma", "rgb mfma", "stores"]
     ideal["view mfma"] = 144 * M
-    ideal["rgb mfma"] = 8 * M
+    ideal["rgb mfma"] = 8 * M      # (operands resident in LDS: no chunk of its own)
     title = "mlp_lp16_kernel: 8 waves x 32 points (two per SIMD) on v_mfma_f32_16x16x32"
 else:
     names, ideal = ["tile start", "inputs + xyz enc", "L0 mfma", "L0 act"], {"L0 mfma": 32 * COLS * M}
