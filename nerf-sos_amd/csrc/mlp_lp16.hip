@@ -428,7 +428,11 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P
                     x[k] = P.rays_o[3ll * ray + k] + m;
                 }
                 u32x4 e2[2];
+#ifdef NSOS_LP16_NOENC      // (A/B builds only: what the xyz encoding costs; wrong results)
+                e2[0] = e2[1] = u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), 0u};
+#else
                 encode16<T, 2, NSOS_XYZ_FREQS, 63>(e2, x, tabs + kTabXyz, q);   // feature 63 (pad) = 1.0: the bias input of layers 0, 5 and the sem+coord head
+#endif
                 ex[0][c] = e2[0];
                 ex[1][c] = e2[1];
             }

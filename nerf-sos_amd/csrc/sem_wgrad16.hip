@@ -182,7 +182,17 @@ __global__ __launch_bounds__(512, 1) void sem_head_wgrad16_kernel(const float* _
     else {
         float* const red = reinterpret_cast<float*>(lds);
         float m = 0.0f;
-        for (long long j = threadIdx.x; j < 2 * n_rays; j += 512) m = fmaxf(m, fabsf(g_sem[j]));
+        // (independent 16-byte loads, four in flight per thread: a scalar loop was sixteen dependent L2 round trips = 6 us per call)
+        const long long n_g = 2 * n_rays, n_q = (((unsigned long long)g_sem & 15) == 0) ? n_g >> 2 : 0;
+        const f32x4* const g4 = reinterpret_cast<const f32x4*>(g_sem);
+        for (long long j = threadIdx.x; j < n_q; j += 4 * 512) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = g4[j + 512 * u < n_q ? j + 512 * u : j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+        }
+        for (long long j = 4 * n_q + threadIdx.x; j < n_g; j += 512) m = fmaxf(m, fabsf(g_sem[j]));
         float c = threadIdx.x < 128 ? fabsf(w2[threadIdx.x]) + fabsf(w2[128 + threadIdx.x]) : 0.0f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
