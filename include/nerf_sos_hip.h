@@ -329,6 +329,19 @@ size_t nsos_mlp_relu_masks_bytes_x3(int64_t n_pts);
 int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
                                           const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                           float* raw, float* acts, void* relu_masks, void* stream);
+/* Full training with 16-bit saved activations (round 4): the same kernels with `acts` [P, NSOS_ACTS_DIM] stored as IEEE half floats
+ * -- the hi parts of the split-fp16 activations as the MFMAs consumed them -- 5.3 KB per point instead of 10.6.  The chain reads
+ * only the two 128-wide heads' ReLU patterns from it (the trunk's come as the forward's bit masks, which are required here); the
+ * weight-gradient reductions take it as their X operand (ldx in ELEMENTS): exact widening, G stays fp32. */
+int32_t nsos_mlp_forward_rays_save_all16_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                            float* raw, void* acts_f16, void* relu_masks, void* stream);
+int32_t nsos_mlp_input_grads_x3_a16(const void* packed, int32_t sem_mode, const float* g_raw, const void* acts_f16,
+                                    const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream);
+int32_t nsos_wgrad_xh(const float* G, int32_t ldg, const void* X_f16, int32_t ldx, int64_t n_pts, int32_t M, int32_t N, float* dW,
+                      int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+int32_t nsos_wgrad_x3_xh(const float* G, int32_t ldg, const void* X_f16, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw, float* db,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* nsos_wgrad for M = N = 256 on the 16-bit matrix pipe: both operands split on the fly into fp16 hi + lo, three MFMAs per
  * product, fp32 accumulation (K7-X3).  |G| and |X| must be within fp16 range (G from nsos_mlp_input_grads_x3 is, by its

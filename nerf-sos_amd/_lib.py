@@ -64,6 +64,8 @@ SIGNATURES = {
     "nsos_wgrad_workspace_bytes": (_sz, []),
     "nsos_wgrad": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _sz, _fp]),
     "nsos_wgrad_x3": (_i32, [_fp, _i32, _fp, _i32, _i64, _fp, _i32, _fp, _fp, _sz, _fp]),
+    "nsos_wgrad_xh": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _sz, _fp]),
+    "nsos_wgrad_x3_xh": (_i32, [_fp, _i32, _fp, _i32, _i64, _fp, _i32, _fp, _fp, _sz, _fp]),
     "nsos_relu_mask": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _fp]),
     "nsos_sem_head_backward": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_sem_head_wgrad_workspace_bytes": (_sz, []),
@@ -82,10 +84,12 @@ SIGNATURES = {
     "nsos_mlp_forward_rays_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_forward_rays_save_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
     "nsos_mlp_forward_rays_save_all_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
+    "nsos_mlp_forward_rays_save_all16_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp]),
     "nsos_mlp_relu_masks_bytes_x3": (_sz, [_i64]),
     "nsos_mlp_bwd_packed_bytes_x3": (_sz, [_i32]),
     "nsos_mlp_bwd_pack_x3": (_i32, [C.POINTER(MlpTensors), _i32, _fp, _sz, _fp]),
     "nsos_mlp_input_grads_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _i64, _fp, _fp, _fp]),
+    "nsos_mlp_input_grads_x3_a16": (_i32, [_fp, _i32, _fp, _fp, _fp, _i64, _fp, _fp, _fp]),
     "nsos_mlp_profile_rays_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_lp_select_kernel": (_i32, [_i32]),
     "nsos_mlp_lp_selected_kernel": (_i32, []),

@@ -29,6 +29,7 @@
 // Compiled with -ffp-contract=off (x = o + d*z stays a separately rounded multiply and add).
 #include "x3_common.h"
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 // aux stream, offsets in 4-byte words
@@ -293,13 +294,19 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                             f32x4{join<0>(hh[q], hl[q]), join<1>(hh[q], hl[q]), join<0>(hh[q + 1], hl[q + 1]), join<1>(hh[q + 1], hl[q + 1])};
                     }
         };
+        // SAVE == 3: `acts` holds 16-bit floats; rows are formed as float pointers at ELEMENT offsets and re-based here
+        auto acts16 = [&](const float* row) { return reinterpret_cast<unsigned short*>(P.acts) + (row - P.acts); };
         auto store_slices = [&](float* row, auto ns_c, const u32x4* sh, const u32x4* sl_) __attribute__((always_inline)) {   // encoded slices: features 16s + 8kg + 2q, +1
 #pragma unroll
             for (int sl = 0; sl < decltype(ns_c)::value; ++sl)
 #pragma unroll
-                for (int q = 0; q < 4; q += 2)
-                    *reinterpret_cast<f32x4*>(row + 16 * sl + 8 * kg + 2 * q) =
-                        f32x4{join<0>(sh[sl][q], sl_[sl][q]), join<1>(sh[sl][q], sl_[sl][q]), join<0>(sh[sl][q + 1], sl_[sl][q + 1]), join<1>(sh[sl][q + 1], sl_[sl][q + 1])};
+                for (int q = 0; q < 4; q += 2) {
+                    if constexpr (SAVE == 3)      // 16-bit activations: the hi words as they are (two packed words = four consecutive features)
+                        *reinterpret_cast<u32x2*>(acts16(row) + 16 * sl + 8 * kg + 2 * q) = u32x2{sh[sl][q], sh[sl][q + 1]};
+                    else
+                        *reinterpret_cast<f32x4*>(row + 16 * sl + 8 * kg + 2 * q) =
+                            f32x4{join<0>(sh[sl][q], sl_[sl][q]), join<1>(sh[sl][q], sl_[sl][q]), join<0>(sh[sl][q + 1], sl_[sl][q + 1]), join<1>(sh[sl][q + 1], sl_[sl][q + 1])};
+                }
         };
         auto store_hidden128 = [&](float* hrow, const f32x16 (&am)[4], const f32x16 (&ax)[4]) __attribute__((always_inline)) {   // relu(Zm + 2^-11 Zx) of a 128-wide layer
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA result -> VALU read wait states
@@ -312,26 +319,38 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) =
-                        f32x4{relu_acc(am[t][4 * q], ax[t][4 * q]), relu_acc(am[t][4 * q + 1], ax[t][4 * q + 1]),
-                              relu_acc(am[t][4 * q + 2], ax[t][4 * q + 2]), relu_acc(am[t][4 * q + 3], ax[t][4 * q + 3])};
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = f32x4{relu_acc(am[t][4 * q], ax[t][4 * q]), relu_acc(am[t][4 * q + 1], ax[t][4 * q + 1]),
+                                          relu_acc(am[t][4 * q + 2], ax[t][4 * q + 2]), relu_acc(am[t][4 * q + 3], ax[t][4 * q + 3])};
+                    if constexpr (SAVE == 3) {
+                        unsigned w0, w1;
+                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w0) : "v"(v[0]), "v"(v[1]));
+                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w1) : "v"(v[2]), "v"(v[3]));
+                        *reinterpret_cast<u32x2*>(acts16(hrow) + 32 * t + 8 * q + 4 * kg) = u32x2{w0, w1};
+                    } else {
+                        *reinterpret_cast<f32x4*>(hrow + 32 * t + 8 * q + 4 * kg) = v;
+                    }
+                }
         };
         const bool valid = gp < P.n_pts;
-        float* const arow = SAVE == 2 ? P.acts + gc * NSOS_ACTS_DIM : nullptr;
+        float* const arow = SAVE >= 2 ? P.acts + gc * NSOS_ACTS_DIM : nullptr;
         auto no_ride = [](auto) {};
         // store number CC * PER + j (of 32 per layer: tile t, register half u, word pair) after group 12 + j * (20 / PER) of chunk CC
         auto ride_store = [&](auto gc_, auto cc_, auto per_, float* row) __attribute__((always_inline)) {
             constexpr int g = decltype(gc_)::value, CC = decltype(cc_)::value, PER = decltype(per_)::value, STRIDE = 20 / PER;
-            if constexpr (SAVE == 2 && g >= 12 && (g - 12) % STRIDE == 0 && (g - 12) / STRIDE < PER) {
+            if constexpr (SAVE >= 2 && g >= 12 && (g - 12) % STRIDE == 0 && (g - 12) / STRIDE < PER) {
                 constexpr int k = CC * PER + (g - 12) / STRIDE, t = k >> 2, u = (k >> 1) & 1, q = 2 * (k & 1);
                 const u32x4 hh = Hh[2 * t + u], hl = Hl[2 * t + u];
-                if (valid)
-                    *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
-                        f32x4{join<0>(hh[q], hl[q]), join<1>(hh[q], hl[q]), join<0>(hh[q + 1], hl[q + 1]), join<1>(hh[q + 1], hl[q + 1])};
+                if (valid) {
+                    if constexpr (SAVE == 3)
+                        *reinterpret_cast<u32x2*>(acts16(row) + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) = u32x2{hh[q], hh[q + 1]};
+                    else
+                        *reinterpret_cast<f32x4*>(row + 32 * t + 8 * (2 * u + (q >> 1)) + 4 * kg) =
+                            f32x4{join<0>(hh[q], hl[q]), join<1>(hh[q], hl[q]), join<0>(hh[q + 1], hl[q + 1]), join<1>(hh[q + 1], hl[q + 1])};
+                }
             }
         };
-        if constexpr (SAVE == 2) {
+        if constexpr (SAVE >= 2) {
             if (valid) store_slices(arow + NSOS_ACTS_X, IC(4), exh, exl);   // slot 63 is the 1.0 pad
         }
 
@@ -342,8 +361,8 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         stamp();  // 2: L0 MFMAs
         // SAVE == 2: the trunk layers' ReLU patterns go to P.masks as bits (16 B per lane per layer, one coalesced store)
         u32x4 relu_bits = {0u, 0u, 0u, 0u};
-        u32x4* const mrow = SAVE == 2 ? reinterpret_cast<u32x4*>(P.masks) + (size_t)tile * 8 * 256 + threadIdx.x : nullptr;
-        if constexpr (SAVE == 2) { activate_bits<8>(Hh, Hl, Zm, Zx, relu_bits); mrow[0] = relu_bits; }
+        u32x4* const mrow = SAVE >= 2 ? reinterpret_cast<u32x4*>(P.masks) + (size_t)tile * 8 * 256 + threadIdx.x : nullptr;
+        if constexpr (SAVE >= 2) { activate_bits<8>(Hh, Hl, Zm, Zx, relu_bits); mrow[0] = relu_bits; }
         else activate<8, true>(Hh, Hl, Zm, Zx);
         stamp();  // 3: L0 activation
         // pts_linears.1..7 (l = 1..7) and feature_linear (l = 8): 8 bias + 128 slice items = 8 chunks of 17
@@ -352,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
             // SAVE == 2: the activations this layer consumes (H of layer l-1) are written to acts from inside its own MFMA stream,
             // 4 x 16 B per lane per chunk: stores issued in a burst after the activation pass made the next chunk's barrier
             // (a counted vmcnt) wait for HBM to take them
-            float* const prow = SAVE == 2 ? arow + 256 * (l - 1) : nullptr;
+            float* const prow = SAVE >= 2 ? arow + 256 * (l - 1) : nullptr;
             static_for<0, 8>([&](auto cc) {
                 run_chunk(IC(17), IC(8), IC(8), IC(17 * decltype(cc)::value), IC(17), IC(0), Zm, Zx, h_h, h_l,
                           [&](auto gc) { ride_store(gc, cc, IC(4), prow); });
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
             }
             stamp();  // 2 + 2l: MFMAs of layer l
             if (l < 8) {
-                if constexpr (SAVE == 2) { activate_bits<8>(Hh, Hl, Zm, Zx, relu_bits); mrow[256 * l] = relu_bits; }
+                if constexpr (SAVE >= 2) { activate_bits<8>(Hh, Hl, Zm, Zx, relu_bits); mrow[256 * l] = relu_bits; }
                 else activate<8, true>(Hh, Hl, Zm, Zx);
             } else {
                 activate<8, false>(Hh, Hl, Zm, Zx);
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
                             store_hidden128(P.sem_hid + gp * 128, sm, sx);
                         }
                     }
-                    if constexpr (SAVE == 2) {
+                    if constexpr (SAVE >= 2) {
                         if (valid) store_hidden128(arow + NSOS_ACTS_SEM, sm, sx);
                     }
                     float ps[2];
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         f32x16 vm[4], vx[4];
         static_for<0, 4>([&](auto cc) {
             run_chunk(IC(17), IC(4), IC(4), IC(17 * decltype(cc)::value), IC(17), IC(0), vm, vx, h_h, h_l,
-                      [&](auto gc) { ride_store(gc, cc, IC(8), SAVE == 2 ? arow + NSOS_ACTS_FEAT : nullptr); });   // H = the feature vector
+                      [&](auto gc) { ride_store(gc, cc, IC(8), SAVE >= 2 ? arow + NSOS_ACTS_FEAT : nullptr); });   // H = the feature vector
         });
         stamp();  // 21: view-branch MFMAs on the feature
         u32x4 edh[2], edl[2];   // the direction encoding is evaluated only now: its registers would not fit beside the trunk
@@ -441,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_kernel(const X3Params P) {
         run_chunk(IC(8), IC(4), IC(0), IC(0), IC(8), IC(0), vm, vx, [&](auto sc) { return edh[decltype(sc)::value & 1]; },
                   [&](auto sc) { return edl[decltype(sc)::value & 1]; }, no_ride);   // 2 slices x 4 tiles = 8 items (16 groups)
         stamp();  // 23: direction MFMAs
-        if constexpr (SAVE == 2) {
+        if constexpr (SAVE >= 2) {
             if (valid) {
                 store_slices(arow + NSOS_ACTS_D, IC(2), edh, edl);   // 27 features, zero pad
                 store_hidden128(arow + NSOS_ACTS_VIEWS, vm, vx);
@@ -648,7 +667,7 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
         NSOS_REQUIRE(sem_in && sem_hid, NSOS_ERR_NULL_POINTER);
         NSOS_REQUIRE(((uintptr_t)sem_in & 15) == 0 && ((uintptr_t)sem_hid & 15) == 0, NSOS_ERR_MISALIGNED);
     }
-    if (save == 2) {
+    if (save >= 2) {
         NSOS_REQUIRE(acts && masks, NSOS_ERR_NULL_POINTER);
         NSOS_REQUIRE(((uintptr_t)acts & 15) == 0 && ((uintptr_t)masks & 15) == 0, NSOS_ERR_MISALIGNED);
     }
@@ -664,6 +683,7 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
     const hipStream_t st = (hipStream_t)stream;
     if (save == 1) return sem_mode == 1 ? launch_x3<1, 1>(p, st) : launch_x3<2, 1>(p, st);
     if (save == 2) return sem_mode == 0 ? launch_x3<0, 2>(p, st) : (sem_mode == 1 ? launch_x3<1, 2>(p, st) : launch_x3<2, 2>(p, st));
+    if (save == 3) return sem_mode == 0 ? launch_x3<0, 3>(p, st) : (sem_mode == 1 ? launch_x3<1, 3>(p, st) : launch_x3<2, 3>(p, st));
     switch (sem_mode) {
         case 0: return launch_x3<0>(p, st);
         case 1: return launch_x3<1>(p, st);
@@ -689,6 +709,15 @@ extern "C" int32_t nsos_mlp_forward_rays_save_all_x3(const void* packed, int32_t
                                                      float* raw, float* acts, void* relu_masks, void* stream) {
     return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr, acts, 2, stream,
                       nullptr, static_cast<unsigned*>(relu_masks));
+}
+
+// the same with `acts` [P, NSOS_ACTS_DIM] in 16-bit floats: the hi parts of the split activations as the MFMAs consumed them (the
+// 128-wide hidden layers rounded to nearest even): 5.3 KB per point instead of 10.6
+extern "C" int32_t nsos_mlp_forward_rays_save_all16_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,
+                                                       const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                       float* raw, void* acts_f16, void* relu_masks, void* stream) {
+    return forward_x3(packed, sem_mode, rays_o, rays_d, viewdirs, z_vals, n_rays, n_samples, raw, nullptr, nullptr,
+                      static_cast<float*>(acts_f16), 3, stream, nullptr, static_cast<unsigned*>(relu_masks));
 }
 
 extern "C" size_t nsos_mlp_relu_masks_bytes_x3(int64_t n_pts) {   // 8 trunk layers x 256 threads x 16 B per 128-point tile

@@ -14,6 +14,7 @@
 // nsos_wgrad.  Products: g_hi.W_hi + g_lo.W_hi + g_hi.(2^11 W_lo), fp32 accumulation, as in the forward kernel.
 #include "x3_common.h"
 
+typedef unsigned u32x2_b __attribute__((ext_vector_type(2)));
 namespace {
 
 // aux stream (fp32 words): head weights in accumulator layout
@@ -43,8 +44,10 @@ struct X3BwdParams {
 };
 
 // BITS: the trunk layers' ReLU masks come as bits (one 16-byte load per lane per layer) instead of as the fp32 activations
-template <int SEM, bool BITS>
+// A16 (with BITS): `acts` holds 16-bit floats (nsos_mlp_forward_rays_save_all16_x3); only the two 128-wide heads' masks are read from it
+template <int SEM, bool BITS, bool A16 = false>
 __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P) {
+    static_assert(BITS || !A16, "16-bit activations come with the forward's bit masks");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 4 x 36 KiB weight slots + 4 KiB head weights
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pj = lane & 31, kg = lane >> 5;
@@ -148,8 +151,18 @@ __global__ __launch_bounds__(256, 1) void mlp_x3_bwd_kernel(const X3BwdParams P)
         auto head_grad = [&](auto no_c, const float* act, float* out, const float* w_lane, const float* g) __attribute__((always_inline)) {
             constexpr int NO = decltype(no_c)::value;
             f32x4 mk[16];
+            if constexpr (A16) {      // `act` was formed as a float pointer at the column's ELEMENT offset: redo it in 2-byte elements
+                const unsigned short* a16 = reinterpret_cast<const unsigned short*>(P.acts) + (act - P.acts);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mk[i] = *reinterpret_cast<const f32x4*>(act + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
+                for (int i = 0; i < 16; ++i) {
+                    const u32x2_b w = *reinterpret_cast<const u32x2_b*>(a16 + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
+                    // stored behind a ReLU: > 0 <=> a non-zero magnitude (as a float for the comparison below)
+                    mk[i] = f32x4{(float)(w[0] & 0x7fffu), (float)((w[0] >> 16) & 0x7fffu), (float)(w[1] & 0x7fffu), (float)((w[1] >> 16) & 0x7fffu)};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mk[i] = *reinterpret_cast<const f32x4*>(act + 32 * (i >> 2) + 8 * (i & 3) + 4 * kg);
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int t = i >> 2, q = i & 3;
@@ -286,19 +299,19 @@ __global__ __launch_bounds__(256) void x3_bwd_pack_kernel(const X3BwdPackParams 
 
 constexpr int kLdsBytes = kSlots * kSlotBytes + kBAuxWords * 4;
 
-template <int SEM, bool BITS>
+template <int SEM, bool BITS, bool A16 = false>
 int32_t launch_x3_bwd(const X3BwdParams& p, hipStream_t stream) {
     static NsosPerDeviceFlag configured_on;
     bool& configured = configured_on.here();
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_bwd_kernel<SEM, BITS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_x3_bwd_kernel<SEM, BITS, A16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return (int32_t)e;
         configured = true;
     }
     const int cus = nsos_device_cus();
     const int grid = p.n_tiles < cus ? p.n_tiles : cus;
-    hipLaunchKernelGGL((mlp_x3_bwd_kernel<SEM, BITS>), dim3(grid), dim3(256), kLdsBytes, stream, p);
+    hipLaunchKernelGGL((mlp_x3_bwd_kernel<SEM, BITS, A16>), dim3(grid), dim3(256), kLdsBytes, stream, p);
     return nsos_launch_status();
 }
 
@@ -339,8 +352,8 @@ extern "C" int32_t nsos_mlp_bwd_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_
     return nsos_launch_status();
 }
 
-extern "C" int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode, const float* g_raw, const float* acts,
-                                           const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream) {
+static int32_t input_grads_x3(const void* packed, int32_t sem_mode, const float* g_raw, const float* acts, bool acts16,
+                              const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream) {
     if (n_pts == 0) return NSOS_OK;
     NSOS_REQUIRE(packed && g_raw && acts && scale && gbuf, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_pts > 0, NSOS_ERR_BAD_SHAPE);
@@ -355,6 +368,19 @@ extern "C" int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode,
     p.n_pts = n_pts;
     p.n_tiles = (int)((n_pts + kTilePts - 1) / kTilePts);
     const hipStream_t st = (hipStream_t)stream;
+    if (acts16) {
+        NSOS_REQUIRE(relu_masks, NSOS_ERR_NULL_POINTER);      // 16-bit activations carry no usable trunk masks of their own
+        return sem_mode == 0 ? launch_x3_bwd<0, true, true>(p, st) : launch_x3_bwd<1, true, true>(p, st);
+    }
     if (relu_masks) return sem_mode == 0 ? launch_x3_bwd<0, true>(p, st) : launch_x3_bwd<1, true>(p, st);
     return sem_mode == 0 ? launch_x3_bwd<0, false>(p, st) : launch_x3_bwd<1, false>(p, st);
+}
+
+extern "C" int32_t nsos_mlp_input_grads_x3(const void* packed, int32_t sem_mode, const float* g_raw, const float* acts,
+                                           const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream) {
+    return input_grads_x3(packed, sem_mode, g_raw, acts, false, relu_masks, n_pts, scale, gbuf, stream);
+}
+extern "C" int32_t nsos_mlp_input_grads_x3_a16(const void* packed, int32_t sem_mode, const float* g_raw, const void* acts_f16,
+                                               const void* relu_masks, int64_t n_pts, const float* scale, float* gbuf, void* stream) {
+    return input_grads_x3(packed, sem_mode, g_raw, static_cast<const float*>(acts_f16), true, relu_masks, n_pts, scale, gbuf, stream);
 }

@@ -23,8 +23,9 @@ namespace {
 constexpr int kWgradMaxBlocks = 256;
 
 // RT = row tiles per wave (1 or 2), NT = column tiles (1..8)
-template <int RT, int NT>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+// XT: element type of X -- float, or _Float16 for activations saved in 16 bits (nsos_mlp_forward_rays_save_all16_x3: exact in fp32)
+template <int RT, int NT, class XT>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__ G, int ldg, const XT* __restrict__ X, int ldx,
                                                        long long n_pts, int M, int N, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, k = lane >> 5;
     const int MT = M >> 5;
@@ -64,13 +65,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
         goff[u] = (int)((u * step + k) * ldg) + 32 * rw_s + i;
         xoff[u] = (int)((u * step + k) * ldx) + i;
     }
-    auto fetch_grp = [&](const float* gb, const float* xb, In (&buf)[U]) {   // all points of the group are in range
+    auto fetch_grp = [&](const float* gb, const XT* xb, In (&buf)[U]) {   // all points of the group are in range
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int r = 0; r < RT; ++r) buf[u].a[r] = gb[goff[u] + 32 * RW * r];   // row tile rw + RW*r
 #pragma unroll
-            for (int t = 0; t < NT; ++t) buf[u].b[t] = xb[xoff[u] + 32 * t];
+            for (int t = 0; t < NT; ++t) buf[u].b[t] = (float)xb[xoff[u] + 32 * t];
         }
     };
     auto compute1 = [&](const In& in) {
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
     if (n_grp > 0) {
         In bufA[U], bufB[U];
         const float* const g0 = G + base * ldg;
-        const float* const x0 = X + base * ldx;
+        const XT* const x0 = X + base * ldx;
         const long long gstride = (long long)U * step * ldg, xstride = (long long)U * step * ldx;
-        auto grp_ptr = [&](const float* p0, long long stride, long long g) { return p0 + (g < n_grp ? g : n_grp - 1) * stride; };
+        auto grp_ptr = [&](auto* p0, long long stride, long long g) { return p0 + (g < n_grp ? g : n_grp - 1) * stride; };
         fetch_grp(g0, x0, bufA);
         long long g = 0;
         for (; g + 1 < n_grp; g += 2) {
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float* __restrict__
         const long long pc = valid ? pt : (n_pts - 1);
         In in;
         const float* grow = G + pc * ldg + 32 * rw + i;
-        const float* xrow = X + pc * ldx + i;
+        const XT* xrow = X + pc * ldx + i;
 #pragma unroll
         for (int r = 0; r < RT; ++r) in.a[r] = valid ? grow[32 * RW * r] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) in.b[t] = xrow[32 * t];
+        for (int t = 0; t < NT; ++t) in.b[t] = (float)xrow[32 * t];
         compute1(in);
     }
     // partial [(block * KW + kw)][M*N + M]
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, i
 // Operand loads run two k-steps ahead in registers.  G is expected in fp16 range (the fused input-gradient kernel's
 // power-of-two scale takes care of that); db is accumulated from the fp32 values.  Output: the same partial layout as
 // wgrad_kernel (KW = 1), reduced by wgrad_reduce_kernel.
-__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+template <class XT>   // X: float, or _Float16 (activations saved in 16 bits: their lo parts are zero, the three-MFMA product stays)
+__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restrict__ G, int ldg, const XT* __restrict__ X, int ldx,
                                                           long long n_pts, float* __restrict__ partial) {
     constexpr int M = 256, N = 256;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 16 * 2 * 1024];   // [buffer][tile 0..15][hi, lo][64 lanes x 16 B]
@@ -211,30 +213,34 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
     // slot j of this thread: column tile T = 4j + wave of [G | X] (T < 8: G), lane position (i, kg): points 8kg .. 8kg+7 of the step.
     // Addressing as in wgrad_kernel: wave-uniform row pointers (scalar unit) + one constant 32-bit lane offset per slot.
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const float* src[4];
-    int ld[4];
+    // (slots 0, 1 are G tiles, slots 2, 3 X tiles for every wave: T < 8 <=> j < 2; addresses in bytes: the two element types differ)
+    const char* src[4];
+    long long ldb[4];     // row stride in bytes
     unsigned voff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int T = 4 * j + wave_s;
-        src[j] = (T < 8 ? G : X) + 32 * (T & 7);
-        ld[j] = T < 8 ? ldg : ldx;
-        voff[j] = (unsigned)(8 * kg * ld[j] + i) * 4u;   // bytes
+        const int esz = j < 2 ? 4 : (int)sizeof(XT);
+        src[j] = j < 2 ? reinterpret_cast<const char*>(G + 32 * (T & 7)) : reinterpret_cast<const char*>(X + 32 * (T & 7));
+        ldb[j] = (long long)(j < 2 ? ldg : ldx) * esz;
+        voff[j] = (unsigned)(8 * kg * ldb[j] + i * esz);   // bytes
     }
     auto fetch = [&](long long step, float (&raw)[4][8]) {               // every point of the step is in range
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned long long rb = (unsigned long long)(src[j] + step * 16 * ld[j]);   // wave-uniform; tell hipcc so
-            typedef const __attribute__((address_space(1))) float* gptr;
+            const unsigned long long rb = (unsigned long long)(src[j] + step * 16 * ldb[j]);   // wave-uniform; tell hipcc so
+            typedef const __attribute__((address_space(1))) char* gptr;
             const gptr row = (gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rb >> 32)) << 32) |
                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)rb));   // (the builtin returns int)
             unsigned vo = voff[j];
             asm volatile("" : "+v"(vo));   // ... and keep LICM from hoisting zext(lane offset) out of the loop, which loses the saddr form
 #pragma unroll
             for (int e = 0; e < 8; ++e) {   // scalar base + zero-extended 32-bit lane offset: global_load_dword v, v_off, s[base]
-                unsigned long long re = (unsigned long long)(row + (long long)e * ld[j]);
+                unsigned long long re = (unsigned long long)(row + (long long)e * ldb[j]);
                 asm("" : "+s"(re));         // keep the row pointer a scalar of its own (hipcc otherwise folds e * ld into the lane offset)
-                raw[j][e] = *reinterpret_cast<gptr>(reinterpret_cast<const __attribute__((address_space(1))) char*>(re) + vo);
+                const auto at = reinterpret_cast<const __attribute__((address_space(1))) char*>(re) + vo;
+                if (j < 2) raw[j][e] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(at);
+                else raw[j][e] = (float)*reinterpret_cast<const __attribute__((address_space(1))) XT*>(at);
             }
         }
     };
@@ -245,7 +251,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const long long p = p0 + e;
-                const float v = src[j][(p < n_pts ? p : n_pts - 1) * ld[j] + i];
+                const char* at = src[j] + (p < n_pts ? p : n_pts - 1) * ldb[j] + i * (j < 2 ? 4 : (int)sizeof(XT));
+                const float v = j < 2 ? *reinterpret_cast<const float*>(at) : (float)*reinterpret_cast<const XT*>(at);
                 raw[j][e] = p < n_pts ? v : 0.0f;
             }
     };
@@ -338,17 +345,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const float* __restric
     }
 }
 
-template <int RT, int NT>
-void launch_wgrad(int blocks, hipStream_t st, const float* G, int ldg, const float* X, int ldx, long long n_pts, int M, int N, float* ws) {
-    hipLaunchKernelGGL((wgrad_kernel<RT, NT>), dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, n_pts, M, N, ws);
+template <int RT, int NT, class XT>
+void launch_wgrad(int blocks, hipStream_t st, const float* G, int ldg, const XT* X, int ldx, long long n_pts, int M, int N, float* ws) {
+    hipLaunchKernelGGL((wgrad_kernel<RT, NT, XT>), dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, n_pts, M, N, ws);
 }
 }  // namespace
 
 // largest case: M = 32 (KW = 4 k-subsets), N = 256, or M = N = 256 (KW = 1)
 extern "C" size_t nsos_wgrad_workspace_bytes(void) { return (size_t)kWgradMaxBlocks * (256 * 256 + 256) * sizeof(float); }
 
-extern "C" int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
-                              float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+template <class XT>
+static int32_t wgrad_entry(const float* G, int32_t ldg, const XT* X, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
+                           float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
     NSOS_REQUIRE(dW && workspace, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_pts >= 0, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_pts == 0 || (G && X), NSOS_ERR_NULL_POINTER);
@@ -362,13 +370,22 @@ extern "C" int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32
     NSOS_REQUIRE(workspace_bytes >= need, NSOS_ERR_BUFFER_TOO_SMALL);
     const hipStream_t st = (hipStream_t)stream;
     float* ws = static_cast<float*>(workspace);
-#define NSOS_WG(R, T) launch_wgrad<R, T>(blocks, st, G, ldg, X, ldx, (long long)n_pts, M, N, ws)
+#define NSOS_WG(R, T) launch_wgrad<R, T, XT>(blocks, st, G, ldg, X, ldx, (long long)n_pts, M, N, ws)
     if (RT == 1) { switch (NT) { case 1: NSOS_WG(1, 1); break; case 2: NSOS_WG(1, 2); break; case 4: NSOS_WG(1, 4); break; default: NSOS_WG(1, 8); break; } }
     else         { switch (NT) { case 1: NSOS_WG(2, 1); break; case 2: NSOS_WG(2, 2); break; case 4: NSOS_WG(2, 4); break; default: NSOS_WG(2, 8); break; } }
 #undef NSOS_WG
     const int tot = M * N + M;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, ws, blocks * KW, M, N, dW, ldw, db);
     return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
+                              float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_entry<float>(G, ldg, X, ldx, n_pts, M, N, dW, ldw, db, workspace, workspace_bytes, stream);
+}
+extern "C" int32_t nsos_wgrad_xh(const float* G, int32_t ldg, const void* X_f16, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
+                                 float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_entry<_Float16>(G, ldg, static_cast<const _Float16*>(X_f16), ldx, n_pts, M, N, dW, ldw, db, workspace, workspace_bytes, stream);
 }
 
 extern "C" int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t ldh, int64_t n_pts, int32_t n_cols, void* stream) {
@@ -383,8 +400,9 @@ extern "C" int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t
     return nsos_launch_status();
 }
 
-extern "C" int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw,
-                                 float* db, void* workspace, size_t workspace_bytes, void* stream) {
+template <class XT>
+static int32_t wgrad_x3_entry(const float* G, int32_t ldg, const XT* X, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw,
+                              float* db, void* workspace, size_t workspace_bytes, void* stream) {
     constexpr int M = 256, N = 256;
     NSOS_REQUIRE(dW && workspace, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(n_pts >= 0, NSOS_ERR_BAD_SHAPE);
@@ -396,8 +414,17 @@ extern "C" int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, in
     NSOS_REQUIRE(workspace_bytes >= (size_t)blocks * ((size_t)M * N + M) * sizeof(float), NSOS_ERR_BUFFER_TOO_SMALL);
     const hipStream_t st = (hipStream_t)stream;
     float* ws = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(wgrad_x3_kernel, dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, (long long)n_pts, ws);
+    hipLaunchKernelGGL(wgrad_x3_kernel<XT>, dim3(blocks), dim3(256), 0, st, G, ldg, X, ldx, (long long)n_pts, ws);
     const int tot = M * N + M;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, ws, blocks, M, N, dW, ldw, db);
     return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw,
+                                 float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_x3_entry<float>(G, ldg, X, ldx, n_pts, dW, ldw, db, workspace, workspace_bytes, stream);
+}
+extern "C" int32_t nsos_wgrad_x3_xh(const float* G, int32_t ldg, const void* X_f16, int32_t ldx, int64_t n_pts, float* dW, int32_t ldw,
+                                    float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_x3_entry<_Float16>(G, ldg, static_cast<const _Float16*>(X_f16), ldx, n_pts, dW, ldw, db, workspace, workspace_bytes, stream);
 }

@@ -695,7 +695,7 @@ ACTS_FEAT, ACTS_VIEWS, ACTS_SEM, ACTS_X, ACTS_D, ACTS_DIM = 2048, 2304, 2432, 25
 
 
 def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
-                              viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32"):
+                              viewdirs: torch.Tensor, z_vals: torch.Tensor, precision: str = "fp32", acts16: bool = False):
     """Training-mode K2 with every layer's activations stored: (raw [R,S,C], acts [R*S, ACTS_DIM], relu bit masks or None).
     precision "fp32" (exact kernel) or "fp16x3" (split-fp16 kernel, fp32-accurate); `packed` must match."""
     if precision not in ("fp32", "fp16x3"):
@@ -705,12 +705,15 @@ def mlp_forward_rays_save_all(packed: torch.Tensor, sem_mode: int, rays_o: torch
     R, S = z_vals.shape
     dev = z_vals.device
     raw = torch.empty((R, S, 4 if sem_mode == SEM_NONE else 6), device=dev, dtype=torch.float32)
-    acts = torch.empty((R * S, ACTS_DIM), device=dev, dtype=torch.float32)
+    if acts16 and precision != "fp16x3":
+        raise NotImplementedError("16-bit saved activations exist for the split-fp16 kernels (precision 'fp16x3')")
+    # acts16: the split kernel's hi parts as they are (IEEE half): 5.3 KB per point instead of 10.6
+    acts = torch.empty((R * S, ACTS_DIM), device=dev, dtype=torch.float16 if acts16 else torch.float32)
     ev = _ev_begin()
     if precision == "fp16x3":   # also returns the trunk layers' ReLU patterns as bit masks (input of mlp_input_grads_x3)
         masks = torch.empty(int(_lib.lib().nsos_mlp_relu_masks_bytes_x3(R * S)) // 4, device=dev, dtype=torch.int32)
-        _lib.check(_lib.lib().nsos_mlp_forward_rays_save_all_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
-                                                                _p(z_vals), R, S, _p(raw), _p(acts), _p(masks), _stream()),
+        fn = _lib.lib().nsos_mlp_forward_rays_save_all16_x3 if acts16 else _lib.lib().nsos_mlp_forward_rays_save_all_x3
+        _lib.check(fn(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw), _p(acts), _p(masks), _stream()),
                    "nsos_mlp_forward_rays_save_all_x3")
         _ev_end(ev, R * S)
         return raw, acts, masks
@@ -729,7 +732,13 @@ def mlp_input_grads_x3(packed_bwd: torch.Tensor, sem_mode: int, g_raw: torch.Ten
     layer's pre-activation), columns as in `acts` (256 l | ACTS_FEAT | ACTS_VIEWS | ACTS_SEM).  `packed_bwd` comes from
     pack_mlp(..., precision="fp16x3_bwd"); `scale` is a 1-element device tensor holding a power of two; `masks` = the bit
     masks mlp_forward_rays_save_all(..., "fp16x3") returned for the same points (None: trunk masks are read from `acts`)."""
-    g_raw, acts = _dev(g_raw, "g_raw"), _dev(acts, "acts")
+    g_raw = _dev(g_raw, "g_raw")
+    a16 = isinstance(acts, torch.Tensor) and acts.dtype == torch.float16
+    if a16:
+        if not acts.is_cuda or masks is None:
+            raise ValueError("mlp_input_grads_x3: 16-bit activations are a GPU tensor and come with the forward's bit masks")
+    else:
+        acts = _dev(acts, "acts")
     P_, C_ = g_raw.shape
     if C_ != (4 if sem_mode == SEM_NONE else 6) or acts.shape != (P_, ACTS_DIM) or not acts.is_contiguous():
         raise ValueError(f"mlp_input_grads_x3: g_raw {tuple(g_raw.shape)} / acts {tuple(acts.shape)} do not fit sem_mode {sem_mode}")
@@ -737,17 +746,17 @@ def mlp_input_grads_x3(packed_bwd: torch.Tensor, sem_mode: int, g_raw: torch.Ten
     gbuf = torch.empty((P_, GBUF_DIM), device=acts.device, dtype=torch.float32)
     if masks is not None and (not masks.is_cuda or masks.numel() * 4 < int(_lib.lib().nsos_mlp_relu_masks_bytes_x3(P_))):
         raise ValueError("mlp_input_grads_x3: `masks` does not belong to these points")
-    _lib.check(_lib.lib().nsos_mlp_input_grads_x3(_p(packed_bwd), sem_mode, _p(g_raw), _p(acts), _p(masks), P_, _p(scale),
-                                                  _p(gbuf), _stream()), "nsos_mlp_input_grads_x3")
+    fn = _lib.lib().nsos_mlp_input_grads_x3_a16 if a16 else _lib.lib().nsos_mlp_input_grads_x3
+    _lib.check(fn(_p(packed_bwd), sem_mode, _p(g_raw), _p(acts), _p(masks), P_, _p(scale), _p(gbuf), _stream()), "nsos_mlp_input_grads_x3")
     return gbuf
 
 
 _WG_WS: Dict[torch.device, torch.Tensor] = {}
 
 
-def _rows(t: torch.Tensor, name: str):
+def _rows(t: torch.Tensor, name: str, half_ok: bool = False):
     """(pointer-bearing tensor, row stride) of a 2-D row-major slice with unit column stride."""
-    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+    if not t.is_cuda or (t.dtype != torch.float32 and not (half_ok and t.dtype == torch.float16)) or t.dim() != 2 or t.stride(1) != 1:
         raise ValueError(f"{name}: need a float32 GPU matrix with contiguous rows, got {t.dtype} {tuple(t.shape)} {t.stride()}")
     return t, t.stride(0)
 
@@ -758,7 +767,8 @@ def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch
     split_fp16: for M = N = 256 run on the 16-bit matrix pipe with split operands (nsos_wgrad_x3); the caller guarantees
     |G|, |X| < 65504 (the fused input-gradient kernel's output is scaled into that range)."""
     G, ldg = _rows(G, "G")
-    X, ldx = _rows(X, "X")
+    X, ldx = _rows(X, "X", half_ok=True)      # 16-bit saved activations (mlp_forward_rays_save_all(..., acts16=True)): widened exactly
+    xh = X.dtype == torch.float16
     dW, ldw = _rows(dW, "dW")
     P_, M = G.shape
     N = X.shape[1]
@@ -769,11 +779,11 @@ def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch
         _WG_WS[dev] = torch.empty(_lib.lib().nsos_wgrad_workspace_bytes() // 4, device=dev, dtype=torch.float32)
     ws = _WG_WS[dev]
     if split_fp16 and M == 256 and N == 256:
-        _lib.check(_lib.lib().nsos_wgrad_x3(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, dW.data_ptr(), ldw, _p(db), _p(ws),
-                                            ws.numel() * 4, _stream()), "nsos_wgrad_x3")
+        fn = _lib.lib().nsos_wgrad_x3_xh if xh else _lib.lib().nsos_wgrad_x3
+        _lib.check(fn(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, dW.data_ptr(), ldw, _p(db), _p(ws), ws.numel() * 4, _stream()), "nsos_wgrad_x3")
         return
-    _lib.check(_lib.lib().nsos_wgrad(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, M, N, dW.data_ptr(), ldw, _p(db), _p(ws),
-                                     ws.numel() * 4, _stream()), "nsos_wgrad")
+    fn = _lib.lib().nsos_wgrad_xh if xh else _lib.lib().nsos_wgrad
+    _lib.check(fn(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, M, N, dW.data_ptr(), ldw, _p(db), _p(ws), ws.numel() * 4, _stream()), "nsos_wgrad")
 
 
 def relu_mask_(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:

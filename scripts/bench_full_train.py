@@ -19,6 +19,7 @@ torch.manual_seed(0)
 net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0).to(dev).train()
 net.mlp_precision = PREC
 net.exact_weight_gradients = "--exact-wgrad" in sys.argv     # fp32 mode only: weight-gradient reductions on the exact-fp32 MFMA
+net.compact_activations = "--compact" in sys.argv            # fp16x3 only: the saved activations as 16-bit floats
 opt = torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.9, 0.999))
 rays = syn.synthetic_rays(R, seed=0, device=dev)
 gt = torch.rand(R, 3, device=dev)
@@ -56,7 +57,8 @@ for _ in range(5):
 f, b, o = (sum(x[i] for x in split) / len(split) * 1e3 for i in range(3))
 out = {"rays": R, "forward_kernel": PREC, "exact_weight_gradients": net.exact_weight_gradients, "ms_per_step": round(ms, 2), "rays_per_s": round(R / ms * 1e3), "forward_ms": round(f, 2), "backward_ms": round(b, 2),
        "adam_ms": round(o, 2), "loss_first": round(losses[0], 5), "loss_last": round(float(l.detach()), 5),
-       "saved_activations_GB": round(R * 256 * 2656 * 4 / 1e9, 2)}
+       "compact_activations": bool(net.compact_activations and PREC == "fp16x3"),
+       "saved_activations_GB": round(R * 256 * 2656 * (2 if net.compact_activations and PREC == "fp16x3" else 4) / 1e9, 2)}
 print(json.dumps(out))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open(f"gpurun_out/bench_full_train_{PREC}.json", "w"), indent=1)

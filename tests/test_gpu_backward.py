@@ -153,6 +153,34 @@ def test_full_backward_192_samples_train_mode_vs_port_autograd(precision):
     assert not bad, bad
 
 
+def test_full_backward_compact_activations():
+    """NeRFNet.compact_activations (opt-in, "fp16x3"): the forward saves 16-bit activations (half the bytes), the chain reads its head
+    masks from them and the weight-gradient reductions widen them: every gradient within 1.5e-3 of its scale of the default's
+    (fp32 activations; the rounding of X to 11 bits does not average out over 10 rays x 192 points), the rendered maps identical."""
+    from helpers import CFGS
+    cfg = tp.PortConfig(n_samples=192, n_importance=0, white_bkgd=True, **CFGS["semcoord"])
+    sd = tp.make_peaky(tp.init_state_dict(cfg, seed=0), gain=8.0, shift=0.5)
+    rays = tp.synthetic_rays(10, seed=8).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    got = {}
+    for compact in (False, True):
+        net = nerf_sos_amd.NeRFNet(N_samples=192, N_importance=0, white_bkgd=True, perturb=1.0, raw_noise_std=0.7, **CFGS["semcoord"]).to(DEV)
+        net.load_state_dict(sd)
+        net.train()
+        net.mlp_precision = "fp16x3"
+        net.compact_activations = compact
+        torch.manual_seed(11)
+        ret = net(rays, (tp.NEAR, tp.FAR))
+        ups = {k: torch.randn(ret[k].shape, generator=torch.Generator().manual_seed(3)).to(DEV) * (0.05 if k == "raw" else 1.0)
+               for k in ("rgb", "semantics", "acc", "weights", "raw")}
+        sum((ret[k] * ups[k]).sum() for k in ups).backward()
+        got[compact] = ({k: ret[k].detach().clone() for k in ups}, {n_: p_.grad.clone() for n_, p_ in net.named_parameters()})
+    for k in got[False][0]:
+        assert torch.equal(got[False][0][k], got[True][0][k]), k
+    worst = max(float((got[True][1][n_] - w).abs().max() / (w.abs().max() + 1e-20)) for n_, w in got[False][1].items())
+    assert 0 < worst <= 1.5e-3, worst
+
+
 def test_full_backward_is_chunk_invariant():
     """NeRFNet.forward renders in ray chunks (models/nerf_net.py:177-187); every chunk is its own autograd node.  The
     gradients must not depend on the chunking (eval mode: no random draws)."""
