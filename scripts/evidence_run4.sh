@@ -31,6 +31,8 @@ else
     python bench.py --config c4 --steps 30 --warmup 5 > $O/e_bench_c4.json 2>/dev/null
     python bench.py --config c5 --steps 3 --warmup 1 > $O/e_bench_c5.json 2>/dev/null
     python scripts/bench_full_train.py 4096 fp16x3 > $O/e_bench_full_train.json 2>/dev/null
+    python scripts/bench_full_train.py 4096 fp16x3 --compact > $O/e_bench_full_train_compact.json 2>/dev/null
+    python scripts/diag/generic_time.py > $O/l_generic_kernel_times.txt 2>&1
     python scripts/diag/graph_step_time.py > $O/d_graph_step_time.txt 2>&1
     cd /tmp
     rocprofv3 --kernel-trace --stats -d $R/$O/deftrace -o t --output-format csv -- python $R/bench.py --no-cpu-baseline > $R/$O/deftrace.log 2>&1
