@@ -29,7 +29,7 @@ extern "C" {
 /* bumped whenever an existing entry point's arguments or buffer formats change (2: 16-bit / tile-major saved operands of
  * nsos_mlp_forward_rays_save16_lp and nsos_sem_head_wgrad_x3; 3: pose_rows in nsos_patch_batch / nsos_pixel_batch; 4: the tile-major
  * sem_hid16 of the default 16-bit kernel, nsos_mlp_save16_layout's NSOS_SEM_HID_TILED bit) */
-#define NSOS_ABI_VERSION 4
+#define NSOS_ABI_VERSION 5
 
 enum {
     NSOS_OK = 0,
@@ -125,6 +125,31 @@ int32_t nsos_mlp_generic_forward_rays(const nsos_generic_mlp* mlp, const void* p
                                       float* raw, void* stream);
 int32_t nsos_mlp_generic_forward_points(const nsos_generic_mlp* mlp, const void* packed, const float* pts, const float* dirs,
                                         int64_t n_pts, float* raw, void* stream);
+
+/* ---- K7-G: training a generic-architecture net (every parameter; autograd of models/nerf_mlp.py:67-100 over the points of a ray
+ * batch, the model the reference trains in engines/trainer.py:201-203 when its constructor arguments are not the shipped ones).
+ *   forward_rays_save  = forward_rays + `acts` [n_rays * n_samples, ld]: per point the two encodings and every Linear's
+ *                        post-activation output, each in a column block padded to 32 with zeros (ld and the blocks: save_layout).
+ *   pack_bwd           the transposed weight streams + the reversed program, into nsos_mlp_generic_bwd_packed_bytes(mlp) bytes
+ *                        (re-pack whenever a weight changed, like nsos_mlp_generic_pack).
+ *   input_grads        one kernel: g_raw [n_pts, out_channels] (d loss / d raw, e.g. from nsos_composite_backward) -> `gbuf`
+ *                        [n_pts, ld]: every Linear's pre-activation gradient in its column block (ReLU masks from `acts`).
+ *   save_layout        table[0] = ld, table[1] = number of Linear ops, then NSOS_GENERIC_LAYOUT_STRIDE ints per op in forward order:
+ *                        position of the Linear in nsos_generic_mlp (pts 0..15, alpha 16, feature 17, views 18, rgb 19, output 20,
+ *                        sem 21..28, geo 29..30), its column block, out_dim, number of input segments, then per segment (3 slots)
+ *                        {column block of the segment's rows in `acts`, rows, first column of the Linear's weight they multiply}.
+ *                        Returns the number of ints written.  dW = gbuf[:, block]^T acts[:, segment block] and db = column sums of
+ *                        gbuf[:, block] are nsos_wgrad calls (M, N in 32-multiples: the blocks' zero padding makes them exact).
+ * Exact-fp32 MFMA like the forward.  No gradient flows to the rays. */
+#define NSOS_GENERIC_LAYOUT_STRIDE 13
+int32_t nsos_mlp_generic_save_layout(const nsos_generic_mlp* mlp, int32_t* table, int32_t capacity);
+int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
+                                           const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                           float* raw, float* acts, void* stream);
+size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp);   /* 0: unsupported description */
+int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, void* stream);
+int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                     float* gbuf, int64_t n_pts, void* stream);
 
 /* ---- K0: pinhole ray generation (SURVEY.md section 8f "next", rank 1) ------------------------------------
  * get_persp_rays (utils/ray.py:12-22; callers data/gen_dataset.py:189,202) for the pixels
@@ -405,7 +430,8 @@ int32_t nsos_composite(const float* raw, const float* z_vals, const float* rays_
 
 /* Backward of nsos_composite w.r.t. raw (autograd of models/renderer.py:35-85; z_vals, rays_d and the noise carry no
  * gradient in the reference).  Upstream gradients g_rgb [R,3], g_sem [R,C-4], g_depth [R], g_acc [R], g_disp [R],
- * g_weights [R,S] may each be NULL (= zero).  g_raw out [R,S,C].  alpha / transmittance / weights are recomputed. */
+ * g_weights [R,S] may each be NULL (= zero).  g_raw out [R,S,C], C = 4 .. 12 (4 + sem_dim).  alpha / transmittance / weights
+ * are recomputed. */
 int32_t nsos_composite_backward(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
                                 float noise_std, int64_t n_rays, int32_t n_samples, int32_t n_ch, int32_t white_bkgd,
                                 const float* g_rgb, const float* g_sem, const float* g_depth, const float* g_acc,

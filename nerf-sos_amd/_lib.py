@@ -24,7 +24,7 @@ class GenericLinear(C.Structure):
     _fields_ = [("weight", _fp), ("bias", _fp), ("out_dim", _i32), ("in_dim", _i32)]
 
 
-GENERIC_MAX_DEPTH, GENERIC_MAX_SEM = 16, 8
+GENERIC_MAX_DEPTH, GENERIC_MAX_SEM, GENERIC_LAYOUT_STRIDE = 16, 8, 13
 
 
 class GenericMlp(C.Structure):
@@ -49,6 +49,11 @@ SIGNATURES = {
     "nsos_mlp_generic_pack": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
     "nsos_mlp_generic_forward_rays": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_generic_forward_points": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _i64, _fp, _fp]),
+    "nsos_mlp_generic_save_layout": (_i32, [C.POINTER(GenericMlp), C.POINTER(C.c_int32), _i32]),
+    "nsos_mlp_generic_forward_rays_save": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
+    "nsos_mlp_generic_bwd_packed_bytes": (_sz, [C.POINTER(GenericMlp)]),
+    "nsos_mlp_generic_pack_bwd": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
+    "nsos_mlp_generic_input_grads": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _i64, _fp]),
     "nsos_generate_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, C.POINTER(C.c_float), _i64, _i64, _fp, _fp, _fp]),
     "nsos_patch_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _i32, _fp, _i32, _fp, _i32, C.POINTER(C.c_int32), _fp,
                                 _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
@@ -122,7 +127,7 @@ SIGNATURES = {
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 
-ABI_VERSION = 4          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
+ABI_VERSION = 5          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
 _lib = None
 
 

@@ -94,3 +94,52 @@ def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, pa
             out[wname] = dWl * inv
         out[bname] = dbl * inv
     return out
+
+
+_CHUNKS = (256, 128, 64, 32)
+
+
+def _chunks(n: int):
+    """A 32-multiple as a sum of nsos_wgrad's tile sizes: [(offset, size)]."""
+    out, o = [], 0
+    while n > 0:
+        c = next(c for c in _CHUNKS if c <= n)
+        out.append((o, c))
+        o, n = o + c, n - c
+    return out
+
+
+def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter of one generic-architecture MLP, by name (K7-G; autograd of models/nerf_mlp.py:67-100 for any
+    depth / width / skip set / head shape).  One kernel runs the whole input-gradient chain over the saved activations
+    (nsos_mlp_generic_input_grads: exact-fp32 MFMA over transposed weight streams, ReLU masks from `acts`) and leaves every
+    Linear's pre-activation gradient in its column block of `gbuf`; each weight gradient is then dW = gbuf[:, block]^T acts[:, segment]
+    on the exact-fp32 reduction kernel (nsos_wgrad), in 32-multiple tiles -- the blocks are zero-padded, so the padded rows and
+    columns come out as exact zeros and are sliced away.  `plan` = the net's ops.GenericPlan (layout of the saved rows)."""
+    gbuf = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts)
+    ld, layout = plan.layout()
+    f32 = dict(device=acts.device, dtype=torch.float32)
+    params = dict(mlp.named_parameters())
+    out: Dict[str, torch.Tensor] = {}
+    pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
+    for name, col, out_dim, segs in layout:
+        w = params[name + ".weight"]
+        Mp = pad(out_dim)
+        dW = torch.zeros((Mp, sum(pad(rows) for _, rows, _ in segs)), **f32)
+        db = torch.zeros((Mp,), **f32)
+        c0, first = 0, True
+        for src_col, rows, _ in segs:
+            for mo, mc in _chunks(Mp):
+                for no, nc in _chunks(pad(rows)):
+                    ops.wgrad(gbuf[:, col + mo: col + mo + mc], acts[:, src_col + no: src_col + no + nc],
+                              dW[mo: mo + mc, c0 + no: c0 + no + nc], db[mo: mo + mc] if first and no == 0 else None)
+            first = False
+            c0 += pad(rows)
+        gw = torch.empty_like(w)
+        c0 = 0
+        for _, rows, wcol in segs:
+            gw[:, wcol: wcol + rows] = dW[:out_dim, c0: c0 + rows]
+            c0 += pad(rows)
+        out[name + ".weight"] = gw
+        out[name + ".bias"] = db[:out_dim].clone()
+    return out

@@ -227,7 +227,8 @@ extern "C" int32_t nsos_composite(const float* raw, const float* z_vals, const f
 // z_vals, rays_d and the noise carry no gradient in the reference (samples are detached, models/sampler.py:159).
 // Any of the upstream gradients may be NULL (= zero).  Rays with acc <= 1e-10 take no gradient through disp (the
 // reference's autograd produces NaN there: -0 * inf).
-template <int IPL>
+// NS = 2: the shipped head (sem_dim <= 2, the arithmetic order the parity tests pin); NS = 8: any sem_dim the generic nets have
+template <int IPL, int NS>
 __global__ __launch_bounds__(256) void composite_backward_kernel(
     const float* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d,
     const float* __restrict__ noise, float noise_std, int64_t n_rays, int S, int C, int white_bkgd,
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
     const int s0 = lane * IPL;
     const int nsem = C - 4;
 
-    float z[IPL + 1], alpha[IPL], tt[IPL], dexp[IPL], col[IPL][3], smv[IPL][2];
+    float z[IPL + 1], alpha[IPL], tt[IPL], dexp[IPL], col[IPL][3], smv[IPL][NS];
 #pragma unroll
     for (int i = 0; i <= IPL; ++i) z[i] = (s0 + i < S) ? zr[s0 + i] : 0.0f;
     double prod = 1.0, tloc[IPL];
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
         dexp[i] = (live && sigma > 0.0f) ? dist * e : 0.0f;   // d alpha / d sigma
 #pragma unroll
         for (int k = 0; k < 3; ++k) col[i][k] = 1.0f / (1.0f + expf(-c[k]));
-        smv[i][0] = nsem > 0 ? c[4] : 0.0f;
-        smv[i][1] = nsem > 1 ? c[5] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) smv[i][k] = nsem > k ? c[4 + k] : 0.0f;
         tloc[i] = prod;
         tt[i] = (1.0f - a) + 1e-10f;
         if (live) prod *= (double)tt[i];
@@ -292,11 +293,15 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
     const float a_ray = (float)s_acc, dep = (float)s_depth;
     const bool empty = a_ray <= 1e-10f;   // depth replaced by 1e10: no gradient through the sum (:72)
 
-    float grgb[3] = {0, 0, 0}, gsem[2] = {0, 0};
+    float grgb[3] = {0, 0, 0}, gsem[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) gsem[k] = 0.0f;
     if (g_rgb)
 #pragma unroll
         for (int k = 0; k < 3; ++k) grgb[k] = g_rgb[3 * r + k];
-    if (g_sem && nsem > 0) { gsem[0] = g_sem[nsem * r]; if (nsem > 1) gsem[1] = g_sem[nsem * r + 1]; }
+    if (g_sem)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) if (nsem > k) gsem[k] = g_sem[nsem * r + k];
     float G_acc = g_acc ? g_acc[r] : 0.0f;
     float G_dep = (g_depth && !empty) ? g_depth[r] : 0.0f;
     if (g_disp && !empty) {
@@ -307,7 +312,12 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
             G_acc += -gq * dep / (a_ray * a_ray);
         }
     }
-    if (white_bkgd) G_acc -= (grgb[0] + grgb[1] + grgb[2]) + (gsem[0] + gsem[1]);   // rgb, sem += 1 - acc (:77-81)
+    if (white_bkgd) {                                                                // rgb, sem += 1 - acc (:77-81)
+        float gs = gsem[0] + gsem[1];
+#pragma unroll
+        for (int k = 2; k < NS; ++k) gs += gsem[k];
+        G_acc -= (grgb[0] + grgb[1] + grgb[2]) + gs;
+    }
 
     float gw[IPL];
     double suf_loc[IPL], tail = 0.0;   // suf_loc[i] = sum over this lane's samples j > i of gw_j w_j
@@ -317,7 +327,12 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
         float g = g_weights && s < S ? g_weights[r * S + s] : 0.0f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) g += grgb[k] * col[i][k];
-        g += gsem[0] * smv[i][0] + gsem[1] * smv[i][1];
+        {
+            float gs = gsem[0] * smv[i][0] + gsem[1] * smv[i][1];
+#pragma unroll
+            for (int k = 2; k < NS; ++k) gs += gsem[k] * smv[i][k];
+            g += gs;
+        }
         g += G_dep * z[i] + G_acc;
         gw[i] = s < S ? g : 0.0f;
         suf_loc[i] = tail;
@@ -342,8 +357,8 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
 #pragma unroll
         for (int k = 0; k < 3; ++k) o[k] = grgb[k] * w[i] * (col[i][k] * (1.0f - col[i][k]));
         o[3] = ga * dexp[i];
-        if (nsem > 0) o[4] = gsem[0] * w[i];
-        if (nsem > 1) o[5] = gsem[1] * w[i];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) if (nsem > k) o[4 + k] = gsem[k] * w[i];
     }
 }
 
@@ -354,14 +369,16 @@ extern "C" int32_t nsos_composite_backward(const float* raw, const float* z_vals
                                            const float* g_weights, float* g_raw, void* stream) {
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(raw && z_vals && rays_d && g_raw, NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(n_ch == 4 || n_ch == 5 || n_ch == 6, NSOS_ERR_UNSUPPORTED);
+    NSOS_REQUIRE(n_ch >= 4 && n_ch <= 12, NSOS_ERR_UNSUPPORTED);     // 4 + sem_dim, sem_dim <= 8 (generic nets)
     NSOS_REQUIRE(n_rays >= 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE(n_samples <= 512, NSOS_ERR_UNSUPPORTED);
     NSOS_REQUIRE((n_rays + 3) / 4 < (int64_t)1 << 31, NSOS_ERR_UNSUPPORTED);
     const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
     const int ipl = (n_samples + 63) / 64;
 #define NSOS_LAUNCH_CB(I)                                                                                              \
-    hipLaunchKernelGGL(composite_backward_kernel<I>, grid, block, 0, (hipStream_t)stream, raw, z_vals, rays_d, noise, \
+    if (n_ch <= 6) hipLaunchKernelGGL((composite_backward_kernel<I, 2>), grid, block, 0, (hipStream_t)stream, raw, z_vals, rays_d, noise, \
+                       noise_std, n_rays, n_samples, n_ch, white_bkgd, g_rgb, g_sem, g_depth, g_acc, g_disp, g_weights, g_raw);        \
+    else hipLaunchKernelGGL((composite_backward_kernel<I, 8>), grid, block, 0, (hipStream_t)stream, raw, z_vals, rays_d, noise, \
                        noise_std, n_rays, n_samples, n_ch, white_bkgd, g_rgb, g_sem, g_depth, g_acc, g_disp, g_weights, g_raw)
     switch (ipl) {
         case 1: NSOS_LAUNCH_CB(1); break;

@@ -24,26 +24,30 @@ using namespace nsos;
 
 namespace {
 
-constexpr int kGenMaxOps = 48, kGenMaxGroups = 56, kGenMaxSeg = 3;
+constexpr int kGenMaxOps = 64, kGenMaxGroups = 56, kGenMaxSeg = 3;   // (ops: the backward program of a 16-deep net with the deepest head has 61)
 constexpr int kGenRowFloats = 32;     // one LDS row = one feature of the tile's 32 points = 128 B
 
-enum { kGenDense = 0, kGenMul = 1 };
+enum { kGenDense = 0, kGenMul = 1, kGenBwdHead = 2, kGenBwdMul = 3 };
 struct GenOp {
-    int kind;        // kGenDense / kGenMul
+    int kind;        // kGenDense / kGenMul; the backward program (build_bwd_program) adds kGenBwdHead / kGenBwdMul
     int out_off;     // LDS float offset of the op's output row 0
     int out_dim;     // rows written (dense: out features; mul: rows multiplied)
     int out_tiles;
-    int relu;        // bit 0: ReLU; bit 1: also write zeros into the pad rows of the last tile (a whole buffer is this op's output)
+    int relu;        // bit 0: ReLU; bit 1: also write zeros into the pad rows of the last tile (a whole buffer is this op's output);
+                     // bit 2 (backward dense): add to what the buffer holds (a second consumer's contribution)
     int n_groups;    // groups of 4 k-steps over all segments, the bias group first
     int w_off;       // float offset of the op's A stream in the packed weights
     int src_off;     // mul: LDS float offset of the factor rows
+    int act_col;     // first column of the op's block (pad32(out_dim) columns) in the saved-activation / gradient rows (training)
+    int aux_col;     // kGenBwdMul: the column block of geo_map_sem's output
     int grp_off[kGenMaxGroups + 8];   // LDS float offset of the first input row of group g (entries past n_groups: the constant buffer)
 };
 struct GenProgram {              // at the head of the packed buffer (device memory); identical on the host (build_program)
     int n_ops, lds_floats, n_out, out_off;
     int x_off, x_rows, x_dim, x_freqs;      // encoded xyz: buffer, padded rows, real rows, octaves (-1: raw coordinates)
     int v_off, v_rows, v_dim, v_freqs;      // encoded view direction (v_dim = 0 without view directions)
-    int ones_off, w_floats, pad0, pad1;
+    int ones_off, w_floats, act_ld, pad1;   // act_ld: floats per point of the saved activations = columns of X | V | every dense op
+    int x_col, v_col, pad2, pad3;
     GenOp ops[kGenMaxOps];
 };
 
@@ -53,6 +57,7 @@ struct GenParams {
     const float* rays_o; const float* rays_d; const float* viewdirs; const float* z_vals;   // ray mode
     const float* pts; const float* dirs;                                                      // point mode
     float* raw;
+    float* acts;          // training variant: [n_pts, act_ld] post-activation outputs of every dense op + both encodings
     long long n_pts;
     int n_samples;
     int n_tiles;
@@ -139,6 +144,10 @@ __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const
     if constexpr (TWO) asm volatile("" : "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]));
 }
 
+// SAVE: the training variant -- every dense op's post-activation output tile and both encodings also go to P.acts (point-major
+// rows of act_ld floats, one 32-aligned column block per op: the layout nsos_wgrad reads its X operand in), straight from the
+// accumulators: lane (point, hi) holds features 8 q + 4 hi + (0..3) of its point = one 16-byte store per q.
+template <bool SAVE>
 __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,6 +188,13 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         const float poison = ((x[0] - x[0]) + (x[1] - x[1])) + ((x[2] - x[2]) + (dv[0] - dv[0])) + ((dv[1] - dv[1]) + (dv[2] - dv[2]));
         for (int f = part; f < G.x_rows; f += 8) lds[G.x_off + f * kGenRowFloats + p] = gen_feature(x, f, G.x_dim, G.x_freqs);
         for (int f = part; f < G.v_rows; f += 8) lds[G.v_off + f * kGenRowFloats + p] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+        if constexpr (SAVE) {
+            if (valid) {       // (recomputed rather than read back from LDS: no barrier in between; blocks are padded to 32 columns with zeros)
+                float* arow = P.acts + gp * G.act_ld;
+                for (int f = part; f < ((G.x_dim + 31) & ~31); f += 8) arow[G.x_col + f] = gen_feature(x, f, G.x_dim, G.x_freqs);
+                for (int f = part; f < ((G.v_dim + 31) & ~31); f += 8) arow[G.v_col + f] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+            }
+        }
         for (int r = part; r < 32; r += 8) lds[out_off + r * kGenRowFloats + p] = 0.0f;
         __syncthreads();
 
@@ -207,6 +223,24 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                     if (row0 < op.out_dim || pad) lds[op.out_off + row0 * kGenRowFloats + pt] = relu ? fmaxf(acc0[r], 0.0f) : acc0[r];
                     if (two && (row0 + 128 < op.out_dim || pad)) lds[op.out_off + (row0 + 128) * kGenRowFloats + pt] = relu ? fmaxf(acc1[r], 0.0f) : acc1[r];
                 }
+                if constexpr (SAVE) {
+                    const long long gpl = (long long)tile * 32 + pt;
+                    if (gpl < P.n_pts) {
+                        float* dst = P.acts + gpl * G.act_ld + op.act_col + 32 * t0 + 4 * hi;
+                        const bool relu = op.relu & 1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v0, v1;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v0[j] = relu ? fmaxf(acc0[4 * q + j], 0.0f) : acc0[4 * q + j];
+                                v1[j] = relu ? fmaxf(acc1[4 * q + j], 0.0f) : acc1[4 * q + j];
+                            }
+                            *reinterpret_cast<f32x4*>(dst + 8 * q) = v0;           // (rows past out_dim: exact zeros, the block's padding)
+                            if (two) *reinterpret_cast<f32x4*>(dst + 128 + 8 * q) = v1;
+                        }
+                    }
+                }
             }
             __syncthreads();
         }
@@ -215,6 +249,127 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
             for (int c = part; c < n_out; c += 8) P.raw[gp * n_out + c] = poison != poison ? __builtin_nanf("") : lds[out_off + c * kGenRowFloats + p];
         __syncthreads();
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------- backward (training)
+// The input-gradient chain of the same program, reversed: gradient buffers live in LDS at the FORWARD buffers' offsets (a
+// buffer's forward lifetime [producer, last consumer] is its gradient's lifetime read backwards, so the forward's ping-pong
+// allocation is valid as it stands).  Per forward dense op o, in reverse order:
+//   kGenBwdHead   dY_o = (gradient buffer of o's output) (x) [saved output > 0]  (ReLU ops; models/nerf_mlp.py:71-72,90), written back
+//                 to LDS and -- point-major, zero-padded to the op's 32-column block -- to gbuf: the G operand of nsos_wgrad
+//   kGenDense     for every input segment that carries a gradient (not the encodings): d(segment) (+)= W_o[:, segment]^T dY_o, the
+//                 same dense_tiles contraction over a TRANSPOSED weight stream (gen_pack_t_kernel), K = o's output features
+//   kGenBwdMul    semantics * mapping (models/nerf_mlp.py:81-83): d sem = g * mapping, d mapping = g * sem (saved values)
+// The weight gradients dW_o = dY_o^T [segments], db_o = column sums are nsos_wgrad calls over (gbuf, acts) column blocks, sequenced
+// by the host (ops.py) from nsos_mlp_generic_save_layout.  Exact fp32 MFMA throughout: the reference's autograd arithmetic up to
+// summation order.
+struct GenBwdParams {
+    const GenProgram* prog;
+    const float* wts;
+    const float* g_raw;       // [n_pts, n_out]
+    const float* acts;        // [n_pts, ld]
+    float* gbuf;              // [n_pts, ld]
+    long long n_pts;
+    int n_tiles;
+};
+
+__global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt = lane & 31, hi = lane >> 5;
+    const __attribute__((address_space(4))) GenProgram& G = *(const __attribute__((address_space(4))) GenProgram*)P.prog;
+    const int n_ops = G.n_ops, n_out = G.n_out, out_off = G.out_off, ld = G.act_ld;
+    {
+        const int row = tid >> 5, col = tid & 31;
+        lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;     // (pad groups carry zero weights: any finite rows do)
+    }
+    for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        const int p = tid & 31, part = tid >> 5;
+        const long long gp = (long long)tile * 32 + p;
+        const bool valid = gp < P.n_pts;
+        const long long gc = valid ? gp : P.n_pts - 1;
+        // d loss / d raw into the OUT rows (points past the end: zero gradient, so nothing of theirs reaches gbuf or a neighbour)
+        for (int r = part; r < 32; r += 8) lds[out_off + r * kGenRowFloats + p] = (r < n_out && valid) ? P.g_raw[gp * n_out + r] : 0.0f;
+        __syncthreads();
+        for (int oi = 0; oi < n_ops; ++oi) {
+            const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
+            if (op.kind == kGenBwdMul) {
+                for (int r = part; r < op.out_dim; r += 8) {
+                    const float g = lds[op.out_off + r * kGenRowFloats + p];
+                    const float sv = P.acts[gc * ld + op.act_col + r], mv = P.acts[gc * ld + op.aux_col + r];
+                    lds[op.out_off + r * kGenRowFloats + p] = g * mv;
+                    lds[op.src_off + r * kGenRowFloats + p] = g * sv;
+                }
+                __syncthreads();
+                continue;
+            }
+            if (op.kind == kGenBwdHead) {
+                const long long gpl = (long long)tile * 32 + pt;
+                const bool vpt = gpl < P.n_pts;
+                const float* arow = P.acts + (vpt ? gpl : P.n_pts - 1) * ld + op.act_col;
+                float* grow = P.gbuf + gpl * ld + op.act_col;
+                const bool relu = op.relu & 1;
+                for (int t = wave; t < op.out_tiles; t += 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = 32 * t + 8 * q + 4 * hi;
+                        f32x4 g, a = {1.0f, 1.0f, 1.0f, 1.0f};
+                        if (relu) a = *reinterpret_cast<const f32x4*>(arow + f0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = f0 + j < op.out_dim ? lds[op.out_off + (f0 + j) * kGenRowFloats + pt] : 0.0f;
+                            g[j] = a[j] > 0.0f ? v : 0.0f;                        // relu'(x) = [x > 0] (ATen threshold_backward)
+                            if (relu) lds[op.out_off + (f0 + j) * kGenRowFloats + pt] = g[j];   // (ReLU outputs own whole pad32 buffers)
+                        }
+                        if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+            const int out_tiles = op.out_tiles;
+            for (int t0 = wave; t0 < out_tiles; t0 += 8) {
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+                const bool two = t0 + 4 < out_tiles;
+                if (two) dense_tiles<true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                else dense_tiles<false>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                const bool pad = op.relu & 2, add = op.relu & 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row0 = 32 * t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row0 < op.out_dim || pad) {
+                        float* d = &lds[op.out_off + row0 * kGenRowFloats + pt];
+                        *d = add ? *d + acc0[r] : acc0[r];
+                    }
+                    if (two && (row0 + 128 < op.out_dim || pad)) {
+                        float* d = &lds[op.out_off + (row0 + 128) * kGenRowFloats + pt];
+                        *d = add ? *d + acc1[r] : acc1[r];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// the transposed A stream of one (forward op, segment): [tile of segment rows][group of 8 output features][lane][4]
+struct GenPackT {
+    const float* w;
+    int in_dim, col0, rows, k_dim, out_tiles, n_groups;
+    float* out;
+};
+__global__ __launch_bounds__(256) void gen_pack_t_kernel(const GenPackT Q) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Q.out_tiles * Q.n_groups * 256;
+    if (gid >= total) return;
+    const int j = (int)(gid & 3), lane = (int)((gid >> 2) & 63);
+    const long long tg = gid >> 8;
+    const int g = (int)(tg % Q.n_groups), t = (int)(tg / Q.n_groups);
+    const int i = lane & 31, hi = lane >> 5, row = 32 * t + i, kr = 8 * g + 2 * j + hi;
+    Q.out[gid] = (row < Q.rows && kr < Q.k_dim) ? Q.w[(long long)kr * Q.in_dim + Q.col0 + row] : 0.0f;
 }
 
 // one launch per op: the op's A stream [tile][group][lane][4]
@@ -247,8 +402,8 @@ __global__ __launch_bounds__(256) void gen_pack_kernel(const GenPackOp Q) {
 }
 
 // ---------------------------------------------------------------------------------------------- host: the program
-struct HostSeg { int buf_off, rows, col0; };
-struct HostOp { GenOp op; const float* w; const float* bias; int in_dim; int n_seg; HostSeg seg[kGenMaxSeg]; };
+struct HostSeg { int buf_off, rows, col0, src_col; };   // src_col: the column block of the saved activations holding the segment's rows
+struct HostOp { GenOp op; const float* w; const float* bias; int in_dim; int n_seg; HostSeg seg[kGenMaxSeg]; int lin_id; int out_buf; };
 struct HostProgram { GenProgram prog; HostOp hops[kGenMaxOps]; int32_t err; };
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -285,6 +440,14 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
     G.lds_floats = off;
     G.n_out = M.use_viewdirs ? 4 + sem_dim : 4;
     int n = 0, w_off = 0;
+    // the saved-activation row of a point (training): [X pad32 | V pad32 | one pad32(out_dim) block per dense op, in program order]
+    G.x_col = 0; G.v_col = pad_to(x_dim, 32);
+    int next_col = G.v_col + pad_to(v_dim, 32);
+    struct { int off, col; } produced[kGenMaxOps + 2];
+    int n_produced = 0;
+    produced[n_produced++] = {G.x_off, G.x_col};
+    if (v_dim) produced[n_produced++] = {G.v_off, G.v_col};
+    auto col_of = [&](int buf_off) { for (int k = n_produced - 1; k >= 0; --k) if (produced[k].off == buf_off) return produced[k].col; return -1; };
     auto dense = [&](const nsos_generic_linear& L, int out_buf, int out_row0, bool relu, int n_seg, const HostSeg* segs) {
         if (n >= kGenMaxOps || !L.weight || !L.bias) { H.err = H.err ? H.err : (n >= kGenMaxOps ? NSOS_ERR_UNSUPPORTED : NSOS_ERR_NULL_POINTER); return; }
         HostOp& ho = H.hops[n];
@@ -296,6 +459,7 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
         for (int s = 0; s < n_seg; ++s) {
             ho.seg[s] = segs[s];
             ho.seg[s].col0 = in_dim;
+            ho.seg[s].src_col = col_of(segs[s].buf_off);
             in_dim += segs[s].rows;
             const int ng = pad_to(segs[s].rows, 8) / 8;
             for (int k = 0; k < ng; ++k) {
@@ -312,22 +476,27 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
         op.n_groups = g; op.w_off = w_off;
         w_off += op.out_tiles * g * 256;
         ho.w = L.weight; ho.bias = L.bias; ho.in_dim = in_dim; ho.n_seg = n_seg;
+        ho.lin_id = (int)(&L - &M.pts[0]);        // position in the description: pts 0-15, alpha, feature, views, rgb, output, sem 21-28, geo 29-30
+        ho.out_buf = out_buf;
+        op.act_col = next_col;
+        next_col += op.out_tiles * 32;
+        produced[n_produced++] = {op.out_off, op.act_col};
         ++n;
     };
-    const HostSeg Xs = {G.x_off, x_dim, 0}, Vs = {G.v_off, v_dim, 0};
+    const HostSeg Xs = {G.x_off, x_dim, 0, 0}, Vs = {G.v_off, v_dim, 0, 0};
     int cur = -1;                                                      // the trunk's current activation buffer
     for (int i = 0; i < D; ++i) {
         const int out = (i & 1) ? HB : HA;
         if (i == 0) dense(M.pts[0], out, 0, true, 1, &Xs);
         else {
-            const HostSeg hs = {cur, W, 0};
+            const HostSeg hs = {cur, W, 0, 0};
             if ((M.skip_mask >> (i - 1)) & 1) { const HostSeg two[2] = {Xs, hs}; dense(M.pts[i], out, 0, true, 2, two); }   // cat([input_pts, h]) (:73-74)
             else dense(M.pts[i], out, 0, true, 1, &hs);
         }
         cur = out;
     }
     const int other = cur == HA ? HB : HA;
-    const HostSeg hs = {cur, W, 0};
+    const HostSeg hs = {cur, W, 0, 0};
     if (!M.use_viewdirs) {
         dense(M.output, G.out_off, 0, false, 1, &hs);                                          // output_linear (:97-98)
     } else {
@@ -341,16 +510,16 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
                     if (M.sem_with_coord) { const HostSeg two[2] = {hs, Xs}; dense(M.sem[0], out, last ? 4 : 0, !last, 2, two); }   // cat([h, input_pts])
                     else dense(M.sem[0], out, last ? 4 : 0, !last, 1, &hs);
                 } else {
-                    const HostSeg ss = {src, src_rows, 0};
+                    const HostSeg ss = {src, src_rows, 0, 0};
                     dense(M.sem[k], out, last ? 4 : 0, !last, 1, &ss);
                 }
                 src = out; src_rows = M.sem[k].out_dim;
             }
             if (M.sem_with_geo) {                                                              // semantics *= geo_map_sem(alpha) (:60, :81-83)
                 const int gbuf = (M.sem_layers & 1) ? SB : SA;                                 // whichever the chain is done with
-                const HostSeg as = {G.out_off + 3 * kGenRowFloats, 1, 0};
+                const HostSeg as = {G.out_off + 3 * kGenRowFloats, 1, 0, 0};
                 dense(M.geo[0], gbuf, 0, true, 1, &as);
-                const HostSeg gs = {gbuf, M.geo[0].out_dim, 0};
+                const HostSeg gs = {gbuf, M.geo[0].out_dim, 0, 0};
                 dense(M.geo[1], G.out_off, 4 + sem_dim, false, 1, &gs);
                 if (n < kGenMaxOps) {
                     GenOp& op = H.hops[n].op;
@@ -361,15 +530,88 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
             }
         }
         dense(M.feature, other, 0, false, 1, &hs);                                             // feature = feature_linear(h) (:86)
-        const HostSeg fv[2] = {{other, W, 0}, Vs};
+        const HostSeg fv[2] = {{other, W, 0, 0}, Vs};
         dense(M.views, SA, 0, true, 2, fv);                                                    // relu(views_linears.0(cat([feature, input_views]))) (:87-90)
-        const HostSeg vh = {SA, M.views.out_dim, 0};
+        const HostSeg vh = {SA, M.views.out_dim, 0, 0};
         dense(M.rgb, G.out_off, 0, false, 1, &vh);                                             // rgb_linear (:92)
     }
     G.n_ops = n;
     G.w_floats = w_off;
+    G.act_ld = next_col;
     for (int i = 0; i < n; ++i) G.ops[i] = H.hops[i].op;
     if (!H.err && G.lds_floats * 4 > 160 * 1024) H.err = NSOS_ERR_UNSUPPORTED;
+}
+
+
+// The backward program of a forward program (see mlp_generic_bwd_kernel).  `T` gets the transposed streams' pack descriptors.
+struct HostBwd { GenProgram prog; GenPackT packs[kGenMaxOps]; int pack_w_off[kGenMaxOps]; int n_packs; int32_t err; };
+void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd& B) {
+    B = HostBwd{};
+    B.err = H.err;
+    if (H.err) return;
+    const GenProgram& F = H.prog;
+    GenProgram& G = B.prog;
+    G = F;
+    G.n_ops = 0;
+    int n = 0, w_off = 0;
+    // which gradient buffers hold a contribution already (a second consumer adds).  OUT is preloaded with d loss / d raw.
+    struct { int off; bool has; } state[16];
+    int n_state = 0;
+    auto has_grad = [&](int off) -> bool& {
+        for (int k = 0; k < n_state; ++k) if (state[k].off == off) return state[k].has;
+        state[n_state] = {off, false};
+        return state[n_state++].has;
+    };
+    auto in_out = [&](int off) { return off >= F.out_off && off < F.out_off + 32 * kGenRowFloats; };
+    int sem_last_col = -1, geo_col = -1;
+    for (int i = 0; i < F.n_ops; ++i) {
+        if (H.hops[i].op.kind != kGenDense) continue;
+        if (H.hops[i].lin_id == 21 + M.sem_layers - 1) sem_last_col = H.hops[i].op.act_col;
+        if (H.hops[i].lin_id == 30) geo_col = H.hops[i].op.act_col;
+    }
+    for (int oi = F.n_ops - 1; oi >= 0; --oi) {
+        const HostOp& ho = H.hops[oi];
+        if (n + 1 + kGenMaxSeg > kGenMaxOps) { B.err = NSOS_ERR_UNSUPPORTED; return; }
+        if (ho.op.kind == kGenMul) {
+            GenOp& op = G.ops[n++];
+            op = GenOp{};
+            op.kind = kGenBwdMul; op.out_off = ho.op.out_off; op.src_off = ho.op.src_off; op.out_dim = ho.op.out_dim;
+            op.act_col = sem_last_col; op.aux_col = geo_col;
+            continue;
+        }
+        {
+            GenOp& op = G.ops[n++];
+            op = GenOp{};
+            op.kind = kGenBwdHead; op.out_off = ho.op.out_off; op.out_dim = ho.op.out_dim; op.out_tiles = ho.op.out_tiles;
+            op.relu = ho.op.relu & 1; op.act_col = ho.op.act_col;
+        }
+        for (int s = 0; s < ho.n_seg; ++s) {
+            const HostSeg& sg = ho.seg[s];
+            if (sg.buf_off == F.x_off || (F.v_dim && sg.buf_off == F.v_off)) continue;     // no gradient flows to the encodings (rays are data)
+            GenOp& op = G.ops[n++];
+            op = GenOp{};
+            op.kind = kGenDense; op.out_off = sg.buf_off; op.out_dim = sg.rows; op.out_tiles = pad_to(sg.rows, 32) / 32;
+            const bool to_out = in_out(sg.buf_off);
+            bool& has = has_grad(to_out ? F.out_off : sg.buf_off);
+            op.relu = (to_out ? 0 : 2) | ((has || to_out) ? 4 : 0);
+            has = true;
+            int g = 0;
+            const int kg = pad_to(ho.op.out_dim, 8) / 8;
+            if (kg > kGenMaxGroups - 3) { B.err = NSOS_ERR_UNSUPPORTED; return; }
+            for (int k = 0; k < kg; ++k) op.grp_off[g++] = ho.op.out_off + 8 * k * kGenRowFloats;
+            while (g % 4) op.grp_off[g++] = F.ones_off;
+            for (int k = g; k < kGenMaxGroups + 8; ++k) op.grp_off[k] = F.ones_off;
+            op.n_groups = g; op.w_off = w_off;
+            GenPackT& Q = B.packs[B.n_packs++];
+            Q = GenPackT{};
+            Q.w = ho.w; Q.in_dim = ho.in_dim; Q.col0 = sg.col0; Q.rows = sg.rows; Q.k_dim = ho.op.out_dim; Q.out_tiles = op.out_tiles; Q.n_groups = g;
+            B.pack_w_off[B.n_packs - 1] = w_off;
+            w_off += op.out_tiles * g * 256;
+        }
+        if (!in_out(ho.op.out_off)) has_grad(ho.out_buf) = false;     // consumed: the buffer's next tenant starts afresh
+    }
+    G.n_ops = n;
+    G.w_floats = w_off;
 }
 
 constexpr size_t kGenHeaderBytes = (sizeof(GenProgram) + 255) / 256 * 256;
@@ -430,12 +672,14 @@ static int32_t generic_launch(const nsos_generic_mlp* mlp, const void* packed, G
     p.n_tiles = (int)((n_pts + 31) / 32);
     const int lds_bytes = H.prog.lds_floats * 4;
     // (per call: the attribute is a property of the kernel on this device, the size a property of the architecture rendered)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* fn = p.acts ? reinterpret_cast<const void*>(&mlp_generic_kernel<true>) : reinterpret_cast<const void*>(&mlp_generic_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int32_t)e;
     const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
     const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
-    hipLaunchKernelGGL(mlp_generic_kernel, dim3(grid), dim3(256), lds_bytes, st, p);
+    if (p.acts) hipLaunchKernelGGL(mlp_generic_kernel<true>, dim3(grid), dim3(256), lds_bytes, st, p);
+    else hipLaunchKernelGGL(mlp_generic_kernel<false>, dim3(grid), dim3(256), lds_bytes, st, p);
     return nsos_launch_status();
 }
 
@@ -460,4 +704,99 @@ extern "C" int32_t nsos_mlp_generic_forward_points(const nsos_generic_mlp* mlp, 
     GenParams p = {};
     p.pts = pts; p.dirs = dirs; p.raw = raw; p.n_samples = 1;
     return generic_launch(mlp, packed, p, n_pts, (hipStream_t)stream);
+}
+
+// ---- training (every parameter of a generic-architecture net): saved activations, the input-gradient chain, the layout table
+extern "C" int32_t nsos_mlp_generic_save_layout(const nsos_generic_mlp* mlp, int32_t* table, int32_t capacity) {
+    NSOS_REQUIRE(mlp && table, NSOS_ERR_NULL_POINTER);
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    if (H.err) return H.err;
+    int n_dense = 0;
+    for (int i = 0; i < H.prog.n_ops; ++i) n_dense += H.hops[i].op.kind == kGenDense;
+    const int need = 2 + n_dense * NSOS_GENERIC_LAYOUT_STRIDE;
+    NSOS_REQUIRE(capacity >= need, NSOS_ERR_BUFFER_TOO_SMALL);
+    int k = 0;
+    table[k++] = H.prog.act_ld;
+    table[k++] = n_dense;
+    for (int i = 0; i < H.prog.n_ops; ++i) {
+        const HostOp& ho = H.hops[i];
+        if (ho.op.kind != kGenDense) continue;
+        table[k++] = ho.lin_id; table[k++] = ho.op.act_col; table[k++] = ho.op.out_dim; table[k++] = ho.n_seg;
+        for (int s = 0; s < kGenMaxSeg; ++s) {
+            table[k++] = s < ho.n_seg ? ho.seg[s].src_col : -1;
+            table[k++] = s < ho.n_seg ? ho.seg[s].rows : 0;
+            table[k++] = s < ho.n_seg ? ho.seg[s].col0 : 0;
+        }
+    }
+    return need;
+}
+
+extern "C" int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
+                                                      const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                      float* raw, float* acts, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed && rays_o && rays_d && z_vals && raw && acts, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!mlp->use_viewdirs || viewdirs, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
+    GenParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals; p.raw = raw; p.acts = acts; p.n_samples = n_samples;
+    return generic_launch(mlp, packed, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
+}
+
+extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp) {
+    if (!mlp) return 0;
+    static thread_local HostProgram H;
+    static thread_local HostBwd B;
+    build_program(*mlp, H);
+    build_bwd_program(*mlp, H, B);
+    if (B.err) return 0;
+    return kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes;
+}
+
+extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, void* stream) {
+    NSOS_REQUIRE(mlp && packed_bwd, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(((uintptr_t)packed_bwd & 15) == 0, NSOS_ERR_MISALIGNED);
+    static thread_local HostProgram H;
+    static thread_local HostBwd B;
+    build_program(*mlp, H);
+    build_bwd_program(*mlp, H, B);
+    if (B.err) return B.err;
+    NSOS_REQUIRE(packed_bytes >= kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes, NSOS_ERR_BUFFER_TOO_SMALL);
+    const hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(packed_bwd, &B.prog, sizeof(GenProgram), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int32_t)e;
+    float* wts = reinterpret_cast<float*>(static_cast<unsigned char*>(packed_bwd) + kGenHeaderBytes);
+    for (int i = 0; i < B.n_packs; ++i) {
+        GenPackT Q = B.packs[i];
+        NSOS_REQUIRE(Q.w, NSOS_ERR_NULL_POINTER);
+        Q.out = wts + B.pack_w_off[i];
+        const long long total = (long long)Q.out_tiles * Q.n_groups * 256;
+        hipLaunchKernelGGL(gen_pack_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Q);
+    }
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                                float* gbuf, int64_t n_pts, void* stream) {
+    if (n_pts == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts > 0 && (n_pts + 31) / 32 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    if (H.err) return H.err;
+    GenBwdParams p = {};
+    p.prog = static_cast<const GenProgram*>(packed_bwd);
+    p.wts = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_bwd) + kGenHeaderBytes);
+    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.n_pts = n_pts; p.n_tiles = (int)((n_pts + 31) / 32);
+    const int lds_bytes = H.prog.lds_floats * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_generic_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int32_t)e;
+    const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
+    const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
+    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    return nsos_launch_status();
 }

@@ -152,9 +152,14 @@ class NeRFMLP(nn.Module):
             if precision != "fp32":
                 raise NotImplementedError(f"nerf_sos_amd: mlp_precision {precision!r} exists for the shipped architecture only "
                                           "(8 x 256, skips [4], multires 10 / 4, view directions, two-Linear head); this net renders in fp32")
-            key = tuple((p.data_ptr(), p._version) for p in params)
-            if self._gplan is None or self._packed_key.get("generic") != key:
+            # (trainable: re-packed on every call, for the reason in the docstring; frozen: keyed by (data_ptr, _version))
+            key = None if any(p.requires_grad for p in params) else tuple((p.data_ptr(), p._version) for p in params)
+            ptrs = tuple(p.data_ptr() for p in params)
+            if self._gplan is None or self._gplan.param_ptrs != ptrs:
                 self._gplan = ops.GenericPlan(self.mlp, self.multires, self.multires_views)
+                self._gplan.param_ptrs = ptrs
+                self._packed_key.pop("generic", None)
+            if key is None or "generic" not in self._packed or self._packed_key.get("generic") != key:
                 self._packed["generic"] = self._gplan.run(self._packed.get("generic"))
                 self._packed_key["generic"] = key
             return self._packed["generic"]
@@ -190,10 +195,22 @@ class NeRFMLP(nn.Module):
         self._frozen_key.clear()
         self._plan = self._gplan = None
 
-    def query_rays(self, rays_o, rays_d, viewdirs, z_vals):
-        """raw [R,S,C] of a generic-architecture net for the points o + d z (NeRFNet's ray path)."""
+    def query_rays(self, rays_o, rays_d, viewdirs, z_vals, save: bool = False):
+        """raw [R,S,C] of a generic-architecture net for the points o + d z (NeRFNet's ray path); save=True: the training variant,
+        (raw, acts) with every Linear's output saved per point (raw bit-identical)."""
         packed = self.packed_weights()
-        return ops.mlp_generic_forward_rays(self._gplan, packed, rays_o, rays_d, viewdirs if self.use_viewdirs else None, z_vals)
+        dirs = viewdirs if self.use_viewdirs else None
+        if save:
+            return ops.mlp_generic_forward_rays_save(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
+        return ops.mlp_generic_forward_rays(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
+
+    def packed_bwd_generic(self) -> torch.Tensor:
+        """The transposed weight streams of the generic input-gradient chain, packed from the CURRENT parameters (every call:
+        training moves them, see packed_weights)."""
+        if self._gplan is None:
+            self.packed_weights()
+        self._packed["generic_bwd"] = self._gplan.run_bwd(self._packed.get("generic_bwd"))
+        return self._packed["generic_bwd"]
 
     def forward(self, inputs, viewdirs=None):
         if self.use_viewdirs and viewdirs is None:
@@ -328,6 +345,11 @@ class _FullRender(torch.autograd.Function):
                                            g_acc=get("acc"), g_disp=get("disp"), g_weights=get("weights"))
             if get("raw") is not None:
                 g_raw = g_raw + get("raw").reshape(g_raw.shape)
+            if sv.get("generic"):
+                from .backward import generic_mlp_backward
+                by_name = generic_mlp_backward(mlp.mlp, mlp._gplan, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]), mlp.packed_bwd_generic())
+                grads += [by_name.get(n) for n in names]
+                continue
             # fused input-gradient chain (K7-X3) for both precisions; "fp32": exact-fp32 weight-gradient reductions and the
             # trunk masks from the saved fp32 activations, "fp16x3": split-fp16 reductions and the forward's bit masks
             by_name = mlp_backward(mlp.mlp, mlp.sem_mode, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
@@ -447,15 +469,12 @@ class NeRFNet(nn.Module):
             raise NotImplementedError(f"nerf_sos_amd.NeRFNet: mlp_precision {self.mlp_precision!r} exists for the shipped architecture only; this one renders in fp32")
         if not trainable:
             return self._render_rays_impl(*args, save=False, **kwargs)[0]
-        if generic:
-            raise NotImplementedError(
-                "nerf_sos_amd.NeRFNet: backward kernels exist for the shipped architecture only (netdepth 8, netwidth 256, multires 10 / 4, "
-                "view directions, two-Linear semantic head); this architecture renders forward-only -- wrap the call in torch.no_grad() "
-                "or freeze every parameter.  There is no autograd fallback on purpose.")
         other = [n for n in trainable if "semantic_linear" not in n]
-        if other:
+        if other or generic:
+            # a generic-architecture net trains through the generic backward kernels whatever subset of its parameters is trainable
+            # (K7-G: every gradient is computed, autograd keeps those of the parameters that ask for one)
             # any backbone parameter trainable (e.g. configs/flower_full.txt trains everything): full backward
-            if self.mlp_precision not in ("fp32", "fp16x3") and not NeRFNet._warned_full_16bit:
+            if not generic and self.mlp_precision not in ("fp32", "fp16x3") and not NeRFNet._warned_full_16bit:
                 # there is no 16-bit full backward (the reference has no 16-bit path at all): a trainable backbone under
                 # "fp16" / "bf16" trains on the split-fp16 kernels -- 16-bit matrix pipe, fp32-grade values, the same gradient
                 # tests as "fp16x3" -- instead of raising; inference and frozen-backbone steps keep the 16-bit kernels
@@ -485,7 +504,11 @@ class NeRFNet(nn.Module):
         saved = {}
 
         def query(net, z, tag):
-            if not net.fast:     # any other architecture: the generic fp32 kernel (forward only; render_rays refused training above)
+            if not net.fast:     # any other architecture: the generic fp32 kernel
+                if save:         # (training a generic net always takes the full backward: _FullRender)
+                    raw, acts = net.query_rays(rays_o, rays_d, viewdirs, z, save=True)
+                    saved[tag] = dict(acts=acts, raw=raw, z=z, generic=True)
+                    return raw
                 return net.query_rays(rays_o, rays_d, viewdirs, z)
             if not save:
                 if self.mlp_precision != "fp32":

@@ -206,6 +206,7 @@ class GenericPlan:
             dst.out_dim, dst.in_dim = int(w.shape[0]), int(w.shape[1])
 
         G = _lib.GenericMlp()
+        names = {}             # position of a Linear in nsos_generic_mlp -> its module's name inside `mlp` (nsos_mlp_generic_save_layout)
         G.depth, G.width = int(mlp.D), int(mlp.W)
         if G.depth > _lib.GENERIC_MAX_DEPTH:
             raise NotImplementedError(f"nerf_sos_amd: netdepth {G.depth} > {_lib.GENERIC_MAX_DEPTH}")
@@ -216,21 +217,29 @@ class GenericPlan:
         G.sem_with_coord = int(bool(mlp.sem_with_coord))
         for i, m in enumerate(mlp.pts_linears):
             lin(G.pts[i], m)
+            names[i] = f"pts_linears.{i}"
         if mlp.use_viewdirs:
             lin(G.alpha, mlp.alpha_linear), lin(G.feature, mlp.feature_linear), lin(G.views, mlp.views_linears[0]), lin(G.rgb, mlp.rgb_linear)
+            names.update({16: "alpha_linear", 17: "feature_linear", 18: "views_linears.0", 19: "rgb_linear"})
         else:
             lin(G.output, mlp.output_linear)
+            names[20] = "output_linear"
         G.sem_layers = G.sem_dim = G.sem_with_geo = 0
         if mlp.use_semantics:
-            linears = [m for m in mlp.semantic_linear.modules() if isinstance(m, torch.nn.Linear)]   # Sequential order = forward order
+            named = [(n, m) for n, m in mlp.semantic_linear.named_modules() if isinstance(m, torch.nn.Linear)]   # Sequential order = forward order
+            linears = [m for _, m in named]
             if len(linears) > _lib.GENERIC_MAX_SEM:
                 raise NotImplementedError(f"nerf_sos_amd: a semantic head of {len(linears)} Linear layers (> {_lib.GENERIC_MAX_SEM})")
             for k, m in enumerate(linears):
                 lin(G.sem[k], m)
+                names[21 + k] = "semantic_linear." + named[k][0]
             G.sem_layers, G.sem_dim = len(linears), int(linears[-1].weight.shape[0])
             if getattr(mlp, "geo_map_sem", None) is not None:
                 G.sem_with_geo = 1
                 lin(G.geo[0], mlp.geo_map_sem[0]), lin(G.geo[1], mlp.geo_map_sem[2])
+                names.update({29: "geo_map_sem.0", 30: "geo_map_sem.2"})
+        self.lin_names = names
+        self._layout = None
         self.desc, self.keep, self.device = G, keep, keep[0].device
         self.ptrs = tuple(t.data_ptr() for t in keep)
         self.nbytes = int(_lib.lib().nsos_mlp_generic_packed_bytes(C.byref(G)))
@@ -247,6 +256,34 @@ class GenericPlan:
         _lib.check(_lib.lib().nsos_mlp_generic_pack(C.byref(self.desc), _p(out), self.nbytes, _stream()), "nsos_mlp_generic_pack")
         return out
 
+    def run_bwd(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The transposed weight streams + the reversed program of the input-gradient chain (nsos_mlp_generic_pack_bwd)."""
+        nbytes = int(_lib.lib().nsos_mlp_generic_bwd_packed_bytes(C.byref(self.desc)))
+        if nbytes == 0:
+            raise NotImplementedError("nerf_sos_amd: this architecture is outside the generic backward kernel's limits")
+        if out is None or out.numel() * 4 < nbytes or out.device != self.device:
+            out = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nsos_mlp_generic_pack_bwd(C.byref(self.desc), _p(out), nbytes, _stream()), "nsos_mlp_generic_pack_bwd")
+        return out
+
+    def layout(self):
+        """(ld, [(module name, column block, out_dim, [(segment's column block in acts, rows, first weight column)])]) in forward
+        order: where every Linear's pre-activation gradient (gbuf) and inputs (acts) sit in a point's saved row
+        (nsos_mlp_generic_save_layout)."""
+        if self._layout is None:
+            cap = 2 + 64 * _lib.GENERIC_LAYOUT_STRIDE
+            table = (C.c_int32 * cap)()
+            n = int(_lib.lib().nsos_mlp_generic_save_layout(C.byref(self.desc), table, cap))
+            if n < 2:
+                _lib.check(n, "nsos_mlp_generic_save_layout")
+            ld, n_ops, ops_ = int(table[0]), int(table[1]), []
+            for i in range(n_ops):
+                e = table[2 + i * _lib.GENERIC_LAYOUT_STRIDE: 2 + (i + 1) * _lib.GENERIC_LAYOUT_STRIDE]
+                segs = [(int(e[4 + 3 * s]), int(e[5 + 3 * s]), int(e[6 + 3 * s])) for s in range(int(e[3]))]
+                ops_.append((self.lin_names[int(e[0])], int(e[1]), int(e[2]), segs))
+            self._layout = (ld, ops_)
+        return self._layout
+
 
 def mlp_generic_forward_rays(plan: GenericPlan, packed: torch.Tensor, rays_o: torch.Tensor, rays_d: torch.Tensor,
                              viewdirs: Optional[torch.Tensor], z_vals: torch.Tensor) -> torch.Tensor:
@@ -261,6 +298,35 @@ def mlp_generic_forward_rays(plan: GenericPlan, packed: torch.Tensor, rays_o: to
                                                         R, S, _p(raw), _stream()), "nsos_mlp_generic_forward_rays")
     _ev_end(ev, R * S)
     return raw
+
+
+def mlp_generic_forward_rays_save(plan: GenericPlan, packed: torch.Tensor, rays_o: torch.Tensor, rays_d: torch.Tensor,
+                                  viewdirs: Optional[torch.Tensor], z_vals: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Training variant of mlp_generic_forward_rays: also returns acts [R*S, ld], every Linear's post-activation output and both
+    encodings per point (nsos_mlp_generic_forward_rays_save; raw is bit-identical to the inference call's)."""
+    rays_o, rays_d, z_vals = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d"), _dev(z_vals, "z_vals")
+    if viewdirs is not None:
+        viewdirs = _dev(viewdirs, "viewdirs")
+    R, S = z_vals.shape
+    ld = plan.layout()[0]
+    raw = torch.empty((R, S, plan.out_channels), device=z_vals.device, dtype=torch.float32)
+    acts = torch.empty((R * S, ld), device=z_vals.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_generic_forward_rays_save(C.byref(plan.desc), _p(packed), _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
+                                                             R, S, _p(raw), _p(acts), _stream()), "nsos_mlp_generic_forward_rays_save")
+    return raw, acts
+
+
+def mlp_generic_input_grads(plan: GenericPlan, packed_bwd: torch.Tensor, g_raw: torch.Tensor, acts: torch.Tensor) -> torch.Tensor:
+    """gbuf [P, ld]: every Linear's pre-activation gradient in its column block, from d loss / d raw [P, C] and the saved
+    activations (nsos_mlp_generic_input_grads: the whole chain in one kernel)."""
+    g_raw, acts = _dev(g_raw, "g_raw"), _dev(acts, "acts")
+    P_ = acts.shape[0]
+    if g_raw.shape != (P_, plan.out_channels):
+        raise ValueError("mlp_generic_input_grads: g_raw must be [P, out_channels]")
+    gbuf = torch.empty_like(acts)
+    _lib.check(_lib.lib().nsos_mlp_generic_input_grads(C.byref(plan.desc), _p(packed_bwd), _p(g_raw), _p(acts), _p(gbuf), P_, _stream()),
+               "nsos_mlp_generic_input_grads")
+    return gbuf
 
 
 def mlp_generic_forward_points(plan: GenericPlan, packed: torch.Tensor, pts: torch.Tensor, dirs: Optional[torch.Tensor]) -> torch.Tensor:

@@ -136,13 +136,105 @@ def test_generic_kernel_on_the_shipped_architecture_equals_the_fused_kernel(gold
             assert err < 2e-5, (name, P, err)
 
 
+def _fine_positions(cfg, ref, R):
+    """The reference's fine sample positions, rebuilt with the port from the reference's coarse weights (bit-identical on CPU)."""
+    near, far = torch.full((R, 1), tp.NEAR), torch.full((R, 1), tp.FAR)
+    z = tp.stratified_z(near, far, cfg.n_samples, None)
+    return tp.importance_z(z, torch.from_numpy(ref["weights0"]), cfg.n_importance, None)[0]
+
+
 @pytest.mark.gpu
-def test_generic_training_is_refused_loudly(golden):
-    cfg, sd = generic_state("d4w128", golden)
-    net = nerf_sos_amd.NeRFNet(**GENERIC_CASES["d4w128"][0]).to(DEV).train()
-    rays = torch.from_numpy(golden("generic")["d4w128__rays"]).to(DEV)
-    with pytest.raises(NotImplementedError):
-        net(rays, (tp.NEAR, tp.FAR))
+@pytest.mark.parametrize("name", NAMES)
+def test_generic_training_vs_reference_autograd(golden, name):
+    """Every parameter of every generic case trainable: the gradients of a random linear functional of all rendered maps against
+    the REAL reference's autograd (tests/golden/generic_grads.npz, make_goldens_generic_grads.py), 1e-4 of each gradient's
+    scale, with the fine positions pinned to the reference's (index flips of the free-running sampler move fine-net gradients by
+    per cents on 24 rays: tests/test_gpu_pins.py).  The training variant's outputs are bit-identical to the inference kernel's."""
+    g, gg = golden("generic"), golden("generic_grads")
+    cfg, sd = generic_state(name, golden)
+    net = nerf_sos_amd.NeRFNet(**GENERIC_CASES[name][0]).to(DEV).eval()
+    net.load_state_dict(sd)
+    rays = torch.from_numpy(g[f"{name}__rays"]).to(DEV)
+    ref = {k[len(name) + 7:]: g[k] for k in g if k.startswith(name + "__out__")}
+    kw = {}
+    if cfg.n_importance > 0:
+        kw["z_fine_override"] = _fine_positions(cfg, ref, rays.shape[1]).to(DEV)
     with torch.no_grad():
-        out = net(rays, (tp.NEAR, tp.FAR))          # train-mode draws, no autograd: renders
-    assert torch.isfinite(out["rgb"]).all()
+        want = net(rays, (tp.NEAR, tp.FAR), **kw)
+    ret = net(rays, (tp.NEAR, tp.FAR), **kw)
+    loss, n_terms = 0.0, 0
+    for k in ret:
+        assert torch.equal(ret[k].detach(), want[k]), f"{name}: the training variant changed {k}"
+        gk = f"{name}__G__{k}"
+        if gk in gg:
+            assert ret[k].requires_grad, k
+            loss = loss + (ret[k] * torch.from_numpy(gg[gk]).to(DEV)).sum()
+            n_terms += 1
+    assert n_terms == sum(1 for k in gg if k.startswith(name + "__G__"))
+    loss.backward()
+    worst, n_checked = {}, 0
+    for n_, p_ in net.named_parameters():
+        got = p_.grad
+        assert got is not None, n_
+        refs = []
+        if f"{name}__grad__{n_}" in gg:
+            refs.append((got, gg[f"{name}__grad__{n_}"]))
+        elif f"{name}__gradrows__{n_}" in gg:
+            refs.append((got[::max(1, got.shape[0] // 24)], gg[f"{name}__gradrows__{n_}"]))
+            refs.append((got[:, ::max(1, got.shape[1] // 24)], gg[f"{name}__gradcols__{n_}"]))
+        for a, b in refs:
+            b = torch.from_numpy(b)
+            assert a.shape == b.shape, (n_, a.shape, b.shape)
+            scale = float(b.abs().max()) + 1e-20
+            worst[n_] = max(worst.get(n_, 0.0), float((a.detach().cpu() - b).abs().max()) / scale)
+        n_checked += bool(refs)
+    assert n_checked == sum(1 for k in gg if k.startswith(name + "__grad")) - sum(1 for k in gg if k.startswith(name + "__gradcols__"))
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    assert not bad, f"{name}: gradients off by more than 1e-4 of their scale: {bad}"
+
+
+@pytest.mark.gpu
+def test_generic_training_head_only_and_ragged(golden):
+    """The shipped recipe on a generic net (only semantic_linear.* trainable, run_nerf.py:307-318): the head's gradients equal the
+    all-parameters run's, nothing else receives one; 37 rays x 16 + 37 x 32 samples (ragged 32-point tiles) in train mode."""
+    name = "d6w96_m6"
+    cfg, sd = generic_state(name, golden)
+    torch.manual_seed(5)
+    rays = tp.synthetic_rays(37, seed=12).to(DEV)
+    grads = []
+    for head_only in (False, True):
+        net = nerf_sos_amd.NeRFNet(**GENERIC_CASES[name][0]).to(DEV).train()
+        net.load_state_dict(sd)
+        net.rng, net.rng_seed = "philox", 7
+        if head_only:
+            for n_, p_ in net.named_parameters():
+                p_.requires_grad_("semantic_linear" in n_)
+        ret = net(rays, (tp.NEAR, tp.FAR))
+        (ret["semantics"].sum() + 0.5 * ret["semantics0"].square().sum() + (0.0 if head_only else ret["rgb"].sum())).backward()
+        grads.append({n_: (None if p_.grad is None else p_.grad.clone()) for n_, p_ in net.named_parameters()})
+    for n_ in grads[0]:
+        if "semantic_linear" in n_:
+            assert torch.equal(grads[0][n_], grads[1][n_]), n_
+            assert float(grads[1][n_].abs().max()) > 0, n_
+        else:
+            assert grads[1][n_] is None and grads[0][n_] is not None, n_
+
+
+@pytest.mark.gpu
+def test_generic_training_step_reduces_the_loss():
+    """Thirty Adam steps of a 4 x 64 net without view directions on a fixed batch: the loss falls (the gradients point downhill and
+    the re-packed streams follow the optimizer)."""
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(netdepth=4, netwidth=64, netdepth_fine=4, netwidth_fine=64, N_samples=16, N_importance=16, viewdirs=False).to(DEV).train()
+    rays = tp.synthetic_rays(64, seed=1).to(DEV)
+    target = torch.rand(64, 3, device=DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-3)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad(set_to_none=True)
+        ret = net(rays, (tp.NEAR, tp.FAR))
+        loss = (ret["rgb"] - target).square().mean() + (ret["rgb0"] - target).square().mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.97 * losses[0] and all(losses[i + 5] < losses[i] for i in range(0, 25, 5)), losses
