@@ -140,16 +140,29 @@ int32_t nsos_mlp_generic_forward_points(const nsos_generic_mlp* mlp, const void*
  *                        {column block of the segment's rows in `acts`, rows, first column of the Linear's weight they multiply}.
  *                        Returns the number of ints written.  dW = gbuf[:, block]^T acts[:, segment block] and db = column sums of
  *                        gbuf[:, block] are nsos_wgrad calls (M, N in 32-multiples: the blocks' zero padding makes them exact).
- * Exact-fp32 MFMA like the forward.  No gradient flows to the rays. */
+ *   input_grads != 0 at pack time: the chain also carries the gradient into the two positional encodings, and
+ *   input_grads_rays   (same kernel) writes d loss / d point [n_pts, 3] and / d view direction [n_pts, 3] (NULL without view
+ *                        directions) through them (autograd of models/embedder.py:34-48); nsos_ray_grad_reduce folds them back onto
+ *                        the rays: pts = o + d z (models/sampler.py:70,166), viewdirs = d / |d| (models/nerf_net.py:160-163) and the
+ *                        renderer's dists * |d| (models/renderer.py:41; from the compositing's own d loss / d sigma in `g_raw` and
+ *                        `raw`, + noise * noise_std as the forward added it) -> g_rays_o, g_rays_d [n_rays, 3].
+ * Exact-fp32 MFMA like the forward. */
 #define NSOS_GENERIC_LAYOUT_STRIDE 13
 int32_t nsos_mlp_generic_save_layout(const nsos_generic_mlp* mlp, int32_t* table, int32_t capacity);
 int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                            float* raw, float* acts, void* stream);
-size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp);   /* 0: unsupported description */
-int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, void* stream);
+size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads);   /* 0: unsupported description */
+int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);
 int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
                                      float* gbuf, int64_t n_pts, void* stream);
+int32_t nsos_mlp_generic_input_grads_rays(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                          float* gbuf, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                          const float* z_vals, int64_t n_rays, int32_t n_samples, float* g_pts, float* g_dirs,
+                                          void* stream);
+int32_t nsos_ray_grad_reduce(const float* g_pts, const float* g_dirs, const float* z_vals, const float* rays_d, const float* raw,
+                             const float* g_raw, const float* noise, float noise_std, int64_t n_rays, int32_t n_samples,
+                             int32_t n_ch, float* g_rays_o, float* g_rays_d, void* stream);
 
 /* ---- K0: pinhole ray generation (SURVEY.md section 8f "next", rank 1) ------------------------------------
  * get_persp_rays (utils/ray.py:12-22; callers data/gen_dataset.py:189,202) for the pixels

@@ -109,14 +109,20 @@ def _chunks(n: int):
     return out
 
 
-def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor) -> Dict[str, torch.Tensor]:
+def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor, rays=None):
     """Gradients of every parameter of one generic-architecture MLP, by name (K7-G; autograd of models/nerf_mlp.py:67-100 for any
     depth / width / skip set / head shape).  One kernel runs the whole input-gradient chain over the saved activations
     (nsos_mlp_generic_input_grads: exact-fp32 MFMA over transposed weight streams, ReLU masks from `acts`) and leaves every
     Linear's pre-activation gradient in its column block of `gbuf`; each weight gradient is then dW = gbuf[:, block]^T acts[:, segment]
     on the exact-fp32 reduction kernel (nsos_wgrad), in 32-multiple tiles -- the blocks are zero-padded, so the padded rows and
-    columns come out as exact zeros and are sliced away.  `plan` = the net's ops.GenericPlan (layout of the saved rows)."""
-    gbuf = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts)
+    columns come out as exact zeros and are sliced away.  `plan` = the net's ops.GenericPlan (layout of the saved rows).
+    rays = (rays_o, rays_d, viewdirs, z_vals) with a `packed_bwd` packed for input gradients: returns (gradients by name, g_pts [P,3],
+    g_dirs [P,3] or None) -- the chain continued through the positional encodings."""
+    g_pts = g_dirs = None
+    if rays is None:
+        gbuf = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts)
+    else:
+        gbuf, g_pts, g_dirs = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts, rays)
     ld, layout = plan.layout()
     f32 = dict(device=acts.device, dtype=torch.float32)
     params = dict(mlp.named_parameters())
@@ -142,4 +148,4 @@ def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, pac
             c0 += pad(rows)
         out[name + ".weight"] = gw
         out[name + ".bias"] = db[:out_dim].clone()
-    return out
+    return out if rays is None else (out, g_pts, g_dirs)

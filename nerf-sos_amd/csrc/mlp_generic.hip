@@ -46,7 +46,7 @@ struct GenProgram {              // at the head of the packed buffer (device mem
     int n_ops, lds_floats, n_out, out_off;
     int x_off, x_rows, x_dim, x_freqs;      // encoded xyz: buffer, padded rows, real rows, octaves (-1: raw coordinates)
     int v_off, v_rows, v_dim, v_freqs;      // encoded view direction (v_dim = 0 without view directions)
-    int ones_off, w_floats, act_ld, pad1;   // act_ld: floats per point of the saved activations = columns of X | V | every dense op
+    int ones_off, w_floats, act_ld, input_grads;   // input_grads (backward program): the chain also fills the encodings' gradient rows   // act_ld: floats per point of the saved activations = columns of X | V | every dense op
     int x_col, v_col, pad2, pad3;
     GenOp ops[kGenMaxOps];
 };
@@ -270,6 +270,11 @@ struct GenBwdParams {
     const float* g_raw;       // [n_pts, n_out]
     const float* acts;        // [n_pts, ld]
     float* gbuf;              // [n_pts, ld]
+    // gradients w.r.t. the points and view directions (programs packed with input_grads; ray mode): the rays of the forward call
+    const float* rays_o; const float* rays_d; const float* viewdirs; const float* z_vals;
+    float* g_pts;             // [n_pts, 3]  d loss / d (o + d z)
+    float* g_dirs;            // [n_pts, 3]  d loss / d viewdirs, per point (NULL without view directions)
+    int n_samples;
     long long n_pts;
     int n_tiles;
 };
@@ -351,6 +356,71 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 }
             }
             __syncthreads();
+        }
+        // ---- d loss / d point and / d view direction through the positional encodings (models/embedder.py:34-48):
+        //      d/dx [x, sin(2^k x), cos(2^k x)] = [1, 2^k cos(2^k x), -2^k sin(2^k x)]; thread (point, part): part 0..2 = xyz, 3..5 = direction
+        if (P.g_pts && part < 6) {
+            const bool isdir = part >= 3;
+            const int c = isdir ? part - 3 : part;
+            if (!isdir || G.v_dim) {
+                const long long ray = gc / P.n_samples;
+                float xv;
+                if (isdir) xv = P.viewdirs[3 * ray + c];
+                else { const float m = P.rays_d[3 * ray + c] * P.z_vals[gc]; xv = P.rays_o[3 * ray + c] + m; }     // as the forward forms it
+                const int off = isdir ? G.v_off : G.x_off, freqs = isdir ? G.v_freqs : G.x_freqs;
+                double g = (double)lds[off + c * kGenRowFloats + p];         // (the octaves' terms carry factors up to 2^(L-1) and cancel: summed in fp64, rounded once)
+                for (int k = 0; k < freqs; ++k) {
+                    const float f = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+                    float sn, cs;
+                    sincos_pe(xv * f, sn, cs);
+                    const float gs = lds[off + (3 + 6 * k + c) * kGenRowFloats + p], gcs = lds[off + (6 + 6 * k + c) * kGenRowFloats + p];
+                    g += (double)f * ((double)cs * (double)gs - (double)sn * (double)gcs);
+                }
+                if (valid) (isdir ? P.g_dirs : P.g_pts)[gp * 3 + c] = (float)g;
+            }
+        }
+    }
+}
+
+// Per ray: the gradients of its points folded back onto the ray (autograd of pts = o + d z, models/sampler.py:70,166; of
+// viewdirs = d / |d|, models/nerf_net.py:160-163; of dists * |d|, models/renderer.py:41).  One wave per ray.
+//   g_o = sum_s g_pts,   g_d = sum_s z_s g_pts + (g_v - v (v . g_v)) / |d| + g_n d / |d|,
+//   g_v = sum_s g_dirs,  g_n = sum_s g_sigma_s relu(sigma_s + noise_s std) / |d|   (d alpha / d |d| = d alpha / d sigma * relu(sigma) / |d|)
+__global__ __launch_bounds__(256) void ray_grad_reduce_kernel(const float* __restrict__ g_pts, const float* __restrict__ g_dirs,
+                                                              const float* __restrict__ z_vals, const float* __restrict__ rays_d,
+                                                              const float* __restrict__ raw, const float* __restrict__ g_raw,
+                                                              const float* __restrict__ noise, float noise_std, long long n_rays, int S, int C,
+                                                              float* __restrict__ g_o, float* __restrict__ g_d) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    double so[3] = {0, 0, 0}, sz[3] = {0, 0, 0}, sv[3] = {0, 0, 0}, sn = 0;
+    for (int s = lane; s < S; s += 64) {
+        const long long q = r * S + s;
+        const float z = z_vals[q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = g_pts[3 * q + c];
+            so[c] += (double)g;
+            sz[c] += (double)(g * z);
+            if (g_dirs) sv[c] += (double)g_dirs[3 * q + c];
+        }
+        float sigma = raw[q * C + 3];
+        if (noise) sigma = sigma + noise[q] * noise_std;
+        sn += (double)(g_raw[q * C + 3] * fmaxf(sigma, 0.0f));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { so[c] = nsos_wave_sum(so[c]); sz[c] = nsos_wave_sum(sz[c]); sv[c] = nsos_wave_sum(sv[c]); }
+    sn = nsos_wave_sum(sn);
+    if (lane == 0) {
+        const double d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const double v[3] = {d[0] / n, d[1] / n, d[2] / n};
+        const double vg = v[0] * sv[0] + v[1] * sv[1] + v[2] * sv[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g_o[3 * r + c] = (float)so[c];
+            g_d[3 * r + c] = (float)(sz[c] + (sv[c] - v[c] * vg) / n + (sn / n) * v[c]);
         }
     }
 }
@@ -545,7 +615,7 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
 
 // The backward program of a forward program (see mlp_generic_bwd_kernel).  `T` gets the transposed streams' pack descriptors.
 struct HostBwd { GenProgram prog; GenPackT packs[kGenMaxOps]; int pack_w_off[kGenMaxOps]; int n_packs; int32_t err; };
-void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd& B) {
+void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd& B, bool input_grads) {
     B = HostBwd{};
     B.err = H.err;
     if (H.err) return;
@@ -587,13 +657,15 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
         }
         for (int s = 0; s < ho.n_seg; ++s) {
             const HostSeg& sg = ho.seg[s];
-            if (sg.buf_off == F.x_off || (F.v_dim && sg.buf_off == F.v_off)) continue;     // no gradient flows to the encodings (rays are data)
+            const bool enc = sg.buf_off == F.x_off || (F.v_dim && sg.buf_off == F.v_off);
+            if (enc && !input_grads) continue;     // rays are data: no gradient flows to the encodings unless the caller asks for it
             GenOp& op = G.ops[n++];
             op = GenOp{};
             op.kind = kGenDense; op.out_off = sg.buf_off; op.out_dim = sg.rows; op.out_tiles = pad_to(sg.rows, 32) / 32;
             const bool to_out = in_out(sg.buf_off);
             bool& has = has_grad(to_out ? F.out_off : sg.buf_off);
-            op.relu = (to_out ? 0 : 2) | ((has || to_out) ? 4 : 0);
+            // (the encodings' buffers hold pad8 rows, OUT is shared: write the real rows only; every other target is a whole pad32 buffer)
+            op.relu = ((to_out || enc) ? 0 : 2) | ((has || to_out) ? 4 : 0);
             has = true;
             int g = 0;
             const int kg = pad_to(ho.op.out_dim, 8) / 8;
@@ -612,6 +684,7 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
     }
     G.n_ops = n;
     G.w_floats = w_off;
+    G.input_grads = input_grads ? 1 : 0;
 }
 
 constexpr size_t kGenHeaderBytes = (sizeof(GenProgram) + 255) / 256 * 256;
@@ -745,23 +818,23 @@ extern "C" int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* ml
     return generic_launch(mlp, packed, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
 }
 
-extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp) {
+extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads) {
     if (!mlp) return 0;
     static thread_local HostProgram H;
     static thread_local HostBwd B;
     build_program(*mlp, H);
-    build_bwd_program(*mlp, H, B);
+    build_bwd_program(*mlp, H, B, input_grads != 0);
     if (B.err) return 0;
     return kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes;
 }
 
-extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, void* stream) {
+extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream) {
     NSOS_REQUIRE(mlp && packed_bwd, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(((uintptr_t)packed_bwd & 15) == 0, NSOS_ERR_MISALIGNED);
     static thread_local HostProgram H;
     static thread_local HostBwd B;
     build_program(*mlp, H);
-    build_bwd_program(*mlp, H, B);
+    build_bwd_program(*mlp, H, B, input_grads != 0);
     if (B.err) return B.err;
     NSOS_REQUIRE(packed_bytes >= kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes, NSOS_ERR_BUFFER_TOO_SMALL);
     const hipStream_t st = (hipStream_t)stream;
@@ -778,25 +851,56 @@ extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* 
     return nsos_launch_status();
 }
 
-extern "C" int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
-                                                float* gbuf, int64_t n_pts, void* stream) {
-    if (n_pts == 0) return NSOS_OK;
-    NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf, NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(n_pts > 0 && (n_pts + 31) / 32 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
-    NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
+static int32_t generic_bwd_launch(const nsos_generic_mlp* mlp, const void* packed_bwd, GenBwdParams p, int64_t n_pts, hipStream_t st) {
     static thread_local HostProgram H;
     build_program(*mlp, H);
     if (H.err) return H.err;
-    GenBwdParams p = {};
     p.prog = static_cast<const GenProgram*>(packed_bwd);
     p.wts = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_bwd) + kGenHeaderBytes);
-    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.n_pts = n_pts; p.n_tiles = (int)((n_pts + 31) / 32);
+    p.n_pts = n_pts; p.n_tiles = (int)((n_pts + 31) / 32);
     const int lds_bytes = H.prog.lds_floats * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_generic_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int32_t)e;
     const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
     const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
-    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(256), lds_bytes, st, p);
+    return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                                float* gbuf, int64_t n_pts, void* stream) {
+    if (n_pts == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts > 0 && (n_pts + 31) / 32 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
+    GenBwdParams p = {};
+    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.n_samples = 1;
+    return generic_bwd_launch(mlp, packed_bwd, p, n_pts, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_generic_input_grads_rays(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                                     float* gbuf, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                                     const float* z_vals, int64_t n_rays, int32_t n_samples, float* g_pts, float* g_dirs,
+                                                     void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf && rays_o && rays_d && z_vals && g_pts, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!mlp->use_viewdirs || (viewdirs && g_dirs), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1 && (n_rays * (int64_t)n_samples + 31) / 32 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
+    GenBwdParams p = {};
+    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;
+    p.g_pts = g_pts; p.g_dirs = mlp->use_viewdirs ? g_dirs : nullptr; p.n_samples = n_samples;
+    return generic_bwd_launch(mlp, packed_bwd, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_ray_grad_reduce(const float* g_pts, const float* g_dirs, const float* z_vals, const float* rays_d, const float* raw,
+                                        const float* g_raw, const float* noise, float noise_std, int64_t n_rays, int32_t n_samples,
+                                        int32_t n_ch, float* g_rays_o, float* g_rays_d, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(g_pts && z_vals && rays_d && raw && g_raw && g_rays_o && g_rays_d, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1 && n_ch >= 4 && (n_rays + 3) / 4 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_pts, g_dirs, z_vals,
+                       rays_d, raw, g_raw, noise, noise_std, (long long)n_rays, (int)n_samples, (int)n_ch, g_rays_o, g_rays_d);
     return nsos_launch_status();
 }

@@ -148,8 +148,8 @@ class NeRFMLP(nn.Module):
         frozen net call invalidate_packed()."""
         named = _named_params(self.mlp)
         params = [p for _, p in named]
-        if not self.fast:
-            if precision != "fp32":
+        if not self.fast or precision == "generic":     # ("generic": the shipped architecture on the generic kernels -- ray gradients)
+            if precision not in ("fp32", "generic"):
                 raise NotImplementedError(f"nerf_sos_amd: mlp_precision {precision!r} exists for the shipped architecture only "
                                           "(8 x 256, skips [4], multires 10 / 4, view directions, two-Linear head); this net renders in fp32")
             # (trainable: re-packed on every call, for the reason in the docstring; frozen: keyed by (data_ptr, _version))
@@ -198,19 +198,20 @@ class NeRFMLP(nn.Module):
     def query_rays(self, rays_o, rays_d, viewdirs, z_vals, save: bool = False):
         """raw [R,S,C] of a generic-architecture net for the points o + d z (NeRFNet's ray path); save=True: the training variant,
         (raw, acts) with every Linear's output saved per point (raw bit-identical)."""
-        packed = self.packed_weights()
+        packed = self.packed_weights("generic")
         dirs = viewdirs if self.use_viewdirs else None
         if save:
             return ops.mlp_generic_forward_rays_save(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
         return ops.mlp_generic_forward_rays(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
 
-    def packed_bwd_generic(self) -> torch.Tensor:
+    def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
         """The transposed weight streams of the generic input-gradient chain, packed from the CURRENT parameters (every call:
-        training moves them, see packed_weights)."""
+        training moves them, see packed_weights); input_grads: the program that also reaches the encodings (ray gradients)."""
         if self._gplan is None:
-            self.packed_weights()
-        self._packed["generic_bwd"] = self._gplan.run_bwd(self._packed.get("generic_bwd"))
-        return self._packed["generic_bwd"]
+            self.packed_weights("generic")
+        key = "generic_bwd_in" if input_grads else "generic_bwd"
+        self._packed[key] = self._gplan.run_bwd(self._packed.get(key), input_grads=input_grads)
+        return self._packed[key]
 
     def forward(self, inputs, viewdirs=None):
         if self.use_viewdirs and viewdirs is None:
@@ -312,9 +313,12 @@ class _FullRender(torch.autograd.Function):
               weight-gradient reductions, all HIP kernels; no library GEMM)."""
 
     @staticmethod
-    def forward(ctx, net, args, kwargs, *params):
+    def forward(ctx, net, args, kwargs, rays_o, rays_d, *params):
+        # rays_o / rays_d are args[0:2] again, as direct inputs: autograd hands their gradients back through this node when they
+        # ask for one (pose refinement); then BOTH nets run on the generic kernels, whose chain reaches the encodings
+        ctx.rays_grad = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         with torch.no_grad():
-            ret, saved = net._render_rays_impl(*args, save="all", **kwargs)
+            ret, saved = net._render_rays_impl(*args, save="all", force_generic=ctx.rays_grad, **kwargs)
         keys = list(ret.keys())
         outs = tuple(ret[k] for k in keys)
         ctx.mark_non_differentiable(*[o for k, o in zip(keys, outs) if k.rstrip("0") in ("z_std", "pts")])
@@ -332,6 +336,7 @@ class _FullRender(torch.autograd.Function):
         g = {k: v for k, v in zip(ctx.keys, gouts) if v is not None}
         has_fine = "fine" in saved
         grads = []
+        g_rays_o = g_rays_d = None
         for tag, mlp in net._sem_nets():
             sv = saved.get(tag)
             names = [n for n, _ in _named_params(mlp.mlp)]
@@ -343,11 +348,20 @@ class _FullRender(torch.autograd.Function):
             g_raw = ops.composite_backward(sv["raw"], sv["z"], saved["rays_d"], sv["noise"], saved["noise_std"],
                                            net.white_bkgd, g_rgb=get("rgb"), g_sem=get("semantics"), g_depth=get("depth"),
                                            g_acc=get("acc"), g_disp=get("disp"), g_weights=get("weights"))
+            g_raw_comp = g_raw                  # the compositing's own part: its sigma column carries d loss / d alpha (ray gradients)
             if get("raw") is not None:
                 g_raw = g_raw + get("raw").reshape(g_raw.shape)
             if sv.get("generic"):
                 from .backward import generic_mlp_backward
-                by_name = generic_mlp_backward(mlp.mlp, mlp._gplan, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]), mlp.packed_bwd_generic())
+                if ctx.rays_grad:
+                    by_name, g_pts, g_dirs = generic_mlp_backward(mlp.mlp, mlp._gplan, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]),
+                                                                  mlp.packed_bwd_generic(input_grads=True),
+                                                                  rays=(saved["rays_o"], saved["rays_d"], saved["viewdirs"], sv["z"]))
+                    go, gd = ops.ray_grad_reduce(g_pts, g_dirs, sv["z"], saved["rays_d"], sv["raw"], g_raw_comp, sv["noise"], saved["noise_std"])
+                    g_rays_o = go if g_rays_o is None else g_rays_o + go
+                    g_rays_d = gd if g_rays_d is None else g_rays_d + gd
+                else:
+                    by_name = generic_mlp_backward(mlp.mlp, mlp._gplan, sv["acts"], g_raw.reshape(-1, g_raw.shape[-1]), mlp.packed_bwd_generic())
                 grads += [by_name.get(n) for n in names]
                 continue
             # fused input-gradient chain (K7-X3) for both precisions; "fp32": exact-fp32 weight-gradient reductions and the
@@ -357,7 +371,7 @@ class _FullRender(torch.autograd.Function):
                                    split_wgrad=net.mlp_precision != "fp32" or net.exact_weight_gradients is False)
             grads += [by_name.get(n) for n in names]
         ctx.saved = None   # release 10 KB/point of activations now (the node lives as long as the caller keeps the loss)
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, g_rays_o, g_rays_d) + tuple(grads)
 
 
 class NeRFNet(nn.Module):
@@ -467,6 +481,17 @@ class NeRFNet(nn.Module):
         generic = not (self.nerf.fast and self.nerf_fine.fast)
         if generic and self.mlp_precision != "fp32":
             raise NotImplementedError(f"nerf_sos_amd.NeRFNet: mlp_precision {self.mlp_precision!r} exists for the shipped architecture only; this one renders in fp32")
+        rays_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad)
+        if rays_grad:
+            # the reference's autograd differentiates through pts = o + d z, viewdirs = d / |d| and dists * |d| (pose refinement):
+            # both nets then run on the generic fp32 kernels, whose input-gradient chain reaches the encodings (_FullRender)
+            if self.mlp_precision != "fp32":
+                raise NotImplementedError("nerf_sos_amd.NeRFNet: gradients with respect to the rays exist in fp32 only (mlp_precision = 'fp32')")
+            if viewdirs is not None:
+                raise NotImplementedError("nerf_sos_amd.NeRFNet: gradients with respect to the rays need viewdirs=None (derived from rays_d, as NeRFNet.forward does)")
+            params = [p_ for _, m in self._sem_nets() for _, p_ in _named_params(m.mlp)]
+            outs = _FullRender.apply(self, args, kwargs, rays_o, rays_d, *params)
+            return dict(zip(self._last_keys, outs))
         if not trainable:
             return self._render_rays_impl(*args, save=False, **kwargs)[0]
         other = [n for n in trainable if "semantic_linear" not in n]
@@ -483,7 +508,7 @@ class NeRFNet(nn.Module):
                               "split-fp16 ('fp16x3') forward and backward kernels: there is no 16-bit full backward", stacklevel=2)
                 NeRFNet._warned_full_16bit = True
             params = [p_ for _, m in self._sem_nets() for _, p_ in _named_params(m.mlp)]
-            outs = _FullRender.apply(self, args, kwargs, *params)
+            outs = _FullRender.apply(self, args, kwargs, rays_o.detach(), rays_d.detach(), *params)
             return dict(zip(self._last_keys, outs))
         params = []
         for _, m in self._sem_nets():
@@ -493,7 +518,7 @@ class NeRFNet(nn.Module):
         return dict(zip(self._last_keys, outs))
 
     def _render_rays_impl(self, rays_o, rays_d, near, far, viewdirs, raw_noise_std, retraw, retpts, save=False,
-                          **kwargs):
+                          force_generic=False, **kwargs):
         perturb = kwargs.get('perturb', self.perturb)
         n_samples = kwargs.get('N_samples', self.N_samples)
         R, dev = rays_d.shape[0], rays_d.device
@@ -504,7 +529,7 @@ class NeRFNet(nn.Module):
         saved = {}
 
         def query(net, z, tag):
-            if not net.fast:     # any other architecture: the generic fp32 kernel
+            if not net.fast or force_generic:     # any other architecture (or ray gradients): the generic fp32 kernels
                 if save:         # (training a generic net always takes the full backward: _FullRender)
                     raw, acts = net.query_rays(rays_o, rays_d, viewdirs, z, save=True)
                     saved[tag] = dict(acts=acts, raw=raw, z=z, generic=True)
@@ -557,6 +582,7 @@ class NeRFNet(nn.Module):
             saved["coarse"]["weights"] = ret['weights']
             saved["coarse"]["noise"] = noise
             saved["rays_d"], saved["noise_std"] = rays_d, raw_noise_std
+            saved["rays_o"], saved["viewdirs"] = rays_o, viewdirs
         if retraw:
             ret['raw'] = raw
         if retpts:
@@ -598,11 +624,7 @@ class NeRFNet(nn.Module):
 
         rays_o, rays_d = ray_batch
         assert rays_o.shape == rays_d.shape
-        if torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad):
-            # the reference's autograd would differentiate through o + d z (pose refinement); these kernels do not, and
-            # returning outputs that silently carry no gradient to the rays is worse than refusing
-            raise NotImplementedError("nerf_sos_amd.NeRFNet: gradients with respect to the rays are not implemented "
-                                      "(detach the rays, or render under torch.no_grad())")
+        # (rays that require a gradient -- pose refinement -- get one: render_rays routes them through _FullRender on the generic kernels)
         old_shape = rays_d.shape
         rays_o = rays_o.reshape(-1, rays_o.shape[-1]).float().contiguous()
         rays_d = rays_d.reshape(-1, rays_d.shape[-1]).float().contiguous()

@@ -256,14 +256,15 @@ class GenericPlan:
         _lib.check(_lib.lib().nsos_mlp_generic_pack(C.byref(self.desc), _p(out), self.nbytes, _stream()), "nsos_mlp_generic_pack")
         return out
 
-    def run_bwd(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The transposed weight streams + the reversed program of the input-gradient chain (nsos_mlp_generic_pack_bwd)."""
-        nbytes = int(_lib.lib().nsos_mlp_generic_bwd_packed_bytes(C.byref(self.desc)))
+    def run_bwd(self, out: Optional[torch.Tensor] = None, input_grads: bool = False) -> torch.Tensor:
+        """The transposed weight streams + the reversed program of the input-gradient chain (nsos_mlp_generic_pack_bwd);
+        input_grads: the chain also reaches the positional encodings (gradients w.r.t. the rays)."""
+        nbytes = int(_lib.lib().nsos_mlp_generic_bwd_packed_bytes(C.byref(self.desc), int(input_grads)))
         if nbytes == 0:
             raise NotImplementedError("nerf_sos_amd: this architecture is outside the generic backward kernel's limits")
         if out is None or out.numel() * 4 < nbytes or out.device != self.device:
             out = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
-        _lib.check(_lib.lib().nsos_mlp_generic_pack_bwd(C.byref(self.desc), _p(out), nbytes, _stream()), "nsos_mlp_generic_pack_bwd")
+        _lib.check(_lib.lib().nsos_mlp_generic_pack_bwd(C.byref(self.desc), _p(out), nbytes, int(input_grads), _stream()), "nsos_mlp_generic_pack_bwd")
         return out
 
     def layout(self):
@@ -316,17 +317,47 @@ def mlp_generic_forward_rays_save(plan: GenericPlan, packed: torch.Tensor, rays_
     return raw, acts
 
 
-def mlp_generic_input_grads(plan: GenericPlan, packed_bwd: torch.Tensor, g_raw: torch.Tensor, acts: torch.Tensor) -> torch.Tensor:
+def mlp_generic_input_grads(plan: GenericPlan, packed_bwd: torch.Tensor, g_raw: torch.Tensor, acts: torch.Tensor, rays=None):
     """gbuf [P, ld]: every Linear's pre-activation gradient in its column block, from d loss / d raw [P, C] and the saved
-    activations (nsos_mlp_generic_input_grads: the whole chain in one kernel)."""
+    activations (nsos_mlp_generic_input_grads: the whole chain in one kernel).  rays = (rays_o, rays_d, viewdirs or None, z_vals)
+    with a `packed_bwd` of run_bwd(input_grads=True): also returns d loss / d point [P,3] and / d view direction [P,3] (or None)."""
     g_raw, acts = _dev(g_raw, "g_raw"), _dev(acts, "acts")
     P_ = acts.shape[0]
     if g_raw.shape != (P_, plan.out_channels):
         raise ValueError("mlp_generic_input_grads: g_raw must be [P, out_channels]")
     gbuf = torch.empty_like(acts)
-    _lib.check(_lib.lib().nsos_mlp_generic_input_grads(C.byref(plan.desc), _p(packed_bwd), _p(g_raw), _p(acts), _p(gbuf), P_, _stream()),
-               "nsos_mlp_generic_input_grads")
-    return gbuf
+    if rays is None:
+        _lib.check(_lib.lib().nsos_mlp_generic_input_grads(C.byref(plan.desc), _p(packed_bwd), _p(g_raw), _p(acts), _p(gbuf), P_, _stream()),
+                   "nsos_mlp_generic_input_grads")
+        return gbuf
+    rays_o, rays_d, viewdirs, z_vals = rays
+    rays_o, rays_d, z_vals = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d"), _dev(z_vals, "z_vals")
+    R, S = z_vals.shape
+    if R * S != P_:
+        raise ValueError("mlp_generic_input_grads: rays do not match the saved activations")
+    g_pts = torch.empty((P_, 3), device=acts.device, dtype=torch.float32)
+    g_dirs = None
+    if plan.desc.use_viewdirs:
+        viewdirs = _dev(viewdirs, "viewdirs")
+        g_dirs = torch.empty((P_, 3), device=acts.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_mlp_generic_input_grads_rays(C.byref(plan.desc), _p(packed_bwd), _p(g_raw), _p(acts), _p(gbuf), _p(rays_o), _p(rays_d),
+                                                            _p(viewdirs) if g_dirs is not None else None, _p(z_vals), R, S, _p(g_pts), _p(g_dirs), _stream()),
+               "nsos_mlp_generic_input_grads_rays")
+    return gbuf, g_pts, g_dirs
+
+
+def ray_grad_reduce(g_pts: torch.Tensor, g_dirs: Optional[torch.Tensor], z_vals: torch.Tensor, rays_d: torch.Tensor, raw: torch.Tensor,
+                    g_raw: torch.Tensor, noise: Optional[torch.Tensor], noise_std: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(g_rays_o, g_rays_d) [R,3] of one pass from its per-point gradients (nsos_ray_grad_reduce): pts = o + d z, viewdirs = d / |d| and
+    the renderer's dists * |d| (g_raw = the COMPOSITING's d loss / d raw, its sigma column carries d loss / d alpha)."""
+    R, S = z_vals.shape
+    Cn = raw.shape[-1]
+    g_o = torch.empty((R, 3), device=z_vals.device, dtype=torch.float32)
+    g_d = torch.empty((R, 3), device=z_vals.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nsos_ray_grad_reduce(_p(_dev(g_pts, "g_pts")), _p(g_dirs), _p(_dev(z_vals, "z_vals")), _p(_dev(rays_d, "rays_d")),
+                                               _p(_dev(raw, "raw")), _p(_dev(g_raw, "g_raw")), _p(noise), float(noise_std), R, S, Cn, _p(g_o), _p(g_d),
+                                               _stream()), "nsos_ray_grad_reduce")
+    return g_o, g_d
 
 
 def mlp_generic_forward_points(plan: GenericPlan, packed: torch.Tensor, pts: torch.Tensor, dirs: Optional[torch.Tensor]) -> torch.Tensor:

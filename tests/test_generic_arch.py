@@ -236,5 +236,5 @@ def test_generic_training_step_reduces_the_loss():
         loss = (ret["rgb"] - target).square().mean() + (ret["rgb0"] - target).square().mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.97 * losses[0] and all(losses[i + 5] < losses[i] for i in range(0, 25, 5)), losses

@@ -1,0 +1,83 @@
+"""Gradients with respect to the rays (VERDICT r03 "missing 6": the reference's autograd flows through pts = o + d z,
+models/sampler.py:70,166; viewdirs = d / |d|, models/nerf_net.py:160-163; dists * |d|, models/renderer.py:41 -- pose refinement).
+Rays that require a gradient route both networks through the generic fp32 kernels, whose input-gradient chain continues through
+the positional encodings (nsos_mlp_generic_input_grads_rays + nsos_ray_grad_reduce).  Goldens: the REAL reference's rays.grad
+(tests/golden/ray_grads.npz, make_goldens_raygrad.py)."""
+import numpy as np
+import pytest
+import torch
+
+import nerf_sos_amd
+from oracle import torch_port as tp
+from helpers import CFGS, GENERIC_CASES, generic_state, ref_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(tag, golden, manifest):
+    if tag in GENERIC_CASES:
+        cfg, sd = generic_state(tag, golden)
+        net = nerf_sos_amd.NeRFNet(**GENERIC_CASES[tag][0])
+    else:
+        name, white = tag.split("_")[0], tag.endswith("_white")
+        cfg = tp.PortConfig(n_importance=128, white_bkgd=white, **CFGS[name])
+        sd = ref_state(name, manifest, peaky=True)
+        net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, white_bkgd=white, **CFGS[name])
+    net = net.to(DEV).eval()
+    net.load_state_dict(sd)
+    return cfg, net
+
+
+@pytest.mark.parametrize("tag", ["semcoord", "sem_white", "d6w96_m6", "noview"])
+def test_ray_gradients_vs_reference_autograd(golden, manifest, tag):
+    """rays.grad of a random linear functional of the rendered maps against the reference's, 2e-4 of each gradient's scale (measured:
+    1.3e-4 on d / d rays_o of the shipped architecture, <= 1e-4 on the other seven -- the gradient passes through the encoding's
+    2^9 octave factor, where both sides' fp32 rounding of the 256-wide chain is amplified and the octaves' terms cancel; summing them in
+    fp64 here did not move it: the residue is the chain's and the reference's own), fine positions pinned to the reference's;
+    parameter gradients come out of the same backward."""
+    g = golden("ray_grads")
+    cfg, net = _build(tag, golden, manifest)
+    rays = torch.from_numpy(g[f"{tag}__rays"]).to(DEV)
+    R = rays.shape[1]
+    near, far = torch.full((R, 1), tp.NEAR), torch.full((R, 1), tp.FAR)
+    z = tp.stratified_z(near, far, cfg.n_samples, None)
+    z_fine = tp.importance_z(z, torch.from_numpy(g[f"{tag}__weights0"]), cfg.n_importance, None)[0].to(DEV)
+    rg = rays.clone().requires_grad_(True)
+    ret = net(rg, (tp.NEAR, tp.FAR), z_fine_override=z_fine)
+    assert np.abs(ret["rgb"].detach().cpu().numpy() - g[f"{tag}__rgb"]).max() <= 1e-4
+    loss = 0.0
+    for k in ret:
+        gk = f"{tag}__G__{k}"
+        if gk in g:
+            assert ret[k].requires_grad, k
+            loss = loss + (ret[k] * torch.from_numpy(g[gk]).to(DEV)).sum()
+    loss.backward()
+    want = g[f"{tag}__g_rays"]
+    got = rg.grad.cpu().numpy()
+    for i, what in enumerate(("rays_o", "rays_d")):
+        scale = np.abs(want[i]).max()
+        err = np.abs(got[i] - want[i]).max() / scale
+        assert err <= 2e-4, f"{tag}: d loss / d {what} off by {err:.2e} of its scale {scale:.3g}"
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_ray_gradients_alone_and_refusals(golden, manifest):
+    """Frozen parameters, rays alone: the same rays.grad; a 16-bit precision refuses loudly; detached rays keep the tuned kernels."""
+    g = golden("ray_grads")
+    cfg, net = _build("semcoord", golden, manifest)
+    rays = torch.from_numpy(g["semcoord__rays"]).to(DEV)
+    grads = []
+    for freeze in (False, True):
+        for p in net.parameters():
+            p.requires_grad_(not freeze)
+        rg = rays.clone().requires_grad_(True)
+        ret = net(rg, (tp.NEAR, tp.FAR))
+        (ret["rgb"].sum() + ret["depth0"].sum()).backward()
+        grads.append(rg.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+    net.mlp_precision = "bf16"
+    with pytest.raises(NotImplementedError):
+        net(rays.clone().requires_grad_(True), (tp.NEAR, tp.FAR))
+    with torch.no_grad():
+        assert torch.isfinite(net(rays, (tp.NEAR, tp.FAR))["rgb"]).all()

@@ -217,14 +217,19 @@ def test_cached_parameter_walk_equals_named_parameters():
         assert all(x is y for (_, x), (_, y) in zip(a, b)) and len(a) == len(b)
 
 
-def test_rays_that_require_grad_are_refused():
-    """The reference's autograd reaches the rays (o + d z); the HIP path has no such backward: refuse instead of returning
-    outputs that silently carry no gradient.  (The check is host-side: no GPU needed.)"""
+def test_rays_that_require_grad_route_or_refuse():
+    """The reference's autograd reaches the rays (o + d z, d / |d|, dists * |d|).  fp32: the render routes through the generic
+    kernels' backward (tests/test_gpu_raygrad.py) -- on this CPU-only box it gets as far as the device check; a 16-bit precision has
+    no such backward and refuses instead of returning outputs that silently carry no gradient.  (Host-side checks: no GPU needed.)"""
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=0)
     rays = torch.zeros(2, 4, 3, requires_grad=True)
+    net.mlp_precision = "bf16"
     with pytest.raises(NotImplementedError, match="rays"):
         net(rays, (1.0, 2.0))
-    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):   # without grad mode it gets as far as the device check
+    net.mlp_precision = "fp32"
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        net(rays, (1.0, 2.0))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU tensor"):
         net(rays, (1.0, 2.0))
 
 
