@@ -131,21 +131,23 @@ def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, pac
     for name, col, out_dim, segs in layout:
         w = params[name + ".weight"]
         Mp = pad(out_dim)
-        dW = torch.zeros((Mp, sum(pad(rows) for _, rows, _ in segs)), **f32)
-        db = torch.zeros((Mp,), **f32)
-        c0, first = 0, True
-        for src_col, rows, _ in segs:
-            for mo, mc in _chunks(Mp):
-                for no, nc in _chunks(pad(rows)):
-                    ops.wgrad(gbuf[:, col + mo: col + mo + mc], acts[:, src_col + no: src_col + no + nc],
-                              dW[mo: mo + mc, c0 + no: c0 + no + nc], db[mo: mo + mc] if first and no == 0 else None)
-            first = False
-            c0 += pad(rows)
         gw = torch.empty_like(w)
-        c0 = 0
-        for _, rows, wcol in segs:
-            gw[:, wcol: wcol + rows] = dW[:out_dim, c0: c0 + rows]
-            c0 += pad(rows)
+        # every (row tile, column tile) of a segment is written by exactly one nsos_wgrad call: no fills.  Aligned shapes (out_dim and the
+        # segment's rows multiples of 32: every hidden layer of a 32-multiple width) land in the parameter's gradient directly; ragged
+        # ones (the encodings' 63 / 27 columns, 1-3-row heads) go through a padded scratch matrix and one slicing copy
+        db = torch.empty((Mp,), **f32)
+        first = True
+        for src_col, rows, wcol in segs:
+            Np = pad(rows)
+            direct = Mp == out_dim and Np == rows
+            dst = gw[:, wcol: wcol + rows] if direct else torch.empty((Mp, Np), **f32)
+            for mo, mc in _chunks(Mp):
+                for no, nc in _chunks(Np):
+                    ops.wgrad(gbuf[:, col + mo: col + mo + mc], acts[:, src_col + no: src_col + no + nc],
+                              dst[mo: mo + mc, no: no + nc], db[mo: mo + mc] if first and no == 0 else None)
+            if not direct:
+                gw[:, wcol: wcol + rows] = dst[:out_dim, :rows]
+            first = False
         out[name + ".weight"] = gw
-        out[name + ".bias"] = db[:out_dim].clone()
+        out[name + ".bias"] = db if Mp == out_dim else db[:out_dim].clone()
     return out if rays is None else (out, g_pts, g_dirs)

@@ -81,3 +81,39 @@ def test_ray_gradients_alone_and_refusals(golden, manifest):
         net(rays.clone().requires_grad_(True), (tp.NEAR, tp.FAR))
     with torch.no_grad():
         assert torch.isfinite(net(rays, (tp.NEAR, tp.FAR))["rgb"]).all()
+
+
+def test_ray_gradients_train_mode_with_noise_vs_port_autograd():
+    """Train mode with injected jitter and sigma noise (the noisy sigma enters d alpha / d |d|), white background, 192 samples per
+    ray, ragged 32-point tiles (10 x 192 = 60 tiles exactly; 7 rays x 50 samples below): rays.grad against autograd through the CPU
+    port (bit-identical to the reference's forward, the same ATen backward formulas), 2e-4 of scale."""
+    for R, S, name in ((10, 192, "semcoord"), (7, 50, "nosem")):
+        cfg = tp.PortConfig(n_samples=S, n_importance=0, white_bkgd=True, **CFGS[name])
+        sd = tp.make_peaky(tp.init_state_dict(cfg, seed=0), gain=8.0, shift=0.5)
+        rays = tp.synthetic_rays(R, seed=8)
+        g = torch.Generator().manual_seed(5)
+        t_rand, noise = torch.rand(R, S, generator=g), torch.randn(R, S, generator=g)
+        rc = rays.clone().requires_grad_(True)
+        ref = tp.render(sd, cfg, rc, (tp.NEAR, tp.FAR), raw_noise_std=0.7, draws_per_chunk=[tp.Draws(t_rand=t_rand, noise0=noise)])
+        ups = {k: torch.randn(ref[k].shape, generator=g) * (0.05 if k == "raw" else 1.0) for k in ("rgb", "acc", "weights", "raw")}
+        sum((ref[k] * ups[k]).sum() for k in ups).backward()
+
+        net = nerf_sos_amd.NeRFNet(N_samples=S, N_importance=0, white_bkgd=True, perturb=1.0, raw_noise_std=0.7, **CFGS[name]).to(DEV)
+        net.load_state_dict(sd)
+        net.train()
+        q = [t_rand.to(DEV), noise.to(DEV)]
+        _rand, _randn = torch.rand, torch.randn
+        torch.rand = lambda *a, **k: q.pop(0)
+        torch.randn = lambda *a, **k: q.pop(0)
+        rg = rays.to(DEV).requires_grad_(True)
+        try:
+            ret = net(rg, (tp.NEAR, tp.FAR))
+        finally:
+            torch.rand, torch.randn = _rand, _randn
+        for k in ups:
+            assert (ret[k].detach().cpu() - ref[k].detach()).abs().max() <= 1e-4 * (1 + ref[k].detach().abs().max()), k
+        sum((ret[k] * ups[k].to(DEV)).sum() for k in ups).backward()
+        for i, what in enumerate(("rays_o", "rays_d")):
+            want = rc.grad[i]
+            err = float((rg.grad[i].cpu() - want).abs().max() / want.abs().max())
+            assert err <= 2e-4, f"{name} {R}x{S}: d loss / d {what} off by {err:.2e} of its scale"
