@@ -86,7 +86,7 @@ def test_ray_gradients_alone_and_refusals(golden, manifest):
 def test_ray_gradients_train_mode_with_noise_vs_port_autograd():
     """Train mode with injected jitter and sigma noise (the noisy sigma enters d alpha / d |d|), white background, 192 samples per
     ray, ragged 32-point tiles (10 x 192 = 60 tiles exactly; 7 rays x 50 samples below): rays.grad against autograd through the CPU
-    port (bit-identical to the reference's forward, the same ATen backward formulas), 2e-4 of scale."""
+    port (bit-identical to the reference's forward, the same ATen backward formulas), 2e-4 of scale; parameter gradients 1e-4."""
     for R, S, name in ((10, 192, "semcoord"), (7, 50, "nosem")):
         cfg = tp.PortConfig(n_samples=S, n_importance=0, white_bkgd=True, **CFGS[name])
         sd = tp.make_peaky(tp.init_state_dict(cfg, seed=0), gain=8.0, shift=0.5)
@@ -94,7 +94,8 @@ def test_ray_gradients_train_mode_with_noise_vs_port_autograd():
         g = torch.Generator().manual_seed(5)
         t_rand, noise = torch.rand(R, S, generator=g), torch.randn(R, S, generator=g)
         rc = rays.clone().requires_grad_(True)
-        ref = tp.render(sd, cfg, rc, (tp.NEAR, tp.FAR), raw_noise_std=0.7, draws_per_chunk=[tp.Draws(t_rand=t_rand, noise0=noise)])
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = tp.render(sdg, cfg, rc, (tp.NEAR, tp.FAR), raw_noise_std=0.7, draws_per_chunk=[tp.Draws(t_rand=t_rand, noise0=noise)])
         ups = {k: torch.randn(ref[k].shape, generator=g) * (0.05 if k == "raw" else 1.0) for k in ("rgb", "acc", "weights", "raw")}
         sum((ref[k] * ups[k]).sum() for k in ups).backward()
 
@@ -117,3 +118,14 @@ def test_ray_gradients_train_mode_with_noise_vs_port_autograd():
             want = rc.grad[i]
             err = float((rg.grad[i].cpu() - want).abs().max() / want.abs().max())
             assert err <= 2e-4, f"{name} {R}x{S}: d loss / d {what} off by {err:.2e} of its scale"
+        # the same backward also produced every parameter's gradient -- here the SHIPPED architecture on the generic kernels (ragged
+        # last tile in the second case): 1e-4 of scale against the port's autograd
+        bad = {}
+        for n_, p_ in net.named_parameters():
+            want = sdg[n_].grad
+            if want is None:           # (nerf_fine of a coarse-only render)
+                continue
+            err = float((p_.grad.cpu() - want).abs().max() / (want.abs().max() + 1e-20))
+            if err > 1e-4:
+                bad[n_] = err
+        assert not bad, bad
