@@ -1,0 +1,69 @@
+"""Host logic of the generic-architecture path (no GPU): the program builder behind nsos_mlp_generic_* is pure host arithmetic, so the
+layout of the saved-activation rows (nsos_mlp_generic_save_layout), the packed sizes and the backward program's size can be checked on
+a CPU-only box.  The description is filled from CPU tensors (their pointers are never dereferenced by these entry points)."""
+import ctypes as C
+
+import pytest
+import torch
+
+import nerf_sos_amd
+from nerf_sos_amd import _lib, ops
+from helpers import GENERIC_CASES
+
+EXTRA = {
+    "shipped": dict(use_semantics=True, sem_with_coord=True),
+    "d16w64_skips": dict(netdepth=16, netwidth=64, netdepth_fine=16, netwidth_fine=64),
+}
+
+
+def _plan(kwargs, monkeypatch):
+    monkeypatch.setattr(ops, "_dev", lambda t, name: t)
+    net = nerf_sos_amd.NeRFNet(**kwargs)
+    m = net.nerf
+    return m, ops.GenericPlan(m.mlp, m.multires, m.multires_views)
+
+
+@pytest.mark.parametrize("name", list(GENERIC_CASES) + list(EXTRA))
+def test_saved_row_layout_is_a_partition(name, monkeypatch):
+    """Every Linear of the module tree appears exactly once, in forward order; column blocks are 32-aligned, disjoint and tile
+    [x block | v block | Linear blocks] = ld exactly; a Linear's segments cover its weight's columns; every segment's source block is
+    the encodings' or an EARLIER Linear's block wide enough for its rows."""
+    kwargs = GENERIC_CASES[name][0] if name in GENERIC_CASES else EXTRA[name]
+    m, plan = _plan(kwargs, monkeypatch)
+    ld, layout = plan.layout()
+    linears = [n for n, mod in m.mlp.named_modules() if isinstance(mod, torch.nn.Linear)]
+    assert sorted(n for n, *_ in layout) == sorted(linears)
+    params = dict(m.mlp.named_parameters())
+    pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
+    x_dim = m.mlp.input_ch
+    v_dim = m.mlp.input_ch_views if m.mlp.use_viewdirs else 0
+    blocks = {0: pad(x_dim)}
+    if v_dim:
+        blocks[pad(x_dim)] = pad(v_dim)
+    end = pad(x_dim) + pad(v_dim)
+    for name_, col, out_dim, segs in layout:
+        w = params[name_ + ".weight"]
+        assert col == end and col % 32 == 0 and out_dim == w.shape[0], (name_, col, end)
+        covered = 0
+        for src_col, rows, wcol in segs:
+            assert wcol == covered and src_col in blocks and blocks[src_col] >= pad(rows) and src_col < col, (name_, src_col, rows)
+            covered += rows
+        assert covered == w.shape[1], (name_, covered, w.shape)
+        blocks[col] = pad(out_dim)
+        end = col + pad(out_dim)
+    assert end == ld
+    lib = _lib.lib()
+    fwd = lib.nsos_mlp_generic_packed_bytes(C.byref(plan.desc))
+    bwd = lib.nsos_mlp_generic_bwd_packed_bytes(C.byref(plan.desc), 0)
+    bwd_in = lib.nsos_mlp_generic_bwd_packed_bytes(C.byref(plan.desc), 1)
+    assert fwd > 0 and 0 < bwd < bwd_in                 # the program that reaches the encodings carries their transposed streams on top
+    assert plan.out_channels == (4 + (m.mlp.semantic_linear[-1].weight.shape[0] if (m.mlp.use_semantics and m.mlp.use_viewdirs) else 0))
+
+
+def test_layout_capacity_and_null_checks():
+    lib = _lib.lib()
+    G = _lib.GenericMlp()
+    table = (C.c_int32 * 4)()
+    assert lib.nsos_mlp_generic_save_layout(C.byref(G), table, 4) < 0          # an empty description is refused, not dereferenced
+    assert lib.nsos_mlp_generic_bwd_packed_bytes(C.byref(G), 0) == 0
+    assert lib.nsos_mlp_generic_save_layout(None, table, 4) < 0
