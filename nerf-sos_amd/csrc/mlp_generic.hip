@@ -24,8 +24,11 @@ using namespace nsos;
 
 namespace {
 
-constexpr int kGenMaxOps = 64, kGenMaxGroups = 56, kGenMaxSeg = 3;   // (ops: the backward program of a 16-deep net with the deepest head has 61)
-constexpr int kGenRowFloats = 32;     // one LDS row = one feature of the tile's 32 points = 128 B
+constexpr int kGenMaxOps = 64, kGenMaxGroups = 112, kGenMaxSeg = 3;   // (ops: the backward program of a 16-deep net with the deepest head has 61)
+// One LDS row = one feature of the tile's points.  32 points (128 B) while the activation buffers fit the LDS; nets too wide for that
+// (W > 256 with the deep semantic head, > 320 without) run on 16-POINT tiles: the buffers halve, lanes 16..31 of a half-wave read the
+// same 16 points again (the matrix instruction's B operand has 32 columns: half of them are duplicates, results of duplicates are
+// dropped) -- half the matrix rate, the same arithmetic per point.  Template parameter RF of the kernels, `row_floats` of the program.
 
 enum { kGenDense = 0, kGenMul = 1, kGenBwdHead = 2, kGenBwdMul = 3 };
 struct GenOp {
@@ -47,7 +50,7 @@ struct GenProgram {              // at the head of the packed buffer (device mem
     int x_off, x_rows, x_dim, x_freqs;      // encoded xyz: buffer, padded rows, real rows, octaves (-1: raw coordinates)
     int v_off, v_rows, v_dim, v_freqs;      // encoded view direction (v_dim = 0 without view directions)
     int ones_off, w_floats, act_ld, input_grads;   // input_grads (backward program): the chain also fills the encodings' gradient rows   // act_ld: floats per point of the saved activations = columns of X | V | every dense op
-    int x_col, v_col, pad2, pad3;
+    int x_col, v_col, row_floats, pad3;
     GenOp ops[kGenMaxOps];
 };
 
@@ -95,9 +98,11 @@ __device__ __forceinline__ unsigned long long gen_uniform64(const void* p) {   /
 // ahead through a register ring with hand-counted waits (the loads are asm: left to itself hipcc rotates the ring with copies
 // and drains the queue at every group).  n_groups is a multiple of 4 (the packer pads with zero-weight groups on the constant
 // buffer); the ring's last four loads run up to 4 KiB past the tile's stream (into the next tile's, or the buffer's tail pad).
-template <bool TWO>
+template <bool TWO, int RF>
 __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const float* lds, int t0, int lane, int pt, int hi,
                                             f32x16& acc0, f32x16& acc1) {
+    constexpr int kGenRowFloats = RF;
+    pt &= RF - 1;                          // 16-point tiles: columns 16..31 of the B operand repeat columns 0..15
     const int ng = op.n_groups;
     const unsigned long long base0 = gen_uniform64(wts + op.w_off + (size_t)t0 * ng * 256);
     const unsigned long long base1 = gen_uniform64(wts + op.w_off + (size_t)(t0 + (TWO ? 4 : 0)) * ng * 256);
@@ -147,24 +152,26 @@ __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const
 // SAVE: the training variant -- every dense op's post-activation output tile and both encodings also go to P.acts (point-major
 // rows of act_ld floats, one 32-aligned column block per op: the layout nsos_wgrad reads its X operand in), straight from the
 // accumulators: lane (point, hi) holds features 8 q + 4 hi + (0..3) of its point = one 16-byte store per q.
-template <bool SAVE>
+template <bool SAVE, int RF>
 __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kGenRowFloats = RF, NP = 256 / RF;      // points per tile; thread (point p, part): NP parts share a point's rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = lane & 31, hi = lane >> 5;
+    const bool own = pt < RF;              // (16-point tiles: lanes 16..31 of a half-wave hold duplicates)
     // the program is read-only and every access is wave-uniform: through the CONSTANT address space the loads are scalar (s_load,
     // lgkm counter) -- as vector-memory loads they shared the vm counter with the A-operand prefetches, and waiting for a group's
     // LDS offset drained the whole prefetch queue
     const __attribute__((address_space(4))) GenProgram& G = *(const __attribute__((address_space(4))) GenProgram*)P.prog;
     const int n_ops = G.n_ops, n_out = G.n_out, out_off = G.out_off;
     {   // the constant input [1, 0, 0, ...] (8 rows): the bias group's B operand
-        const int row = tid >> 5, col = tid & 31;
-        lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;
+        const int row = tid / RF, col = tid % RF;
+        if (row < 8) lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;
     }
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         // ---- inputs and encodings: thread (point p, part): features part, part + 8, ...
-        const int p = tid & 31, part = tid >> 5;
-        const long long gp = (long long)tile * 32 + p;
+        const int p = tid % RF, part = tid / RF;
+        const long long gp = (long long)tile * RF + p;
         const bool valid = gp < P.n_pts;
         const long long gc = valid ? gp : P.n_pts - 1;
         float x[3], dv[3] = {0.0f, 0.0f, 0.0f};
@@ -186,22 +193,22 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         }
         // NaN / Inf in a point's inputs must come out as NaN (v_max(0, NaN) = 0 would launder them at the first ReLU)
         const float poison = ((x[0] - x[0]) + (x[1] - x[1])) + ((x[2] - x[2]) + (dv[0] - dv[0])) + ((dv[1] - dv[1]) + (dv[2] - dv[2]));
-        for (int f = part; f < G.x_rows; f += 8) lds[G.x_off + f * kGenRowFloats + p] = gen_feature(x, f, G.x_dim, G.x_freqs);
-        for (int f = part; f < G.v_rows; f += 8) lds[G.v_off + f * kGenRowFloats + p] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+        for (int f = part; f < G.x_rows; f += NP) lds[G.x_off + f * kGenRowFloats + p] = gen_feature(x, f, G.x_dim, G.x_freqs);
+        for (int f = part; f < G.v_rows; f += NP) lds[G.v_off + f * kGenRowFloats + p] = gen_feature(dv, f, G.v_dim, G.v_freqs);
         if constexpr (SAVE) {
             if (valid) {       // (recomputed rather than read back from LDS: no barrier in between; blocks are padded to 32 columns with zeros)
                 float* arow = P.acts + gp * G.act_ld;
-                for (int f = part; f < ((G.x_dim + 31) & ~31); f += 8) arow[G.x_col + f] = gen_feature(x, f, G.x_dim, G.x_freqs);
-                for (int f = part; f < ((G.v_dim + 31) & ~31); f += 8) arow[G.v_col + f] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+                for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = gen_feature(x, f, G.x_dim, G.x_freqs);
+                for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = gen_feature(dv, f, G.v_dim, G.v_freqs);
             }
         }
-        for (int r = part; r < 32; r += 8) lds[out_off + r * kGenRowFloats + p] = 0.0f;
+        for (int r = part; r < 32; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
         __syncthreads();
 
         for (int oi = 0; oi < n_ops; ++oi) {
             const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
             if (op.kind == kGenMul) {       // semantics * geo_map_sem(alpha) (models/nerf_mlp.py:81-83)
-                for (int r = part; r < op.out_dim; r += 8) lds[op.out_off + r * kGenRowFloats + p] *= lds[op.src_off + r * kGenRowFloats + p];
+                for (int r = part; r < op.out_dim; r += NP) lds[op.out_off + r * kGenRowFloats + p] *= lds[op.src_off + r * kGenRowFloats + p];
                 __syncthreads();
                 continue;
             }
@@ -211,8 +218,8 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
                 const bool two = t0 + 4 < out_tiles;          // wave-uniform
-                if (two) dense_tiles<true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
-                else dense_tiles<false>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                if (two) dense_tiles<true, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                else dense_tiles<false, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 // accumulator register r of lane (j, hi) = output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi of point j
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -220,12 +227,12 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                     // (rows past out_dim have all-zero weights: their accumulators are exactly 0 -- written only where the buffer's pad
                     //  rows are read by a later op as zero-weighted inputs, never into the shared OUT buffer)
                     const bool relu = op.relu & 1, pad = op.relu & 2;
-                    if (row0 < op.out_dim || pad) lds[op.out_off + row0 * kGenRowFloats + pt] = relu ? fmaxf(acc0[r], 0.0f) : acc0[r];
-                    if (two && (row0 + 128 < op.out_dim || pad)) lds[op.out_off + (row0 + 128) * kGenRowFloats + pt] = relu ? fmaxf(acc1[r], 0.0f) : acc1[r];
+                    if (own && (row0 < op.out_dim || pad)) lds[op.out_off + row0 * kGenRowFloats + pt] = relu ? fmaxf(acc0[r], 0.0f) : acc0[r];
+                    if (own && two && (row0 + 128 < op.out_dim || pad)) lds[op.out_off + (row0 + 128) * kGenRowFloats + pt] = relu ? fmaxf(acc1[r], 0.0f) : acc1[r];
                 }
                 if constexpr (SAVE) {
-                    const long long gpl = (long long)tile * 32 + pt;
-                    if (gpl < P.n_pts) {
+                    const long long gpl = (long long)tile * RF + pt;
+                    if (own && gpl < P.n_pts) {
                         float* dst = P.acts + gpl * G.act_ld + op.act_col + 32 * t0 + 4 * hi;
                         const bool relu = op.relu & 1;
 #pragma unroll
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         }
         // ---- raw[p, c] = OUT[c][p]   (models/nerf_mlp.py:93-98: cat([rgb, alpha, semantics]) / output_linear)
         if (valid)
-            for (int c = part; c < n_out; c += 8) P.raw[gp * n_out + c] = poison != poison ? __builtin_nanf("") : lds[out_off + c * kGenRowFloats + p];
+            for (int c = part; c < n_out; c += NP) P.raw[gp * n_out + c] = poison != poison ? __builtin_nanf("") : lds[out_off + c * kGenRowFloats + p];
         __syncthreads();
     }
 }
@@ -279,28 +286,31 @@ struct GenBwdParams {
     int n_tiles;
 };
 
+template <int RF>
 __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kGenRowFloats = RF, NP = 256 / RF;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = lane & 31, hi = lane >> 5;
+    const bool own = pt < RF;
     const __attribute__((address_space(4))) GenProgram& G = *(const __attribute__((address_space(4))) GenProgram*)P.prog;
     const int n_ops = G.n_ops, n_out = G.n_out, out_off = G.out_off, ld = G.act_ld;
     {
-        const int row = tid >> 5, col = tid & 31;
-        lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;     // (pad groups carry zero weights: any finite rows do)
+        const int row = tid / RF, col = tid % RF;
+        if (row < 8) lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;     // (pad groups carry zero weights: any finite rows do)
     }
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-        const int p = tid & 31, part = tid >> 5;
-        const long long gp = (long long)tile * 32 + p;
+        const int p = tid % RF, part = tid / RF;
+        const long long gp = (long long)tile * RF + p;
         const bool valid = gp < P.n_pts;
         const long long gc = valid ? gp : P.n_pts - 1;
         // d loss / d raw into the OUT rows (points past the end: zero gradient, so nothing of theirs reaches gbuf or a neighbour)
-        for (int r = part; r < 32; r += 8) lds[out_off + r * kGenRowFloats + p] = (r < n_out && valid) ? P.g_raw[gp * n_out + r] : 0.0f;
+        for (int r = part; r < 32; r += NP) lds[out_off + r * kGenRowFloats + p] = (r < n_out && valid) ? P.g_raw[gp * n_out + r] : 0.0f;
         __syncthreads();
         for (int oi = 0; oi < n_ops; ++oi) {
             const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
             if (op.kind == kGenBwdMul) {
-                for (int r = part; r < op.out_dim; r += 8) {
+                for (int r = part; r < op.out_dim; r += NP) {
                     const float g = lds[op.out_off + r * kGenRowFloats + p];
                     const float sv = P.acts[gc * ld + op.act_col + r], mv = P.acts[gc * ld + op.aux_col + r];
                     lds[op.out_off + r * kGenRowFloats + p] = g * mv;
@@ -310,8 +320,8 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 continue;
             }
             if (op.kind == kGenBwdHead) {
-                const long long gpl = (long long)tile * 32 + pt;
-                const bool vpt = gpl < P.n_pts;
+                const long long gpl = (long long)tile * RF + pt;
+                const bool vpt = own && gpl < P.n_pts;
                 const float* arow = P.acts + (vpt ? gpl : P.n_pts - 1) * ld + op.act_col;
                 float* grow = P.gbuf + gpl * ld + op.act_col;
                 const bool relu = op.relu & 1;
@@ -323,9 +333,9 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                         if (relu) a = *reinterpret_cast<const f32x4*>(arow + f0);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float v = f0 + j < op.out_dim ? lds[op.out_off + (f0 + j) * kGenRowFloats + pt] : 0.0f;
+                            const float v = (own && f0 + j < op.out_dim) ? lds[op.out_off + (f0 + j) * kGenRowFloats + pt] : 0.0f;
                             g[j] = a[j] > 0.0f ? v : 0.0f;                        // relu'(x) = [x > 0] (ATen threshold_backward)
-                            if (relu) lds[op.out_off + (f0 + j) * kGenRowFloats + pt] = g[j];   // (ReLU outputs own whole pad32 buffers)
+                            if (relu && own) lds[op.out_off + (f0 + j) * kGenRowFloats + pt] = g[j];   // (ReLU outputs own whole pad32 buffers)
                         }
                         if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
                     }
@@ -339,17 +349,17 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
                 const bool two = t0 + 4 < out_tiles;
-                if (two) dense_tiles<true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
-                else dense_tiles<false>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                if (two) dense_tiles<true, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                else dense_tiles<false, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 const bool pad = op.relu & 2, add = op.relu & 4;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row0 = 32 * t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row0 < op.out_dim || pad) {
+                    if (own && (row0 < op.out_dim || pad)) {
                         float* d = &lds[op.out_off + row0 * kGenRowFloats + pt];
                         *d = add ? *d + acc0[r] : acc0[r];
                     }
-                    if (two && (row0 + 128 < op.out_dim || pad)) {
+                    if (own && two && (row0 + 128 < op.out_dim || pad)) {
                         float* d = &lds[op.out_off + (row0 + 128) * kGenRowFloats + pt];
                         *d = add ? *d + acc1[r] : acc1[r];
                     }
@@ -480,7 +490,7 @@ inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // Mirrors MLP.__init__ / MLP.forward (models/nerf_mlp.py:40-100) and NeRFMLP.__init__ (:136-166) as a sequence of dense ops over
 // LDS activation buffers.  Pure host arithmetic: pack and every launch rebuild it from the same description.
-void build_program(const nsos_generic_mlp& M, HostProgram& H) {
+void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenRowFloats) {
     H = HostProgram{};
     GenProgram& G = H.prog;
     H.err = NSOS_OK;
@@ -608,8 +618,16 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
     G.n_ops = n;
     G.w_floats = w_off;
     G.act_ld = next_col;
+    G.row_floats = kGenRowFloats;
     for (int i = 0; i < n; ++i) G.ops[i] = H.hops[i].op;
-    if (!H.err && G.lds_floats * 4 > 160 * 1024) H.err = NSOS_ERR_UNSUPPORTED;
+    if (!H.err && G.lds_floats * 4 > 160 * 1024) H.err = NSOS_ERR_BUFFER_TOO_SMALL;      // (build_program: try narrower point tiles)
+}
+
+// 32-point tiles while the activation buffers fit the LDS, 16-point tiles for wider nets (see kGenRowFloats)
+void build_program(const nsos_generic_mlp& M, HostProgram& H) {
+    build_program_rf(M, H, 32);
+    if (H.err == NSOS_ERR_BUFFER_TOO_SMALL) build_program_rf(M, H, 16);
+    if (H.err == NSOS_ERR_BUFFER_TOO_SMALL) H.err = NSOS_ERR_UNSUPPORTED;
 }
 
 
@@ -620,6 +638,7 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
     B.err = H.err;
     if (H.err) return;
     const GenProgram& F = H.prog;
+    const int kGenRowFloats = F.row_floats;
     GenProgram& G = B.prog;
     G = F;
     G.n_ops = 0;
@@ -738,21 +757,28 @@ static int32_t generic_launch(const nsos_generic_mlp* mlp, const void* packed, G
     static thread_local HostProgram H;
     build_program(*mlp, H);
     if (H.err) return H.err;
-    NSOS_REQUIRE((n_pts + 31) / 32 < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    const int rf = H.prog.row_floats;
+    NSOS_REQUIRE((n_pts + rf - 1) / rf < (1ll << 31), NSOS_ERR_UNSUPPORTED);
     p.prog = static_cast<const GenProgram*>(packed);
     p.wts = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed) + kGenHeaderBytes);
     p.n_pts = n_pts;
-    p.n_tiles = (int)((n_pts + 31) / 32);
+    p.n_tiles = (int)((n_pts + rf - 1) / rf);
     const int lds_bytes = H.prog.lds_floats * 4;
     // (per call: the attribute is a property of the kernel on this device, the size a property of the architecture rendered)
-    const void* fn = p.acts ? reinterpret_cast<const void*>(&mlp_generic_kernel<true>) : reinterpret_cast<const void*>(&mlp_generic_kernel<false>);
+    const void* fn = rf == 32 ? (p.acts ? reinterpret_cast<const void*>(&mlp_generic_kernel<true, 32>) : reinterpret_cast<const void*>(&mlp_generic_kernel<false, 32>))
+                              : (p.acts ? reinterpret_cast<const void*>(&mlp_generic_kernel<true, 16>) : reinterpret_cast<const void*>(&mlp_generic_kernel<false, 16>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int32_t)e;
     const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
     const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
-    if (p.acts) hipLaunchKernelGGL(mlp_generic_kernel<true>, dim3(grid), dim3(256), lds_bytes, st, p);
-    else hipLaunchKernelGGL(mlp_generic_kernel<false>, dim3(grid), dim3(256), lds_bytes, st, p);
+    if (rf == 32) {
+        if (p.acts) hipLaunchKernelGGL((mlp_generic_kernel<true, 32>), dim3(grid), dim3(256), lds_bytes, st, p);
+        else hipLaunchKernelGGL((mlp_generic_kernel<false, 32>), dim3(grid), dim3(256), lds_bytes, st, p);
+    } else {
+        if (p.acts) hipLaunchKernelGGL((mlp_generic_kernel<true, 16>), dim3(grid), dim3(256), lds_bytes, st, p);
+        else hipLaunchKernelGGL((mlp_generic_kernel<false, 16>), dim3(grid), dim3(256), lds_bytes, st, p);
+    }
     return nsos_launch_status();
 }
 
@@ -857,14 +883,17 @@ static int32_t generic_bwd_launch(const nsos_generic_mlp* mlp, const void* packe
     if (H.err) return H.err;
     p.prog = static_cast<const GenProgram*>(packed_bwd);
     p.wts = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed_bwd) + kGenHeaderBytes);
-    p.n_pts = n_pts; p.n_tiles = (int)((n_pts + 31) / 32);
+    const int rf = H.prog.row_floats;
+    p.n_pts = n_pts; p.n_tiles = (int)((n_pts + rf - 1) / rf);
     const int lds_bytes = H.prog.lds_floats * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_generic_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(rf == 32 ? reinterpret_cast<const void*>(&mlp_generic_bwd_kernel<32>) : reinterpret_cast<const void*>(&mlp_generic_bwd_kernel<16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int32_t)e;
     const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
     const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
-    hipLaunchKernelGGL(mlp_generic_bwd_kernel, dim3(grid), dim3(256), lds_bytes, st, p);
+    if (rf == 32) hipLaunchKernelGGL(mlp_generic_bwd_kernel<32>, dim3(grid), dim3(256), lds_bytes, st, p);
+    else hipLaunchKernelGGL(mlp_generic_bwd_kernel<16>, dim3(grid), dim3(256), lds_bytes, st, p);
     return nsos_launch_status();
 }
 
@@ -872,7 +901,7 @@ extern "C" int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, con
                                                 float* gbuf, int64_t n_pts, void* stream) {
     if (n_pts == 0) return NSOS_OK;
     NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf, NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(n_pts > 0 && (n_pts + 31) / 32 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_pts > 0 && (n_pts + 15) / 16 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
     GenBwdParams p = {};
     p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.n_samples = 1;
@@ -886,7 +915,7 @@ extern "C" int32_t nsos_mlp_generic_input_grads_rays(const nsos_generic_mlp* mlp
     if (n_rays == 0) return NSOS_OK;
     NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf && rays_o && rays_d && z_vals && g_pts, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(!mlp->use_viewdirs || (viewdirs && g_dirs), NSOS_ERR_NULL_POINTER);
-    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1 && (n_rays * (int64_t)n_samples + 31) / 32 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1 && (n_rays * (int64_t)n_samples + 15) / 16 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
     NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
     GenBwdParams p = {};
     p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals;

@@ -57,6 +57,10 @@ CASES = {
                 dict(use_embed=False, use_viewdirs=False, net_width=128, n_samples=16, n_importance=0)),
     "sem7": (dict(netdepth=8, netwidth=256, N_samples=12, N_importance=12, use_semantics=True, sem_dim=7),
              dict(n_samples=12, n_importance=12, use_semantics=True, sem_dim=7)),
+    # wider than the 32-point tiles' LDS budget: the kernels' 16-point tiles (appended: the earlier cases' seeds stand)
+    "w512_deepsem": (dict(netdepth=4, netwidth=512, netdepth_fine=4, netwidth_fine=512, N_samples=8, N_importance=8, use_semantics=True,
+                          sem_layer=3, sem_with_coord=True),
+                     dict(net_depth=4, net_width=512, n_samples=8, n_importance=8, use_semantics=True, sem_layer=3, sem_with_coord=True)),
 }
 
 

@@ -13,6 +13,7 @@ from helpers import GENERIC_CASES
 EXTRA = {
     "shipped": dict(use_semantics=True, sem_with_coord=True),
     "d16w64_skips": dict(netdepth=16, netwidth=64, netdepth_fine=16, netwidth_fine=64),
+    "w768": dict(netwidth=768, netwidth_fine=768, use_semantics=True, sem_with_coord=True),       # 16-point tiles, two-Linear head
 }
 
 
@@ -67,3 +68,12 @@ def test_layout_capacity_and_null_checks():
     assert lib.nsos_mlp_generic_save_layout(C.byref(G), table, 4) < 0          # an empty description is refused, not dereferenced
     assert lib.nsos_mlp_generic_bwd_packed_bytes(C.byref(G), 0) == 0
     assert lib.nsos_mlp_generic_save_layout(None, table, 4) < 0
+
+
+def test_widths_beyond_the_lds_budget_are_refused(monkeypatch):
+    """32-point tiles to W = 256 (deep head) / 320, 16-point tiles to 512 / 768 (include/nerf_sos_hip.h); beyond that the constructor
+    succeeds (parameters only) and the first pack raises NotImplementedError -- nothing renders wrongly."""
+    for kwargs in (dict(netwidth=1024, netwidth_fine=1024), dict(netwidth=640, netwidth_fine=640, use_semantics=True, sem_layer=4)):
+        with pytest.raises(NotImplementedError):
+            _plan(kwargs, monkeypatch)
+    _plan(dict(netwidth=512, netwidth_fine=512, use_semantics=True, sem_layer=4), monkeypatch)
