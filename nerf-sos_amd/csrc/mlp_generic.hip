@@ -50,7 +50,7 @@ struct GenProgram {              // at the head of the packed buffer (device mem
     int x_off, x_rows, x_dim, x_freqs;      // encoded xyz: buffer, padded rows, real rows, octaves (-1: raw coordinates)
     int v_off, v_rows, v_dim, v_freqs;      // encoded view direction (v_dim = 0 without view directions)
     int ones_off, w_floats, act_ld, input_grads;   // input_grads (backward program): the chain also fills the encodings' gradient rows   // act_ld: floats per point of the saved activations = columns of X | V | every dense op
-    int x_col, v_col, row_floats, pad3;
+    int x_col, v_col, row_floats, out_rows;
     GenOp ops[kGenMaxOps];
 };
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = gen_feature(dv, f, G.v_dim, G.v_freqs);
             }
         }
-        for (int r = part; r < 32; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
+        for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
         __syncthreads();
 
         for (int oi = 0; oi < n_ops; ++oi) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
         const bool valid = gp < P.n_pts;
         const long long gc = valid ? gp : P.n_pts - 1;
         // d loss / d raw into the OUT rows (points past the end: zero gradient, so nothing of theirs reaches gbuf or a neighbour)
-        for (int r = part; r < 32; r += NP) lds[out_off + r * kGenRowFloats + p] = (r < n_out && valid) ? P.g_raw[gp * n_out + r] : 0.0f;
+        for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = (r < n_out && valid) ? P.g_raw[gp * n_out + r] : 0.0f;
         __syncthreads();
         for (int oi = 0; oi < n_ops; ++oi) {
             const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
@@ -514,9 +514,16 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     const int HA = alloc(Wp), HB = alloc(Wp);
     // the head buffers: semantic chain (widths W ... W/2) and the view branch's hidden layer (W/2)
     const int sw = sem ? (M.sem_layers > 2 ? Wp : Hp) : 0;
-    const int sa_rows = sw > Hp ? sw : (M.use_viewdirs ? Hp : 0), sb_rows = sem && (M.sem_layers > 2 || M.sem_with_geo) ? (sw > Hp ? sw : Hp) : 0;
+    // Buffers of their own only where nothing dead can be borrowed.  The two-Linear semantic head keeps its hidden layer in the trunk's
+    // free ping-pong buffer (the feature layer overwrites it afterwards: by then it is consumed), the view branch's hidden layer goes
+    // into the trunk's OUTPUT buffer (dead once feature_linear has read it: alpha and the semantic head run before).  Only deep
+    // semantic chains and geo_map_sem's hidden layer need SA / SB.  A shipped-like net (W = 256, view directions, two-Linear head) then
+    // takes 79 KiB per tile instead of 97: TWO workgroups per CU (one's barriers and single-tile heads under the other's MFMAs).
+    const bool own_sem_bufs = sem && (M.sem_layers > 2 || M.sem_with_geo);
+    const int sa_rows = own_sem_bufs ? (sw > Hp ? sw : Hp) : 0, sb_rows = own_sem_bufs ? (sw > Hp ? sw : Hp) : 0;
     const int SA = alloc(sa_rows), SB = alloc(sb_rows);
-    G.out_off = alloc(32);
+    G.out_rows = (sem && M.sem_with_geo) ? 32 : 16;      // rows 0..2 rgb, 3 sigma, 4.. logits (<= 8), then geo_map_sem's (<= 8); the widest read is 8 rows from row 4
+    G.out_off = alloc(G.out_rows);
     G.lds_floats = off;
     G.n_out = M.use_viewdirs ? 4 + sem_dim : 4;
     int n = 0, w_off = 0;
@@ -585,7 +592,7 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
             int src = -1, src_rows = 0;
             for (int k = 0; k < M.sem_layers; ++k) {                                           // semantic_linear (:58-64, :79-80)
                 const bool last = k == M.sem_layers - 1;
-                const int out = last ? G.out_off : ((k & 1) ? SB : SA);
+                const int out = last ? G.out_off : (own_sem_bufs ? ((k & 1) ? SB : SA) : other);
                 if (k == 0) {
                     if (M.sem_with_coord) { const HostSeg two[2] = {hs, Xs}; dense(M.sem[0], out, last ? 4 : 0, !last, 2, two); }   // cat([h, input_pts])
                     else dense(M.sem[0], out, last ? 4 : 0, !last, 1, &hs);
@@ -611,8 +618,8 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
         }
         dense(M.feature, other, 0, false, 1, &hs);                                             // feature = feature_linear(h) (:86)
         const HostSeg fv[2] = {{other, W, 0, 0}, Vs};
-        dense(M.views, SA, 0, true, 2, fv);                                                    // relu(views_linears.0(cat([feature, input_views]))) (:87-90)
-        const HostSeg vh = {SA, M.views.out_dim, 0, 0};
+        dense(M.views, cur, 0, true, 2, fv);                                                   // relu(views_linears.0(cat([feature, input_views]))) (:87-90)
+        const HostSeg vh = {cur, M.views.out_dim, 0, 0};
         dense(M.rgb, G.out_off, 0, false, 1, &vh);                                             // rgb_linear (:92)
     }
     G.n_ops = n;
@@ -651,7 +658,7 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
         state[n_state] = {off, false};
         return state[n_state++].has;
     };
-    auto in_out = [&](int off) { return off >= F.out_off && off < F.out_off + 32 * kGenRowFloats; };
+    auto in_out = [&](int off) { return off >= F.out_off && off < F.out_off + F.out_rows * kGenRowFloats; };
     int sem_last_col = -1, geo_col = -1;
     for (int i = 0; i < F.n_ops; ++i) {
         if (H.hops[i].op.kind != kGenDense) continue;

@@ -14,6 +14,7 @@ EXTRA = {
     "shipped": dict(use_semantics=True, sem_with_coord=True),
     "d16w64_skips": dict(netdepth=16, netwidth=64, netdepth_fine=16, netwidth_fine=64),
     "w768": dict(netwidth=768, netwidth_fine=768, use_semantics=True, sem_with_coord=True),       # 16-point tiles, two-Linear head
+    "w512": dict(netwidth=512, netwidth_fine=512),                                                  # 32-point tiles still fit
 }
 
 
@@ -71,9 +72,10 @@ def test_layout_capacity_and_null_checks():
 
 
 def test_widths_beyond_the_lds_budget_are_refused(monkeypatch):
-    """32-point tiles to W = 256 (deep head) / 320, 16-point tiles to 512 / 768 (include/nerf_sos_hip.h); beyond that the constructor
-    succeeds (parameters only) and the first pack raises NotImplementedError -- nothing renders wrongly."""
+    """32-point tiles to W = 576 (288 with a deep semantic head), 16-point tiles to 800 (608) (include/nerf_sos_hip.h); beyond that the
+    constructor succeeds (parameters only) and the first pack raises NotImplementedError -- nothing renders wrongly."""
     for kwargs in (dict(netwidth=1024, netwidth_fine=1024), dict(netwidth=640, netwidth_fine=640, use_semantics=True, sem_layer=4)):
         with pytest.raises(NotImplementedError):
             _plan(kwargs, monkeypatch)
-    _plan(dict(netwidth=512, netwidth_fine=512, use_semantics=True, sem_layer=4), monkeypatch)
+    _plan(dict(netwidth=608, netwidth_fine=608, use_semantics=True, sem_layer=4), monkeypatch)
+    _plan(dict(netwidth=800, netwidth_fine=800, use_semantics=True, sem_with_coord=True), monkeypatch)
