@@ -22,7 +22,8 @@ ARCHS = {
     "8x256_no_viewdirs": dict(viewdirs=False),
     "8x256_sem_dim7_geo": dict(use_semantics=True, sem_dim=7, sem_with_geo=True),
     "6x96_multires6": dict(netdepth=6, netwidth=96, netdepth_fine=6, netwidth_fine=96, multires=6, multires_views=2),
-    "8x512_16_point_tiles": dict(netwidth=512, netwidth_fine=512),
+    "8x512": dict(netwidth=512, netwidth_fine=512),
+    "8x512_deep_head_16_point_tiles": dict(netwidth=512, netwidth_fine=512, use_semantics=True, sem_layer=3),
 }
 for name, kw in ARCHS.items():
     torch.manual_seed(0)
