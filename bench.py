@@ -880,6 +880,64 @@ def _strip(res):
 
 
 # ---------------------------------------------------------------------------------------------------------------- main
+def run_generic_paths(ctx, rays_n: int = 4096, steps: int = 4):
+    """The paths no BASELINE config names but the drop-in contract includes, timed briefly on the generic fp32 kernels (csrc/mlp_generic.hip):
+    a FULL training step of a non-shipped architecture (8 x 256 without view directions: render in train mode, MSE on rgb + rgb0,
+    backward through both nets, Adam) and a pose-refinement step on the shipped architecture (rays require grad, frozen net)."""
+    import time
+    import torch
+    import nerf_sos_amd
+    from nerf_sos_amd import synthetic as syn
+    dev = ctx.dev
+    out = {"what": "generic-architecture training (any ctor kwargs of models/nerf_mlp.py:40-64) and gradients w.r.t. the rays, 4096 rays x (64 + 128), "
+                   "exact-fp32 MFMA; whole steps, wall clock between synchronisations"}
+    rays = syn.synthetic_rays(rays_n, seed=0, device=dev)
+    gt = torch.rand(rays_n, 3, device=dev)
+
+    def clock(step):
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    torch.manual_seed(0)
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, perturb=1.0, raw_noise_std=1.0, viewdirs=False).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    macs = sum(p.numel() for n, p in net.nerf.named_parameters() if n.endswith("weight")) * 64 + \
+        sum(p.numel() for n, p in net.nerf_fine.named_parameters() if n.endswith("weight")) * 192
+
+    def train_step():
+        opt.zero_grad()
+        ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+        (((ret["rgb"] - gt) ** 2).mean() + ((ret["rgb0"] - gt) ** 2).mean()).backward()
+        opt.step()
+
+    ms = clock(train_step)
+    out["train_8x256_no_viewdirs"] = {"ms_per_step": round(ms, 3), "rays_per_s": round(rays_n / ms * 1e3),
+                                      "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point": round(6 * macs * rays_n / ms / 1e9 / 157.3, 3)}
+    del net, opt
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(dev).eval()
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+
+    def pose_step():
+        r = rays.clone().requires_grad_(True)
+        ret = net(r, (syn.NEAR, syn.FAR), retraw=False)
+        ((ret["rgb"] - gt) ** 2).mean().backward()
+        return r.grad
+
+    ms = clock(pose_step)
+    g = pose_step()
+    out["pose_step_shipped_architecture"] = {"ms_per_step": round(ms, 3), "rays_per_s": round(rays_n / ms * 1e3), "g_rays_finite": bool(torch.isfinite(g).all())}
+    del net
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -945,6 +1003,8 @@ def main():
                 v["what"] = "BASELINE configs[2]: one 64x64 patch = 4096 rays, sem+coord head, bf16 MFMA: train-mode render + appearance & geometric correlation losses + semantic-head backward + Adam"
                 add_traffic(v.get("roofline"), "c3_bf16")
                 variants["c3_bf16"] = v
+            if ctx.world == 1:
+                variants["generic_paths_fp32"] = run_generic_paths(ctx)
             v = _strip(run_c5(ctx, args, "fp16", 2 if ctx.world == 1 else 4, 1, blocks=5))
             v["what"] = ("BASELINE configs[4]: full 1008x756 image, 65536-ray chunks, fp16 MFMA, sem+coord, rays generated on device, on-device "
                          "softmax/argmax; row blocks sharded over the GPUs (strong scaling, no collective); a step = one image")
