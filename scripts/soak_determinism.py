@@ -17,31 +17,45 @@ STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 
 
+GENERIC = {   # modes on the generic-architecture kernels (csrc/mlp_generic.hip): every parameter trains
+    "gen6x96": dict(netdepth=6, netwidth=96, netdepth_fine=6, netwidth_fine=96, multires=6, multires_views=2, sem_layer=3),   # 32-point tiles, 3 WGs / CU
+    "gen8x256": dict(),                                                # the shipped shape forced onto them: rays require grad (pose refinement)
+    "gen4x512d": dict(netdepth=4, netwidth=512, netdepth_fine=4, netwidth_fine=512, sem_layer=3),    # 16-point tiles
+}
+
+
 def run(mode: str, precision: str):
     torch.manual_seed(0)
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True, perturb=1.0,
-                               raw_noise_std=1.0).to(dev).train()
+                               raw_noise_std=1.0, **GENERIC.get(mode, {})).to(dev).train()
     if mode == "frozen":                                  # run_nerf.py:307-318 (--fix_backbone)
         for n_, p_ in net.named_parameters():
             p_.requires_grad = "semantic_linear" in n_
     net.mlp_precision = precision
     opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4)
-    rays = syn.synthetic_rays(R, seed=1, device=dev)
+    rays = syn.synthetic_rays(R if mode != "gen4x512d" else min(R, 512), seed=1, device=dev)
+    if mode == "gen8x256":
+        rays = rays.clone().requires_grad_(True)          # -> both nets on the generic kernels, gradients to the rays as well
+        opt.add_param_group({"params": [rays], "lr": 1e-4})
     gen = torch.Generator(dev).manual_seed(7)
-    gt, gt_sem = torch.rand(R, 3, device=dev, generator=gen), torch.rand(R, 2, device=dev, generator=gen)
+    Rn = rays.shape[1]
+    gt, gt_sem = torch.rand(Rn, 3, device=dev, generator=gen), torch.rand(Rn, 2, device=dev, generator=gen)
     torch.manual_seed(123)                                # the render's own draws (jitter, sigma noise)
     losses = []
     for _ in range(STEPS):
         opt.zero_grad()
         ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
         loss = ((ret["semantics"] - gt_sem) ** 2).mean() + ((ret["semantics0"] - gt_sem) ** 2).mean()
-        if mode == "full":
+        if mode == "full" or mode in GENERIC:
             loss = loss + ((ret["rgb"] - gt) ** 2).mean() + ((ret["rgb0"] - gt) ** 2).mean()
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
-    return {n: p.detach().clone() for n, p in net.named_parameters()}, losses
+    params = {n: p.detach().clone() for n, p in net.named_parameters()}
+    if mode == "gen8x256":
+        params["rays"] = rays.detach().clone()
+    return params, losses
 
 
 def run_sharded_step(precision: str):
@@ -83,7 +97,8 @@ for precision in ("bf16", "fp32"):
     ok_all &= ok
     out[f"c4_step_{precision}"] = {"steps": STEPS, "bit_identical": not bad, "losses_identical": la == lb, "loss_first": la[0], "loss_last": la[-1]}
     print(f"c4step {precision:7s}: {'OK' if ok else 'MISMATCH'}  loss {la[0]:.5f} -> {la[-1]:.5f}", flush=True)
-for mode, precision in (("full", "fp32"), ("full", "fp16x3"), ("frozen", "fp32"), ("frozen", "fp16x3"), ("frozen", "bf16"), ("frozen", "fp16")):
+for mode, precision in (("full", "fp32"), ("full", "fp16x3"), ("frozen", "fp32"), ("frozen", "fp16x3"), ("frozen", "bf16"), ("frozen", "fp16"),
+                        ("gen6x96", "fp32"), ("gen8x256", "fp32"), ("gen4x512d", "fp32")):
     a, la = run(mode, precision)
     b, lb = run(mode, precision)
     bad = [n for n in a if not torch.equal(a[n], b[n])]
