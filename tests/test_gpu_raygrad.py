@@ -129,3 +129,19 @@ def test_ray_gradients_train_mode_with_noise_vs_port_autograd():
             if err > 1e-4:
                 bad[n_] = err
         assert not bad, bad
+
+
+def test_ray_gradients_are_chunk_invariant(golden, manifest):
+    """NeRFNet.forward renders in ray chunks (models/nerf_net.py:177-187), every chunk its own autograd node over a slice of the rays:
+    rays.grad does not depend on the chunking (eval mode; rows of different chunks never mix, so bit for bit)."""
+    g = golden("ray_grads")
+    rays = torch.from_numpy(g["semcoord__rays"]).to(DEV)
+    grads = []
+    for chunk in (1 << 15, 5):
+        cfg, net = _build("semcoord", golden, manifest)
+        net.chunk = chunk
+        rg = rays.clone().requires_grad_(True)
+        ret = net(rg, (tp.NEAR, tp.FAR))
+        (ret["rgb"].sum() + ret["acc0"].sum()).backward()
+        grads.append(rg.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
