@@ -110,6 +110,33 @@ def test_generic_render_vs_reference(golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["d6w96_m6", "d4w128"])
+def test_generic_render_at_c2_size(golden, name):
+    """BASELINE C2 size (4096 rays x (64 + 128)) on a generic architecture against the CPU port (bit-identical to the reference on CPU):
+    the coarse pass strictly within 1e-4 on every key; with the port's fine positions handed in, every fine key strictly within 1e-4 on
+    all 4096 rays (the free-running sampler's index flips are measured on the shipped path: tests/test_gpu_pins.py)."""
+    import os
+    cfg0, sd = generic_state(name, golden)
+    kw_net = dict(GENERIC_CASES[name][0], N_samples=64, N_importance=128)
+    cfg = tp.PortConfig(**dict(GENERIC_CASES[name][1], n_samples=64, n_importance=128))
+    rays = tp.synthetic_rays(4096, seed=0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = tp.render(sd, cfg, rays, (tp.NEAR, tp.FAR))
+    near, far = torch.full((4096, 1), tp.NEAR), torch.full((4096, 1), tp.FAR)
+    z = tp.stratified_z(near, far, 64, None)
+    z_fine = tp.importance_z(z, ref["weights0"], 128, None)[0]
+    net = nerf_sos_amd.NeRFNet(**kw_net).to(DEV).eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        out = net(rays.to(DEV), (tp.NEAR, tp.FAR), z_fine_override=z_fine.to(DEV))
+    assert sorted(out) == sorted(ref)
+    for k in ref:
+        if k != "z_std":
+            close(out[k].cpu().numpy(), ref[k].numpy(), what=f"{name} at C2 size: {k}")
+
+
+@pytest.mark.gpu
 def test_generic_kernel_on_the_shipped_architecture_equals_the_fused_kernel(golden, manifest):
     """The generic kernel fed the SHIPPED architecture (MLP.fast forced off) against the hand-scheduled exact-fp32 kernel: both are
     fmaf chains on the same matrix instruction, in different contraction orders -- agreement to fp32 rounding, far inside 1e-4;
