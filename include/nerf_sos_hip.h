@@ -98,9 +98,8 @@ int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* p
  * Exact-fp32 MFMA arithmetic (fmaf chains, bias first), forward only.  raw: [n, 4 + sem_dim] (4 without view directions).
  * The shipped architecture (8 x 256, skips {4}, 10 / 4 octaves, view directions, two-Linear head) should use nsos_mlp_forward_*:
  * this path is ~2x slower there.  Limits: depth <= 16, sem_layers <= 8, 4 + sem_dim (x 2 with sem_with_geo) <= 32, and the per-tile
- * activation buffers (ceil(W / 32) * 32 rows each) within 160 KiB of LDS: 32-point tiles up to W = 576 (288 with a deep semantic
- * head or sem_with_geo), 16-point tiles (half the matrix rate; chosen automatically) up to W = 800 (608); NSOS_ERR_UNSUPPORTED
- * otherwise. */
+ * activation buffers (ceil(W / 32) * 32 rows each) within 160 KiB of LDS: 32-point tiles up to W = 576 (384 with a deep semantic
+ * head), 16-point tiles (half the matrix rate; chosen automatically) up to W = 800; NSOS_ERR_UNSUPPORTED otherwise. */
 #define NSOS_GENERIC_MAX_DEPTH 16
 #define NSOS_GENERIC_MAX_SEM 8
 typedef struct nsos_generic_linear {

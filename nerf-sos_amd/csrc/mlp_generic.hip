@@ -505,7 +505,7 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     // the skip set: layer i's output is concatenated with the input (i in skips) -- the LAST layer must not be one (the heads
     // take W inputs: the reference itself fails there)
     if (D >= 1 && ((M.skip_mask >> (D - 1)) & 1)) { H.err = NSOS_ERR_UNSUPPORTED; return; }
-    // LDS buffers (float offsets): ONES | X | V | HA | HB | SA | SB | OUT
+    // LDS buffers (float offsets): ONES | X | V | HA | HB | SA | OUT
     int off = 0;
     auto alloc = [&](int rows) { const int o = off; off += rows * kGenRowFloats; return o; };
     G.ones_off = alloc(8);
@@ -517,11 +517,13 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     // Buffers of their own only where nothing dead can be borrowed.  The two-Linear semantic head keeps its hidden layer in the trunk's
     // free ping-pong buffer (the feature layer overwrites it afterwards: by then it is consumed), the view branch's hidden layer goes
     // into the trunk's OUTPUT buffer (dead once feature_linear has read it: alpha and the semantic head run before).  Only deep
-    // semantic chains and geo_map_sem's hidden layer need SA / SB.  A shipped-like net (W = 256, view directions, two-Linear head) then
+    // semantic chains and geo_map_sem's hidden layer need a buffer of their own (SA).  A shipped-like net (W = 256, view directions, two-Linear head) then
     // takes 79 KiB per tile instead of 97: TWO workgroups per CU (one's barriers and single-tile heads under the other's MFMAs).
+    // A deep semantic chain alternates between that free ping-pong buffer and ONE buffer of its own (SA); geo_map_sem's hidden layer
+    // runs after the chain and takes SA as well.
     const bool own_sem_bufs = sem && (M.sem_layers > 2 || M.sem_with_geo);
-    const int sa_rows = own_sem_bufs ? (sw > Hp ? sw : Hp) : 0, sb_rows = own_sem_bufs ? (sw > Hp ? sw : Hp) : 0;
-    const int SA = alloc(sa_rows), SB = alloc(sb_rows);
+    const int sa_rows = own_sem_bufs ? (M.sem_layers > 2 && sw > Hp ? sw : Hp) : 0;
+    const int SA = alloc(sa_rows);
     G.out_rows = (sem && M.sem_with_geo) ? 32 : 16;      // rows 0..2 rgb, 3 sigma, 4.. logits (<= 8), then geo_map_sem's (<= 8); the widest read is 8 rows from row 4
     G.out_off = alloc(G.out_rows);
     G.lds_floats = off;
@@ -592,7 +594,7 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
             int src = -1, src_rows = 0;
             for (int k = 0; k < M.sem_layers; ++k) {                                           // semantic_linear (:58-64, :79-80)
                 const bool last = k == M.sem_layers - 1;
-                const int out = last ? G.out_off : (own_sem_bufs ? ((k & 1) ? SB : SA) : other);
+                const int out = last ? G.out_off : ((k & 1) ? SA : other);
                 if (k == 0) {
                     if (M.sem_with_coord) { const HostSeg two[2] = {hs, Xs}; dense(M.sem[0], out, last ? 4 : 0, !last, 2, two); }   // cat([h, input_pts])
                     else dense(M.sem[0], out, last ? 4 : 0, !last, 1, &hs);
@@ -603,7 +605,7 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
                 src = out; src_rows = M.sem[k].out_dim;
             }
             if (M.sem_with_geo) {                                                              // semantics *= geo_map_sem(alpha) (:60, :81-83)
-                const int gbuf = (M.sem_layers & 1) ? SB : SA;                                 // whichever the chain is done with
+                const int gbuf = SA;                                                           // (the chain is done with it)
                 const HostSeg as = {G.out_off + 3 * kGenRowFloats, 1, 0, 0};
                 dense(M.geo[0], gbuf, 0, true, 1, &as);
                 const HostSeg gs = {gbuf, M.geo[0].out_dim, 0, 0};

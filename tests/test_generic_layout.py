@@ -72,10 +72,10 @@ def test_layout_capacity_and_null_checks():
 
 
 def test_widths_beyond_the_lds_budget_are_refused(monkeypatch):
-    """32-point tiles to W = 576 (288 with a deep semantic head), 16-point tiles to 800 (608) (include/nerf_sos_hip.h); beyond that the
+    """32-point tiles to W = 576 (384 with a deep semantic head), 16-point tiles to 800 (include/nerf_sos_hip.h); beyond that the
     constructor succeeds (parameters only) and the first pack raises NotImplementedError -- nothing renders wrongly."""
-    for kwargs in (dict(netwidth=1024, netwidth_fine=1024), dict(netwidth=640, netwidth_fine=640, use_semantics=True, sem_layer=4)):
+    for kwargs in (dict(netwidth=1024, netwidth_fine=1024), dict(netwidth=832, netwidth_fine=832, use_semantics=True, sem_layer=4)):
         with pytest.raises(NotImplementedError):
             _plan(kwargs, monkeypatch)
-    _plan(dict(netwidth=608, netwidth_fine=608, use_semantics=True, sem_layer=4), monkeypatch)
+    _plan(dict(netwidth=800, netwidth_fine=800, use_semantics=True, sem_layer=4), monkeypatch)
     _plan(dict(netwidth=800, netwidth_fine=800, use_semantics=True, sem_with_coord=True), monkeypatch)
