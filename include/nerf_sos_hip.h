@@ -95,7 +95,7 @@ int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* p
  * embedding: the raw 3-vector), use_viewdirs (0: output_linear only, :97-98), the semantic head as its Linear modules in order
  * (sem_layers of them: 2 for sem_layer <= 2, sem_layer otherwise, :58-63; ReLU between them), sem_with_coord (cat([h,
  * input_pts]), :79), sem_with_geo (geo[0..1] = geo_map_sem's two Linears on alpha; semantics *= mapping, :60,:81-83).
- * Exact-fp32 MFMA arithmetic (fmaf chains, bias first), forward only.  raw: [n, 4 + sem_dim] (4 without view directions).
+ * Exact-fp32 MFMA arithmetic (fmaf chains, bias first); training: the K7-G entries below.  raw: [n, 4 + sem_dim] (4 without view directions).
  * The shipped architecture (8 x 256, skips {4}, 10 / 4 octaves, view directions, two-Linear head) should use nsos_mlp_forward_*:
  * this path is ~2x slower there.  Limits: depth <= 16, sem_layers <= 8, 4 + sem_dim (x 2 with sem_with_geo) <= 32, and the per-tile
  * activation buffers (ceil(W / 32) * 32 rows each) within 160 KiB of LDS: 32-point tiles up to W = 576 (384 with a deep semantic

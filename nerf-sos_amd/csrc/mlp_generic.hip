@@ -3,7 +3,7 @@
 // (output_linear), the deep semantic head (sem_layer > 2), sem_dim, sem_with_geo.  The shipped architecture (8 x 256, skip 4,
 // multires 10 / 4, view directions, the two-layer head) has its own hand-scheduled kernels (mlp_fused.hip and the 16-bit
 // family); everything else renders through this one, on the same exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32:
-// bitwise an fmaf chain), forward only.
+// bitwise an fmaf chain); the backward of the same program (training, ray gradients) is further down.
 //
 // Mapping.  A workgroup = 4 waves = one per SIMD = one tile of 32 points.  The network is a PROGRAM of dense ops
 // (nsos_generic_mlp -> build_program below, mirroring MLP.forward line by line); every op reads its inputs from and writes

@@ -26,7 +26,7 @@ from . import ops
 # The architecture every shipped NeRF-SOS config uses (netdepth=8, netwidth=256, skips=[4], viewdirs=True, use_embed=True,
 # multires=10, multires_views=4, sem_layer<=2, sem_dim=2, sem_with_geo=False) has hand-scheduled kernels in three precisions and
 # backward kernels; every other architecture the reference's constructors accept renders through the generic fp32 kernel
-# (MLP.fast below; csrc/mlp_generic.hip), forward only.  conv_embed=True is the one constructor argument refused outright.
+# (MLP.fast below; csrc/mlp_generic.hip): inference, training of any parameter subset, gradients to the rays.  conv_embed=True is the one constructor argument refused outright.
 
 
 def _named_params(module: nn.Module):
@@ -57,7 +57,7 @@ class MLP(nn.Module):
     weights, with the reference's module names (state_dict keys).  `fast` marks the architecture every shipped config uses
     (8 x 256, skips [4], 63 / 27 encoded inputs, view directions, the two-Linear head with sem_dim 2): that one runs on the
     hand-scheduled kernels (exact fp32, 16-bit, split-fp16; training); everything else renders through the generic fp32
-    kernel (csrc/mlp_generic.hip), forward only."""
+    kernels (csrc/mlp_generic.hip): inference and training."""
 
     def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=(4,), use_viewdirs=True,
                  use_semantics=True, sem_layer=2, sem_dim=2, sem_with_coord=False, sem_with_geo=False):
@@ -475,7 +475,8 @@ class NeRFNet(nn.Module):
         (models/nerf_net.py:71-130).  Random tensors are drawn on the rays' device in the reference's
         order (rand[R,S], randn[R,S], rand[R,N], randn[R,S+N]) and handed to the kernels.
         Under autograd: only semantic heads trainable (the shipped --fix_backbone recipe) -> _FrozenBackboneRender;
-        anything else trainable -> _FullRender (every parameter, fp32)."""
+        anything else trainable, any trainable generic-architecture net, or rays that require grad -> _FullRender (every
+        parameter; the latter two on the generic fp32 kernels)."""
         args = (rays_o, rays_d, near, far, viewdirs, raw_noise_std, retraw, retpts)
         trainable = _trainable(self)
         generic = not (self.nerf.fast and self.nerf_fine.fast)
