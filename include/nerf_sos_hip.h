@@ -161,6 +161,15 @@ int32_t nsos_mlp_generic_input_grads_rays(const nsos_generic_mlp* mlp, const voi
                                           float* gbuf, const float* rays_o, const float* rays_d, const float* viewdirs,
                                           const float* z_vals, int64_t n_rays, int32_t n_samples, float* g_pts, float* g_dirs,
                                           void* stream);
+/* The same two kernels for the point-query entry (NeRFMLP.forward, models/nerf_mlp.py:179-215) and for MLP.forward's own input, the
+ * PRE-ENCODED row [n, input_ch + input_ch_views] (models/nerf_mlp.py:67-68; `encoded` non-NULL: pts / dirs are not read, encodings
+ * are taken as given), with saved activations (acts may be NULL: inference) -- and their input gradients (packed with input_grads):
+ * d loss / d point and / d direction through the encodings, or (g_encoded non-NULL) d loss / d the encoded inputs themselves. */
+int32_t nsos_mlp_generic_forward_points_save(const nsos_generic_mlp* mlp, const void* packed, const float* pts, const float* dirs,
+                                             const float* encoded, int64_t n_pts, float* raw, float* acts, void* stream);
+int32_t nsos_mlp_generic_input_grads_points(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                            float* gbuf, const float* pts, const float* dirs, int64_t n_pts, float* g_pts,
+                                            float* g_dirs, float* g_encoded, void* stream);
 int32_t nsos_ray_grad_reduce(const float* g_pts, const float* g_dirs, const float* z_vals, const float* rays_d, const float* raw,
                              const float* g_raw, const float* noise, float noise_std, int64_t n_rays, int32_t n_samples,
                              int32_t n_ch, float* g_rays_o, float* g_rays_d, void* stream);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "nsos_mlp_generic_pack_bwd": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _i32, _fp]),
     "nsos_mlp_generic_input_grads": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _i64, _fp]),
     "nsos_mlp_generic_input_grads_rays": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
+    "nsos_mlp_generic_forward_points_save": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _i64, _fp, _fp, _fp]),
+    "nsos_mlp_generic_input_grads_points": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _fp, _fp, _fp]),
     "nsos_ray_grad_reduce": (_i32, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _f32, _i64, _i32, _i32, _fp, _fp, _fp]),
     "nsos_generate_rays": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, C.POINTER(C.c_float), _i64, _i64, _fp, _fp, _fp]),
     "nsos_patch_batch": (_i32, [_i32, _i32, _f32, _f32, _f32, _f32, _fp, _i32, _i32, _i32, _fp, _i32, _fp, _i32, C.POINTER(C.c_int32), _fp,

@@ -109,7 +109,7 @@ def _chunks(n: int):
     return out
 
 
-def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor, rays=None):
+def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor, rays=None, points=None):
     """Gradients of every parameter of one generic-architecture MLP, by name (K7-G; autograd of models/nerf_mlp.py:67-100 for any
     depth / width / skip set / head shape).  One kernel runs the whole input-gradient chain over the saved activations
     (nsos_mlp_generic_input_grads: exact-fp32 MFMA over transposed weight streams, ReLU masks from `acts`) and leaves every
@@ -117,9 +117,16 @@ def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, pac
     on the exact-fp32 reduction kernel (nsos_wgrad), in 32-multiple tiles -- the blocks are zero-padded, so the padded rows and
     columns come out as exact zeros and are sliced away.  `plan` = the net's ops.GenericPlan (layout of the saved rows).
     rays = (rays_o, rays_d, viewdirs, z_vals) with a `packed_bwd` packed for input gradients: returns (gradients by name, g_pts [P,3],
-    g_dirs [P,3] or None) -- the chain continued through the positional encodings."""
+    g_dirs [P,3] or None) -- the chain continued through the positional encodings.  points = (pts, dirs) / ("encoded",): the same for a
+    point query / for MLP.forward's pre-encoded input (then g_pts is the gradient of the encoded row)."""
     g_pts = g_dirs = None
-    if rays is None:
+    if points is not None:         # a point query: points = (pts, dirs or None) or ("encoded",): gradients to the query's own inputs
+        if isinstance(points[0], str):
+            gbuf, g_pts, g_dirs = ops.mlp_generic_input_grads_points(plan, packed_bwd, g_raw, acts, None, None, encoded=True)
+        else:
+            gbuf, g_pts, g_dirs = ops.mlp_generic_input_grads_points(plan, packed_bwd, g_raw, acts, points[0], points[1])
+        rays = points
+    elif rays is None:
         gbuf = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts)
     else:
         gbuf, g_pts, g_dirs = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts, rays)

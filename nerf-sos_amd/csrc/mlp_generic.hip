@@ -59,6 +59,7 @@ struct GenParams {
     const float* wts;
     const float* rays_o; const float* rays_d; const float* viewdirs; const float* z_vals;   // ray mode
     const float* pts; const float* dirs;                                                      // point mode
+    const float* enc;     // pre-encoded mode (MLP.forward's own input, models/nerf_mlp.py:67-68): [n_pts, x_dim + v_dim], encodings as given
     float* raw;
     float* acts;          // training variant: [n_pts, act_ld] post-activation outputs of every dense op + both encodings
     long long n_pts;
@@ -174,8 +175,10 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         const long long gp = (long long)tile * RF + p;
         const bool valid = gp < P.n_pts;
         const long long gc = valid ? gp : P.n_pts - 1;
-        float x[3], dv[3] = {0.0f, 0.0f, 0.0f};
-        if (P.pts) {
+        float x[3] = {0.0f, 0.0f, 0.0f}, dv[3] = {0.0f, 0.0f, 0.0f};
+        const float* erow = P.enc ? P.enc + gc * (G.x_dim + G.v_dim) : nullptr;
+        if (P.enc) {
+        } else if (P.pts) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 x[c] = P.pts[3 * gc + c];
@@ -192,14 +195,19 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
             }
         }
         // NaN / Inf in a point's inputs must come out as NaN (v_max(0, NaN) = 0 would launder them at the first ReLU)
-        const float poison = ((x[0] - x[0]) + (x[1] - x[1])) + ((x[2] - x[2]) + (dv[0] - dv[0])) + ((dv[1] - dv[1]) + (dv[2] - dv[2]));
-        for (int f = part; f < G.x_rows; f += NP) lds[G.x_off + f * kGenRowFloats + p] = gen_feature(x, f, G.x_dim, G.x_freqs);
-        for (int f = part; f < G.v_rows; f += NP) lds[G.v_off + f * kGenRowFloats + p] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+        float poison = ((x[0] - x[0]) + (x[1] - x[1])) + ((x[2] - x[2]) + (dv[0] - dv[0])) + ((dv[1] - dv[1]) + (dv[2] - dv[2]));
+        // encoded feature f of the point: evaluated here, or (pre-encoded mode) read as given
+        auto x_feat = [&](int f) { return erow ? (f < G.x_dim ? erow[f] : 0.0f) : gen_feature(x, f, G.x_dim, G.x_freqs); };
+        auto v_feat = [&](int f) { return erow ? (f < G.v_dim ? erow[G.x_dim + f] : 0.0f) : gen_feature(dv, f, G.v_dim, G.v_freqs); };
+        if (erow)      // (every part of a point scans the whole row: each writes some of the point's output channels)
+            for (int f = 0; f < G.x_dim + G.v_dim; ++f) poison += erow[f] - erow[f];
+        for (int f = part; f < G.x_rows; f += NP) lds[G.x_off + f * kGenRowFloats + p] = x_feat(f);
+        for (int f = part; f < G.v_rows; f += NP) lds[G.v_off + f * kGenRowFloats + p] = v_feat(f);
         if constexpr (SAVE) {
-            if (valid) {       // (recomputed rather than read back from LDS: no barrier in between; blocks are padded to 32 columns with zeros)
+            if (valid) {       // (evaluated again rather than read back from LDS: no barrier in between; blocks are padded to 32 columns with zeros)
                 float* arow = P.acts + gp * G.act_ld;
-                for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = gen_feature(x, f, G.x_dim, G.x_freqs);
-                for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = gen_feature(dv, f, G.v_dim, G.v_freqs);
+                for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = x_feat(f);
+                for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = v_feat(f);
             }
         }
         for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
@@ -279,8 +287,10 @@ struct GenBwdParams {
     float* gbuf;              // [n_pts, ld]
     // gradients w.r.t. the points and view directions (programs packed with input_grads; ray mode): the rays of the forward call
     const float* rays_o; const float* rays_d; const float* viewdirs; const float* z_vals;
+    const float* pts; const float* dirs;      // ... or the points / per-point directions of a point query
     float* g_pts;             // [n_pts, 3]  d loss / d (o + d z)
     float* g_dirs;            // [n_pts, 3]  d loss / d viewdirs, per point (NULL without view directions)
+    float* g_enc;             // pre-encoded mode: [n_pts, x_dim + v_dim]  d loss / d the encoded inputs themselves
     int n_samples;
     long long n_pts;
     int n_tiles;
@@ -369,13 +379,20 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
         }
         // ---- d loss / d point and / d view direction through the positional encodings (models/embedder.py:34-48):
         //      d/dx [x, sin(2^k x), cos(2^k x)] = [1, 2^k cos(2^k x), -2^k sin(2^k x)]; thread (point, part): part 0..2 = xyz, 3..5 = direction
-        if (P.g_pts && part < 6) {
+        if (P.g_enc) {
+            if (valid) {
+                float* grow = P.g_enc + gp * (G.x_dim + G.v_dim);
+                for (int f = part; f < G.x_dim; f += NP) grow[f] = lds[G.x_off + f * kGenRowFloats + p];
+                for (int f = part; f < G.v_dim; f += NP) grow[G.x_dim + f] = lds[G.v_off + f * kGenRowFloats + p];
+            }
+        } else if (P.g_pts && part < 6) {
             const bool isdir = part >= 3;
             const int c = isdir ? part - 3 : part;
             if (!isdir || G.v_dim) {
                 const long long ray = gc / P.n_samples;
                 float xv;
-                if (isdir) xv = P.viewdirs[3 * ray + c];
+                if (P.pts) xv = isdir ? P.dirs[3 * gc + c] : P.pts[3 * gc + c];
+                else if (isdir) xv = P.viewdirs[3 * ray + c];
                 else { const float m = P.rays_d[3 * ray + c] * P.z_vals[gc]; xv = P.rays_o[3 * ray + c] + m; }     // as the forward forms it
                 const int off = isdir ? G.v_off : G.x_off, freqs = isdir ? G.v_freqs : G.x_freqs;
                 double g = (double)lds[off + c * kGenRowFloats + p];         // (the octaves' terms carry factors up to 2^(L-1) and cancel: summed in fp64, rounded once)
@@ -941,4 +958,32 @@ extern "C" int32_t nsos_ray_grad_reduce(const float* g_pts, const float* g_dirs,
     hipLaunchKernelGGL(ray_grad_reduce_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_pts, g_dirs, z_vals,
                        rays_d, raw, g_raw, noise, noise_std, (long long)n_rays, (int)n_samples, (int)n_ch, g_rays_o, g_rays_d);
     return nsos_launch_status();
+}
+
+// ---- point queries and pre-encoded inputs under autograd (NeRFMLP.forward, MLP.forward: models/nerf_mlp.py:179-215, 67-100)
+extern "C" int32_t nsos_mlp_generic_forward_points_save(const nsos_generic_mlp* mlp, const void* packed, const float* pts, const float* dirs,
+                                                        const float* encoded, int64_t n_pts, float* raw, float* acts, void* stream) {
+    if (n_pts == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed && raw && (encoded || pts), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(encoded || !mlp->use_viewdirs || dirs, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts > 0, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
+    GenParams p = {};
+    p.pts = encoded ? nullptr : pts; p.dirs = encoded ? nullptr : dirs; p.enc = encoded; p.raw = raw; p.acts = acts; p.n_samples = 1;
+    return generic_launch(mlp, packed, p, n_pts, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_generic_input_grads_points(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
+                                                       float* gbuf, const float* pts, const float* dirs, int64_t n_pts, float* g_pts,
+                                                       float* g_dirs, float* g_encoded, void* stream) {
+    if (n_pts == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed_bwd && g_raw && acts && gbuf, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(g_encoded || (pts && g_pts && (!mlp->use_viewdirs || (dirs && g_dirs))), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_pts > 0 && (n_pts + 15) / 16 < (1ll << 31), NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE((((uintptr_t)acts | (uintptr_t)gbuf) & 15) == 0, NSOS_ERR_MISALIGNED);
+    GenBwdParams p = {};
+    p.g_raw = g_raw; p.acts = acts; p.gbuf = gbuf; p.n_samples = 1;
+    if (g_encoded) p.g_enc = g_encoded;
+    else { p.pts = pts; p.dirs = dirs; p.g_pts = g_pts; p.g_dirs = mlp->use_viewdirs ? g_dirs : nullptr; }
+    return generic_bwd_launch(mlp, packed_bwd, p, n_pts, (hipStream_t)stream);
 }

@@ -93,9 +93,51 @@ class MLP(nn.Module):
     def sem_mode(self) -> int:
         return ops.sem_mode_of(self.use_semantics, self.sem_with_coord)
 
-    def forward(self, x):  # the reference's MLP.forward takes pre-encoded inputs; the fused kernel never builds them
-        raise NotImplementedError("nerf_sos_amd.MLP holds parameters only; query points through NeRFMLP "
-                                  "(positional encoding and all layers are fused in one HIP kernel)")
+    # ---- MLP.forward on PRE-ENCODED inputs (models/nerf_mlp.py:67-100): no in-scope caller uses it (NeRFMLP / NeRFNet own the encoding
+    #      and fuse it into the kernels), but it is the reference's signature: the generic kernels read the encoded row as given.
+    def _generic_plan(self):
+        ptrs = tuple(p.data_ptr() for p in self.parameters())
+        if self.__dict__.get("_enc_plan") is None or self._enc_plan.param_ptrs != ptrs:
+            def octaves(ch):
+                if ch == 3:
+                    return None
+                if ch < 3 or (ch - 3) % 6:
+                    raise NotImplementedError(f"nerf_sos_amd.MLP.forward: an input of {ch} channels is not 3 + 6 L (models/embedder.py:21-32)")
+                return (ch - 3) // 6
+            self.__dict__["_enc_plan"] = ops.GenericPlan(self, octaves(self.input_ch), octaves(self.input_ch_views) if self.use_viewdirs else None)
+            self._enc_plan.param_ptrs = ptrs
+            self.__dict__["_enc_packed"] = {}
+        return self._enc_plan
+
+    def packed_weights(self, precision: str = "generic") -> torch.Tensor:
+        plan = self._generic_plan()
+        self._enc_packed["generic"] = plan.run(self._enc_packed.get("generic"))       # (every call: see NeRFMLP.packed_weights)
+        return self._enc_packed["generic"]
+
+    def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
+        plan = self._generic_plan()
+        key = "generic_bwd_in" if input_grads else "generic_bwd"
+        self._enc_packed[key] = plan.run_bwd(self._enc_packed.get(key), input_grads=input_grads)
+        return self._enc_packed[key]
+
+    def __getstate__(self):  # copy.deepcopy / pickling: the plan holds raw device pointers, the streams are derived data
+        state = self.__dict__.copy()
+        state.pop("_enc_plan", None), state.pop("_enc_packed", None)
+        return state
+
+    def forward(self, x):
+        """outputs [..., 4 (+ sem_dim)] for pre-encoded inputs x [..., input_ch + input_ch_views] (models/nerf_mlp.py:67-100), fp32 on the
+        generic kernels; differentiable w.r.t. the parameters and x."""
+        width = self.input_ch + (self.input_ch_views if self.use_viewdirs else 0)
+        if x.shape[-1] != width:
+            raise ValueError(f"nerf_sos_amd.MLP.forward: expected {width} encoded channels, got {x.shape[-1]}")
+        lead = x.shape[:-1]
+        flat = x.reshape(-1, width).float()
+        if torch.is_grad_enabled() and (flat.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raw = _GenericQuery.apply(self, self, "encoded", flat, None, *[p for _, p in _named_params(self)])
+        else:
+            raw = ops.mlp_generic_forward_points_save(self._generic_plan(), self.packed_weights(), None, None, encoded=flat.contiguous(), save=False)[0]
+        return raw.reshape(list(lead) + [raw.shape[-1]])
 
 
 class NeRFMLP(nn.Module):
@@ -217,10 +259,18 @@ class NeRFMLP(nn.Module):
         if self.use_viewdirs and viewdirs is None:
             raise ValueError("nerf_sos_amd.NeRFMLP: this net was built with viewdirs=True: pass the view directions "
                              "(the reference fails in embeddirs(None) here, models/nerf_mlp.py:203)")
-        _no_autograd(self, "NeRFMLP.forward")
         lead = inputs.shape[:-1]
         pts = inputs.reshape(-1, inputs.shape[-1]).float()
         dirs = viewdirs.expand(inputs.shape).reshape(-1, viewdirs.shape[-1]).float() if self.use_viewdirs else None
+        if torch.is_grad_enabled() and (_trainable(self) or pts.requires_grad or (dirs is not None and dirs.requires_grad)):
+            # the reference's point query is an ordinary differentiable module: here it runs on the generic fp32 kernels (any
+            # architecture, the shipped one included), with gradients to the parameters, the points and the directions
+            if self.mlp_precision != "fp32":
+                raise NotImplementedError(f"nerf_sos_amd.NeRFMLP.forward: gradients of a point query exist in fp32 only (mlp_precision = {self.mlp_precision!r}): "
+                                          "run it under torch.no_grad() or set mlp_precision = 'fp32'")
+            raw = _GenericQuery.apply(self, self.mlp, "points", pts.contiguous(), None if dirs is None else dirs.contiguous(),
+                                      *[p for _, p in _named_params(self.mlp)])
+            return raw.reshape(list(lead) + [raw.shape[-1]])
         if self.fast and self.mlp_precision != "fp32":
             # the 16-bit / split-fp16 kernels take rays: every point is a ray of one sample with o = the point, d = 0, z = 0
             # (o + 0 * 0 is the point, bit for bit), its direction the ray's view direction
@@ -240,12 +290,41 @@ def _trainable(module: nn.Module):
     return [n for n, p in _named_params(module) if p.requires_grad]
 
 
-def _no_autograd(module: nn.Module, what: str):
-    if _trainable(module):
-        raise NotImplementedError(
-            f"{what}: no backward kernel for this call -- run it under torch.no_grad() or freeze the parameters.  "
-            "(Gradients are implemented for NeRFNet.forward/render_rays with the reference's frozen-backbone recipe; "
-            "there is no autograd fallback on purpose.)")
+class _GenericQuery(torch.autograd.Function):
+    """A point query (NeRFMLP.forward: mode "points", a = pts [P,3], b = dirs [P,3] or None) or MLP.forward on pre-encoded inputs (mode
+    "encoded", a = x [P, input_ch + input_ch_views]) under autograd, on the generic kernels: forward = nsos_mlp_generic_forward_points_save
+    (saved activations), backward = the input-gradient chain + the weight-gradient reductions (backward.generic_mlp_backward),
+    continued to the query's own inputs when they ask for a gradient.  `owner` holds the streams (packed_weights("generic"),
+    packed_bwd_generic, the plan), `mlp` the parameters."""
+
+    @staticmethod
+    def forward(ctx, owner, mlp, mode, a, b, *params):
+        packed = owner.packed_weights("generic")
+        plan = owner._gplan if hasattr(owner, "_gplan") else owner._generic_plan()
+        with torch.no_grad():
+            if mode == "encoded":
+                raw, acts = ops.mlp_generic_forward_points_save(plan, packed, None, None, encoded=a.contiguous())
+            else:
+                raw, acts = ops.mlp_generic_forward_points_save(plan, packed, a, b)
+        ctx.owner, ctx.mlp, ctx.mode, ctx.plan, ctx.acts, ctx.a, ctx.b = owner, mlp, mode, plan, acts, a, b
+        ctx.in_grad = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        from .backward import generic_mlp_backward
+        if ctx.acts is None:
+            raise RuntimeError("nerf_sos_amd: backward through the same point query twice (the saved activations were released)")
+        g_a = g_b = None
+        packed_bwd = ctx.owner.packed_bwd_generic(input_grads=ctx.in_grad)
+        g_raw = g_raw.contiguous()
+        if ctx.in_grad:
+            points = ("encoded",) if ctx.mode == "encoded" else (ctx.a, ctx.b)
+            by_name, g_a, g_b = generic_mlp_backward(ctx.mlp, ctx.plan, ctx.acts, g_raw, packed_bwd, points=points)
+        else:
+            by_name = generic_mlp_backward(ctx.mlp, ctx.plan, ctx.acts, g_raw, packed_bwd)
+        ctx.acts = None
+        return (None, None, None, g_a, g_b) + tuple(by_name.get(n) for n, _ in _named_params(ctx.mlp))
 
 
 _SEM_KEYS = ("semantic_linear.0.weight", "semantic_linear.0.bias", "semantic_linear.2.weight", "semantic_linear.2.bias")

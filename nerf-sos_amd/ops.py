@@ -346,6 +346,48 @@ def mlp_generic_input_grads(plan: GenericPlan, packed_bwd: torch.Tensor, g_raw: 
     return gbuf, g_pts, g_dirs
 
 
+def mlp_generic_forward_points_save(plan: GenericPlan, packed: torch.Tensor, pts: Optional[torch.Tensor], dirs: Optional[torch.Tensor],
+                                    encoded: Optional[torch.Tensor] = None, save: bool = True):
+    """Point query of the generic kernels with saved activations: (raw [P,C], acts [P,ld] or None).  encoded [P, input_ch +
+    input_ch_views]: MLP.forward's own pre-encoded input instead of points and directions (nsos_mlp_generic_forward_points_save)."""
+    if encoded is not None:
+        encoded = _dev(encoded, "encoded")
+        P_ = encoded.shape[0]
+    else:
+        pts = _dev(pts, "pts")
+        dirs = _dev(dirs, "dirs") if dirs is not None else None
+        P_ = pts.shape[0]
+    dev = (encoded if encoded is not None else pts).device
+    raw = torch.empty((P_, plan.out_channels), device=dev, dtype=torch.float32)
+    acts = torch.empty((P_, plan.layout()[0]), device=dev, dtype=torch.float32) if save else None
+    _lib.check(_lib.lib().nsos_mlp_generic_forward_points_save(C.byref(plan.desc), _p(packed), _p(pts) if encoded is None else None,
+                                                               _p(dirs) if encoded is None else None, _p(encoded), P_, _p(raw), _p(acts), _stream()),
+               "nsos_mlp_generic_forward_points_save")
+    return raw, acts
+
+
+def mlp_generic_input_grads_points(plan: GenericPlan, packed_bwd: torch.Tensor, g_raw: torch.Tensor, acts: torch.Tensor,
+                                   pts: Optional[torch.Tensor], dirs: Optional[torch.Tensor], encoded: bool = False):
+    """(gbuf, g_pts, g_dirs) of a point query -- or, encoded=True, (gbuf, g_encoded [P, input_ch + input_ch_views], None): the
+    input-gradient chain of mlp_generic_input_grads continued to the query's own inputs (`packed_bwd` of run_bwd(input_grads=True))."""
+    g_raw, acts = _dev(g_raw, "g_raw"), _dev(acts, "acts")
+    P_ = acts.shape[0]
+    gbuf = torch.empty_like(acts)
+    f32 = dict(device=acts.device, dtype=torch.float32)
+    g_pts = g_dirs = g_enc = None
+    if encoded:
+        x_dim = 3 if plan.desc.xyz_freqs < 0 else 3 + 6 * plan.desc.xyz_freqs
+        v_dim = 0 if not plan.desc.use_viewdirs else (3 if plan.desc.dir_freqs < 0 else 3 + 6 * plan.desc.dir_freqs)
+        g_enc = torch.empty((P_, x_dim + v_dim), **f32)
+    else:
+        g_pts = torch.empty((P_, 3), **f32)
+        g_dirs = torch.empty((P_, 3), **f32) if plan.desc.use_viewdirs else None
+    _lib.check(_lib.lib().nsos_mlp_generic_input_grads_points(C.byref(plan.desc), _p(packed_bwd), _p(g_raw), _p(acts), _p(gbuf),
+                                                              _p(pts) if not encoded else None, _p(dirs) if (not encoded and dirs is not None) else None,
+                                                              P_, _p(g_pts), _p(g_dirs), _p(g_enc), _stream()), "nsos_mlp_generic_input_grads_points")
+    return (gbuf, g_enc, None) if encoded else (gbuf, g_pts, g_dirs)
+
+
 def ray_grad_reduce(g_pts: torch.Tensor, g_dirs: Optional[torch.Tensor], z_vals: torch.Tensor, rays_d: torch.Tensor, raw: torch.Tensor,
                     g_raw: torch.Tensor, noise: Optional[torch.Tensor], noise_std: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """(g_rays_o, g_rays_d) [R,3] of one pass from its per-point gradients (nsos_ray_grad_reduce): pts = o + d z, viewdirs = d / |d| and

@@ -71,6 +71,10 @@ def test_no_cpu_fallback():
         net(rays, (1.2, 14.72))
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
         net.nerf_fine(torch.zeros(4, 3), viewdirs=torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):          # under autograd (the generic kernels' path) as well
+        net.nerf_fine(torch.zeros(4, 3), viewdirs=torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):          # MLP.forward on pre-encoded rows
+        net.nerf.mlp(torch.zeros(4, 90))
 
 
 def test_product_never_imports_oracle():
