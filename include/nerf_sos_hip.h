@@ -120,6 +120,9 @@ typedef struct nsos_generic_mlp {
 size_t nsos_mlp_generic_packed_bytes(const nsos_generic_mlp* mlp);      /* 0: unsupported description */
 int32_t nsos_mlp_generic_out_channels(const nsos_generic_mlp* mlp);    /* 0: unsupported description */
 int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream);
+/* Weights only, into a buffer nsos_mlp_generic_pack filled before for the same architecture (the program at its head depends on the
+ * architecture alone): kernels only -- no host-to-device copy, so a training step that re-packs can be captured in a HIP graph. */
+int32_t nsos_mlp_generic_repack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream);
 /* `mlp` must describe the same architecture `packed` was packed for (its tensor pointers are not read here). */
 int32_t nsos_mlp_generic_forward_rays(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
                                       const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
@@ -155,6 +158,7 @@ int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const vo
                                            float* raw, float* acts, void* stream);
 size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads);   /* 0: unsupported description */
 int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);
+int32_t nsos_mlp_generic_repack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);  /* as nsos_mlp_generic_repack */
 int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
                                      float* gbuf, int64_t n_pts, void* stream);
 int32_t nsos_mlp_generic_input_grads_rays(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "nsos_mlp_generic_packed_bytes": (_sz, [C.POINTER(GenericMlp)]),
     "nsos_mlp_generic_out_channels": (_i32, [C.POINTER(GenericMlp)]),
     "nsos_mlp_generic_pack": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
+    "nsos_mlp_generic_repack": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
+    "nsos_mlp_generic_repack_bwd": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _i32, _fp]),
     "nsos_mlp_generic_forward_rays": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_generic_forward_points": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _i64, _fp, _fp]),
     "nsos_mlp_generic_save_layout": (_i32, [C.POINTER(GenericMlp), C.POINTER(C.c_int32), _i32]),

@@ -753,7 +753,7 @@ extern "C" int32_t nsos_mlp_generic_out_channels(const nsos_generic_mlp* mlp) {
     return H.err ? 0 : H.prog.n_out;
 }
 
-extern "C" int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream) {
+static int32_t generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream, bool with_header) {
     NSOS_REQUIRE(mlp && packed, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(((uintptr_t)packed & 15) == 0, NSOS_ERR_MISALIGNED);
     static thread_local HostProgram H;
@@ -761,9 +761,12 @@ extern "C" int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* pack
     if (H.err) return H.err;
     NSOS_REQUIRE(packed_bytes >= kGenHeaderBytes + (size_t)H.prog.w_floats * 4 + kGenTailBytes, NSOS_ERR_BUFFER_TOO_SMALL);
     const hipStream_t st = (hipStream_t)stream;
-    // the program travels with the weights (pageable host memory: the copy is staged by the runtime before the call returns)
-    hipError_t e = hipMemcpyAsync(packed, &H.prog, sizeof(GenProgram), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return (int32_t)e;
+    // the program travels with the weights (pageable host memory: the copy is staged by the runtime before the call returns).  It depends
+    // on the architecture alone: a re-pack after a weight update (nsos_mlp_generic_repack) leaves it where it is -- kernels only, capturable
+    if (with_header) {
+        hipError_t e = hipMemcpyAsync(packed, &H.prog, sizeof(GenProgram), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return (int32_t)e;
+    }
     float* wts = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + kGenHeaderBytes);
     for (int i = 0; i < H.prog.n_ops; ++i) {
         const HostOp& ho = H.hops[i];
@@ -777,6 +780,13 @@ extern "C" int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* pack
         hipLaunchKernelGGL(gen_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Q);
     }
     return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_mlp_generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream) {
+    return generic_pack(mlp, packed, packed_bytes, stream, true);
+}
+extern "C" int32_t nsos_mlp_generic_repack(const nsos_generic_mlp* mlp, void* packed, size_t packed_bytes, void* stream) {
+    return generic_pack(mlp, packed, packed_bytes, stream, false);
 }
 
 static int32_t generic_launch(const nsos_generic_mlp* mlp, const void* packed, GenParams p, int64_t n_pts, hipStream_t st) {
@@ -880,7 +890,7 @@ extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp,
     return kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes;
 }
 
-extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream) {
+static int32_t generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream, bool with_header) {
     NSOS_REQUIRE(mlp && packed_bwd, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(((uintptr_t)packed_bwd & 15) == 0, NSOS_ERR_MISALIGNED);
     static thread_local HostProgram H;
@@ -890,8 +900,10 @@ extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* 
     if (B.err) return B.err;
     NSOS_REQUIRE(packed_bytes >= kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes, NSOS_ERR_BUFFER_TOO_SMALL);
     const hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemcpyAsync(packed_bwd, &B.prog, sizeof(GenProgram), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return (int32_t)e;
+    if (with_header) {
+        hipError_t e = hipMemcpyAsync(packed_bwd, &B.prog, sizeof(GenProgram), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return (int32_t)e;
+    }
     float* wts = reinterpret_cast<float*>(static_cast<unsigned char*>(packed_bwd) + kGenHeaderBytes);
     for (int i = 0; i < B.n_packs; ++i) {
         GenPackT Q = B.packs[i];
@@ -901,6 +913,13 @@ extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* 
         hipLaunchKernelGGL(gen_pack_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Q);
     }
     return nsos_launch_status();
+}
+
+extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream) {
+    return generic_pack_bwd(mlp, packed_bwd, packed_bytes, input_grads, stream, true);
+}
+extern "C" int32_t nsos_mlp_generic_repack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream) {
+    return generic_pack_bwd(mlp, packed_bwd, packed_bytes, input_grads, stream, false);
 }
 
 static int32_t generic_bwd_launch(const nsos_generic_mlp* mlp, const void* packed_bwd, GenBwdParams p, int64_t n_pts, hipStream_t st) {

@@ -265,3 +265,62 @@ def test_generic_training_step_reduces_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.97 * losses[0] and all(losses[i + 5] < losses[i] for i in range(0, 25, 5)), losses
+
+
+@pytest.mark.gpu
+def test_generic_net_in_hip_graphs(golden):
+    """A trainable generic-architecture net inside HIP graphs: the weight streams are re-packed INSIDE the graph by kernels alone
+    (nsos_mlp_generic_repack: the program header stays where the first pack put it), so (1) a GraphedRender replay equals the eager render
+    and follows an in-place parameter update, and (2) a whole captured training step (train-mode render with the device-side Philox
+    counter, MSE, backward through both nets on the generic kernels, capturable Adam) replays to the same parameters as eager steps."""
+    name = "d6w96_m6"
+    cfg, sd = generic_state(name, golden)
+    rays = tp.synthetic_rays(96, seed=4).to(DEV)
+    net = nerf_sos_amd.NeRFNet(**GENERIC_CASES[name][0]).to(DEV).eval()
+    net.load_state_dict(sd)
+    gr = nerf_sos_amd.GraphedRender(net, 96, (tp.NEAR, tp.FAR))
+    with torch.no_grad():
+        want = net(rays, (tp.NEAR, tp.FAR))
+        got = {k: v.clone() for k, v in gr(rays).items()}
+        assert all(torch.equal(got[k], want[k]) for k in want)
+        net.nerf_fine.mlp.rgb_linear.bias.add_(0.25)          # what an optimizer step does: in place
+        want2 = net(rays, (tp.NEAR, tp.FAR))
+        got2 = gr(rays)
+        assert torch.equal(got2["rgb"], want2["rgb"]) and not torch.equal(want2["rgb"], want["rgb"])
+
+    def make():
+        torch.manual_seed(0)
+        n = nerf_sos_amd.NeRFNet(**GENERIC_CASES[name][0]).to(DEV).train()
+        n.load_state_dict(sd)
+        n.rng, n.rng_seed = "philox", 3
+        n.use_device_rng_counter(DEV)
+        return n, torch.optim.Adam(n.parameters(), lr=1e-3, capturable=True)
+
+    target = torch.rand(96, 3, device=DEV)
+
+    def step(n, opt):
+        opt.zero_grad(set_to_none=False)
+        ret = n(rays, (tp.NEAR, tp.FAR), retraw=False)
+        loss = ((ret["rgb"] - target) ** 2).mean() + ((ret["semantics0"]) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    a, opt_a = make()
+    for _ in range(5):                 # = 2 eager warm-up steps + 3 replays (the capture itself executes nothing)
+        step(a, opt_a)
+    b, opt_b = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(b, opt_b)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(b, opt_b)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), f"captured training step diverged from eager in {n_}"
