@@ -324,3 +324,74 @@ def test_generic_net_in_hip_graphs(golden):
     torch.cuda.synchronize()
     for (n_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(pa, pb), f"captured training step diverged from eager in {n_}"
+
+
+def _fuzz_config(seed):
+    import random
+    r = random.Random(seed)
+    viewdirs = r.random() < 0.75
+    embed = True if viewdirs else r.random() < 0.7
+    sem = viewdirs and r.random() < 0.7
+    kw = dict(netdepth=r.choice([1, 2, 3, 5, 6, 7, 9, 12]), netwidth=r.choice([8, 40, 64, 100, 136, 256, 320]),
+              multires=r.choice([0, 1, 3, 7, 10]), multires_views=r.choice([0, 1, 4, 5]), viewdirs=viewdirs, use_embed=embed,
+              use_semantics=sem, sem_layer=r.choice([2, 2, 3, 4, 5]), sem_dim=r.choice([1, 2, 3, 8]),
+              sem_with_coord=r.random() < 0.5, sem_with_geo=r.random() < 0.35, white_bkgd=r.random() < 0.5,
+              N_samples=r.choice([6, 8, 11]), N_importance=r.choice([0, 8, 13]))
+    kw["netdepth_fine"], kw["netwidth_fine"] = kw["netdepth"], kw["netwidth"]
+    port = dict(net_depth=kw["netdepth"], net_width=kw["netwidth"], multires=kw["multires"], multires_views=kw["multires_views"],
+                use_viewdirs=viewdirs, use_embed=embed, use_semantics=sem, sem_layer=kw["sem_layer"], sem_dim=kw["sem_dim"],
+                sem_with_coord=kw["sem_with_coord"], sem_with_geo=kw["sem_with_geo"], white_bkgd=kw["white_bkgd"],
+                n_samples=kw["N_samples"], n_importance=kw["N_importance"])
+    return kw, port
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(14))
+def test_generic_fuzz_forward_and_gradients_vs_port(seed):
+    """Randomly drawn constructor arguments (depths 1-12, widths 8-320 incl. non-multiples of 32, 0-10 octaves, every head shape, with and
+    without view directions / embedding / white background): the module tree loads the port's state dict strictly, the render equals the
+    port's within 1e-4 (fine pass on the port's positions) and every parameter's gradient of a random functional equals the port's autograd
+    within 1e-4 of its scale.  (The port is pinned bit for bit to the real reference on the eight committed cases; here it extrapolates.)"""
+    kw, port_kw = _fuzz_config(seed)
+    cfg = tp.PortConfig(**port_kw)
+    sd = {k: v.clone() for k, v in tp.init_state_dict(cfg, seed=seed).items()}
+    for net_ in ("nerf", "nerf_fine"):
+        for k in (f"{net_}.mlp.alpha_linear", f"{net_}.mlp.output_linear"):
+            if k + ".weight" in sd and (net_ == "nerf" or cfg.n_importance > 0):
+                row = slice(None) if "alpha" in k else slice(3, 4)
+                sd[k + ".weight"][row] *= 40.0
+                sd[k + ".bias"][row] = sd[k + ".bias"][row] * 40.0 + 1.0
+    if cfg.n_importance == 0:
+        for k in [k for k in sd if k.startswith("nerf.")]:
+            sd["nerf_fine." + k[len("nerf."):]] = sd[k]
+    net = nerf_sos_amd.NeRFNet(**kw).to(DEV).eval()
+    net.load_state_dict(sd)                                   # strict: same names and shapes as the port's view of the reference
+    if net.nerf.fast:
+        pytest.skip("drew the shipped architecture")
+    rays = tp.synthetic_rays(19, seed=seed)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = tp.render(sdg, cfg, rays, (tp.NEAR, tp.FAR))
+    gen = torch.Generator().manual_seed(seed)
+    ups = {k: torch.randn(ref[k].shape, generator=gen) * (0.05 if k.startswith("raw") else 1.0)
+           for k in ref if k.rstrip("0") in ("rgb", "semantics", "acc", "weights", "raw") and ref[k].numel()}
+    sum((ref[k] * ups[k]).sum() for k in ups).backward()
+    extra = {}
+    if cfg.n_importance > 0:
+        R = rays.shape[1]
+        z = tp.stratified_z(torch.full((R, 1), tp.NEAR), torch.full((R, 1), tp.FAR), cfg.n_samples, None)
+        extra["z_fine_override"] = tp.importance_z(z, ref["weights0"].detach(), cfg.n_importance, None)[0].to(DEV)
+    out = net(rays.to(DEV), (tp.NEAR, tp.FAR), **extra)
+    assert sorted(out) == sorted(ref), (kw, sorted(out), sorted(ref))
+    for k in ref:
+        if k != "z_std":
+            close(out[k].detach().cpu().numpy(), ref[k].detach().numpy(), what=f"fuzz {seed} {kw}: {k}")
+    sum((out[k] * ups[k].to(DEV)).sum() for k in ups).backward()
+    bad = {}
+    for n_, p_ in net.named_parameters():
+        want = sdg[n_].grad
+        if want is None:
+            continue
+        e = float((p_.grad.cpu() - want).abs().max() / (want.abs().max() + 1e-20))
+        if e > 1e-4:
+            bad[n_] = e
+    assert not bad, (kw, bad)
