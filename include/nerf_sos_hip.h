@@ -158,6 +158,12 @@ int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const vo
                                            float* raw, float* acts, void* stream);
 size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads);   /* 0: unsupported description */
 int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);
+/* The chain for a SUBSET of trainable Linears (bit p of `trainable` = position p of the Linear in nsos_generic_mlp, as in save_layout):
+ * only the pre-activation gradients of those Linears and of everything downstream of them are formed -- with a frozen backbone (the
+ * shipped recipe, run_nerf.py:307-318) the chain stops at the semantic head.  gbuf blocks of the other Linears are left unwritten.
+ * with_header = 0: weights only, as nsos_mlp_generic_repack (same subset as the pack that wrote the header).  No input gradients. */
+int32_t nsos_mlp_generic_pack_bwd_subset(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, uint32_t trainable,
+                                         int32_t with_header, void* stream);
 int32_t nsos_mlp_generic_repack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);  /* as nsos_mlp_generic_repack */
 int32_t nsos_mlp_generic_input_grads(const nsos_generic_mlp* mlp, const void* packed_bwd, const float* g_raw, const float* acts,
                                      float* gbuf, int64_t n_pts, void* stream);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nsos_mlp_generic_out_channels": (_i32, [C.POINTER(GenericMlp)]),
     "nsos_mlp_generic_pack": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
     "nsos_mlp_generic_repack": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _fp]),
+    "nsos_mlp_generic_pack_bwd_subset": (_i32, [C.POINTER(GenericMlp), _fp, _sz, C.c_uint32, _i32, _fp]),
     "nsos_mlp_generic_repack_bwd": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _i32, _fp]),
     "nsos_mlp_generic_forward_rays": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "nsos_mlp_generic_forward_points": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _i64, _fp, _fp]),

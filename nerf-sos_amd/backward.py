@@ -109,7 +109,8 @@ def _chunks(n: int):
     return out
 
 
-def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor, rays=None, points=None):
+def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, packed_bwd: torch.Tensor, rays=None, points=None,
+                         skip_frozen: bool = True):
     """Gradients of every parameter of one generic-architecture MLP, by name (K7-G; autograd of models/nerf_mlp.py:67-100 for any
     depth / width / skip set / head shape).  One kernel runs the whole input-gradient chain over the saved activations
     (nsos_mlp_generic_input_grads: exact-fp32 MFMA over transposed weight streams, ReLU masks from `acts`) and leaves every
@@ -137,6 +138,8 @@ def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, pac
     pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
     for name, col, out_dim, segs in layout:
         w = params[name + ".weight"]
+        if skip_frozen and not (w.requires_grad or params[name + ".bias"].requires_grad):
+            continue       # a frozen Linear (e.g. the whole backbone under the head-only recipe): no reduction, autograd wants no gradient for it
         Mp = pad(out_dim)
         gw = torch.empty_like(w)
         # every (row tile, column tile) of a segment is written by exactly one nsos_wgrad call: no fills.  Aligned shapes (out_dim and the

@@ -659,7 +659,7 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
 
 // The backward program of a forward program (see mlp_generic_bwd_kernel).  `T` gets the transposed streams' pack descriptors.
 struct HostBwd { GenProgram prog; GenPackT packs[kGenMaxOps]; int pack_w_off[kGenMaxOps]; int n_packs; int32_t err; };
-void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd& B, bool input_grads) {
+void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd& B, bool input_grads, unsigned trainable = ~0u) {
     B = HostBwd{};
     B.err = H.err;
     if (H.err) return;
@@ -684,26 +684,48 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
         if (H.hops[i].lin_id == 21 + M.sem_layers - 1) sem_last_col = H.hops[i].op.act_col;
         if (H.hops[i].lin_id == 30) geo_col = H.hops[i].op.act_col;
     }
+    // Which pre-activation gradients are needed at all: those of a trainable Linear (bit lin_id of `trainable`) and of everything
+    // DOWNSTREAM of one (a gradient reaches a Linear through all of its consumers).  need[o] = trainable[o] or need[a producer of o's
+    // inputs], in forward order.  With the backbone frozen (the shipped recipe) the chain stops at the semantic head: no trunk, view
+    // branch or sigma steps.  Gradients to the inputs need everything.
+    bool need[kGenMaxOps];
+    auto producer_of = [&](int src_col) { for (int k = 0; k < F.n_ops; ++k) if (H.hops[k].op.kind == kGenDense && H.hops[k].op.act_col == src_col) return k; return -1; };
+    int sem_last_op = -1, geo1_op = -1;
+    for (int oi = 0; oi < F.n_ops; ++oi) {
+        const HostOp& ho = H.hops[oi];
+        need[oi] = input_grads;
+        if (ho.op.kind != kGenDense) continue;
+        if (ho.lin_id == 21 + M.sem_layers - 1) sem_last_op = oi;
+        if (ho.lin_id == 30) geo1_op = oi;
+        if ((trainable >> ho.lin_id) & 1u) need[oi] = true;
+        for (int s = 0; s < ho.n_seg && !need[oi]; ++s) {
+            const bool enc = ho.seg[s].buf_off == F.x_off || (F.v_dim && ho.seg[s].buf_off == F.v_off);
+            const int pr = enc ? -1 : producer_of(ho.seg[s].src_col);
+            if (pr >= 0 && pr < oi && need[pr]) need[oi] = true;
+        }
+    }
     for (int oi = F.n_ops - 1; oi >= 0; --oi) {
         const HostOp& ho = H.hops[oi];
         if (n + 1 + kGenMaxSeg > kGenMaxOps) { B.err = NSOS_ERR_UNSUPPORTED; return; }
         if (ho.op.kind == kGenMul) {
+            if (!((sem_last_op >= 0 && need[sem_last_op]) || (geo1_op >= 0 && need[geo1_op]))) continue;
             GenOp& op = G.ops[n++];
             op = GenOp{};
             op.kind = kGenBwdMul; op.out_off = ho.op.out_off; op.src_off = ho.op.src_off; op.out_dim = ho.op.out_dim;
             op.act_col = sem_last_col; op.aux_col = geo_col;
             continue;
         }
-        {
+        if (need[oi]) {
             GenOp& op = G.ops[n++];
             op = GenOp{};
             op.kind = kGenBwdHead; op.out_off = ho.op.out_off; op.out_dim = ho.op.out_dim; op.out_tiles = ho.op.out_tiles;
             op.relu = ho.op.relu & 1; op.act_col = ho.op.act_col;
         }
-        for (int s = 0; s < ho.n_seg; ++s) {
+        for (int s = 0; s < ho.n_seg && need[oi]; ++s) {
             const HostSeg& sg = ho.seg[s];
             const bool enc = sg.buf_off == F.x_off || (F.v_dim && sg.buf_off == F.v_off);
             if (enc && !input_grads) continue;     // rays are data: no gradient flows to the encodings unless the caller asks for it
+            if (!enc) { const int pr = producer_of(sg.src_col); if (pr < 0 || !need[pr]) continue; }     // nobody upstream wants it
             GenOp& op = G.ops[n++];
             op = GenOp{};
             op.kind = kGenDense; op.out_off = sg.buf_off; op.out_dim = sg.rows; op.out_tiles = pad_to(sg.rows, 32) / 32;
@@ -880,7 +902,7 @@ extern "C" int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* ml
     return generic_launch(mlp, packed, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
 }
 
-extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads) {
+extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads) {   // (the full program: an upper bound for every trainable subset)
     if (!mlp) return 0;
     static thread_local HostProgram H;
     static thread_local HostBwd B;
@@ -890,13 +912,14 @@ extern "C" size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp,
     return kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes;
 }
 
-static int32_t generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream, bool with_header) {
+static int32_t generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream, bool with_header,
+                                unsigned trainable = ~0u) {
     NSOS_REQUIRE(mlp && packed_bwd, NSOS_ERR_NULL_POINTER);
     NSOS_REQUIRE(((uintptr_t)packed_bwd & 15) == 0, NSOS_ERR_MISALIGNED);
     static thread_local HostProgram H;
     static thread_local HostBwd B;
     build_program(*mlp, H);
-    build_bwd_program(*mlp, H, B, input_grads != 0);
+    build_bwd_program(*mlp, H, B, input_grads != 0, trainable);
     if (B.err) return B.err;
     NSOS_REQUIRE(packed_bytes >= kGenHeaderBytes + (size_t)B.prog.w_floats * 4 + kGenTailBytes, NSOS_ERR_BUFFER_TOO_SMALL);
     const hipStream_t st = (hipStream_t)stream;
@@ -920,6 +943,10 @@ extern "C" int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* 
 }
 extern "C" int32_t nsos_mlp_generic_repack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream) {
     return generic_pack_bwd(mlp, packed_bwd, packed_bytes, input_grads, stream, false);
+}
+extern "C" int32_t nsos_mlp_generic_pack_bwd_subset(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, uint32_t trainable,
+                                                    int32_t with_header, void* stream) {
+    return generic_pack_bwd(mlp, packed_bwd, packed_bytes, 0, stream, with_header != 0, trainable);
 }
 
 static int32_t generic_bwd_launch(const nsos_generic_mlp* mlp, const void* packed_bwd, GenBwdParams p, int64_t n_pts, hipStream_t st) {

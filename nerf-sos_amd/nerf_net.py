@@ -116,8 +116,9 @@ class MLP(nn.Module):
 
     def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
         plan = self._generic_plan()
-        key = "generic_bwd_in" if input_grads else "generic_bwd"
-        self._enc_packed[key] = plan.run_bwd(self._enc_packed.get(key), input_grads=input_grads)
+        mask = None if input_grads else plan.trainable_mask(self)
+        key = "generic_bwd_in" if input_grads else ("generic_bwd" if mask is None else "generic_bwd_sub")
+        self._enc_packed[key] = plan.run_bwd(self._enc_packed.get(key), input_grads=input_grads, trainable=mask)
         return self._enc_packed[key]
 
     def __getstate__(self):  # copy.deepcopy / pickling: the plan holds raw device pointers, the streams are derived data
@@ -248,11 +249,13 @@ class NeRFMLP(nn.Module):
 
     def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
         """The transposed weight streams of the generic input-gradient chain, packed from the CURRENT parameters (every call:
-        training moves them, see packed_weights); input_grads: the program that also reaches the encodings (ray gradients)."""
+        training moves them, see packed_weights); input_grads: the program that also reaches the encodings (ray gradients).
+        Without input gradients the chain is cut to what the parameters that require grad need (frozen backbone: the head alone)."""
         if self._gplan is None:
             self.packed_weights("generic")
-        key = "generic_bwd_in" if input_grads else "generic_bwd"
-        self._packed[key] = self._gplan.run_bwd(self._packed.get(key), input_grads=input_grads)
+        mask = None if input_grads else self._gplan.trainable_mask(self.mlp)
+        key = "generic_bwd_in" if input_grads else ("generic_bwd" if mask is None else "generic_bwd_sub")
+        self._packed[key] = self._gplan.run_bwd(self._packed.get(key), input_grads=input_grads, trainable=mask)
         return self._packed[key]
 
     def forward(self, inputs, viewdirs=None):

@@ -264,10 +264,32 @@ class GenericPlan:
             self._keep_bufs["fwd"] = out            # (the pointer stays this buffer's while the plan lives)
         return out
 
-    def run_bwd(self, out: Optional[torch.Tensor] = None, input_grads: bool = False) -> torch.Tensor:
+    def trainable_mask(self, mlp) -> Optional[int]:
+        """Bit p set = the Linear at position p of the description has a parameter that requires grad; None: all of them do."""
+        params = dict(mlp.named_parameters())
+        mask = sum(1 << p for p, n in self.lin_names.items() if params[n + ".weight"].requires_grad or params[n + ".bias"].requires_grad)
+        return None if mask == sum(1 << p for p in self.lin_names) else mask
+
+    def run_bwd(self, out: Optional[torch.Tensor] = None, input_grads: bool = False, trainable: Optional[int] = None) -> torch.Tensor:
         """The transposed weight streams + the reversed program of the input-gradient chain (nsos_mlp_generic_pack_bwd);
-        input_grads: the chain also reaches the positional encodings (gradients w.r.t. the rays)."""
+        input_grads: the chain also reaches the positional encodings (gradients w.r.t. the rays); trainable (a trainable_mask()):
+        the chain only as far as a trainable Linear needs it (nsos_mlp_generic_pack_bwd_subset; not with input_grads)."""
         nbytes = int(_lib.lib().nsos_mlp_generic_bwd_packed_bytes(C.byref(self.desc), int(input_grads)))
+        if trainable is not None and not input_grads:
+            if nbytes == 0:
+                raise NotImplementedError("nerf_sos_amd: this architecture is outside the generic backward kernel's limits")
+            if out is None or out.numel() * 4 < nbytes or out.device != self.device:
+                out = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
+            key = ("sub", int(trainable))
+            fresh = self._headers.get(key) != out.data_ptr()
+            _lib.check(_lib.lib().nsos_mlp_generic_pack_bwd_subset(C.byref(self.desc), _p(out), nbytes, int(trainable), int(fresh), _stream()),
+                       "nsos_mlp_generic_pack_bwd_subset")
+            if fresh:
+                for k in [k for k, v in self._headers.items() if v == out.data_ptr()]:
+                    del self._headers[k]        # the buffer held another program
+                self._headers[key] = out.data_ptr()
+                self._keep_bufs[key] = out
+            return out
         if nbytes == 0:
             raise NotImplementedError("nerf_sos_amd: this architecture is outside the generic backward kernel's limits")
         if out is None or out.numel() * 4 < nbytes or out.device != self.device:

@@ -221,30 +221,39 @@ def test_generic_training_vs_reference_autograd(golden, name):
 
 
 @pytest.mark.gpu
-def test_generic_training_head_only_and_ragged(golden):
-    """The shipped recipe on a generic net (only semantic_linear.* trainable, run_nerf.py:307-318): the head's gradients equal the
-    all-parameters run's, nothing else receives one; 37 rays x 16 + 37 x 32 samples (ragged 32-point tiles) in train mode."""
-    name = "d6w96_m6"
+@pytest.mark.parametrize("name", ["d6w96_m6", "deepsem3_geo"])
+def test_generic_training_of_parameter_subsets(golden, name):
+    """The shipped recipe on a generic net (only semantic_linear.* trainable, run_nerf.py:307-318) and other subsets: the input-gradient
+    chain is cut to what the trainable Linears need (nsos_mlp_generic_pack_bwd_subset: with a frozen backbone it stops at the head), the
+    trainable parameters' gradients equal the all-parameters run's bit for bit, nothing else receives one; 37 rays x 16 + 37 x 32
+    samples (ragged 32-point tiles) in train mode."""
     cfg, sd = generic_state(name, golden)
-    torch.manual_seed(5)
     rays = tp.synthetic_rays(37, seed=12).to(DEV)
-    grads = []
-    for head_only in (False, True):
+    subsets = [None, ("semantic_linear",), ("alpha_linear", "pts_linears.3."), ("rgb_linear", "nerf_fine.mlp.pts_linears.0.")]
+    if name == "deepsem3_geo":
+        subsets += [("geo_map_sem",), ("semantic_linear.2.",)]
+    full = None
+    for subset in subsets:
         net = nerf_sos_amd.NeRFNet(**GENERIC_CASES[name][0]).to(DEV).train()
         net.load_state_dict(sd)
         net.rng, net.rng_seed = "philox", 7
-        if head_only:
-            for n_, p_ in net.named_parameters():
-                p_.requires_grad_("semantic_linear" in n_)
+        chosen = lambda n_: subset is None or any(t in n_ for t in subset)  # noqa: E731
+        for n_, p_ in net.named_parameters():
+            p_.requires_grad_(chosen(n_))
         ret = net(rays, (tp.NEAR, tp.FAR))
-        (ret["semantics"].sum() + 0.5 * ret["semantics0"].square().sum() + (0.0 if head_only else ret["rgb"].sum())).backward()
-        grads.append({n_: (None if p_.grad is None else p_.grad.clone()) for n_, p_ in net.named_parameters()})
-    for n_ in grads[0]:
-        if "semantic_linear" in n_:
-            assert torch.equal(grads[0][n_], grads[1][n_]), n_
-            assert float(grads[1][n_].abs().max()) > 0, n_
-        else:
-            assert grads[1][n_] is None and grads[0][n_] is not None, n_
+        (ret["semantics"].sum() + 0.5 * ret["semantics0"].square().sum() + ret["rgb"].sum() + ret["acc0"].sum()).backward()
+        grads = {n_: (None if p_.grad is None else p_.grad.clone()) for n_, p_ in net.named_parameters()}
+        if subset is None:
+            full = grads
+            continue
+        n_sel = 0
+        for n_ in grads:
+            if chosen(n_):
+                assert grads[n_] is not None and torch.equal(grads[n_], full[n_]), (subset, n_)
+                n_sel += 1
+            else:
+                assert grads[n_] is None, (subset, n_)
+        assert n_sel >= 2, subset
 
 
 @pytest.mark.gpu
