@@ -156,6 +156,11 @@ int32_t nsos_mlp_generic_save_layout(const nsos_generic_mlp* mlp, int32_t* table
 int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                            float* raw, float* acts, void* stream);
+/* forward_rays_save for a trainable subset (the mask of nsos_mlp_generic_pack_bwd_subset): only the blocks that subset's backward reads
+ * are stored (inputs of the trainable Linears, outputs of the ReLU layers downstream of one); the other columns of `acts` stay unwritten. */
+int32_t nsos_mlp_generic_forward_rays_save_subset(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
+                                                  const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                  float* raw, float* acts, uint32_t trainable, void* stream);
 size_t nsos_mlp_generic_bwd_packed_bytes(const nsos_generic_mlp* mlp, int32_t input_grads);   /* 0: unsupported description */
 int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);
 /* The chain for a SUBSET of trainable Linears (bit p of `trainable` = position p of the Linear in nsos_generic_mlp, as in save_layout):

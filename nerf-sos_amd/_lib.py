@@ -54,6 +54,7 @@ SIGNATURES = {
     "nsos_mlp_generic_forward_points": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _i64, _fp, _fp]),
     "nsos_mlp_generic_save_layout": (_i32, [C.POINTER(GenericMlp), C.POINTER(C.c_int32), _i32]),
     "nsos_mlp_generic_forward_rays_save": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
+    "nsos_mlp_generic_forward_rays_save_subset": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, C.c_uint32, _fp]),
     "nsos_mlp_generic_bwd_packed_bytes": (_sz, [C.POINTER(GenericMlp), _i32]),
     "nsos_mlp_generic_pack_bwd": (_i32, [C.POINTER(GenericMlp), _fp, _sz, _i32, _fp]),
     "nsos_mlp_generic_input_grads": (_i32, [C.POINTER(GenericMlp), _fp, _fp, _fp, _fp, _i64, _fp]),

@@ -62,6 +62,7 @@ struct GenParams {
     const float* enc;     // pre-encoded mode (MLP.forward's own input, models/nerf_mlp.py:67-68): [n_pts, x_dim + v_dim], encodings as given
     float* raw;
     float* acts;          // training variant: [n_pts, act_ld] post-activation outputs of every dense op + both encodings
+    unsigned long long save_mask;   // ... bit oi: op oi's block is stored; bit 62 / 63: the xyz / direction encoding (all ones: everything)
     long long n_pts;
     int n_samples;
     int n_tiles;
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         if constexpr (SAVE) {
             if (valid) {       // (evaluated again rather than read back from LDS: no barrier in between; blocks are padded to 32 columns with zeros)
                 float* arow = P.acts + gp * G.act_ld;
-                for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = x_feat(f);
-                for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = v_feat(f);
+                if ((P.save_mask >> 62) & 1) for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = x_feat(f);
+                if ((P.save_mask >> 63) & 1) for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = v_feat(f);
             }
         }
         for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 }
                 if constexpr (SAVE) {
                     const long long gpl = (long long)tile * RF + pt;
-                    if (own && gpl < P.n_pts) {
+                    if (own && gpl < P.n_pts && ((P.save_mask >> oi) & 1)) {
                         float* dst = P.acts + gpl * G.act_ld + op.act_col + 32 * t0 + 4 * hi;
                         const bool relu = op.relu & 1;
 #pragma unroll
@@ -657,6 +658,55 @@ void build_program(const nsos_generic_mlp& M, HostProgram& H) {
 }
 
 
+int producer_op(const HostProgram& H, int src_col) {
+    for (int k = 0; k < H.prog.n_ops; ++k) if (H.hops[k].op.kind == kGenDense && H.hops[k].op.act_col == src_col) return k;
+    return -1;
+}
+// need[o]: is the pre-activation gradient of forward op o formed at all (see build_bwd_program)
+void compute_need(const nsos_generic_mlp& M, const HostProgram& H, bool input_grads, unsigned trainable, bool* need, int& sem_last_op, int& geo1_op) {
+    const GenProgram& F = H.prog;
+    sem_last_op = geo1_op = -1;
+    for (int oi = 0; oi < F.n_ops; ++oi) {
+        const HostOp& ho = H.hops[oi];
+        need[oi] = input_grads;
+        if (ho.op.kind != kGenDense) continue;
+        if (ho.lin_id == 21 + M.sem_layers - 1) sem_last_op = oi;
+        if (ho.lin_id == 30) geo1_op = oi;
+        if ((trainable >> ho.lin_id) & 1u) need[oi] = true;
+        for (int s = 0; s < ho.n_seg && !need[oi]; ++s) {
+            const bool enc = ho.seg[s].buf_off == F.x_off || (F.v_dim && ho.seg[s].buf_off == F.v_off);
+            const int pr = enc ? -1 : producer_op(H, ho.seg[s].src_col);
+            if (pr >= 0 && pr < oi && need[pr]) need[oi] = true;
+        }
+    }
+}
+// Which blocks of the saved-activation row a backward for this trainable subset reads: the inputs of a trainable Linear (the X operand of
+// its weight-gradient reduction), the outputs of ReLU ops whose gradient is formed (their masks), the two factors of semantics * mapping.
+unsigned long long save_mask_for(const nsos_generic_mlp& M, const HostProgram& H, unsigned trainable) {
+    if (trainable == ~0u) return ~0ull;
+    const GenProgram& F = H.prog;
+    bool need[kGenMaxOps];
+    int sem_last_op, geo1_op;
+    compute_need(M, H, false, trainable, need, sem_last_op, geo1_op);
+    unsigned long long m = 0;
+    for (int oi = 0; oi < F.n_ops; ++oi) {
+        const HostOp& ho = H.hops[oi];
+        if (ho.op.kind != kGenDense) continue;
+        if (need[oi] && (ho.op.relu & 1)) m |= 1ull << oi;
+        if (!((trainable >> ho.lin_id) & 1u)) continue;
+        for (int s = 0; s < ho.n_seg; ++s) {
+            if (ho.seg[s].buf_off == F.x_off) m |= 1ull << 62;
+            else if (F.v_dim && ho.seg[s].buf_off == F.v_off) m |= 1ull << 63;
+            else { const int pr = producer_op(H, ho.seg[s].src_col); if (pr >= 0) m |= 1ull << pr; }
+        }
+    }
+    if ((sem_last_op >= 0 && need[sem_last_op]) || (geo1_op >= 0 && need[geo1_op])) {
+        if (sem_last_op >= 0) m |= 1ull << sem_last_op;
+        if (geo1_op >= 0) m |= 1ull << geo1_op;
+    }
+    return m;
+}
+
 // The backward program of a forward program (see mlp_generic_bwd_kernel).  `T` gets the transposed streams' pack descriptors.
 struct HostBwd { GenProgram prog; GenPackT packs[kGenMaxOps]; int pack_w_off[kGenMaxOps]; int n_packs; int32_t err; };
 void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd& B, bool input_grads, unsigned trainable = ~0u) {
@@ -689,21 +739,9 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
     // inputs], in forward order.  With the backbone frozen (the shipped recipe) the chain stops at the semantic head: no trunk, view
     // branch or sigma steps.  Gradients to the inputs need everything.
     bool need[kGenMaxOps];
-    auto producer_of = [&](int src_col) { for (int k = 0; k < F.n_ops; ++k) if (H.hops[k].op.kind == kGenDense && H.hops[k].op.act_col == src_col) return k; return -1; };
+    auto producer_of = [&](int src_col) { return producer_op(H, src_col); };
     int sem_last_op = -1, geo1_op = -1;
-    for (int oi = 0; oi < F.n_ops; ++oi) {
-        const HostOp& ho = H.hops[oi];
-        need[oi] = input_grads;
-        if (ho.op.kind != kGenDense) continue;
-        if (ho.lin_id == 21 + M.sem_layers - 1) sem_last_op = oi;
-        if (ho.lin_id == 30) geo1_op = oi;
-        if ((trainable >> ho.lin_id) & 1u) need[oi] = true;
-        for (int s = 0; s < ho.n_seg && !need[oi]; ++s) {
-            const bool enc = ho.seg[s].buf_off == F.x_off || (F.v_dim && ho.seg[s].buf_off == F.v_off);
-            const int pr = enc ? -1 : producer_of(ho.seg[s].src_col);
-            if (pr >= 0 && pr < oi && need[pr]) need[oi] = true;
-        }
-    }
+    compute_need(M, H, input_grads, trainable, need, sem_last_op, geo1_op);
     for (int oi = F.n_ops - 1; oi >= 0; --oi) {
         const HostOp& ho = H.hops[oi];
         if (n + 1 + kGenMaxSeg > kGenMaxOps) { B.err = NSOS_ERR_UNSUPPORTED; return; }
@@ -899,6 +937,24 @@ extern "C" int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* ml
     NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
     GenParams p = {};
     p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals; p.raw = raw; p.acts = acts; p.n_samples = n_samples;
+    p.save_mask = ~0ull;
+    return generic_launch(mlp, packed, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
+}
+
+extern "C" int32_t nsos_mlp_generic_forward_rays_save_subset(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
+                                                             const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
+                                                             float* raw, float* acts, uint32_t trainable, void* stream) {
+    if (n_rays == 0) return NSOS_OK;
+    NSOS_REQUIRE(mlp && packed && rays_o && rays_d && z_vals && raw && acts, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(!mlp->use_viewdirs || viewdirs, NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_rays > 0 && n_samples >= 1, NSOS_ERR_BAD_SHAPE);
+    NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
+    static thread_local HostProgram H;
+    build_program(*mlp, H);
+    if (H.err) return H.err;
+    GenParams p = {};
+    p.rays_o = rays_o; p.rays_d = rays_d; p.viewdirs = viewdirs; p.z_vals = z_vals; p.raw = raw; p.acts = acts; p.n_samples = n_samples;
+    p.save_mask = save_mask_for(*mlp, H, trainable);
     return generic_launch(mlp, packed, p, n_rays * (int64_t)n_samples, (hipStream_t)stream);
 }
 
@@ -1016,6 +1072,7 @@ extern "C" int32_t nsos_mlp_generic_forward_points_save(const nsos_generic_mlp* 
     NSOS_REQUIRE(((uintptr_t)acts & 15) == 0, NSOS_ERR_MISALIGNED);
     GenParams p = {};
     p.pts = encoded ? nullptr : pts; p.dirs = encoded ? nullptr : dirs; p.enc = encoded; p.raw = raw; p.acts = acts; p.n_samples = 1;
+    p.save_mask = ~0ull;
     return generic_launch(mlp, packed, p, n_pts, (hipStream_t)stream);
 }
 

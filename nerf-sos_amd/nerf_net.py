@@ -238,13 +238,14 @@ class NeRFMLP(nn.Module):
         self._frozen_key.clear()
         self._plan = self._gplan = None
 
-    def query_rays(self, rays_o, rays_d, viewdirs, z_vals, save: bool = False):
+    def query_rays(self, rays_o, rays_d, viewdirs, z_vals, save: bool = False, subset: bool = False):
         """raw [R,S,C] of a generic-architecture net for the points o + d z (NeRFNet's ray path); save=True: the training variant,
         (raw, acts) with every Linear's output saved per point (raw bit-identical)."""
         packed = self.packed_weights("generic")
         dirs = viewdirs if self.use_viewdirs else None
-        if save:
-            return ops.mlp_generic_forward_rays_save(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
+        if save:   # subset: store only what the backward of the parameters that require grad reads (no input gradients then)
+            return ops.mlp_generic_forward_rays_save(self._gplan, packed, rays_o, rays_d, dirs, z_vals,
+                                                     trainable=self._gplan.trainable_mask(self.mlp) if subset else None)
         return ops.mlp_generic_forward_rays(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
 
     def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
@@ -614,7 +615,7 @@ class NeRFNet(nn.Module):
         def query(net, z, tag):
             if not net.fast or force_generic:     # any other architecture (or ray gradients): the generic fp32 kernels
                 if save:         # (training a generic net always takes the full backward: _FullRender)
-                    raw, acts = net.query_rays(rays_o, rays_d, viewdirs, z, save=True)
+                    raw, acts = net.query_rays(rays_o, rays_d, viewdirs, z, save=True, subset=not force_generic)
                     saved[tag] = dict(acts=acts, raw=raw, z=z, generic=True)
                     return raw
                 return net.query_rays(rays_o, rays_d, viewdirs, z)

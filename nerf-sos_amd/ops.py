@@ -338,7 +338,7 @@ def mlp_generic_forward_rays(plan: GenericPlan, packed: torch.Tensor, rays_o: to
 
 
 def mlp_generic_forward_rays_save(plan: GenericPlan, packed: torch.Tensor, rays_o: torch.Tensor, rays_d: torch.Tensor,
-                                  viewdirs: Optional[torch.Tensor], z_vals: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+                                  viewdirs: Optional[torch.Tensor], z_vals: torch.Tensor, trainable: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Training variant of mlp_generic_forward_rays: also returns acts [R*S, ld], every Linear's post-activation output and both
     encodings per point (nsos_mlp_generic_forward_rays_save; raw is bit-identical to the inference call's)."""
     rays_o, rays_d, z_vals = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d"), _dev(z_vals, "z_vals")
@@ -348,6 +348,11 @@ def mlp_generic_forward_rays_save(plan: GenericPlan, packed: torch.Tensor, rays_
     ld = plan.layout()[0]
     raw = torch.empty((R, S, plan.out_channels), device=z_vals.device, dtype=torch.float32)
     acts = torch.empty((R * S, ld), device=z_vals.device, dtype=torch.float32)
+    if trainable is not None:      # a GenericPlan.trainable_mask(): store only what that subset's backward reads
+        _lib.check(_lib.lib().nsos_mlp_generic_forward_rays_save_subset(C.byref(plan.desc), _p(packed), _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
+                                                                        R, S, _p(raw), _p(acts), int(trainable), _stream()),
+                   "nsos_mlp_generic_forward_rays_save_subset")
+        return raw, acts
     _lib.check(_lib.lib().nsos_mlp_generic_forward_rays_save(C.byref(plan.desc), _p(packed), _p(rays_o), _p(rays_d), _p(viewdirs), _p(z_vals),
                                                              R, S, _p(raw), _p(acts), _stream()), "nsos_mlp_generic_forward_rays_save")
     return raw, acts
