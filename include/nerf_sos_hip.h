@@ -97,7 +97,7 @@ int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* p
  * input_pts]), :79), sem_with_geo (geo[0..1] = geo_map_sem's two Linears on alpha; semantics *= mapping, :60,:81-83).
  * Exact-fp32 MFMA arithmetic (fmaf chains, bias first); training: the K7-G entries below.  raw: [n, 4 + sem_dim] (4 without view directions).
  * The shipped architecture (8 x 256, skips {4}, 10 / 4 octaves, view directions, two-Linear head) should use nsos_mlp_forward_*:
- * this path is ~2x slower there.  Limits: depth <= 16, sem_layers <= 8, 4 + sem_dim (x 2 with sem_with_geo) <= 32, and the per-tile
+ * this path is ~2x slower there.  Limits: depth <= 16, sem_layers <= 8, sem_dim <= 8, and the per-tile
  * activation buffers (ceil(W / 32) * 32 rows each) within 160 KiB of LDS: 32-point tiles up to W = 576 (384 with a deep semantic
  * head), 16-point tiles (half the matrix rate; chosen automatically) up to W = 800; NSOS_ERR_UNSUPPORTED otherwise. */
 #define NSOS_GENERIC_MAX_DEPTH 16

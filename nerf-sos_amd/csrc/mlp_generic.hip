@@ -519,7 +519,10 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     const int Wp = pad_to(W, 32), Hp = pad_to(W / 2 > 0 ? W / 2 : 1, 32);
     const bool sem = M.use_viewdirs && M.use_semantics && M.sem_layers > 0;     // without view directions the reference never runs the head (:97-98)
     const int sem_dim = sem ? M.sem_dim : 0;
-    if (sem && (sem_dim < 1 || 4 + sem_dim * (M.sem_with_geo ? 2 : 1) > 32)) { H.err = NSOS_ERR_UNSUPPORTED; return; }
+    // sem_dim <= 8: OUT holds rows 4 .. 4 + sem_dim - 1 of logits (+ as many of geo_map_sem) in 16 (32) rows and the kernels read
+    // them as ONE 8-row k-group from row 4 (9 .. 28 passed the old `<= 32 rows` check and wrote past the LDS allocation);
+    // nsos_composite_backward's channel limit (4 + 8) is the same number.
+    if (sem && (sem_dim < 1 || sem_dim > 8)) { H.err = NSOS_ERR_UNSUPPORTED; return; }
     // the skip set: layer i's output is concatenated with the input (i in skips) -- the LAST layer must not be one (the heads
     // take W inputs: the reference itself fails there)
     if (D >= 1 && ((M.skip_mask >> (D - 1)) & 1)) { H.err = NSOS_ERR_UNSUPPORTED; return; }

@@ -6,6 +6,8 @@ Every function requires contiguous fp32 CUDA(ROCm) tensors and launches on the c
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import operator
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -210,7 +212,7 @@ class GenericPlan:
         G.depth, G.width = int(mlp.D), int(mlp.W)
         if G.depth > _lib.GENERIC_MAX_DEPTH:
             raise NotImplementedError(f"nerf_sos_amd: netdepth {G.depth} > {_lib.GENERIC_MAX_DEPTH}")
-        G.skip_mask = sum(1 << int(i) for i in mlp.skips if 0 <= int(i) < G.depth)
+        G.skip_mask = functools.reduce(operator.or_, (1 << int(i) for i in set(mlp.skips) if 0 <= int(i) < G.depth), 0)   # `i in self.skips`: repeats count once
         G.xyz_freqs = -1 if multires is None else int(multires)
         G.dir_freqs = -1 if multires_views is None else int(multires_views)
         G.use_viewdirs, G.use_semantics = int(bool(mlp.use_viewdirs)), int(bool(mlp.use_semantics))
@@ -234,6 +236,9 @@ class GenericPlan:
                 lin(G.sem[k], m)
                 names[21 + k] = "semantic_linear." + named[k][0]
             G.sem_layers, G.sem_dim = len(linears), int(linears[-1].weight.shape[0])
+            if G.sem_dim > 8 and mlp.use_viewdirs:
+                raise NotImplementedError(f"nerf_sos_amd: sem_dim {G.sem_dim} > 8 (the generic kernels' output tile and the compositing "
+                                          "backward hold at most 8 semantic channels)")
             if getattr(mlp, "geo_map_sem", None) is not None:
                 G.sem_with_geo = 1
                 lin(G.geo[0], mlp.geo_map_sem[0]), lin(G.geo[1], mlp.geo_map_sem[2])
@@ -249,7 +254,7 @@ class GenericPlan:
             raise NotImplementedError(
                 "nerf_sos_amd: this architecture is outside the generic kernel's limits (include/nerf_sos_hip.h: depth <= 16, "
                 "activation buffers of ceil(W/32)*32 rows within 160 KiB of LDS -- W <= 256 with the deep semantic head --, "
-                "4 + sem_dim (x2 with sem_with_geo) <= 32 output rows, a skip on the last layer is the reference's own shape error)")
+                "sem_dim <= 8, a skip on the last layer is the reference's own shape error)")
 
     def run(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Pack into `out` (or a new buffer).  A buffer this plan filled before keeps its program header: only the weights are

@@ -79,3 +79,20 @@ def test_widths_beyond_the_lds_budget_are_refused(monkeypatch):
             _plan(kwargs, monkeypatch)
     _plan(dict(netwidth=800, netwidth_fine=800, use_semantics=True, sem_layer=4), monkeypatch)
     _plan(dict(netwidth=800, netwidth_fine=800, use_semantics=True, sem_with_coord=True), monkeypatch)
+
+
+def test_semantic_channel_limit_and_repeated_skips(monkeypatch):
+    """sem_dim 9 .. 28 used to pass the program builder's row check and overflow the OUT buffer in LDS; the limit is 8
+    (the output tile's one k-group of logits = nsos_composite_backward's channel limit) and both the Python plan and the C entry
+    refuse more.  A repeated skip index means what `i in self.skips` means in the reference (models/nerf_mlp.py:73): once."""
+    _plan(dict(use_semantics=True, sem_dim=8), monkeypatch)
+    for sem_dim in (9, 13, 16, 28):
+        with pytest.raises(NotImplementedError):
+            _plan(dict(use_semantics=True, sem_dim=sem_dim), monkeypatch)
+    m, plan = _plan(dict(use_semantics=True, sem_dim=8), monkeypatch)
+    plan.desc.sem_dim = 16                                   # straight at the C ABI: the builder itself refuses
+    assert _lib.lib().nsos_mlp_generic_packed_bytes(C.byref(plan.desc)) == 0
+    monkeypatch.setattr(ops, "_dev", lambda t, name: t)
+    m1 = nerf_sos_amd.NeRFMLP(net_depth=6, skips=[2, 2, 4])
+    p1 = ops.GenericPlan(m1.mlp, m1.multires, m1.multires_views)
+    assert p1.desc.skip_mask == (1 << 2) | (1 << 4)

@@ -145,3 +145,37 @@ def test_ray_gradients_are_chunk_invariant(golden, manifest):
         (ret["rgb"].sum() + ret["acc0"].sum()).backward()
         grads.append(rg.grad.clone())
     assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
+def test_returned_points_carry_a_gradient_to_the_rays(golden, manifest):
+    """retpts=True: pts = o + d z is differentiable with respect to the rays in the reference (models/sampler.py:70,166; z detached).
+    A loss on ret['pts'] / ret['pts0'] must reach rays.grad (it was silently dropped): the extra gradient equals
+    d/do = sum_s U, d/dd = sum_s z U with z recovered from the returned points."""
+    g = golden("ray_grads")
+    cfg, net = _build("semcoord", golden, manifest)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    rays = torch.from_numpy(g["semcoord__rays"]).to(DEV)
+    grads = {}
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    U = U0 = None
+    for with_pts in (False, True):
+        rg = rays.clone().requires_grad_(True)
+        ret = net(rg, (tp.NEAR, tp.FAR), retpts=True)
+        loss = ret["rgb"].sum()
+        if with_pts:
+            assert ret["pts"].requires_grad and ret["pts0"].requires_grad
+            U = torch.randn(ret["pts"].shape, device=DEV, generator=gen)
+            U0 = torch.randn(ret["pts0"].shape, device=DEV, generator=gen)
+            loss = loss + (ret["pts"] * U).sum() + (ret["pts0"] * U0).sum()
+        loss.backward()
+        grads[with_pts] = rg.grad.clone()
+        pts, pts0 = ret["pts"].detach(), ret["pts0"].detach()
+    o, d = rays[0], rays[1]
+    want_o = U.sum(1) + U0.sum(1)
+    zf = ((pts - o[:, None]) * d[:, None]).sum(-1) / (d * d).sum(-1, keepdim=True)
+    zc = ((pts0 - o[:, None]) * d[:, None]).sum(-1) / (d * d).sum(-1, keepdim=True)
+    want_d = (U * zf[..., None]).sum(1) + (U0 * zc[..., None]).sum(1)
+    extra = grads[True] - grads[False]
+    assert float((extra[0] - want_o).abs().max()) <= 1e-4 * float(want_o.abs().max())
+    assert float((extra[1] - want_d).abs().max()) <= 1e-4 * float(want_d.abs().max())
