@@ -256,9 +256,9 @@ def render_parity(got: dict, ref: dict, tol: float = 1e-4):
     importance samples where the cdf is flat (the reference's own fp64-vs-fp32 sensitivity is of the same size; DESIGN.md
     section 2, tests/test_gpu_pins.py)."""
     import torch
-    keys = [k for k in ("rgb", "depth", "acc", "disp", "weights", "raw", "z_std", "rgb0", "depth0", "acc0", "disp0", "weights0", "raw0")
-            if k in got and k in ref]
-    per_key, bad_any = {}, None
+    keys = [k for k in ("rgb", "depth", "acc", "disp", "semantics", "weights", "raw", "z_std", "rgb0", "depth0", "acc0", "disp0", "semantics0",
+                        "weights0", "raw0") if k in got and k in ref]
+    per_key, bad_any, bad_maps = {}, None, None
     for k in keys:
         a = got[k].detach().float().cpu().reshape(ref[k].shape)
         b = ref[k].float()
@@ -277,6 +277,8 @@ def render_parity(got: dict, ref: dict, tol: float = 1e-4):
             per_key[k]["gpu_nonfinite_where_ref_finite"] = int(nonfinite.sum())
         if not k.endswith("0") and k != "raw":
             bad_any = rays_out if bad_any is None else (bad_any | rays_out)
+        if k in ("rgb", "depth", "acc", "disp", "semantics"):
+            bad_maps = rays_out if bad_maps is None else (bad_maps | rays_out)
 
     def psnr(k):
         mse = float(((got[k].detach().float().cpu().reshape(ref[k].shape) - ref[k]) ** 2).mean())
@@ -288,6 +290,9 @@ def render_parity(got: dict, ref: dict, tol: float = 1e-4):
             "tolerance": "|gpu - ref| <= 1e-4 * (1 + |ref|)",
             "coarse_pass_all_rays_inside_1e-4": coarse_ok,
             "frac_rays_outside_1e-4_any_fine_map": round(float(bad_any.float().mean()), 5) if bad_any is not None else None,
+            # the rendered maps alone (without the per-sample weights and the sampler's z_std, which sit on the importance sampler's
+            # discontinuities: bin flips, and on trained fields the `denom < 1e-5` switch of models/sampler.py:117-118)
+            "frac_rays_outside_1e-4_image_maps": round(float(bad_maps.float().mean()), 5) if bad_maps is not None else None,
             "per_key": per_key}
 
 
@@ -393,6 +398,144 @@ def add_traffic(roof, key: str):
     else:
         roof["traffic_note"] = "profiles/r04/traffic.json was measured on a different build of this kernel: not reported"
     return roof
+
+
+TRAINED_CKPT = os.path.join(ROOT, "tests", "golden", "trained_scene.ckpt")
+PEAK_HBM_TBPS = 8.0                          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def trained_field_parity(torch, dev, n_rays: int = 4096):
+    """`parity.trained_field`: the checkpoint trained on the procedural scene (tests/golden/trained_scene.ckpt,
+    scripts/make_trained_scene.py) rendered on `n_rays` pixels of the four held-out views by the exact fp32 kernels and by the CPU
+    port (bit-identical to the reference on CPU, asserted on this very checkpoint by tests/golden/make_goldens_trained.py): the
+    same per-key table and yardstick as the default-init and dense fields, plus every other precision against the PORT's render
+    (PSNR, max-abs, label agreement).  Outside every timed region; ~10 s of host work."""
+    import numpy as np
+    import nerf_sos_amd
+    from nerf_sos_amd import io as nio, ops, synthetic as syn
+    from oracle import torch_port as tp            # the checker, never the product path
+    scene = syn.ProceduralScene()
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True).to(dev).eval()
+    nio.load_checkpoint(TRAINED_CKPT, net)
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator().manual_seed(0)
+    per_view = n_rays // len(scene.i_test)
+    K = syn.intrinsics(scene.h, scene.w, scene.focal)
+    rays, pix = [], []
+    for i in scene.i_test:
+        sel = torch.randperm(scene.h * scene.w, generator=g)[:per_view]
+        full = ops.generate_rays(scene.h, scene.w, K, scene.poses[i, :3, :4], dev).reshape(2, -1, 3)
+        rays.append(full[:, sel.to(dev)])
+        pix.append((i, sel))
+    rays = torch.cat(rays, 1).contiguous()
+    bounds = (scene.NEAR, scene.FAR)
+    outs = {}
+    with torch.no_grad():
+        for prec in ("fp32", "fp16x3", "bf16", "fp16"):
+            net.mlp_precision = prec
+            outs[prec] = {k: v.detach().clone() for k, v in net(rays, bounds).items()}
+    inds = gpu_bisect_indices(torch, outs["fp32"], rays, N_COARSE, N_IMPORTANCE, *bounds)
+    torch.cuda.synchronize()
+    cfg = tp.PortConfig(n_samples=N_COARSE, n_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True, pts_chunk=1024 * 256)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rays_c = rays.cpu()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = tp.render(sd, cfg, rays_c, bounds, retraw=True)
+    res = render_parity(outs["fp32"], ref)
+    res["yardstick"] = parity_yardstick(tp, sd, cfg, rays_c, ref, outs["fp32"], inds)
+    gt = np.concatenate([scene.trace(*(t.double().cpu().numpy() for t in (rays[0][j * per_view:(j + 1) * per_view], rays[1][j * per_view:(j + 1) * per_view])))[0]
+                         for j in range(len(scene.i_test))])
+    psnr_gt = lambda a: round(float(-10 * np.log10(np.mean((a.detach().float().cpu().numpy() - gt) ** 2))), 2)  # noqa: E731
+    res["field"] = {"what": "shipped architecture trained on synthetic.ProceduralScene by this package on an MI355X (8000 all-parameter steps "
+                            "+ 1500 steps of the --fix_backbone head recipe; profiles/r05/a_trained_scene_training_log.json); rays: "
+                            f"{per_view} random pixels of each of the {len(scene.i_test)} held-out views",
+                    "reference_psnr_vs_analytic_gt_db": psnr_gt(ref["rgb"]), "gpu_fp32_psnr_vs_analytic_gt_db": psnr_gt(outs["fp32"]["rgb"]),
+                    "mean_acc": round(float(ref["acc"].mean()), 4)}
+    lab_ref = ref["semantics"].argmax(-1)
+    q = {}
+    for prec in ("fp16x3", "bf16", "fp16"):
+        o = outs[prec]
+        d = o["rgb"].cpu().double() - ref["rgb"].double()
+        q[prec] = {"psnr_db_rgb_vs_reference": round(float(-10 * torch.log10((d ** 2).mean() + 1e-30)), 2),
+                   "max_abs_rgb": float(d.abs().max()), "label_agreement": round(float((o["semantics"].cpu().argmax(-1) == lab_ref).float().mean()), 5),
+                   "max_rel_depth": float(((o["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs()).max()),
+                   "psnr_vs_analytic_gt_db": psnr_gt(o["rgb"])}
+    res["other_precisions_vs_reference"] = q
+    return res
+
+
+def hbm_kernel_rooflines(torch, dev, n_rays: int = 65536):
+    """HBM rooflines of the path's memory-bound kernels at the C5 chunk (65 536 rays, sem+coord: 6 channels): algorithmic bytes
+    (every input read once, every output written once) / mean HIP-event time of 20 back-to-back launches, against 8 TB/s.
+    north_star: "evidenced by rocprof HBM GB/s" -- profiles/r05 holds the rocprofv3 kernel trace of the same launches."""
+    from nerf_sos_amd import ops, synthetic as syn
+    R = n_rays
+    g = torch.Generator(device=dev).manual_seed(0)
+    rays = syn.image_rays(dev, (0, R))
+    d = rays[1].contiguous()
+    near, far = torch.full((R,), syn.NEAR, device=dev), torch.full((R,), syn.FAR, device=dev)
+    raw0 = torch.randn(R, N_COARSE, 6, device=dev, generator=g)
+    raw1 = torch.randn(R, N_FINE, 6, device=dev, generator=g)
+    z0, _ = ops.ray_setup(d, near, far, N_COARSE, None)
+    _, z1, _, _ = ops.composite_importance(raw0, z0, d, N_IMPORTANCE)
+    cases = {
+        "ray_setup_kernel": (lambda: ops.ray_setup(d, near, far, N_COARSE, None), R * (12 + 8 + 4 * N_COARSE + 12)),
+        "composite_importance_kernel": (lambda: ops.composite_importance(raw0, z0, d, N_IMPORTANCE),
+                                        R * (4 * N_COARSE * 6 + 4 * N_COARSE + 12 + 4 * N_COARSE + 32 + 4 * N_FINE + 4 * N_IMPORTANCE + 4)),
+        "composite_kernel<3>": (lambda: ops.composite(raw1, z1, d), R * (4 * N_FINE * 6 + 4 * N_FINE + 12 + 4 * N_FINE + 32)),
+    }
+    out = {}
+    for name, (fn, nbytes) in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        out[name] = {"bound": "hbm", "achieved": round(nbytes / us / 1e6, 3), "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+                     "frac": round(nbytes / us / 1e6 / PEAK_HBM_TBPS, 4), "kernel_us": round(us, 1), "algorithmic_mb": round(nbytes / 1e6, 1)}
+    return out
+
+
+def c5_trained_quality(torch, dev, precision: str, chunk: int = 65536):
+    """C5's `quality` on the TRAINED field: the full 1008x756 image of held-out pose 0 (the scene's field of view) in `precision`
+    and through the exact fp32 kernels (= the reference within 1e-4 on this field, parity.trained_field), PSNR / max-abs / labels,
+    and both against the analytic image.  Outside the timed region."""
+    import math
+    import numpy as np
+    import nerf_sos_amd
+    from nerf_sos_amd import io as nio, ops, synthetic as syn
+    scene = syn.ProceduralScene()
+    net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True, ray_chunk=chunk).to(dev).eval()
+    nio.load_checkpoint(TRAINED_CKPT, net)
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    i = scene.i_test[0]
+    H, W = syn.H, syn.W
+    focal = scene.focal * W / scene.w
+    rays = ops.generate_rays(H, W, syn.intrinsics(H, W, focal), scene.poses[i, :3, :4], dev).reshape(2, -1, 3)
+    res = {}
+    with torch.no_grad():
+        for prec in (precision, "fp32"):
+            net.mlp_precision = prec
+            ret = net(rays, (scene.NEAR, scene.FAR), retraw=False)
+            res[prec] = (ret["rgb"].clone(), ops.eval_postprocess(semantics=ret["semantics"])["sem"].clone(), ret["depth"].clone())
+    gt_rgb, gt_lab, _ = scene.view(i, H, W)
+    gt = torch.from_numpy(gt_rgb.reshape(-1, 3)).to(dev)
+    lo, hi = res[precision], res["fp32"]
+    mse = float(((lo[0] - hi[0]) ** 2).mean())
+    psnr = lambda a: round(-10.0 * math.log10(max(float(((a - gt) ** 2).mean()), 1e-30)), 2)   # noqa: E731
+    return {"psnr_db_rgb_vs_exact_fp32": round(-10.0 * math.log10(max(mse, 1e-30)), 2), "max_abs_rgb": float((lo[0] - hi[0]).abs().max()),
+            "label_agreement": round(float((lo[1] == hi[1]).float().mean()), 6),
+            "max_rel_depth": float(((lo[2] - hi[2]).abs() / hi[2].abs()).max()),
+            "psnr_vs_analytic_image_db": {precision: psnr(lo[0]), "fp32": psnr(hi[0])},
+            "what": f"full {W}x{H} image of held-out pose {i} of the TRAINED procedural scene (tests/golden/trained_scene.ckpt), {precision} vs the exact-fp32 kernels"}
+
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -585,10 +728,13 @@ def timed_blocks(ctx, step, warmup: int, steps: int, blocks: int):
 
 def speed_fields(ctx, rays_per_rank_step: int, steps: int, dt: float, per_rank):
     rates = [rays_per_rank_step * steps / t for t in per_rank]
-    return {"value": round(ctx.world * rays_per_rank_step * steps / dt, 1), "unit": "rays/s",
-            "ms_per_step": round(1e3 * dt / steps, 4),
-            "host_enqueue_ms_per_step": round(1e3 * getattr(ctx, "host_enqueue_s", 0.0) / steps, 4),   # rank 0's Python + launch time
-            "per_rank_rays_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1)}}
+    res = {"value": round(ctx.world * rays_per_rank_step * steps / dt, 1), "unit": "rays/s",
+           "ms_per_step": round(1e3 * dt / steps, 4),
+           "host_enqueue_ms_per_step": round(1e3 * getattr(ctx, "host_enqueue_s", 0.0) / steps, 4),   # rank 0's Python + launch time
+           "per_rank_rays_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1)}}
+    if ctx.world > 1:     # every rank's host share: at 16-bit rates an 8-GPU step is bound by the slowest HOST, not by xGMI
+        res["host_enqueue_ms_per_step_by_rank"] = [round(1e3 * t / steps, 4) for t in ctx.gather_times(getattr(ctx, "host_enqueue_s", 0.0))]
+    return res
 
 
 # ------------------------------------------------------------------------------------------------------------------ c2
@@ -756,26 +902,35 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
     # The same step as ONE HIP graph (single process only: graphs.GraphedPatchStep -- device-side Philox counter, loss generator
     # registered with the graph, capturable fused Adam; bit-identical to the eager step, tests/test_gpu_configs.py): one
     # hipGraphLaunch per step, the host out of the loop.  Timed over `steps` replays, outside the eager timed region.
+    # N > 1 (round 5): the step's four collectives are captured too when the group runs on RCCL; a gloo group (the one-GPU CI) or a
+    # capture RCCL refuses falls back to the eager step inside GraphedPatchStep -- `captured` / `fallback` say which ran.
     graph = None
-    if ctx.world == 1:
-        try:
-            opt_g = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4, fused=True, capturable=True)
-            g = nerf_sos_amd.GraphedPatchStep(net, opt_g, rays, (syn.NEAR, syn.FAR), feat, cls_, corr, geo, contrast, correlation_w=1.0,
-                                              geo_w=0.01, contrast_w=0.01, seed=0, warmup=2)
-            for _ in range(3):
-                g()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                g()
-            host = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            dtg = time.perf_counter() - t0
-            graph = {"ms_per_step": round(1e3 * dtg / steps, 4), "host_enqueue_ms_per_step": round(1e3 * host / steps, 4),
-                     "rays_per_s": round(n_rays * steps / dtg, 1), "loss": round(float(g.loss), 6),
-                     "what": "the whole step (render, losses, backward, Adam) captured once and replayed: GraphedPatchStep"}
-        except Exception as e:   # the eager numbers above stand on their own
-            graph = {"error": repr(e)[:300]}
+    try:
+        opt_g = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-4, fused=True, capturable=True)
+        g = nerf_sos_amd.GraphedPatchStep(net, opt_g, rays, (syn.NEAR, syn.FAR), feat, cls_, corr, geo, contrast, correlation_w=1.0,
+                                          geo_w=0.01, contrast_w=0.01, seed=0, warmup=2, n_patches=B)
+        for _ in range(3):
+            g()
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        ctx.barrier()
+        dtg = time.perf_counter() - t0
+        graph = {"ms_per_step": round(1e3 * dtg / steps, 4), "host_enqueue_ms_per_step": round(1e3 * host / steps, 4),
+                 "rays_per_s": round(ctx.world * n_rays * steps / dtg, 1), "loss": round(float(g.loss), 6), "captured": g.graph is not None,
+                 "what": "the whole step (render, losses, backward, Adam; N > 1: and its four collectives) captured once and replayed: GraphedPatchStep"}
+        if g.capture_fallback:
+            graph["fallback"] = g.capture_fallback
+        if ctx.world > 1:
+            graph["host_enqueue_ms_per_step_by_rank"] = [round(1e3 * t / steps, 4) for t in ctx.gather_times(host)]
+        sharding.reset_collective_counts()
+    except Exception as e:   # the eager numbers above stand on their own
+        graph = {"error": repr(e)[:300]}
+        if ctx.world > 1:
+            raise                # (a rank that dropped out of the collective sequence would hang the others: fail loudly instead)
     # diagnostics, outside the timed regions: three more eager steps with every collective bracketed by HIP events and host clocks
     # (sharding.COLLECTIVE_EVENTS) and the optimizer bracketed here -- what the first real multi-GPU run needs to be read from one line
     sharding.COLLECTIVE_EVENTS = {}
@@ -871,8 +1026,97 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1):
                        "mean_acc": round(float(hi["acc"].mean()), 4), "field": field,
                        "what": f"{rays.shape[1]} rays of the image through a dense field, {precision} vs the exact-fp32 kernels"}
     res.update(roofline=roof, rays_per_gpu=n_rays, precision=precision, image=f"{syn.W}x{syn.H}", chunk=chunk,
-               finite=bool(torch.isfinite(state["rgb"]).all().item()), quality=quality)
+               finite=bool(torch.isfinite(state["rgb"]).all().item()), quality_dense_random_field=quality)
+    if ctx.rank == 0:
+        del net
+        torch.cuda.empty_cache()
+        if precision != "fp32":
+            res["quality"] = c5_trained_quality(torch, ctx.dev, precision, chunk)
+        res["hbm_kernels"] = hbm_kernel_rooflines(torch, ctx.dev, chunk)
     return res
+
+
+def compact_line(line: dict) -> dict:
+    """The ONE line of the contract, under 6 KB: the headline fields in full, `roofline` and `cpu_baseline` with their required
+    keys, one short summary per parity field and per variant.  Everything else (per-key tables, timing blocks, traffic detail,
+    step breakdowns, the long descriptions) is in the `bench_detail` line printed just before and in ./bench_detail.json."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+    def roof(r):
+        if not r:
+            return None
+        c = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"))
+        c["kernel"] = str(r.get("kernel", ""))[:72]
+        if "traffic_detail" in r:
+            c["traffic_ratio_to_algorithmic"] = r["traffic_detail"].get("ratio_to_algorithmic")
+        for k in ("whole_path_frac", "whole_step_frac_forward_flops_only"):
+            if k in r:
+                c[k] = r[k]
+        c.setdefault("traffic", None)
+        return c
+
+    out = pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "data", "host_enqueue_ms_per_step", "finite", "loss"))
+    cfg = dict(line.get("config", {}))
+    cfg["workload"] = str(cfg.get("workload", ""))[:230]
+    out["config"] = cfg
+    out["roofline"] = roof(line.get("roofline"))
+    cb = line.get("cpu_baseline")
+    if cb:
+        c = pick(cb, ("value", "unit", "cores", "kind", "physical_cores"))
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        if "all_physical_cores" in cb:
+            c["all_physical_cores_rays_per_s"] = cb["all_physical_cores"].get("value")
+        if "frozen_recipe_train_step" in cb:
+            c["frozen_recipe_train_step_rays_per_s"] = cb["frozen_recipe_train_step"].get("value")
+        if cb.get("value"):
+            c["gpu_over_cpu"] = round(line["value"] / cb["value"], 1)
+        out["cpu_baseline"] = c
+    par = line.get("parity")
+    if par:
+        cp = {}
+        for name, f in par.items():
+            if not isinstance(f, dict) or "per_key" not in f:
+                continue
+            y = f.get("yardstick", {})
+            e = {"psnr_db_rgb": f["psnr_db"].get("rgb"), "coarse_all_inside_1e-4": f["coarse_pass_all_rays_inside_1e-4"],
+                 "frac_rays_outside_1e-4_any_fine_map": f["frac_rays_outside_1e-4_any_fine_map"],
+                 "frac_rays_outside_1e-4_image_maps": f.get("frac_rays_outside_1e-4_image_maps"),
+                 "gpu_rays_outside": y.get("gpu_rays_outside"), "reference_self_rays_outside": y.get("reference_self_sensitivity_rays_outside"),
+                 "index_flip_rays": y.get("index_flip_rays"), "rays": y.get("rays"),
+                 "max_abs_raw0_minus_fp64": y.get("max_abs_raw0_minus_fp64")}
+            if "other_precisions_vs_reference" in f:
+                e["vs_reference"] = {k: pick(v, ("psnr_db_rgb_vs_reference", "max_abs_rgb", "label_agreement")) for k, v in f["other_precisions_vs_reference"].items()}
+                e["reference_psnr_vs_analytic_gt_db"] = f["field"].get("reference_psnr_vs_analytic_gt_db")
+            cp[name] = e
+        out["parity"] = cp
+    if line.get("variants"):
+        cv = {}
+        for name, v in line["variants"].items():
+            if "value" not in v:                       # generic_paths_fp32: two sub-records
+                cv[name] = {k: pick(x, ("ms_per_step", "rays_per_s", "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point")) for k, x in v.items() if isinstance(x, dict)}
+                continue
+            e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "finite", "loss", "max_abs_rgb0_vs_exact_fp32"))
+            e["roofline"] = pick(roof(v.get("roofline")) or {}, ("frac", "kernel_ms", "kernel", "traffic", "whole_path_frac", "whole_step_frac_forward_flops_only"))
+            if "timing_blocks" in v:
+                e["ms_per_step_min_max"] = [v["timing_blocks"]["ms_per_step_min"], v["timing_blocks"]["ms_per_step_max"]]
+            g = v.get("whole_step_graph")
+            if isinstance(g, dict):
+                e["replayed"] = pick(g, ("ms_per_step", "rays_per_s", "host_enqueue_ms_per_step"))
+            if isinstance(v.get("quality"), dict):
+                e["quality_trained_field"] = pick(v["quality"], ("psnr_db_rgb_vs_exact_fp32", "max_abs_rgb", "label_agreement", "psnr_vs_analytic_image_db"))
+            if isinstance(v.get("hbm_kernels"), dict):
+                e["hbm_kernels"] = {k: pick(x, ("achieved", "frac", "kernel_us")) for k, x in v["hbm_kernels"].items()}
+            cv[name] = e
+        out["variants"] = cv
+    for k in ("quality", "hbm_kernels", "collectives", "whole_step_graph"):
+        if k in line and line[k] is not None:
+            out[k] = line[k] if k != "quality" else pick(line[k], ("psnr_db_rgb_vs_exact_fp32", "max_abs_rgb", "label_agreement", "psnr_vs_analytic_image_db"))
+    d = line.get("distributed", {})
+    out["distributed"] = pick(d, ("backend", "ranks_seen_by_collective", "calls_per_step_by_kind", "step_breakdown_ms", "host_enqueue_ms_per_step_by_rank"))
+    out["detail"] = "full tables: the stdout line before this one ({\"bench_detail\": ...}) and ./bench_detail.json"
+    return out
 
 
 def _strip(res):
@@ -880,7 +1124,7 @@ def _strip(res):
 
 
 # ---------------------------------------------------------------------------------------------------------------- main
-def run_generic_paths(ctx, rays_n: int = 4096, steps: int = 4):
+def run_generic_paths(ctx, rays_n: int = 4096, steps: int = 10):
     """The paths no BASELINE config names but the drop-in contract includes, timed briefly on the generic fp32 kernels (csrc/mlp_generic.hip):
     a FULL training step of a non-shipped architecture (8 x 256 without view directions: render in train mode, MSE on rgb + rgb0,
     backward through both nets, Adam) and a pose-refinement step on the shipped architecture (rays require grad, frozen net)."""
@@ -1031,7 +1275,8 @@ def main():
         line["roofline"] = add_traffic(res["roofline"], "c3_bf16" if args.config == "c3" else "c4_bf16") if prec == "bf16" else res["roofline"]
         line["collectives"] = res["collectives"]
         dist_info.update(collective_ms_by_kind=res.get("collective_ms_by_kind"), step_breakdown_ms=res.get("step_breakdown_ms"),
-                         calls_per_step_by_kind=res["collectives"]["calls_per_step_by_kind"])
+                         calls_per_step_by_kind=res["collectives"]["calls_per_step_by_kind"],
+                         host_enqueue_ms_per_step_by_rank=res.get("host_enqueue_ms_per_step_by_rank"))
         line["loss"] = res["loss"]
         line["whole_step_graph"] = res.get("whole_step_graph")
         line["contrastive_loss"] = res.get("contrastive_loss")
@@ -1072,7 +1317,20 @@ def main():
             line["cpu_baseline"], parity = cpu_baseline(gpu, dense=dense)
             if parity is not None:
                 line["parity"] = parity
-        print(json.dumps(line), flush=True)
+                if os.path.exists(TRAINED_CKPT) and prec == "fp32":
+                    del net, gpu, dense
+                    torch.cuda.empty_cache()
+                    parity["trained_field"] = trained_field_parity(torch, ctx.dev)
+        # The driver keeps the last 8 KB of stdout: the FULL record goes out first (one line, {"bench_detail": ...}, and
+        # ./bench_detail.json), then the line the contract asks for -- every headline field, every variant's value / ms / roofline,
+        # the parity summaries -- kept under 6 KB so that it survives whole.
+        print(json.dumps({"bench_detail": line}), flush=True)
+        try:
+            with open(os.path.join(os.getcwd(), "bench_detail.json"), "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError:
+            pass
+        print(json.dumps(compact_line(line)), flush=True)
     if ctx.world > 1:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()

@@ -76,18 +76,33 @@ class GraphedPatchStep:
         re-pack on every call), so a replay renders with the weights the previous replay's update produced;
       * static inputs: `rays`, `feat`, `cls_tokens` are the graph's own buffers -- `load()` copies a new batch into them.
     `eager_step()` runs the very same function without the graph (same generator, same counter): replay k and eager step k
-    produce the same bits (tests/test_gpu_sharded.py).  Single process only: with a process group the collectives between
-    the segments are host-driven (gloo) or would need RCCL's capture support, which this build could not be tested against.
+    produce the same bits (tests/test_gpu_sharded.py).
+
+    N > 1 (round 5): under a process group `rays` / `feat` / `cls_tokens` are this rank's patches (patch b -> rank
+    b mod N) and `n_patches` the batch's size; the step's four collectives (sharding.sharded_patch_step) are captured with the
+    kernels when the group runs on RCCL ("nccl": its work is enqueued on a stream and joins the capture like any kernel) -- the
+    eager step spends 1.25 of its 2.8 ms on host enqueue (profiles/r04/d_graph_step_time.txt), which is what an 8-GPU step would
+    otherwise be bound by.  A group whose collectives are host-driven (gloo) cannot be captured, and a capture that RCCL refuses
+    raises inside torch: both fall back to the eager step AUTOMATICALLY (`self.graph is None`, the reason in
+    `self.capture_fallback`), so the caller's loop is the same either way.  Every rank must construct the object (the warm-up
+    steps and the capture issue collectives).
     """
 
     def __init__(self, net, optimizer, rays: torch.Tensor, bounds: Tuple[float, float], feat: torch.Tensor, cls_tokens: torch.Tensor,
                  corr_loss=None, geo_loss=None, contrast_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01,
-                 contrast_w: float = 0.0, seed: int = 0, overlap_losses: bool = True, warmup: int = 3, capture: bool = True):
+                 contrast_w: float = 0.0, seed: int = 0, overlap_losses: bool = True, warmup: int = 3, capture: bool = True,
+                 group=None, n_patches: int = None):
         import torch.distributed as dist
         from . import sharding
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise NotImplementedError("GraphedPatchStep captures the single-process step; run sharding.sharded_patch_step eagerly "
-                                      "under a process group")
+        self.group, self.capture_fallback = group, None
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            if n_patches is None:
+                raise ValueError("GraphedPatchStep under a process group: pass n_patches (the size of the whole patch batch)")
+            if capture and dist.get_backend(group) != "nccl":
+                capture = False
+                self.capture_fallback = (f"process group backend {dist.get_backend(group)!r}: its collectives are driven by the host "
+                                         "and cannot be captured in a HIP graph; stepping eagerly")
         if not net.training:
             raise ValueError("GraphedPatchStep captures the train-mode step: call net.train() first")
         if net.rng != "philox":
@@ -98,7 +113,7 @@ class GraphedPatchStep:
                 raise ValueError("GraphedPatchStep: construct the optimizer with capturable=True (its step counter must live on the device)")
         dev = rays.device
         self.net, self.opt, self._sharding = net, optimizer, sharding
-        self.n_patches = int(rays.shape[1])
+        self.n_patches = int(rays.shape[1]) if n_patches is None else int(n_patches)
         self.rays, self.feat, self.cls = rays.clone(), feat.clone(), cls_tokens.clone()
         near, far = bounds
         n_rays = self.rays[0].numel() // 3
@@ -120,15 +135,30 @@ class GraphedPatchStep:
                     self.eager_step()
             torch.cuda.current_stream(dev).wait_stream(side)
             self.opt.zero_grad(set_to_none=True)          # the captured backward allocates the gradients in the graph's pool
-            self.graph = torch.cuda.CUDAGraph()
-            self.graph.register_generator_state(self.generator)
-            with torch.cuda.graph(self.graph):
-                self._step()
+            graph = torch.cuda.CUDAGraph()
+            graph.register_generator_state(self.generator)
+            if world == 1:
+                with torch.cuda.graph(graph):
+                    self._step()
+                self.graph = graph
+            else:
+                # RCCL work inside a capture: supported by ProcessGroupNCCL (the collective is enqueued on its stream, which the
+                # capture follows through the wait).  If this build refuses, every rank refuses alike (same library, same calls):
+                # fall back to eager on all of them instead of leaving the job half captured.
+                try:
+                    with torch.cuda.graph(graph):
+                        self._step()
+                    self.graph = graph
+                except Exception as e:   # noqa: BLE001  (torch raises RuntimeError / DistBackendError depending on where it fails)
+                    self.graph = None
+                    self.capture_fallback = f"capture of the sharded step failed ({type(e).__name__}: {str(e)[:200]}); stepping eagerly"
+                    torch.cuda.synchronize(dev)
+                    self.opt.zero_grad(set_to_none=True)
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
         loss = self._sharding.sharded_patch_step(self.net, self.rays, self.bounds, self.n_patches, self.feat, self.cls,
-                                                 generator=self.generator, group=None, **self.losses)
+                                                 generator=self.generator, group=self.group, **self.losses)
         self.opt.step()
         self.loss.copy_(loss)
 

@@ -68,7 +68,7 @@ def reset_collective_counts() -> Dict[str, int]:
 def collective(kind: str, launch: Callable[..., "dist.Work"], group=None):
     """Run `launch(async_op=True)` (a torch.distributed collective) under the watchdog and count it under `kind`."""
     COLLECTIVE_COUNTS[kind] = COLLECTIVE_COUNTS.get(kind, 0) + 1
-    if COLLECTIVE_EVENTS is not None and torch.cuda.is_available():
+    if COLLECTIVE_EVENTS is not None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
         import time
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()

@@ -42,8 +42,10 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 // ops: [16 sets][4096 lanes] u32x4; sets 0..7 = weight-like, 8..15 = activation-like (the host decides the distributions)
-template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP, bool SWAP>
-__global__ __launch_bounds__(512, 1) void k(const u32x4* __restrict__ ops, const unsigned char* __restrict__ wstream, float* out,
+//   WPS     waves per SIMD: 2 = 512-thread workgroups (the kernels' shape), 1 = 256-thread workgroups with up to 512 registers per
+//           wave (round 5: the only way a 64-point wave -- LDSN 2, DMAN 15 -- fits its registers: 128 H_in + 128 H_out + 64 acc)
+template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP, bool SWAP, int WPS>
+__global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops, const unsigned char* __restrict__ wstream, float* out,
                                             unsigned long long* stamps, int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -53,13 +55,13 @@ __global__ __launch_bounds__(512, 1) void k(const u32x4* __restrict__ ops, const
         x[i] = ops[(size_t)(8 + i) * 4096 + blockIdx.x % 8 * 512 + threadIdx.x];
     }
     if (LDSN) {   // fill the LDS image with weight-like operands
-        for (int o = threadIdx.x * 16; o < kLdsBytes; o += 512 * 16)
+        for (int o = threadIdx.x * 16; o < kLdsBytes; o += 256 * WPS * 16)
             *reinterpret_cast<u32x4*>(lds + o) = ops[(size_t)((o >> 16) & 7) * 4096 + ((o >> 4) & 4095)];
     }
     __syncthreads();
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     // this wave's read cursor in the LDS image: two 48 KiB windows, alternating per iteration; reads stay below 128 KiB
-    unsigned raddr = lds_base + lane * 16 + (unsigned)wave * 4096u;
+    unsigned raddr = lds_base + lane * 16 + (unsigned)wave * 4096u;   // (WPS 1: four waves, the same per-wave pattern)
     constexpr int NACC32 = 6, NACC16 = 12;
     f32x16 acc[NACC32];
     f32x4 acd[NACC16];
@@ -149,18 +151,18 @@ static unsigned short f2b(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); u 
 
 struct Bufs { u32x4* ops; unsigned char* wstream; float* out; unsigned long long* stamps; };
 
-template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP = 0, bool SWAP = false>
+template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP = 0, bool SWAP = false, int WPS = 2>
 void run(const char* name, const Bufs& B, int iters) {
-    auto kern = k<BF, SHAPE, LDSN, DMAN, VALU, SLEEP, SWAP>;
+    auto kern = k<BF, SHAPE, LDSN, DMAN, VALU, SLEEP, SWAP, WPS>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), kLdsBytes, 0, B.ops, B.wstream, B.out, B.stamps, 200);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(256 * WPS), kLdsBytes, 0, B.ops, B.wstream, B.out, B.stamps, 200);
     hipDeviceSynchronize();
     float best = 1e30f;
     double busy = 0, clock = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), kLdsBytes, 0, B.ops, B.wstream, B.out, B.stamps, iters);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(256 * WPS), kLdsBytes, 0, B.ops, B.wstream, B.out, B.stamps, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) {
@@ -170,15 +172,15 @@ void run(const char* name, const Bufs& B, int iters) {
             double span = 0;
             for (int b = 0; b < 256; ++b) {
                 unsigned long long lo = ~0ull, hi = 0;
-                for (int w = 0; w < 8; ++w) { lo = h[(b * 8 + w) * 2] < lo ? h[(b * 8 + w) * 2] : lo; hi = h[(b * 8 + w) * 2 + 1] > hi ? h[(b * 8 + w) * 2 + 1] : hi; }
+                for (int w = 0; w < 4 * WPS; ++w) { lo = h[(b * 8 + w) * 2] < lo ? h[(b * 8 + w) * 2] : lo; hi = h[(b * 8 + w) * 2 + 1] > hi ? h[(b * 8 + w) * 2 + 1] : hi; }
                 span += (double)(hi - lo);
             }
             span /= 256;
-            busy = 2.0 * 48.0 * iters * 32.0 / span;     // two waves per SIMD x units x 32 pipe cycles per unit
+            busy = WPS * 48.0 * iters * 32.0 / span;     // waves per SIMD x units x 32 pipe cycles per unit
             clock = span / (ms * 1e6);
         }
     }
-    const double flop = 2.0 * 32 * 32 * 16 * 48.0 * iters * 256 * 8;
+    const double flop = 2.0 * 32 * 32 * 16 * 48.0 * iters * 256 * 4 * WPS;
     const double tf = flop / (best * 1e-3) / 1e12;
     printf("%-5s %-36s %8.3f ms  chip %7.1f TFLOP/s = %.3f of 2516 | pipe busy %.3f at %.3f GHz (s_memtime span)\n", BF ? "bf16" : "f16", name, best,
            tf, tf / 2516.6, busy, clock);
@@ -218,6 +220,13 @@ void all(const Bufs& B, std::vector<unsigned short>& h, int iters) {
     run<BF, 16, 1, 7, 0>("16x16x32 lds/1 dma/7", B, iters);
     run<BF, 16, 1, 7, 1>("16x16x32 lds/1 dma/7 valu 1", B, iters);
     run<BF, 16, 2, 15, 1>("16x16x32 lds/2 dma/15 valu 1", B, iters);
+    // one wave per SIMD (round 5): what a 64-point wave with all of H_in / H_out in its 512 registers could sustain
+    run<BF, 16, 0, 0, 0, 0, false, 1>("16x16x32 regs, ONE wave/SIMD", B, iters);
+    run<BF, 16, 2, 0, 0, 0, false, 1>("16x16x32 lds/2, ONE wave/SIMD", B, iters);
+    run<BF, 16, 2, 15, 0, 0, false, 1>("16x16x32 lds/2 dma/15, ONE wave/SIMD", B, iters);
+    run<BF, 16, 2, 15, 1, 0, false, 1>("16x16x32 lds/2 dma/15 valu 1, ONE wave/SIMD", B, iters);
+    run<BF, 16, 2, 7, 1, 0, false, 1>("16x16x32 lds/2 dma/7 valu 1, ONE wave/SIMD", B, iters);
+    run<BF, 32, 2, 15, 1, 0, false, 1>("32x32x16 lds/2 dma/15 valu 1, ONE wave/SIMD (= lp4)", B, iters);
     fill(true);
     run<BF, 32, 0, 0, 0>("32x32x16 regs, dense N(0,1) both", B, iters);
     run<BF, 16, 0, 0, 0>("16x16x32 regs, dense N(0,1) both", B, iters);

@@ -906,10 +906,20 @@ def test_heads_only_repack_equals_a_full_pack(manifest, name, precision):
     a = mlp.packed_weights(precision).clone()
     with torch.no_grad():
         params["semantic_linear.2.bias"].add_(1.0)
+        params["semantic_linear.0.weight"].mul_(1.25)
     b = mlp.packed_weights(precision)
     assert not torch.equal(a.view(torch.int32), b.view(torch.int32))
     full = plan.run(None, precision)
-    assert not torch.equal(b.view(torch.int32), full.view(torch.int32))        # (the streams of the kernels not selected keep the old heads)
+    # the stream of the selected kernel, stream 0 (the fall-back kernel's: fp32 sem_in saves, >= 2^31 points -- ADVICE r04) and the
+    # vector-ALU heads' block are current; the remaining stream (mlp_lp8_kernel's) keeps the old heads until the next full pack
+    assert not torch.equal(b.view(torch.int32), full.view(torch.int32))
+    r_sel = ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z)
+    assert torch.equal(r_sel, ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
+    try:   # stream 0 is current too: the round-1 kernel renders the new heads from the partly re-packed buffer
+        _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(1), "select")
+        assert torch.equal(ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z), ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
+    finally:
+        _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(3), "select")
     assert torch.equal(ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z), ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
     # a change of the kernel selection forces a full pack (the other streams' heads would be stale)
     try:

@@ -205,8 +205,9 @@ def test_free_running_render_at_c2_size(manifest, peaky):
          OWN rounding error: its coarse network evaluated in fp64 (and rounded to fp32 once) instead of fp32, everything
          else unchanged, gives N_self rays in which the reference leaves the 1e-4 band around ITSELF.  "HIP vs reference"
          carries TWO independent realisations of that rounding noise (the HIP path's and the reference's, each against the
-         exact values), "reference vs fp64" one: sqrt(2) N_self is the expectation for a coarse pass exactly as accurate as
-         the reference's.  Measured (round 4, deterministic: eval mode, fixed seeds): 34 vs N_self 21 (default-init), 43 vs 26
+         exact values), "reference vs fp64" one: for a coarse pass exactly as accurate as the reference's the expectation lies
+         between sqrt(2) N_self (rays leaving the band by a continuous amplitude) and 2 N_self (rays moved by a discrete flip: the
+         union of two independent rare-event sets).  Measured (round 4, deterministic: eval mode, fixed seeds): 34 vs N_self 21 (default-init), 43 vs 26
          (spiky) = 1.62 / 1.65 N_self; asserted <= 1.5 N_self + 8 (round 3 allowed 2 N_self + 8).  bench.py prints the same
          pair for the headline batch (`parity.*.yardstick`: 41 vs 47 on the dense field, 0 vs 0 on the default-init one)."""
     cfg = tp.PortConfig(n_importance=128, **CFGS["semcoord"])
@@ -263,7 +264,12 @@ def test_free_running_render_at_c2_size(manifest, peaky):
     print(f"C2 size, {'spiky' if peaky else 'default-init'} field: {flip_rays} rays with an index flip; max |raw0 - fp64 raw0|: reference "
           f"{e_ref:.2e}, HIP {e_hip:.2e}; rays outside 1e-4 of the reference: HIP {n_hip} ({100 * n_hip / 4096:.2f} %), the reference "
           f"with an fp64 coarse network {n_self} ({100 * n_self / 4096:.2f} %)")
-    assert e_hip <= 2.0 * e_ref + 1e-7, "the coarse raw must be as close to the exact values as the reference's own"
+    # measured 1.44 (default-init: 9.7e-8 vs 6.7e-8) and 1.62 (spiky, this net: 4.05e-6 vs 2.50e-6; bench's dense field 1.30): the kernel's
+    # k-sequential fmaf chain against ATen's blocked summation.  VERDICT r04 next-8 asked for 1.5 x or a chain blocked in four partial
+    # sums: the latter needs four accumulator sets where the kernel's 128 AGPRs hold one (csrc/mlp_fused.hip: 512 registers, all in
+    # use), so the bar is tightened to what is measured (was 2 x) and the trained-field pin (tests/test_gpu_trained.py) shows the
+    # distance where it matters: 3.62e-5 vs the reference's own 3.43e-5 = 1.06 x on trained weights.
+    assert e_hip <= 1.75 * e_ref + 2e-8, "the coarse raw must be as close to the exact values as the reference's own"
     assert n_hip <= 1.5 * n_self + 8, f"{n_hip} rays outside 1e-4 vs {n_self} for the reference against its own fp64 coarse pass"
     mse = float(((N(out['rgb']) - N(ref['rgb'])) ** 2).mean())
     assert 10 * np.log10(1.0 / max(mse, 1e-30)) > 75.0, "PSNR of rgb vs the reference path"

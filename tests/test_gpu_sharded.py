@@ -250,3 +250,91 @@ def _watchdog_worker(rank, port, q):
             dist.destroy_process_group()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------- the sharded step as a HIP graph (round 5)
+def _graph_worker(rank, world, port, backend, q):
+    """Every rank: GraphedPatchStep under the process group (captured with its four collectives on RCCL; automatic eager fall-back on
+    gloo) for three steps, and a twin net stepped eagerly by sharding.sharded_patch_step with the same generator / Philox counter:
+    same loss and same parameters after every step, on every rank."""
+    import nerf_sos_amd
+    from nerf_sos_amd import sharding, synthetic as syn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok, why = True, []
+        B, P = 4, 16
+        rays, feat, cls_ = _batch(B, P, dev)
+        own = sharding.local_patches(B, rank, world)
+        nets, opts, steps = [], [], []
+        for twin in range(2):
+            net = _build(dev)
+            net.perturb, net.raw_noise_std = 1.0, 1.0
+            net.render_kwargs_train.update(perturb=1.0, raw_noise_std=1.0)
+            net.rng, net.rng_seed = "philox", 3 + rank
+            opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-3, fused=True, capturable=True)
+            corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+            g = nerf_sos_amd.GraphedPatchStep(net, opt, rays[:, own].contiguous(), (syn.NEAR, syn.FAR), feat[own], cls_[own], corr, geo,
+                                              seed=21, warmup=2, capture=(twin == 0), n_patches=B)
+            nets.append(net), opts.append(opt), steps.append(g)
+        graphed, eager = steps
+        if backend == "gloo":
+            if graphed.graph is not None or "gloo" not in (graphed.capture_fallback or ""):
+                ok = False
+                why.append(f"a gloo group must fall back to eager: graph={graphed.graph}, reason={graphed.capture_fallback!r}")
+        elif graphed.graph is None:
+            why.append(f"RCCL capture fell back: {graphed.capture_fallback}")      # allowed (reported), the numbers below must still agree
+        for k in range(3):
+            la, lb = float(graphed()), float(eager())
+            if abs(la - lb) > 1e-6 * (1 + abs(lb)):
+                ok = False
+                why.append(f"step {k}: loss {la} (graphed) vs {lb} (eager)")
+        for (n_, p_), (_, r_) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+            if p_.requires_grad and not torch.equal(p_, r_):
+                err = float((p_ - r_).abs().max())
+                if err > 1e-7:
+                    ok = False
+                    why.append(f"{n_}: graphed and eager parameters differ by {err:.2e} after three steps")
+        # the ranks hold the same parameters (one gradient all-reduce per step)
+        flat = torch.cat([p_.detach().reshape(-1) for p_ in nets[0].parameters() if p_.requires_grad])
+        mx, mn = flat.clone(), flat.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        if not torch.equal(mx, mn):
+            ok = False
+            why.append("the ranks' parameters diverged")
+        q.put((rank, ok, "; ".join(why)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_graph(backend, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 211 + (7 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[:2] for r in res) == [(r_, True) for r_ in range(world)], res
+    return res
+
+
+@pytest.mark.timeout(600)
+def test_graphed_step_under_a_gloo_group_falls_back_to_eager():
+    _run_graph("gloo")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has one")
+def test_graphed_step_two_ranks_over_rccl():
+    """The first multi-GPU box answers whether this build's RCCL accepts the capture: either way the replayed and the eager step
+    must agree; the outcome (captured / fell back, with the reason) is printed."""
+    print(_run_graph("nccl"))
