@@ -1058,6 +1058,7 @@ def compact_line(line: dict) -> dict:
 
     out = pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                       "dtype", "data", "host_enqueue_ms_per_step", "finite", "loss"))
+    out["vs_baseline"] = line.get("vs_baseline")          # (null: BASELINE.md holds no published number for this metric)
     cfg = dict(line.get("config", {}))
     cfg["workload"] = str(cfg.get("workload", ""))[:230]
     out["config"] = cfg
@@ -1097,7 +1098,7 @@ def compact_line(line: dict) -> dict:
             if "value" not in v:                       # generic_paths_fp32: two sub-records
                 cv[name] = {k: pick(x, ("ms_per_step", "rays_per_s", "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point")) for k, x in v.items() if isinstance(x, dict)}
                 continue
-            e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "finite", "loss", "max_abs_rgb0_vs_exact_fp32"))
+            e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_by_rank", "finite", "loss", "max_abs_rgb0_vs_exact_fp32"))
             e["roofline"] = pick(roof(v.get("roofline")) or {}, ("frac", "kernel_ms", "kernel", "traffic", "whole_path_frac", "whole_step_frac_forward_flops_only"))
             if "timing_blocks" in v:
                 e["ms_per_step_min_max"] = [v["timing_blocks"]["ms_per_step_min"], v["timing_blocks"]["ms_per_step_max"]]

@@ -60,8 +60,16 @@ __device__ __forceinline__ float composite_ray(const int64_t r, const int lane, 
             for (int k = 0; k < 6; ++k) c[k] = k < C ? lp[k] : 0.0f;
         } else {
             const float* gp = rr + (int64_t)(live ? s : 0) * C;
+            if (C == 6 || C == 4) {              // rows of 24 / 16 bytes: 8-byte aligned pairs (three / two loads instead of six / four)
+                const float2* gp2 = reinterpret_cast<const float2*>(gp);
+                const float2 a = gp2[0], b = gp2[1];
+                c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y;
+                c[4] = c[5] = 0.0f;
+                if (C == 6) { const float2 e = gp2[2]; c[4] = e.x; c[5] = e.y; }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) c[k] = k < C ? gp[k] : 0.0f;
+                for (int k = 0; k < 6; ++k) c[k] = k < C ? gp[k] : 0.0f;
+            }
         }
         float dist = (s + 1 < S) ? (z[i + 1] - z[i]) : 1e10f;  // :35-37
         dist = dist * norm;
@@ -77,15 +85,9 @@ __device__ __forceinline__ float composite_ray(const int64_t r, const int lane, 
         tloc[i] = prod;
         if (live) prod *= (double)((1.0f - a) + 1e-10f);  // :57
     }
-    // exclusive scan of the lane products across the wave
-    double incl = prod;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(incl, off, NSOS_WAVE);
-        if (lane >= off) incl *= o;
-    }
-    double excl = __shfl_up(incl, 1, NSOS_WAVE);
-    if (lane == 0) excl = 1.0;
+    // exclusive scan of the lane products across the wave (DPP: no LDS round trips, common.h)
+    const double incl = nsos_wave_scan_incl<true>(prod);
+    const double excl = nsos_wave_shr1(incl, 1.0);
 
     double s_rgb[3] = {0, 0, 0}, s_sem[2] = {0, 0}, s_depth = 0, s_acc = 0;
 #pragma unroll

@@ -13,6 +13,7 @@ __device__ __forceinline__ bool nan_last_gt(float a, float b) { return (a > b) |
 
 template <int CAP_S, int CAP_M>
 struct ImportanceLdsT {
+    static constexpr int kCapS = CAP_S, kCapM = CAP_M;
     float cdf[CAP_S];    // S - 1 used
     float bins[CAP_S];   // S - 1 used
     float vals[CAP_M];   // coarse z (S) followed by the new samples (N)
@@ -31,10 +32,15 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
     double s1 = 0.0;
     for (int i = lane; i < N; i += 64) {
         const float u = u_in ? u_in[r * N + i] : nsos_linspace01(i, N);
-        int lo = 0, hi = NB;  // searchsorted(right=True): count of entries <= u
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (L.cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        // searchsorted(right=True): count of entries <= u.  Branch-free descent over powers of two (round 5: the while-loop form cost
+        // ~12 instructions and one exec-mask round trip per step; the kernel is issue-bound at one wave per ray): the same count for
+        // every nondecreasing cdf.
+        int lo = 0;
+#pragma unroll
+        for (int step = LDS::kCapS / 2; step >= 1; step >>= 1) {
+            const int t = lo + step;
+            const float c = L.cdf[(t <= NB ? t : NB) - 1];
+            lo = (t <= NB && c <= u) ? t : lo;
         }
         if (inds_out) inds_out[r * N + i] = lo;
         const int below = lo - 1 > 0 ? lo - 1 : 0;
@@ -78,15 +84,18 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
         int np = 64;
         while (np < N) np <<= 1;
         const int nq = np >> 6;
-        float v[QMAX];
-        // padding orders after EVERYTHING, NaNs included (a +inf pad would sort in front of a poisoned ray's NaN samples and
-        // push them out of the first N slots): a NaN of its own bit pattern, recognised by the comparator.  Should a
-        // sample carry the same pattern it is a NaN like any other, and a NaN is what comes back.
-        const float kPad = __uint_as_float(0x7fffffffu);
-        auto is_pad = [](float x) { return __float_as_uint(x) == 0x7fffffffu; };
-        auto gt = [&](float a, float b) { return is_pad(b) ? false : (is_pad(a) ? true : nan_last_gt(a, b)); };
+        // Sorted as unsigned KEYS (round 5): key(x) is monotone in x for every non-NaN float (sign bit flipped for x >= 0, all bits
+        // for x < 0), NaNs and the padding share the largest key -- both order after everything, as torch.sort orders NaNs, and a
+        // poisoned ray's NaN samples stay inside the first N slots because only padding can tie with them.  A compare-exchange is then
+        // v_min_u32 / v_max_u32 (the float comparator with its NaN and padding cases was ~15 instructions per element and stage:
+        // 180 of the 266 us of a 65 536-ray train-mode launch).  A NaN comes back as the canonical quiet NaN.
+        unsigned v[QMAX];
+        auto key = [](float x) -> unsigned {
+            const unsigned b = __float_as_uint(x);
+            return (x != x) ? 0xffffffffu : (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u));
+        };
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) v[q] = (q < nq && q * 64 + lane < N) ? smp[q * 64 + lane] : kPad;
+        for (int q = 0; q < QMAX; ++q) v[q] = (q < nq && q * 64 + lane < N) ? key(smp[q * 64 + lane]) : 0xffffffffu;
         for (int k = 2; k <= np; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 if (j >= 64) {                       // partner element lives in another register of the same lane
@@ -94,24 +103,21 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
 #pragma unroll
                     for (int q = 0; q < QMAX; ++q) {
                         if (q < nq && (q & dq) == 0) {
-                            const int e = q * 64 + lane;
-                            const bool up = (e & k) == 0;
-                            const float a = v[q], b = v[q | dq];
-                            const bool swap = up ? gt(a, b) : gt(b, a);
-                            v[q] = swap ? b : a;
-                            v[q | dq] = swap ? a : b;
+                            const bool up = ((q * 64 + lane) & k) == 0;
+                            const unsigned a = v[q], b = v[q | dq];
+                            const unsigned mn = a < b ? a : b, mx = a < b ? b : a;
+                            v[q] = up ? mn : mx;
+                            v[q | dq] = up ? mx : mn;
                         }
                     }
                 } else {                             // partner element lives in lane ^ j, same register
 #pragma unroll
                     for (int q = 0; q < QMAX; ++q) {
                         if (q < nq) {
-                            const int e = q * 64 + lane;
-                            const bool up = (e & k) == 0, lower = (lane & j) == 0;
-                            const float o = __shfl_xor(v[q], j, NSOS_WAVE);
-                            // this lane keeps the smaller of the pair iff (up == lower); select, never fmin/fmax: those drop NaNs
-                            const bool take = (up == lower) ? gt(v[q], o) : gt(o, v[q]);
-                            v[q] = take ? o : v[q];
+                            const bool up = ((q * 64 + lane) & k) == 0, lower = (lane & j) == 0;
+                            const unsigned o = (unsigned)__shfl_xor((int)v[q], j, NSOS_WAVE);
+                            const unsigned mn = v[q] < o ? v[q] : o, mx = v[q] < o ? o : v[q];
+                            v[q] = (up == lower) ? mn : mx;      // this lane keeps the smaller of the pair iff (up == lower)
                         }
                     }
                 }
@@ -119,7 +125,10 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
         }
 #pragma unroll
         for (int q = 0; q < QMAX; ++q)
-            if (q < nq && q * 64 + lane < N) smp[q * 64 + lane] = v[q];
+            if (q < nq && q * 64 + lane < N) {
+                const unsigned kq = v[q];
+                smp[q * 64 + lane] = __uint_as_float(kq ^ ((kq >> 31) ? 0x80000000u : 0xffffffffu));   // (key 0xffffffff -> 0x7fffffff: NaN)
+            }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -142,21 +151,25 @@ __device__ __forceinline__ void importance_tail(LDS& L, const int64_t r, const i
         }
         return;
     }
-    for (int j = lane; j < S; j += 64) {             // coarse z_j: count of samples strictly below it
+    for (int j = lane; j < S; j += 64) {             // coarse z_j: count of samples strictly below it (both lists are in order here)
         const float z = L.vals[j];
-        int lo = 0, hi = N;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (nan_last_gt(z, smp[mid])) lo = mid + 1; else hi = mid;
+        int lo = 0;
+#pragma unroll
+        for (int step = 256; step >= 1; step >>= 1) {        // N <= NSOS_MAX_IMPORTANCE = 448 < 512
+            const int t = lo + step;
+            const float o = smp[(t <= N ? t : N) - 1];
+            lo = (t <= N && nan_last_gt(z, o)) ? t : lo;
         }
         z_fine[r * M + j + lo] = z;
     }
     for (int i = lane; i < N; i += 64) {             // sample s_k: count of coarse z <= s_k
         const float sv = smp[i];
-        int lo = 0, hi = S;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (!nan_last_gt(L.vals[mid], sv)) lo = mid + 1; else hi = mid;
+        int lo = 0;
+#pragma unroll
+        for (int step = LDS::kCapS; step >= 1; step >>= 1) {     // (the count reaches S itself: one more step than the cdf search)
+            const int t = lo + step;
+            const float o = L.vals[(t <= S ? t : S) - 1];
+            lo = (t <= S && !nan_last_gt(o, sv)) ? t : lo;
         }
         z_fine[r * M + i + lo] = sv;
     }
@@ -186,12 +199,7 @@ __device__ __forceinline__ void importance_ray(ImportanceLds& L, const int64_t r
         const float w = inner ? (wlane + 1e-5f) : 0.0f;
         const float fsum = (float)nsos_wave_sum((double)w);
         const float pdf = inner ? (w / fsum) : 0.0f;
-        double run = (double)pdf;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double o = __shfl_up(run, off, NSOS_WAVE);
-            if (lane >= off) run += o;
-        }
+        const double run = nsos_wave_scan_incl<false>((double)pdf);   // (DPP scan: common.h)
         cdf = (float)run;  // lane 0: pdf 0 -> 0
     }
     if (lane < NB) {
