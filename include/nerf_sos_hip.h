@@ -28,8 +28,9 @@ extern "C" {
 
 /* bumped whenever an existing entry point's arguments or buffer formats change (2: 16-bit / tile-major saved operands of
  * nsos_mlp_forward_rays_save16_lp and nsos_sem_head_wgrad_x3; 3: pose_rows in nsos_patch_batch / nsos_pixel_batch; 4: the tile-major
- * sem_hid16 of the default 16-bit kernel, nsos_mlp_save16_layout's NSOS_SEM_HID_TILED bit) */
-#define NSOS_ABI_VERSION 5
+ * sem_hid16 of the default 16-bit kernel, nsos_mlp_save16_layout's NSOS_SEM_HID_TILED bit; 6: `scale` of nsos_mlp_input_grads_x3[_a16]
+ * is three floats -- trunk scale, colour-branch factor, semantic-branch factor) */
+#define NSOS_ABI_VERSION 6
 
 enum {
     NSOS_OK = 0,
@@ -418,8 +419,11 @@ int32_t nsos_wgrad_x3(const float* G, int32_t ldg, const float* X, int32_t ldx, 
  * acts [P,NSOS_ACTS_DIM] saved by nsos_mlp_forward_rays_save_all[_x3] it writes gbuf [P,NSOS_GBUF_DIM], the gradients
  * with respect to every layer's pre-activation in the column map of acts (256 l: pts_linears.l, NSOS_ACTS_FEAT:
  * feature_linear output, NSOS_ACTS_VIEWS: views_linears.0, NSOS_ACTS_SEM: semantic_linear.0), each the GEMM input of
- * nsos_wgrad.  `scale` (device scalar, a power of two bringing max |g_raw| to ~2^4) is applied to g_raw on load: all of
- * gbuf is scaled by it and the weight gradients must be divided by it.  relu_masks: the bit masks written by
+ * nsos_wgrad.  `scale`: THREE powers of two in device memory, applied to g_raw on load -- scale[0] brings max |g_raw| over all
+ * channels to ~2^4 (the trunk's columns 256 l of gbuf carry it); scale[1] >= 1 is the colour branch's extra factor (blocks
+ * NSOS_ACTS_VIEWS and NSOS_ACTS_FEAT carry scale[0] scale[1]); scale[2] >= 1 the semantic branch's (block NSOS_ACTS_SEM carries
+ * scale[0] scale[2]): a branch whose upstream gradient is decades under the largest one keeps fp16's full precision (ABI 6).  The
+ * weight gradients must be divided by the scale their gbuf block carries.  relu_masks: the bit masks written by
  * nsos_mlp_forward_rays_save_all_x3 for the same points, or NULL to derive the trunk masks from acts (fp32 reads).
  * Weights are packed (transposed, split fp16) by
  * nsos_mlp_bwd_pack_x3 into nsos_mlp_bwd_packed_bytes_x3 bytes. */

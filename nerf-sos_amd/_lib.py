@@ -135,7 +135,7 @@ SIGNATURES = {
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 
-ABI_VERSION = 5          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
+ABI_VERSION = 6          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
 _lib = None
 
 

@@ -39,10 +39,17 @@ def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, pa
     # fp16 has 5 exponent bits: bring max |g_raw| to ~2^4 with an exact power of two (no host sync), undo on the results.
     # 2^4 leaves a factor 2^12 of growth along the chain before fp16 overflows and 2^-18 of shrinkage before the hi parts
     # go subnormal (layer gains of trained NeRFs are O(1)).
-    amax = g_raw.abs().max().clamp_min(1e-30)
-    scale = torch.exp2(torch.floor(torch.log2(16.0 / amax))).clamp(2.0 ** -60, 2.0 ** 60).reshape(1)
-    inv = 1.0 / scale
-    gbuf = ops.mlp_input_grads_x3(packed_bwd, sem_mode, g_raw, acts, scale, masks)   # masks: ReLU bit masks of the forward, or None
+    # Round 5: per BRANCH.  The colour channels (0..2), sigma (3) and the logits (4..) of g_raw come from different losses -- img2mse's
+    # batch mean next to per-logit gradients of the correlation losses -- and sit decades apart; a branch scaled by the common factor
+    # alone loses its lo parts to fp16's subnormals (2-5e-4 of scale in feature_linear's gradient on a trained field).  scale3 =
+    # [trunk scale, colour factor, semantic factor] (csrc/mlp_x3_bwd.hip); inv_* undo them on the blocks that carry them.
+    am = g_raw.abs().amax(0)                                                   # [C]
+    grp = torch.stack([am.max(), am[:3].max(), am[4:].max() if C > 4 else am.max()]).clamp_min(1e-30)
+    lg = torch.floor(torch.log2(torch.cat([16.0 / grp[:1], grp[:1] / grp[1:]])))
+    scale3 = torch.exp2(torch.cat([lg[:1].clamp(-60, 60), lg[1:].clamp(0, 40)]))
+    inv = 1.0 / scale3[0:1]
+    inv_rgb, inv_sem = inv / scale3[1:2], inv / scale3[2:3]
+    gbuf = ops.mlp_input_grads_x3(packed_bwd, sem_mode, g_raw, acts, scale3, masks)   # masks: ReLU bit masks of the forward, or None
     G = lambda a, n: gbuf[:, a:a + n]    # noqa: E731
     out: Dict[str, torch.Tensor] = {}
 
@@ -61,10 +68,10 @@ def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, pa
     dWv, db = torch.empty((128, W + 32), **f32), torch.empty((128,), **f32)
     ops.wgrad(G(ACTS_VIEWS, 128), col(ACTS_FEAT, W), dWv[:, :W], db)
     ops.wgrad(G(ACTS_VIEWS, 128), col(ACTS_D, 32), dWv[:, W:])
-    out["views_linears.0.weight"], out["views_linears.0.bias"] = dWv[:, :W + 27] * inv, db * inv
+    out["views_linears.0.weight"], out["views_linears.0.bias"] = dWv[:, :W + 27] * inv_rgb, db * inv_rgb
     dWf, dbf = torch.empty((W, W), **f32), torch.empty((W,), **f32)
     ops.wgrad(G(ACTS_FEAT, W), h(7), dWf, dbf, split_fp16=split_wgrad)
-    out["feature_linear.weight"], out["feature_linear.bias"] = dWf * inv, dbf * inv
+    out["feature_linear.weight"], out["feature_linear.bias"] = dWf * inv_rgb, dbf * inv_rgb
     if sem_mode != SEM_NONE:
         dWs, dbs = torch.empty((128, W + 64), **f32), torch.empty((128,), **f32)
         ops.wgrad(G(ACTS_SEM, 128), h(7), dWs[:, :W], dbs)
@@ -72,7 +79,7 @@ def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, pa
         if sem_mode == SEM_COORD:
             ops.wgrad(G(ACTS_SEM, 128), col(ACTS_X, 64), dWs[:, W:])
             n_in = W + 63
-        out["semantic_linear.0.weight"], out["semantic_linear.0.bias"] = dWs[:, :n_in] * inv, dbs * inv
+        out["semantic_linear.0.weight"], out["semantic_linear.0.bias"] = dWs[:, :n_in] * inv_sem, dbs * inv_sem
     tmp_x = torch.empty((W, 64), **f32)
     for l in range(7, -1, -1):
         g = G(W * l, W)

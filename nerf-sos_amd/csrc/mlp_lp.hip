@@ -478,11 +478,13 @@ extern "C" int32_t nsos_mlp_pack_lp(const nsos_mlp_tensors* T_, int32_t sem_mode
 }
 // Only what depends on semantic_linear.*: the head's chunks of all three streams (chunks 30.. of each: the trunk's 30 chunks come
 // first in every layout) and the aux block.  For the shipped training recipe (--fix_backbone: only the semantic heads train,
-// run_nerf.py:307-318) a step re-packs 3 chunks instead of 37-40 -- in the stream of the kernel that is selected NOW
-// (nsos_mlp_lp_selected_kernel) AND in stream 0 + the aux block (round 5, ADVICE r04: forward_rays_lp falls back to the round-1
-// kernel on stream 0 for fp32 sem_in saves and launches of >= 2^31 points, whatever is selected -- it must never see stale heads);
-// `packed` must hold a full pack of the same trunk, and after nsos_mlp_lp_select_kernel the next pack must be a full one (the
-// remaining stream's heads are stale).
+// run_nerf.py:307-318) a step re-packs 3 chunks instead of 37-40 -- and only in the stream of the kernel that is selected NOW
+// (nsos_mlp_lp_selected_kernel: one launch per net and step instead of three); `packed` must hold a full pack of the same trunk.
+// CONTRACT: after a heads-only re-pack only the selected kernel's stream is current.  A launch that takes another stream -- after
+// nsos_mlp_lp_select_kernel, or forward_rays_lp's fall-back to the round-1 kernel on stream 0 (fp32 sem_in saves:
+// nsos_mlp_forward_rays_save_lp; launches of >= 2^31 points) -- needs a FULL pack first.  The Python layer enforces it: ops.PackPlan
+// tags the buffer and ops.mlp_forward_rays_lp / mlp_forward_rays_save raise instead of rendering stale heads (re-packing
+// stream 0 on every step as well was tried first: +10 us per C3 step for a path no training step takes).
 extern "C" int32_t nsos_mlp_pack_lp_heads(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_t dtype, void* packed,
                                           size_t packed_bytes, void* stream) {
     NSOS_REQUIRE(sem_mode == NSOS_SEM_PLAIN || sem_mode == NSOS_SEM_COORD, NSOS_ERR_UNSUPPORTED);
@@ -502,7 +504,7 @@ static int32_t pack_lp_impl(const nsos_mlp_tensors* T_, int32_t sem_mode, int32_
     const int X = NSOS_XYZ_DIM, W = NSOS_NET_WIDTH;
     const int selected = lp_waves_per_simd();
     for (int layout = 0; layout < 2; ++layout) {   // 0: slice-major hidden layers (mlp_lp_kernel), 1: tile-pair-major (mlp_lp8_kernel)
-        if (heads_only && layout != 0 && selected != layout + 1) continue;   // stream 0 always: forward_rays_lp's fallback (fp32 sem_in saves, >= 2^31 points) runs on it
+        if (heads_only && selected != layout + 1) continue;
         LpPackParams P = {};
         int n = 0;
         auto add = [&](const float* w, const float* bias, int in_dim, int col, int kind, int a0, int ng) {

@@ -188,9 +188,22 @@ class PackPlan:
             _lib.check(L.nsos_mlp_bwd_pack_x3(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_bwd_pack_x3")
         elif heads_only and self.sem_mode != SEM_NONE:
             _lib.check(L.nsos_mlp_pack_lp_heads(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp_heads")
+            out._nsos_partial = lp_selected_kernel()       # only this kernel's stream holds the new heads (check_lp_stream)
         else:
             _lib.check(L.nsos_mlp_pack_lp(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp")
+            out._nsos_partial = None
         return out
+
+
+def check_lp_stream(packed: torch.Tensor, kernel: int) -> None:
+    """A 16-bit weight buffer that had a heads-only re-pack (PackPlan.run(heads_only=True)) holds current semantic-head weights in
+    ONE of its three streams.  Called with the kernel a launch is about to run on (1 = mlp_lp_kernel, the fall-back for fp32 sem_in
+    saves and >= 2^31 points; 2 = lp8; 3 = lp16): raises instead of rendering with stale heads."""
+    cur = getattr(packed, "_nsos_partial", None)
+    if cur is not None and cur != kernel:
+        raise RuntimeError(f"nerf_sos_amd: this packed 16-bit weight buffer was last updated by a heads-only re-pack for kernel {cur}; the "
+                           f"launch needs kernel {kernel}'s stream, whose semantic-head weights are stale -- do a full pack first "
+                           "(PackPlan.run(..., heads_only=False), or NeRFMLP.invalidate_packed())")
 
 
 class GenericPlan:
@@ -511,6 +524,7 @@ def mlp_forward_rays_lp(packed: torch.Tensor, sem_mode: int, precision: str, ray
         _lib.check(_lib.lib().nsos_mlp_forward_rays_x3(_p(packed), sem_mode, _p(rays_o), _p(rays_d), _p(viewdirs),
                                                        _p(z_vals), R, S, _p(raw), _stream()), "nsos_mlp_forward_rays_x3")
     else:
+        check_lp_stream(packed, 1 if R * S >= (1 << 31) else lp_selected_kernel())
         _lib.check(_lib.lib().nsos_mlp_forward_rays_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o), _p(rays_d),
                                                        _p(viewdirs), _p(z_vals), R, S, _p(raw), _stream()),
                    "nsos_mlp_forward_rays_lp")
@@ -558,11 +572,13 @@ def mlp_forward_rays_save(packed: torch.Tensor, sem_mode: int, rays_o: torch.Ten
                                                             _p(z_vals), R, S, _p(raw), _p(sem_in), _p(sem_hid), _stream()),
                    "nsos_mlp_forward_rays_save_x3")
     elif compact:
+        check_lp_stream(packed, 1 if (R * S >= (1 << 31) or lp_selected_kernel() == 1) else lp_selected_kernel())
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save16_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o),
                                                               _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
                                                               _p(sem_in), _p(sem_hid), _stream()),
                    "nsos_mlp_forward_rays_save16_lp")
     else:
+        check_lp_stream(packed, 1)                 # fp32 sem_in / sem_hid come from the round-1 kernel whatever is selected
         _lib.check(_lib.lib().nsos_mlp_forward_rays_save_lp(_p(packed), sem_mode, DTYPES[precision], _p(rays_o),
                                                             _p(rays_d), _p(viewdirs), _p(z_vals), R, S, _p(raw),
                                                             _p(sem_in), _p(sem_hid), _stream()),
@@ -915,7 +931,8 @@ def mlp_input_grads_x3(packed_bwd: torch.Tensor, sem_mode: int, g_raw: torch.Ten
                        scale: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused split-fp16 input-gradient chain of the full backward (K7-X3): gbuf [P, GBUF_DIM] = scale * (d loss / d every
     layer's pre-activation), columns as in `acts` (256 l | ACTS_FEAT | ACTS_VIEWS | ACTS_SEM).  `packed_bwd` comes from
-    pack_mlp(..., precision="fp16x3_bwd"); `scale` is a 1-element device tensor holding a power of two; `masks` = the bit
+    pack_mlp(..., precision="fp16x3_bwd"); `scale` is a 3-element device tensor of powers of two -- trunk scale, colour-branch
+    factor, semantic-branch factor (include/nerf_sos_hip.h; a 1-element tensor means factors of 1) --; `masks` = the bit
     masks mlp_forward_rays_save_all(..., "fp16x3") returned for the same points (None: trunk masks are read from `acts`)."""
     g_raw = _dev(g_raw, "g_raw")
     a16 = isinstance(acts, torch.Tensor) and acts.dtype == torch.float16
@@ -927,7 +944,12 @@ def mlp_input_grads_x3(packed_bwd: torch.Tensor, sem_mode: int, g_raw: torch.Ten
     P_, C_ = g_raw.shape
     if C_ != (4 if sem_mode == SEM_NONE else 6) or acts.shape != (P_, ACTS_DIM) or not acts.is_contiguous():
         raise ValueError(f"mlp_input_grads_x3: g_raw {tuple(g_raw.shape)} / acts {tuple(acts.shape)} do not fit sem_mode {sem_mode}")
-    scale = _dev(scale.reshape(1), "scale")
+    scale = scale.reshape(-1)
+    if scale.numel() == 1:
+        scale = torch.cat([scale, torch.ones(2, device=scale.device, dtype=scale.dtype)])
+    if scale.numel() != 3:
+        raise ValueError("mlp_input_grads_x3: `scale` holds one or three powers of two")
+    scale = _dev(scale.float(), "scale")
     gbuf = torch.empty((P_, GBUF_DIM), device=acts.device, dtype=torch.float32)
     if masks is not None and (not masks.is_cuda or masks.numel() * 4 < int(_lib.lib().nsos_mlp_relu_masks_bytes_x3(P_))):
         raise ValueError("mlp_input_grads_x3: `masks` does not belong to these points")

@@ -44,7 +44,10 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 // ops: [16 sets][4096 lanes] u32x4; sets 0..7 = weight-like, 8..15 = activation-like (the host decides the distributions)
 //   WPS     waves per SIMD: 2 = 512-thread workgroups (the kernels' shape), 1 = 256-thread workgroups with up to 512 registers per
 //           wave (round 5: the only way a 64-point wave -- LDSN 2, DMAN 15 -- fits its registers: 128 H_in + 128 H_out + 64 acc)
-template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP, bool SWAP, int WPS>
+//   X3      split-fp16 stream (round 5): per step TWO 1 KiB ring reads (W_hi, W_lo tiles) and THREE MFMAs (W_hi h_hi, W_hi h_lo, W_lo h_hi)
+//           on one 16-point column (SHAPE 16, what fits two waves per SIMD: H hi+lo of 32 points would be 256 registers) or one
+//           32-point column (SHAPE 32, one wave per SIMD: today's mlp_x3_kernel); DMAN counts steps (all waves share the 2 KiB)
+template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP, bool SWAP, int WPS, bool X3 = false>
 __global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops, const unsigned char* __restrict__ wstream, float* out,
                                             unsigned long long* stamps, int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops,
         w[i] = ops[(size_t)i * 4096 + blockIdx.x % 8 * 512 + threadIdx.x];
         x[i] = ops[(size_t)(8 + i) * 4096 + blockIdx.x % 8 * 512 + threadIdx.x];
     }
-    if (LDSN) {   // fill the LDS image with weight-like operands
+    if (LDSN || X3) {   // fill the LDS image with weight-like operands
         for (int o = threadIdx.x * 16; o < kLdsBytes; o += 256 * WPS * 16)
             *reinterpret_cast<u32x4*>(lds + o) = ops[(size_t)((o >> 16) & 7) * 4096 + ((o >> 4) & 4095)];
     }
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops,
     for (int t = 0; t < NACC16; ++t) acd[t] = f32x4{0, 0, 0, 0};
     f32x4 ring[4];
     unsigned sink = 0;
-    if (LDSN) {
+    if (LDSN || X3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[i]) : "v"(raddr), "i"(i * 1024) : "memory");
     }
@@ -80,6 +83,49 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops,
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 48; ++g) {
+            if constexpr (X3) {
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); PIN();
+                const u32x4 whi = __builtin_bit_cast(u32x4, ring[(2 * g) % 4]), wlo = __builtin_bit_cast(u32x4, ring[(2 * g + 1) % 4]);
+                const u32x4 xh = x[(g / 8 + g) % 8], xl = x[(g / 8 + g + 3) % 8];
+                if constexpr (SHAPE == 32) {
+                    const int t = (3 * g) % NACC32;            // (independent accumulators: the kernel interleaves tiles the same way)
+                    acc[t] = mfma32<BF>(whi, xh, acc[t]);
+                    acc[t + 1] = mfma32<BF>(whi, xl, acc[t + 1]);
+                    acc[t + 2] = mfma32<BF>(wlo, xh, acc[t + 2]);
+                } else {
+                    const int t = (3 * g) % NACC16;
+                    acd[t] = mfma16<BF>(whi, xh, acd[t]);
+                    acd[t + 1] = mfma16<BF>(whi, xl, acd[t + 1]);
+                    acd[t + 2] = mfma16<BF>(wlo, xh, acd[t + 2]);
+                }
+                PIN();
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[(2 * g) % 4]) : "v"(raddr), "i"(((2 * g + 4) % 48) * 1024) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[(2 * g + 1) % 4]) : "v"(raddr), "i"(((2 * g + 5) % 48) * 1024) : "memory");
+                if (g % DMAN == 1) {
+                    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    unsigned keep;
+                    const unsigned long long sp = (unsigned long long)(wstream + (dsrc % (1200u * 1024u)));
+                    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sp), hi = __builtin_amdgcn_readfirstlane((unsigned)(sp >> 32));
+                    const void* src = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "s"(ddst), "v"((unsigned)(lane * 16)), "s"(src) : "memory");
+                    dsrc += 8 * 1024;
+                }
+                if constexpr (VALU > 0) {       // the riding split: cvt hi, subtract, cvt lo, max  (~2 per MFMA output pair)
+#pragma unroll
+                    for (int v = 0; v < VALU; ++v) {
+                        unsigned r;
+                        float p, q;
+                        if constexpr (SHAPE == 32) { const int u = (3 * g + 3) % NACC32; p = acc[u][(g + 2 * v) & 15]; q = acc[u][(g + 2 * v + 1) & 15]; }
+                        else { const int u = (3 * g + 6) % NACC16; p = acd[u][(g + v) & 3]; q = acd[u + 1][(g + v + 1) & 3]; }
+                        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
+                        asm volatile("v_pk_max_i16 %0, %0, 0" : "+v"(r));
+                        sink ^= r;
+                    }
+                }
+                PIN();
+                continue;
+            }
             u32x4 a = w[g % 8];
             if constexpr (LDSN > 0) {
                 if (g % LDSN == 0) { asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); PIN(); }
@@ -129,7 +175,7 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops,
             }
             PIN();
         }
-        if constexpr (LDSN > 0) raddr = (it & 1) ? raddr - 48u * 1024u : raddr + 48u * 1024u;
+        if constexpr (LDSN > 0 || X3) raddr = (it & 1) ? raddr - 48u * 1024u : raddr + 48u * 1024u;
         if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
         if ((it & 63) == 63) {
             for (int t = 0; t < NACC32; ++t) acc[t] *= 0.25f;
@@ -141,7 +187,7 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(const u32x4* __restrict__ ops,
     float s = (float)(sink & 1);
     for (int t = 0; t < NACC32; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
     for (int t = 0; t < NACC16; ++t) for (int r = 0; r < 4; ++r) s += acd[t][r];
-    if (LDSN) for (int i = 0; i < 4; ++i) s += ring[i][0] * 1e-30f;
+    if (LDSN || X3) for (int i = 0; i < 4; ++i) s += ring[i][0] * 1e-30f;
     out[blockIdx.x * 512 + threadIdx.x] = s;
     if (lane == 0) { stamps[(blockIdx.x * 8 + wave) * 2] = t0; stamps[(blockIdx.x * 8 + wave) * 2 + 1] = t1; }
 }
@@ -151,9 +197,9 @@ static unsigned short f2b(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); u 
 
 struct Bufs { u32x4* ops; unsigned char* wstream; float* out; unsigned long long* stamps; };
 
-template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP = 0, bool SWAP = false, int WPS = 2>
+template <bool BF, int SHAPE, int LDSN, int DMAN, int VALU, int SLEEP = 0, bool SWAP = false, int WPS = 2, bool X3 = false>
 void run(const char* name, const Bufs& B, int iters) {
-    auto kern = k<BF, SHAPE, LDSN, DMAN, VALU, SLEEP, SWAP, WPS>;
+    auto kern = k<BF, SHAPE, LDSN, DMAN, VALU, SLEEP, SWAP, WPS, X3>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     hipLaunchKernelGGL(kern, dim3(256), dim3(256 * WPS), kLdsBytes, 0, B.ops, B.wstream, B.out, B.stamps, 200);
     hipDeviceSynchronize();
@@ -176,11 +222,11 @@ void run(const char* name, const Bufs& B, int iters) {
                 span += (double)(hi - lo);
             }
             span /= 256;
-            busy = WPS * 48.0 * iters * 32.0 / span;     // waves per SIMD x units x 32 pipe cycles per unit
+            busy = WPS * 48.0 * iters * 32.0 * (X3 ? (SHAPE == 32 ? 3.0 : 1.5) : 1.0) / span;     // waves per SIMD x units x 32 pipe cycles per unit
             clock = span / (ms * 1e6);
         }
     }
-    const double flop = 2.0 * 32 * 32 * 16 * 48.0 * iters * 256 * 4 * WPS;
+    const double flop = 2.0 * 32 * 32 * 16 * 48.0 * iters * 256 * 4 * WPS * (X3 ? (SHAPE == 32 ? 3.0 : 1.5) : 1.0);
     const double tf = flop / (best * 1e-3) / 1e12;
     printf("%-5s %-36s %8.3f ms  chip %7.1f TFLOP/s = %.3f of 2516 | pipe busy %.3f at %.3f GHz (s_memtime span)\n", BF ? "bf16" : "f16", name, best,
            tf, tf / 2516.6, busy, clock);
@@ -227,6 +273,11 @@ void all(const Bufs& B, std::vector<unsigned short>& h, int iters) {
     run<BF, 16, 2, 15, 1, 0, false, 1>("16x16x32 lds/2 dma/15 valu 1, ONE wave/SIMD", B, iters);
     run<BF, 16, 2, 7, 1, 0, false, 1>("16x16x32 lds/2 dma/7 valu 1, ONE wave/SIMD", B, iters);
     run<BF, 32, 2, 15, 1, 0, false, 1>("32x32x16 lds/2 dma/15 valu 1, ONE wave/SIMD (= lp4)", B, iters);
+    // the split-fp16 stream (mlp_x3_kernel): today's shape against the 16x16x32 re-tile VERDICT r04 #3 asks about
+    run<BF, 32, 0, 2, 2, 0, false, 1, true>("x3: 32x32x16, ONE wave/SIMD, 32-pt col, dma/2 (= mlp_x3 today)", B, iters);
+    run<BF, 16, 0, 4, 2, 0, false, 2, true>("x3: 16x16x32, two waves/SIMD, 16-pt col, dma/4 (the re-tile)", B, iters);
+    run<BF, 16, 0, 4, 0, 0, false, 2, true>("x3: 16x16x32, two waves/SIMD, 16-pt col, dma/4, no VALU", B, iters);
+    run<BF, 16, 0, 2, 2, 0, false, 1, true>("x3: 16x16x32, ONE wave/SIMD, 16-pt col, dma/2", B, iters);
     fill(true);
     run<BF, 32, 0, 0, 0>("32x32x16 regs, dense N(0,1) both", B, iters);
     run<BF, 16, 0, 0, 0>("16x16x32 regs, dense N(0,1) both", B, iters);

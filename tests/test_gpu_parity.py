@@ -910,16 +910,21 @@ def test_heads_only_repack_equals_a_full_pack(manifest, name, precision):
     b = mlp.packed_weights(precision)
     assert not torch.equal(a.view(torch.int32), b.view(torch.int32))
     full = plan.run(None, precision)
-    # the stream of the selected kernel, stream 0 (the fall-back kernel's: fp32 sem_in saves, >= 2^31 points -- ADVICE r04) and the
-    # vector-ALU heads' block are current; the remaining stream (mlp_lp8_kernel's) keeps the old heads until the next full pack
+    # only the stream of the selected kernel is current; the others keep the old heads until the next full pack
     assert not torch.equal(b.view(torch.int32), full.view(torch.int32))
     r_sel = ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z)
     assert torch.equal(r_sel, ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
-    try:   # stream 0 is current too: the round-1 kernel renders the new heads from the partly re-packed buffer
+    # ... and a launch that would take another stream REFUSES instead of rendering stale heads: the fp32-sem_in save
+    # always runs the round-1 kernel on stream 0; so does any launch once another kernel is selected
+    with pytest.raises(RuntimeError, match="heads-only"):
+        ops.mlp_forward_rays_save(b, mlp.sem_mode, o, d, v, z, precision, compact=False)
+    try:
         _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(1), "select")
-        assert torch.equal(ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z), ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
+        with pytest.raises(RuntimeError, match="heads-only"):
+            ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z)
     finally:
         _lib.check(_lib.lib().nsos_mlp_lp_select_kernel(3), "select")
+    ops.mlp_forward_rays_save(full, mlp.sem_mode, o, d, v, z, precision, compact=False)      # (a full pack serves every stream)
     assert torch.equal(ops.mlp_forward_rays_lp(b, mlp.sem_mode, precision, o, d, v, z), ops.mlp_forward_rays_lp(full, mlp.sem_mode, precision, o, d, v, z))
     # a change of the kernel selection forces a full pack (the other streams' heads would be stale)
     try:
