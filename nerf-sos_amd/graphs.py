@@ -157,10 +157,9 @@ class GraphedPatchStep:
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
-        loss = self._sharding.sharded_patch_step(self.net, self.rays, self.bounds, self.n_patches, self.feat, self.cls,
-                                                 generator=self.generator, group=self.group, **self.losses)
+        self._sharding.sharded_patch_step(self.net, self.rays, self.bounds, self.n_patches, self.feat, self.cls,
+                                          generator=self.generator, group=self.group, loss_out=self.loss, **self.losses)
         self.opt.step()
-        self.loss.copy_(loss)
 
     def eager_step(self) -> torch.Tensor:
         """One step without the graph (the reference for the bit-identity test, and the warm-up)."""

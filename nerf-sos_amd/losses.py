@@ -139,7 +139,7 @@ class CorrelationLoss(nn.Module):
         self._queued = list(coords)
 
     def _launcher(self, orig_feats: torch.Tensor, code_shape, sim_matrix: Optional[torch.Tensor], weight: float = 1.0,
-                  neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None):
+                  neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None, loss_out: Optional[torch.Tensor] = None):
         if coords is None and getattr(self, "_queued", None):
             coords = self._queued.pop(0)
         """Draws the sample coordinates and the negatives (the reference's order: rand1, rand2, negatives) and returns
@@ -167,7 +167,7 @@ class CorrelationLoss(nn.Module):
             code = code.detach()
             nbytes = lib.nsos_corr_workspace_bytes(0, B, S * S, Cf)
             ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
-            loss = torch.empty((), device=dev, dtype=torch.float32)
+            loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)   # (loss_out: a slot of the step's loss buffer)
             if _is_channel_last_view(code):
                 # the renderer's `semantics` [B,P,P,C] seen through .permute(0,3,1,2): read (and differentiated) in place
                 nhwc = _dev(code.permute(0, 2, 3, 1), "orig_code")
@@ -186,7 +186,8 @@ class CorrelationLoss(nn.Module):
         return launch
 
     def rows_phased(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor], rows: Sequence[int],
-                    exchange, weight: float = 1.0, neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None):
+                    exchange, weight: float = 1.0, neg: Optional[torch.Tensor] = None, coords: Optional[torch.Tensor] = None,
+                    loss_out: Optional[torch.Tensor] = None):
         """The row-partitioned evaluation for the patch-sharded step (`nsos_app_correlation_loss_rows`): every rank passes the
         whole batch and ITS patches `rows`, draws the same coordinates (a generator seeded alike on every rank), and runs
         phase 0 -> [sum `means` over the ranks] -> phase 1 -> [sum `sums`] -> phase 2.  Returns (run(phase), (loss, grad)):
@@ -214,7 +215,7 @@ class CorrelationLoss(nn.Module):
         nhwc = _is_channel_last_view(code)
         code = _dev(code.permute(0, 2, 3, 1), "orig_code") if nhwc else _dev(code, "orig_code")
         grad = torch.empty_like(code)
-        loss = torch.empty((), device=dev, dtype=torch.float32)
+        loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
         nbytes = lib.nsos_corr_workspace_bytes(0, B, S * S, Cf)
         ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
         from .sharding import device_index
@@ -234,10 +235,10 @@ class CorrelationLoss(nn.Module):
 
     def value_and_grad(self, orig_feats: torch.Tensor, orig_code: torch.Tensor, sim_matrix: Optional[torch.Tensor],
                        weight: float = 1.0, neg: Optional[torch.Tensor] = None, want_grad: bool = True,
-                       coords: Optional[torch.Tensor] = None):
+                       coords: Optional[torch.Tensor] = None, loss_out: Optional[torch.Tensor] = None):
         """(weight * loss, weight * d loss / d orig_code) straight from the launch, outside autograd -- for a training step that
         sums the gradients of several losses itself and enters autograd once (sharding._losses_and_backward)."""
-        return self._launcher(orig_feats, orig_code.shape, sim_matrix, weight, neg, coords)(orig_code, want_grad)
+        return self._launcher(orig_feats, orig_code.shape, sim_matrix, weight, neg, coords, loss_out)(orig_code, want_grad)
 
 
 class GeoCorrelationLoss(CorrelationLoss):
@@ -311,7 +312,7 @@ class GeoCorrelationLoss(CorrelationLoss):
 
 
     def _pair_launcher(self, depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, weight: float = 1.0,
-                       neg: Optional[torch.Tensor] = None, grad_mode: Optional[bool] = None):
+                       neg: Optional[torch.Tensor] = None, grad_mode: Optional[bool] = None, loss_out: Optional[torch.Tensor] = None):
         """launch(code0, code1, want_grad) -> (weight * stacked-mean loss, its gradients) of forward_pair's evaluation.
         `grad_mode`: the group-wide switch for the gradient's role-sum all-reduce (default: the caller's autograd mode)."""
         if self.rand_neg:
@@ -341,7 +342,7 @@ class GeoCorrelationLoss(CorrelationLoss):
             c0, c1 = _dev(c0.detach(), "code0"), _dev(c1.detach(), "code1")
             nbytes = lib.nsos_corr_workspace_bytes(1, 2 * B, H * W, 0)
             ws = torch.empty((nbytes + 15) // 16 * 2, device=dev, dtype=torch.float64)
-            loss = torch.empty((), device=dev, dtype=torch.float32)
+            loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
             g0 = torch.empty_like(c0) if want_grad else None
             g1 = torch.empty_like(c1) if want_grad else None
             rows_t = device_index(rows2, torch.int32, dev)
@@ -374,18 +375,18 @@ class GeoCorrelationLoss(CorrelationLoss):
         return 2.0 * _PairFn.apply(code0, code1, self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group))
 
     def pair_value_and_grads(self, depth, code0, code1, ray_o, ray_d, sim_matrix, rows=None, group=None, weight: float = 1.0,
-                             neg: Optional[torch.Tensor] = None, grad_mode: Optional[bool] = None):
+                             neg: Optional[torch.Tensor] = None, grad_mode: Optional[bool] = None, loss_out: Optional[torch.Tensor] = None):
         """(weight * forward_pair(...), weight * d / d code0, weight * d / d code1) straight from the launches, outside autograd
         (see CorrelationLoss.value_and_grad); the factor 2 of the stacked mean and `weight` ride on the kernel's weights."""
-        launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, 2.0 * float(weight), neg, grad_mode)
+        launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, group, 2.0 * float(weight), neg, grad_mode, loss_out)
         want = torch.is_grad_enabled() if grad_mode is None else bool(grad_mode)
         return launch(code0, code1, want)
 
     def pair_phased(self, depth, code0, code1, ray_o, ray_d, sim_matrix, rows, exchange, weight: float = 1.0,
-                    neg: Optional[torch.Tensor] = None):
+                    neg: Optional[torch.Tensor] = None, loss_out: Optional[torch.Tensor] = None):
         """pair_value_and_grads split at its two reductions: (run(phase), (loss, grad0, grad1)) with the reduced slots in
         `exchange` = (means [8] fp64, sums [exchange_floats(2 B, P P)] fp32) -- see rows_phased."""
-        launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, None, 2.0 * float(weight), neg, True)
+        launch = self._pair_launcher(depth, code0, code1, ray_o, ray_d, sim_matrix, rows, None, 2.0 * float(weight), neg, True, loss_out)
         return launch(code0, code1, True, exchange)
 
 

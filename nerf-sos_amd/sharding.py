@@ -298,7 +298,7 @@ def _direct_losses(corr_loss, geo_loss) -> bool:
 
 
 def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
-                   contrast_loss=None, contrast_w=0.0):
+                   contrast_loss=None, contrast_w=0.0, loss_out=None):
     """The loss section with the gradient bookkeeping done here instead of by autograd: every loss launch already returns
     d loss / d code, the loss weights ride on the kernels' own weights, the negatives are found once, the four gradients are
     summed by one multi-tensor launch, and autograd is entered ONCE, at the two rendered semantic maps
@@ -322,6 +322,9 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             neg2 = torch.cat([n_, n_ + B])
         neg = neg2[:B]
         xy = corr_loss.draw_coords(2, B, dev)      # both evaluations' coordinates in one launch (rand1, rand2 of s0, then of s1)
+        # the three evaluations write their loss into slots of ONE buffer: the step's total is one reduction launch (straight into
+        # `loss_out` when the caller has a place for it) instead of a stack (cat), a sum and a copy
+        lbuf = torch.empty(3, device=dev, dtype=torch.float32)
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # N > 1: all three evaluations row-partitioned (each rank the pair sets of its own patches), their phases interleaved
@@ -334,10 +337,10 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             means = torch.zeros(24, device=dev, dtype=torch.float64)
             sums = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
             xs = torch.split(sums, sizes)
-            run_a0, (la0, ga0) = corr_loss.rows_phased(f, s0, sim, own, (means[0:8], xs[1]), correlation_w, neg, xy[0])
-            run_a1, (la1, ga1) = corr_loss.rows_phased(f, s1, sim, own, (means[8:16], xs[2]), correlation_w, neg, xy[1])
+            run_a0, (la0, ga0) = corr_loss.rows_phased(f, s0, sim, own, (means[0:8], xs[1]), correlation_w, neg, xy[0], loss_out=lbuf[0])
+            run_a1, (la1, ga1) = corr_loss.rows_phased(f, s1, sim, own, (means[8:16], xs[2]), correlation_w, neg, xy[1], loss_out=lbuf[1])
             run_g, (lg, gg0, gg1) = geo_loss.pair_phased(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
-                                                        sim, own, (means[16:24], xs[0]), geo_w, neg2)
+                                                        sim, own, (means[16:24], xs[0]), geo_w, neg2, loss_out=lbuf[2])
             runs = (run_g, run_a0, run_a1)
             for r_ in runs:
                 r_(0)
@@ -352,20 +355,20 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for t in (f, s0, s1, neg2):
+                for t in (f, s0, s1, neg2, lbuf):
                     t.record_stream(side)
                 xy.record_stream(side)
-                la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0])
-                la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1])
+                la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0], loss_out=lbuf[0])
+                la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1], loss_out=lbuf[1])
         else:
-            la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0])
-            la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1])
+            la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0], loss_out=lbuf[0])
+            la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1], loss_out=lbuf[1])
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
             lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
-                                                          sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True)
+                                                          sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True, loss_out=lbuf[2])
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-            for t in (la0, la1, ga0, ga1):
+            for t in (ga0, ga1):
                 t.record_stream(torch.cuda.current_stream(dev))
         # gradients w.r.t. the channel-last maps: the appearance loss hands back [B,C,P,P] views of [B,P,P,C] buffers
         torch._foreach_add_([gg0, gg1], [ga0.permute(0, 2, 3, 1), ga1.permute(0, 2, 3, 1)])
@@ -377,7 +380,12 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
         with torch.enable_grad():
             c = (contrast_w * contrast_loss(full["cls_"])).reshape(())
     with torch.no_grad():
-        loss = torch.stack([la0, la1, lg]).sum() if c is None else torch.stack([la0, la1, lg, c.detach()]).sum()
+        if c is None:
+            loss = torch.sum(lbuf, dim=0, out=loss_out) if loss_out is not None else lbuf.sum()
+        else:
+            loss = torch.cat([lbuf, c.detach().reshape(1)]).sum()
+            if loss_out is not None:
+                loss = loss_out.copy_(loss)
     roots = [(t, g) for t, g in ((full["semantics0"], gg0), (full["semantics"], gg1)) if t.requires_grad]
     if c is not None and c.requires_grad:
         roots.append((c, torch.ones_like(c)))
@@ -387,11 +395,11 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
 
 
 def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
-                         contrast_loss=None, contrast_w=0.0):
+                         contrast_loss=None, contrast_w=0.0, loss_out=None):
     """The loss section of `sharded_patch_step` (engines/trainer.py:127-166) and the backward through this rank's patches."""
     if _direct_losses(corr_loss, geo_loss):
         return _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group, overlap_losses,
-                              contrast_loss, contrast_w)
+                              contrast_loss, contrast_w, loss_out)
     loss = None
     # The appearance loss is a train of small launches (121 sample points per patch: grids of a few hundred threads), the
     # geometric one a few chip-filling ones with one workgroup per CU: on a stream of its own the former runs in the latter's
@@ -445,6 +453,9 @@ def _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, 
         raise ValueError("sharded_patch_step: give at least one of corr_loss / geo_loss / contrast_loss")
     if loss.requires_grad:
         loss.backward()
+    if loss_out is not None:
+        loss_out.copy_(loss.detach())
+        return loss_out
     return loss
 
 
@@ -452,7 +463,7 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
                        corr_loss=None, geo_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01, step: int = 0,
                        seed: Optional[int] = 0, group=None, timings: Optional[dict] = None,
                        overlap_losses: bool = True, contrast_loss=None, contrast_w: float = 0.0,
-                       generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                       generator: Optional[torch.Generator] = None, loss_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One patch-mode training step of the path with the patch batch sharded over the ranks -- the loss section of
     `train_one_step` (engines/trainer.py:101-166) re-stated for one process per GPU:
 
@@ -513,7 +524,7 @@ def sharded_patch_step(net, rays: torch.Tensor, bounds, n_patches: int, feat: to
     lent = [(m, getattr(m, "generator", None)) for m in (corr_loss, geo_loss) if m is not None and gen is not None]
     try:
         loss = _losses_and_backward(net, full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation_w, geo_w, dev, group,
-                                    overlap_losses, contrast_loss, contrast_w)
+                                    overlap_losses, contrast_loss, contrast_w, loss_out)   # (loss_out: a 0-dim tensor the total is written into)
     finally:
         for m, g0 in lent:
             m.generator = g0
