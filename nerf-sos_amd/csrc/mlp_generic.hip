@@ -14,7 +14,9 @@
 //   B operand  lane (point j, hi): row 2 ks + hi of the segment, one ds_read_b32 per k-step (conflict-free: 64 consecutive words)
 //   A operand  one global_load_dwordx4 per group and tile from the packed stream [tile][group][lane][4] (L2-resident: the
 //              whole net is 0.3-3 MB), prefetched four groups ahead -- no LDS staging, no barrier inside an op
-//   bias       a leading group whose input is the constant buffer [1, 0, ...]: acc = fma(bias, 1, 0), then the chain
+//   bias       the accumulators' initial value, from a per-tile table in the packed stream (round 5).  Until then the bias was a leading
+//              GROUP on a constant buffer [1, 0, ...]: 4 k-steps for one useful row, and it pushed a 256-wide layer from 32 groups to 33,
+//              padded to 36 -- 11 % of every trunk layer's matrix time (20 % of a 128-wide head's) spent on zeros
 // One __syncthreads per op.  Small heads (alpha, rgb, logits: one tile) occupy one wave; at 8 x 256 that is ~10 % of a tile's
 // time -- this kernel buys generality, the fast paths keep the shipped configs.
 // Ceiling: 2 x 64-cycle MFMAs per k-step and wave against 16 B/lane of A operand per 4 k-steps: ~8 B/clk/CU from L2.
@@ -22,6 +24,10 @@
 
 using namespace nsos;
 
+#ifdef NSOS_GEN_PROF   // diagnostic build (scripts/diag/gen_prof.py): s_memtime stamps per op and phase, workgroup 1, every wave
+__device__ unsigned long long nsos_gen_prof[4][2][64];   // [wave][0: work, 1: barrier wait][slot: 0 = tiles, 1 = encode, 2 + op, 62 = output]
+#define GEN_PROF_T() __builtin_amdgcn_s_memtime()
+#endif
 namespace {
 
 constexpr int kGenMaxOps = 64, kGenMaxGroups = 112, kGenMaxSeg = 3;   // (ops: the backward program of a 16-deep net with the deepest head has 61)
@@ -38,11 +44,13 @@ struct GenOp {
     int out_tiles;
     int relu;        // bit 0: ReLU; bit 1: also write zeros into the pad rows of the last tile (a whole buffer is this op's output);
                      // bit 2 (backward dense): add to what the buffer holds (a second consumer's contribution)
-    int n_groups;    // groups of 4 k-steps over all segments, the bias group first
+    int n_groups;    // groups of 4 k-steps over all segments (a multiple of 4: padded with zero-weight groups on the constant buffer)
     int w_off;       // float offset of the op's A stream in the packed weights
     int src_off;     // mul: LDS float offset of the factor rows
     int act_col;     // first column of the op's block (pad32(out_dim) columns) in the saved-activation / gradient rows (training)
     int aux_col;     // kGenBwdMul: the column block of geo_map_sem's output
+    int b_off;       // forward dense op: float offset of the bias table [out_tiles][2 (hi)][16] in the packed weights -- the accumulators'
+                     // initial values (acc = bias, then the fmaf chain: the same numbers as a leading fma(bias, 1, 0)); 0: none (backward ops)
     int grp_off[kGenMaxGroups + 8];   // LDS float offset of the first input row of group g (entries past n_groups: the constant buffer)
 };
 struct GenProgram {              // at the head of the packed buffer (device memory); identical on the host (build_program)
@@ -166,11 +174,24 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
     // LDS offset drained the whole prefetch queue
     const __attribute__((address_space(4))) GenProgram& G = *(const __attribute__((address_space(4))) GenProgram*)P.prog;
     const int n_ops = G.n_ops, n_out = G.n_out, out_off = G.out_off;
-    {   // the constant input [1, 0, 0, ...] (8 rows): the bias group's B operand
+    {   // a constant buffer (8 finite rows): the B operand of the zero-weight pad groups
         const int row = tid / RF, col = tid % RF;
         if (row < 8) lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;
     }
+#ifdef NSOS_GEN_PROF
+    unsigned long long pw[64], pb[64];
+    for (int k = 0; k < 64; ++k) pw[k] = pb[k] = 0;
+#endif
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+#ifdef NSOS_GEN_PROF
+        unsigned long long tp = GEN_PROF_T(), tq;
+        pw[0] += 1;
+#define GEN_PROF_WORK(k) do { tq = GEN_PROF_T(); pw[k] += tq - tp; tp = tq; } while (0)
+#define GEN_PROF_BAR(k) do { tq = GEN_PROF_T(); pb[k] += tq - tp; tp = tq; } while (0)
+#else
+#define GEN_PROF_WORK(k)
+#define GEN_PROF_BAR(k)
+#endif
         // ---- inputs and encodings: thread (point p, part): features part, part + 8, ...
         const int p = tid % RF, part = tid / RF;
         const long long gp = (long long)tile * RF + p;
@@ -212,7 +233,9 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
             }
         }
         for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
+        GEN_PROF_WORK(1);
         __syncthreads();
+        GEN_PROF_BAR(1);
 
         for (int oi = 0; oi < n_ops; ++oi) {
             const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
@@ -221,50 +244,93 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 __syncthreads();
                 continue;
             }
-            const int out_tiles = op.out_tiles;
+            // the op's scalars, read ONCE from the program and pinned in SGPRs: as plain constant-address-space reads hipcc re-issued the
+            // s_load of op.out_off (and waited for it with lgkmcnt(0)) in front of EVERY accumulator store of the epilogue -- 32 exposed
+            // scalar-cache round trips per op and wave, about a quarter of a 256 x 256 layer's time (round 5, found in the ISA)
+            int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu, o_act = op.act_col, o_boff = op.b_off;
+            asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags), "+s"(o_act), "+s"(o_boff));
+            const bool relu = o_flags & 1, padw = o_flags & 2;
             for (int t0 = wave; t0 < out_tiles; t0 += 8) {
                 f32x16 acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
                 const bool two = t0 + 4 < out_tiles;          // wave-uniform
+                {   // acc = bias: register r of lane (j, hi) is output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi -- 16 floats per (tile, hi)
+                    const f32x4* b0 = reinterpret_cast<const f32x4*>(P.wts + o_boff + (t0 * 2 + hi) * 16);
+                    const f32x4* b1 = reinterpret_cast<const f32x4*>(P.wts + o_boff + ((two ? t0 + 4 : t0) * 2 + hi) * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v0 = b0[q], v1 = b1[q];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { acc0[4 * q + j] = v0[j]; acc1[4 * q + j] = v1[j]; }
+                    }
+                }
                 if (two) dense_tiles<true, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 else dense_tiles<false, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
-                // accumulator register r of lane (j, hi) = output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi of point j
+                if (relu) {     // (asm: fmaxf is two instructions -- a canonicalising v_max x, x in front of the v_max 0, x; same values, a NaN -> 0 either way)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row0 = 32 * t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    // (rows past out_dim have all-zero weights: their accumulators are exactly 0 -- written only where the buffer's pad
-                    //  rows are read by a later op as zero-weighted inputs, never into the shared OUT buffer)
-                    const bool relu = op.relu & 1, pad = op.relu & 2;
-                    if (own && (row0 < op.out_dim || pad)) lds[op.out_off + row0 * kGenRowFloats + pt] = relu ? fmaxf(acc0[r], 0.0f) : acc0[r];
-                    if (own && two && (row0 + 128 < op.out_dim || pad)) lds[op.out_off + (row0 + 128) * kGenRowFloats + pt] = relu ? fmaxf(acc1[r], 0.0f) : acc1[r];
+                    for (int r = 0; r < 16; ++r) {
+                        float a = acc0[r], b = acc1[r];
+                        asm("v_max_f32 %0, 0, %0" : "+v"(a));
+                        asm("v_max_f32 %0, 0, %0" : "+v"(b));
+                        acc0[r] = a; acc1[r] = b;
+                    }
+                }
+                // accumulator register r of lane (j, hi) = output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi of point j: row stride RF floats, so
+                // the 16 stores of a tile are one base address + compile-time offsets.  (Rows past out_dim have all-zero weights: their
+                // accumulators are exactly 0 -- written only where the buffer's pad rows are read by a later op as zero-weighted inputs, never
+                // into the shared OUT buffer.)  A tile wholly inside the op's rows (every tile of a 32-multiple width) takes the branch-free path.
+                if (RF == 32 || own) {
+                    float* d0 = lds + o_off + (32 * t0 + 4 * hi) * kGenRowFloats + pt;
+                    const int rb = 32 * t0 + 4 * hi;
+                    if (padw || 32 * t0 + 32 <= o_dim) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) d0[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc0[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (rb + (r & 3) + 8 * (r >> 2) < o_dim) d0[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc0[r];
+                    }
+                    if (two) {
+                        float* d1 = d0 + 128 * kGenRowFloats;
+                        if (padw || 32 * t0 + 160 <= o_dim) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d1[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc1[r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (rb + 128 + (r & 3) + 8 * (r >> 2) < o_dim) d1[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc1[r];
+                        }
+                    }
                 }
                 if constexpr (SAVE) {
                     const long long gpl = (long long)tile * RF + pt;
                     if (own && gpl < P.n_pts && ((P.save_mask >> oi) & 1)) {
-                        float* dst = P.acts + gpl * G.act_ld + op.act_col + 32 * t0 + 4 * hi;
-                        const bool relu = op.relu & 1;
+                        float* dst = P.acts + gpl * G.act_ld + o_act + 32 * t0 + 4 * hi;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             f32x4 v0, v1;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                v0[j] = relu ? fmaxf(acc0[4 * q + j], 0.0f) : acc0[4 * q + j];
-                                v1[j] = relu ? fmaxf(acc1[4 * q + j], 0.0f) : acc1[4 * q + j];
-                            }
+                            for (int j = 0; j < 4; ++j) { v0[j] = acc0[4 * q + j]; v1[j] = acc1[4 * q + j]; }
                             *reinterpret_cast<f32x4*>(dst + 8 * q) = v0;           // (rows past out_dim: exact zeros, the block's padding)
                             if (two) *reinterpret_cast<f32x4*>(dst + 128 + 8 * q) = v1;
                         }
                     }
                 }
             }
+            GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
             __syncthreads();
+            GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
         }
         // ---- raw[p, c] = OUT[c][p]   (models/nerf_mlp.py:93-98: cat([rgb, alpha, semantics]) / output_linear)
         if (valid)
             for (int c = part; c < n_out; c += NP) P.raw[gp * n_out + c] = poison != poison ? __builtin_nanf("") : lds[out_off + c * kGenRowFloats + p];
+        GEN_PROF_WORK(62);
         __syncthreads();
+        GEN_PROF_BAR(62);
     }
+#ifdef NSOS_GEN_PROF
+    if (blockIdx.x == 1 && lane == 0)
+        for (int k = 0; k < 64; ++k) { nsos_gen_prof[wave][0][k] = pw[k]; nsos_gen_prof[wave][1][k] = pb[k]; }
+#endif
 }
 
 
@@ -331,12 +397,31 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 continue;
             }
             if (op.kind == kGenBwdHead) {
+                int h_tiles = op.out_tiles, h_off = op.out_off, h_dim = op.out_dim, h_flags = op.relu, h_act = op.act_col;     // pinned: see the forward kernel
+                asm volatile("" : "+s"(h_tiles), "+s"(h_off), "+s"(h_dim), "+s"(h_flags), "+s"(h_act));
                 const long long gpl = (long long)tile * RF + pt;
                 const bool vpt = own && gpl < P.n_pts;
-                const float* arow = P.acts + (vpt ? gpl : P.n_pts - 1) * ld + op.act_col;
-                float* grow = P.gbuf + gpl * ld + op.act_col;
-                const bool relu = op.relu & 1;
-                for (int t = wave; t < op.out_tiles; t += 4) {
+                const float* arow = P.acts + (vpt ? gpl : P.n_pts - 1) * ld + h_act;
+                float* grow = P.gbuf + gpl * ld + h_act;
+                const bool relu = h_flags & 1;
+                for (int t = wave; t < h_tiles; t += 4) {
+                    float* lrow = lds + h_off + (32 * t + 4 * hi) * kGenRowFloats + pt;
+                    if (32 * t + 32 <= h_dim && (RF == 32 || own)) {       // a tile wholly inside the op's rows: no per-element tests
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int f0 = 32 * t + 8 * q + 4 * hi;
+                            f32x4 g, a = {1.0f, 1.0f, 1.0f, 1.0f};
+                            if (relu) a = *reinterpret_cast<const f32x4*>(arow + f0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float v = lrow[(8 * q + j) * kGenRowFloats];
+                                g[j] = a[j] > 0.0f ? v : 0.0f;                        // relu'(x) = [x > 0] (ATen threshold_backward)
+                                if (relu) lrow[(8 * q + j) * kGenRowFloats] = g[j];   // (ReLU outputs own whole pad32 buffers)
+                            }
+                            if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int f0 = 32 * t + 8 * q + 4 * hi;
@@ -344,9 +429,9 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                         if (relu) a = *reinterpret_cast<const f32x4*>(arow + f0);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float v = (own && f0 + j < op.out_dim) ? lds[op.out_off + (f0 + j) * kGenRowFloats + pt] : 0.0f;
-                            g[j] = a[j] > 0.0f ? v : 0.0f;                        // relu'(x) = [x > 0] (ATen threshold_backward)
-                            if (relu && own) lds[op.out_off + (f0 + j) * kGenRowFloats + pt] = g[j];   // (ReLU outputs own whole pad32 buffers)
+                            const float v = (own && f0 + j < h_dim) ? lds[h_off + (f0 + j) * kGenRowFloats + pt] : 0.0f;
+                            g[j] = a[j] > 0.0f ? v : 0.0f;
+                            if (relu && own) lds[h_off + (f0 + j) * kGenRowFloats + pt] = g[j];
                         }
                         if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
                     }
@@ -354,7 +439,9 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 __syncthreads();
                 continue;
             }
-            const int out_tiles = op.out_tiles;
+            int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu;      // pinned: see the forward kernel
+            asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags));
+            const bool padw = o_flags & 2, add = o_flags & 4;
             for (int t0 = wave; t0 < out_tiles; t0 += 8) {
                 f32x16 acc0, acc1;
 #pragma unroll
@@ -362,18 +449,30 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 const bool two = t0 + 4 < out_tiles;
                 if (two) dense_tiles<true, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 else dense_tiles<false, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
-                const bool pad = op.relu & 2, add = op.relu & 4;
+                if (RF == 32 || own) {
+                    float* d0 = lds + o_off + (32 * t0 + 4 * hi) * kGenRowFloats + pt;
+                    const int rb = 32 * t0 + 4 * hi;
+                    auto put = [&](float* d, const f32x16& acc, int rbase, bool full) {
+                        if (full && add) {
+                            float old[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row0 = 32 * t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (own && (row0 < op.out_dim || pad)) {
-                        float* d = &lds[op.out_off + row0 * kGenRowFloats + pt];
-                        *d = add ? *d + acc0[r] : acc0[r];
-                    }
-                    if (own && two && (row0 + 128 < op.out_dim || pad)) {
-                        float* d = &lds[op.out_off + (row0 + 128) * kGenRowFloats + pt];
-                        *d = add ? *d + acc1[r] : acc1[r];
-                    }
+                            for (int r = 0; r < 16; ++r) old[r] = d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = old[r] + acc[r];
+                        } else if (full) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc[r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (rbase + (r & 3) + 8 * (r >> 2) < o_dim) {
+                                    float* e = d + ((r & 3) + 8 * (r >> 2)) * kGenRowFloats;
+                                    *e = add ? *e + acc[r] : acc[r];
+                                }
+                        }
+                    };
+                    put(d0, acc0, rb, padw || 32 * t0 + 32 <= o_dim);
+                    if (two) put(d0 + 128 * kGenRowFloats, acc1, rb + 128, padw || 32 * t0 + 160 <= o_dim);
                 }
             }
             __syncthreads();
@@ -479,22 +578,24 @@ struct GenPackOp {
 };
 __global__ __launch_bounds__(256) void gen_pack_kernel(const GenPackOp Q) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)Q.out_tiles * Q.n_groups * 256;
+    const long long stream = (long long)Q.out_tiles * Q.n_groups * 256, total = stream + (long long)Q.out_tiles * 32;
     if (gid >= total) return;
+    if (gid >= stream) {                                // the bias table behind the stream: [tile][hi][16] in accumulator-register order
+        const int idx = (int)(gid - stream), t = idx >> 5, hi = (idx >> 4) & 1, r = idx & 15;
+        const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        Q.out[gid] = (Q.bias && row < Q.out_dim) ? Q.bias[row] : 0.0f;
+        return;
+    }
     const int j = (int)(gid & 3), lane = (int)((gid >> 2) & 63);
     const long long tg = gid >> 8;
     const int g = (int)(tg % Q.n_groups), t = (int)(tg / Q.n_groups);
     const int i = lane & 31, hi = lane >> 5, row = 32 * t + i;
     float v = 0.0f;
     if (row < Q.out_dim) {
-        if (g == 0) {                                   // bias group: input row 0 is the constant 1
-            if (2 * j + hi == 0) v = Q.bias ? Q.bias[row] : 0.0f;
-        } else {
-            int gl = g - 1, s = 0;
-            while (s < Q.n_seg && gl >= Q.seg_groups[s]) { gl -= Q.seg_groups[s]; ++s; }
-            const int kr = 8 * gl + 2 * j + hi;
-            if (s < Q.n_seg && kr < Q.seg_rows[s]) v = Q.w[(long long)row * Q.in_dim + Q.seg_col0[s] + kr];     // (s == n_seg: a pad group)
-        }
+        int gl = g, s = 0;
+        while (s < Q.n_seg && gl >= Q.seg_groups[s]) { gl -= Q.seg_groups[s]; ++s; }
+        const int kr = 8 * gl + 2 * j + hi;
+        if (s < Q.n_seg && kr < Q.seg_rows[s]) v = Q.w[(long long)row * Q.in_dim + Q.seg_col0[s] + kr];     // (s == n_seg: a pad group)
     }
     Q.out[gid] = v;
 }
@@ -565,7 +666,6 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
         op.kind = kGenDense; op.out_off = out_buf + out_row0 * kGenRowFloats; op.out_dim = L.out_dim; op.out_tiles = pad_to(L.out_dim, 32) / 32;
         op.relu = (relu ? 1 : 0) | (out_buf != G.out_off ? 2 : 0);
         int g = 0, in_dim = 0;
-        op.grp_off[g++] = G.ones_off;
         for (int s = 0; s < n_seg; ++s) {
             ho.seg[s] = segs[s];
             ho.seg[s].col0 = in_dim;
@@ -584,7 +684,8 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
         }
         for (int k = g; k < kGenMaxGroups + 8; ++k) op.grp_off[k] = G.ones_off;
         op.n_groups = g; op.w_off = w_off;
-        w_off += op.out_tiles * g * 256;
+        op.b_off = w_off + op.out_tiles * g * 256;        // the bias table sits behind the op's A stream
+        w_off += op.out_tiles * g * 256 + op.out_tiles * 32;
         ho.w = L.weight; ho.bias = L.bias; ho.in_dim = in_dim; ho.n_seg = n_seg;
         ho.lin_id = (int)(&L - &M.pts[0]);        // position in the description: pts 0-15, alpha, feature, views, rgb, output, sem 21-28, geo 29-30
         ho.out_buf = out_buf;
@@ -839,7 +940,7 @@ static int32_t generic_pack(const nsos_generic_mlp* mlp, void* packed, size_t pa
         Q.n_groups = ho.op.n_groups; Q.n_seg = ho.n_seg;
         for (int s = 0; s < ho.n_seg; ++s) { Q.seg_col0[s] = ho.seg[s].col0; Q.seg_rows[s] = ho.seg[s].rows; Q.seg_groups[s] = pad_to(ho.seg[s].rows, 8) / 8; }
         Q.out = wts + ho.op.w_off;
-        const long long total = (long long)Q.out_tiles * Q.n_groups * 256;
+        const long long total = (long long)Q.out_tiles * Q.n_groups * 256 + (long long)Q.out_tiles * 32;      // stream + bias table
         hipLaunchKernelGGL(gen_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Q);
     }
     return nsos_launch_status();
@@ -1093,3 +1194,9 @@ extern "C" int32_t nsos_mlp_generic_input_grads_points(const nsos_generic_mlp* m
     else { p.pts = pts; p.dirs = dirs; p.g_pts = g_pts; p.g_dirs = mlp->use_viewdirs ? g_dirs : nullptr; }
     return generic_bwd_launch(mlp, packed_bwd, p, n_pts, (hipStream_t)stream);
 }
+
+#ifdef NSOS_GEN_PROF
+extern "C" int32_t nsos_gen_prof_read(unsigned long long* out) {
+    return (int32_t)hipMemcpyFromSymbol(out, HIP_SYMBOL(nsos_gen_prof), sizeof(unsigned long long) * 4 * 2 * 64);
+}
+#endif
