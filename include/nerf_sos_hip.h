@@ -29,8 +29,9 @@ extern "C" {
 /* bumped whenever an existing entry point's arguments or buffer formats change (2: 16-bit / tile-major saved operands of
  * nsos_mlp_forward_rays_save16_lp and nsos_sem_head_wgrad_x3; 3: pose_rows in nsos_patch_batch / nsos_pixel_batch; 4: the tile-major
  * sem_hid16 of the default 16-bit kernel, nsos_mlp_save16_layout's NSOS_SEM_HID_TILED bit; 6: `scale` of nsos_mlp_input_grads_x3[_a16]
- * is three floats -- trunk scale, colour-branch factor, semantic-branch factor) */
-#define NSOS_ABI_VERSION 6
+ * is three floats -- trunk scale, colour-branch factor, semantic-branch factor; 7: the generic kernels' packed program gained a field
+ * (GenOp::ksplit_off: an older binding's buffer sizes still agree, but the two sides must match) + nsos_wgrad_batch) */
+#define NSOS_ABI_VERSION 7
 
 enum {
     NSOS_OK = 0,
@@ -293,6 +294,16 @@ size_t nsos_wgrad_workspace_bytes(void);
 int32_t nsos_wgrad(const float* G, int32_t ldg, const float* X, int32_t ldx, int64_t n_pts, int32_t M, int32_t N,
                    float* dW, int32_t ldw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t ldh, int64_t n_pts, int32_t n_cols, void* stream);
+/* nsos_wgrad_batch (ABI 7): a list of nsos_wgrad reductions over column blocks of ONE (G, X) pair -- all weight gradients of a
+ * generic-architecture net (autograd of every Linear of models/nerf_mlp.py:40-64) in one call.  Item i: dW = out + w_off [M, N] with row
+ * stride ldw = sum_p G[p, g_col : g_col + M]^T X[p, x_col : x_col + N], db = out + b_off [M] (b_off < 0: none); offsets in floats.  Items
+ * run in list order and share the workspace; each is exactly one nsos_wgrad call (same numbers). */
+typedef struct nsos_wgrad_item {
+    int64_t w_off, b_off;
+    int32_t g_col, x_col, M, N, ldw, reserved;
+} nsos_wgrad_item;
+int32_t nsos_wgrad_batch(const nsos_wgrad_item* items, int32_t n_items, const float* G, int32_t ldg, const float* X, int32_t ldx,
+                         int64_t n_pts, float* out, void* workspace, size_t workspace_bytes, void* stream);
 int32_t nsos_sem_head_backward(const float* weights, const float* g_semantics, const float* sem2_w,
                                const float* sem_hid, int64_t n_rays, int32_t n_samples, float* g_hid,
                                float* g_logits, void* stream);

@@ -37,6 +37,11 @@ class GenericMlp(C.Structure):
                 ("sem", GenericLinear * GENERIC_MAX_SEM), ("geo", GenericLinear * 2)]
 
 
+class WgradItem(C.Structure):
+    """struct nsos_wgrad_item"""
+    _fields_ = [("w_off", _i64), ("b_off", _i64), ("g_col", _i32), ("x_col", _i32), ("M", _i32), ("N", _i32), ("ldw", _i32), ("reserved", _i32)]
+
+
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks)
 SIGNATURES = {
     "nsos_abi_version": (_i32, []),
@@ -80,6 +85,7 @@ SIGNATURES = {
     "nsos_wgrad_xh": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _sz, _fp]),
     "nsos_wgrad_x3_xh": (_i32, [_fp, _i32, _fp, _i32, _i64, _fp, _i32, _fp, _fp, _sz, _fp]),
     "nsos_relu_mask": (_i32, [_fp, _i32, _fp, _i32, _i64, _i32, _fp]),
+    "nsos_wgrad_batch": (_i32, [C.POINTER(WgradItem), _i32, _fp, _i32, _fp, _i32, _i64, _fp, _fp, _sz, _fp]),
     "nsos_sem_head_backward": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_sem_head_wgrad_workspace_bytes": (_sz, []),
     "nsos_sem_head_wgrad": (_i32, [_fp, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp, _fp, _sz, _fp, _i32, _fp]),
@@ -135,7 +141,7 @@ SIGNATURES = {
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 
-ABI_VERSION = 6          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
+ABI_VERSION = 7          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
 _lib = None
 
 

@@ -104,6 +104,7 @@ def mlp_backward(mlp, sem_mode: int, acts: torch.Tensor, g_raw: torch.Tensor, pa
 
 
 _CHUNKS = (256, 128, 64, 32)
+_WG_PLANS: dict = {}
 
 
 def _chunks(n: int):
@@ -113,6 +114,73 @@ def _chunks(n: int):
         c = next(c for c in _CHUNKS if c <= n)
         out.append((o, c))
         o, n = o + c, n - c
+    return out
+
+
+def _wgrad_plan(plan, wanted: tuple):
+    """The reductions of one generic net as ONE nsos_wgrad_batch list (cached per plan and set of Linears): per wanted Linear a block
+    [pad32(out_dim), sum of pad32(segment rows)] + a bias row in one flat output buffer, every (row tile, column tile) of every segment
+    one item.  The saved blocks are zero-padded, so padded rows / columns come out as exact zeros and are sliced away afterwards.
+    Returns (ctypes item array, n_items, floats of the flat buffer, [(name, out_dim, w_off, Mp, Kp, b_off, [(rows, wcol, column in the
+    block)], aligned)])."""
+    import ctypes as C
+    from . import _lib
+    key = (id(plan), wanted)
+    hit = _WG_PLANS.get(key)
+    if hit is not None and hit[0] is plan:
+        return hit[1]
+    pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
+    _, layout = plan.layout()
+    items, blocks, off = [], [], 0
+    for name, col, out_dim, segs in layout:
+        if name not in wanted:
+            continue
+        Mp, Kp = pad(out_dim), sum(pad(rows) for _, rows, _ in segs)
+        w_off, b_off = off, off + Mp * Kp
+        off = b_off + Mp
+        kc, placed, first = 0, [], True
+        for src_col, rows, wcol in segs:
+            Np = pad(rows)
+            for mo, mc in _chunks(Mp):
+                for no, nc in _chunks(Np):
+                    items.append((w_off + mo * Kp + kc + no, (b_off + mo) if (first and no == 0) else -1, col + mo, src_col + no, mc, nc, Kp))
+            placed.append((rows, wcol, kc))
+            kc += Np
+            first = False
+        aligned = Mp == out_dim and all(pad(r) == r for r, _, _ in placed) and all(w == k for _, w, k in placed)
+        blocks.append((name, out_dim, w_off, Mp, Kp, b_off, placed, aligned))
+    arr = (_lib.WgradItem * max(len(items), 1))()
+    for i, (w, b, g, x, m, n, ldw) in enumerate(items):
+        arr[i].w_off, arr[i].b_off, arr[i].g_col, arr[i].x_col, arr[i].M, arr[i].N, arr[i].ldw = w, b, g, x, m, n, ldw
+    res = (arr, len(items), off, blocks)
+    if len(_WG_PLANS) > 64:
+        _WG_PLANS.clear()
+    _WG_PLANS[key] = (plan, res)
+    return res
+
+
+def generic_weight_grads(mlp, plan, gbuf: torch.Tensor, acts: torch.Tensor, skip_frozen: bool = True) -> Dict[str, torch.Tensor]:
+    """dW = gbuf[:, block]^T acts[:, segment], db = column sums for every (trainable) Linear of a generic net: one nsos_wgrad_batch call
+    into one flat buffer, then views (32-aligned Linears: the gradient IS the block) or one slicing copy per ragged Linear (the
+    encodings' 63 / 27 columns, 1-3-row heads).  Round 5: until then one Python-level nsos_wgrad call per tile with three tensor
+    slicings each -- 40-110 calls per pass, most of a small net's backward time."""
+    from . import _lib
+    params = dict(mlp.named_parameters())
+    wanted = tuple(name for name, _, _, _ in plan.layout()[1]
+                   if not skip_frozen or params[name + ".weight"].requires_grad or params[name + ".bias"].requires_grad)
+    arr, n_items, floats, blocks = _wgrad_plan(plan, wanted)
+    flat = torch.empty((max(floats, 1),), device=acts.device, dtype=torch.float32)
+    ops.wgrad_batch(arr, n_items, gbuf, acts, flat)
+    out: Dict[str, torch.Tensor] = {}
+    for name, out_dim, w_off, Mp, Kp, b_off, placed, aligned in blocks:
+        blk = flat[w_off: w_off + Mp * Kp].view(Mp, Kp)
+        if aligned:
+            out[name + ".weight"] = blk
+        elif len(placed) == 1:
+            out[name + ".weight"] = blk[:out_dim, :placed[0][0]].contiguous()
+        else:
+            out[name + ".weight"] = torch.cat([blk[:out_dim, kc: kc + rows] for rows, _, kc in placed], dim=1)
+        out[name + ".bias"] = flat[b_off: b_off + out_dim]
     return out
 
 
@@ -138,33 +206,5 @@ def generic_mlp_backward(mlp, plan, acts: torch.Tensor, g_raw: torch.Tensor, pac
         gbuf = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts)
     else:
         gbuf, g_pts, g_dirs = ops.mlp_generic_input_grads(plan, packed_bwd, g_raw, acts, rays)
-    ld, layout = plan.layout()
-    f32 = dict(device=acts.device, dtype=torch.float32)
-    params = dict(mlp.named_parameters())
-    out: Dict[str, torch.Tensor] = {}
-    pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
-    for name, col, out_dim, segs in layout:
-        w = params[name + ".weight"]
-        if skip_frozen and not (w.requires_grad or params[name + ".bias"].requires_grad):
-            continue       # a frozen Linear (e.g. the whole backbone under the head-only recipe): no reduction, autograd wants no gradient for it
-        Mp = pad(out_dim)
-        gw = torch.empty_like(w)
-        # every (row tile, column tile) of a segment is written by exactly one nsos_wgrad call: no fills.  Aligned shapes (out_dim and the
-        # segment's rows multiples of 32: every hidden layer of a 32-multiple width) land in the parameter's gradient directly; ragged
-        # ones (the encodings' 63 / 27 columns, 1-3-row heads) go through a padded scratch matrix and one slicing copy
-        db = torch.empty((Mp,), **f32)
-        first = True
-        for src_col, rows, wcol in segs:
-            Np = pad(rows)
-            direct = Mp == out_dim and Np == rows
-            dst = gw[:, wcol: wcol + rows] if direct else torch.empty((Mp, Np), **f32)
-            for mo, mc in _chunks(Mp):
-                for no, nc in _chunks(Np):
-                    ops.wgrad(gbuf[:, col + mo: col + mo + mc], acts[:, src_col + no: src_col + no + nc],
-                              dst[mo: mo + mc, no: no + nc], db[mo: mo + mc] if first and no == 0 else None)
-            if not direct:
-                gw[:, wcol: wcol + rows] = dst[:out_dim, :rows]
-            first = False
-        out[name + ".weight"] = gw
-        out[name + ".bias"] = db if Mp == out_dim else db[:out_dim].clone()
+    out = generic_weight_grads(mlp, plan, gbuf, acts, skip_frozen)
     return out if rays is None else (out, g_pts, g_dirs)

@@ -49,6 +49,8 @@ struct GenOp {
     int src_off;     // mul: LDS float offset of the factor rows
     int act_col;     // first column of the op's block (pad32(out_dim) columns) in the saved-activation / gradient rows (training)
     int aux_col;     // kGenBwdMul: the column block of geo_map_sem's output
+    int ksplit_off;  // forward dense op, 0 = none: a ONE-tile op with <= 8 outputs (alpha, rgb, output_linear) whose K range is split over the
+                     // four waves -- LDS float offset of 24 dead rows (3 slabs x 8) for the partial sums of waves 1..3; n_groups is then a multiple of 16
     int b_off;       // forward dense op: float offset of the bias table [out_tiles][2 (hi)][16] in the packed weights -- the accumulators'
                      // initial values (acc = bias, then the fmaf chain: the same numbers as a leading fma(bias, 1, 0)); 0: none (backward ops)
     int grp_off[kGenMaxGroups + 8];   // LDS float offset of the first input row of group g (entries past n_groups: the constant buffer)
@@ -108,14 +110,18 @@ __device__ __forceinline__ unsigned long long gen_uniform64(const void* p) {   /
 // ahead through a register ring with hand-counted waits (the loads are asm: left to itself hipcc rotates the ring with copies
 // and drains the queue at every group).  n_groups is a multiple of 4 (the packer pads with zero-weight groups on the constant
 // buffer); the ring's last four loads run up to 4 KiB past the tile's stream (into the next tile's, or the buffer's tail pad).
-template <bool TWO, int RF>
+// BIAS: the accumulators start from the op's bias table (forward; b_off = its float offset): the table's loads are issued BEHIND the
+// ring's first eight and everything is awaited once -- one L2 round trip in front of an op's first MFMA instead of two (the table
+// first, waited for, then the ring: what hipcc made of loads written in front of the call).
+template <bool TWO, int RF, bool BIAS = false>
 __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const float* lds, int t0, int lane, int pt, int hi,
-                                            f32x16& acc0, f32x16& acc1) {
+                                            f32x16& acc0, f32x16& acc1, int b_off = 0, int g0 = 0, int ng_part = 0) {
     constexpr int kGenRowFloats = RF;
     pt &= RF - 1;                          // 16-point tiles: columns 16..31 of the B operand repeat columns 0..15
-    const int ng = op.n_groups;
-    const unsigned long long base0 = gen_uniform64(wts + op.w_off + (size_t)t0 * ng * 256);
-    const unsigned long long base1 = gen_uniform64(wts + op.w_off + (size_t)(t0 + (TWO ? 4 : 0)) * ng * 256);
+    const int ng_all = op.n_groups;
+    const int ng = ng_part ? ng_part : ng_all;          // (K-split ops: this wave's groups g0 .. g0 + ng_part - 1 of the tile's stream)
+    const unsigned long long base0 = gen_uniform64(wts + op.w_off + (size_t)t0 * ng_all * 256 + (size_t)g0 * 256);
+    const unsigned long long base1 = gen_uniform64(wts + op.w_off + (size_t)(t0 + (TWO ? 4 : 0)) * ng_all * 256);
     unsigned voff = (unsigned)lane * 16u;
     f32x4 r0[4], r1[4];
     gen_ld_off<0>(r0[0], voff, base0);
@@ -127,15 +133,28 @@ __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const
     gen_ld_off<3072>(r0[3], voff, base0);
     if constexpr (TWO) gen_ld_off<3072>(r1[3], voff, base1);
     voff += 4096u;
+    if constexpr (BIAS) {   // register r of lane (j, hi) is output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi: table [tile][hi][16], tile t0 + 4 is 512 B on
+        const unsigned long long bb = gen_uniform64(wts + b_off + (size_t)t0 * 32);
+        const unsigned boff = (unsigned)hi * 64u;
+        f32x4 v0[4], v1[4];
+        gen_ld_off<0>(v0[0], boff, bb); gen_ld_off<16>(v0[1], boff, bb); gen_ld_off<32>(v0[2], boff, bb); gen_ld_off<48>(v0[3], boff, bb);
+        if constexpr (TWO) { gen_ld_off<512>(v1[0], boff, bb); gen_ld_off<528>(v1[1], boff, bb); gen_ld_off<544>(v1[2], boff, bb); gen_ld_off<560>(v1[3], boff, bb); }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]) : : "memory");
+        if constexpr (TWO) asm volatile("" : "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc0[4 * q + j] = v0[q][j]; if constexpr (TWO) acc1[4 * q + j] = v1[q][j]; }
+    }
     // B operands one group ahead (LDS latency under the previous group's MFMAs); the last prefetch reads group `ng`: a valid
     // table entry (the table is padded past kGenMaxGroups) pointing at the constant buffer
-    const float* bp0 = lds + op.grp_off[0] + hi * kGenRowFloats + pt;
+    const float* bp0 = lds + op.grp_off[g0] + hi * kGenRowFloats + pt;
     float bn0 = bp0[0], bn1 = bp0[2 * kGenRowFloats], bn2 = bp0[4 * kGenRowFloats], bn3 = bp0[6 * kGenRowFloats];
     for (int g = 0; g < ng; g += 4) {
         static_for<0, 4>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const float b0 = bn0, b1 = bn1, b2 = bn2, b3 = bn3;
-            const float* bp = lds + op.grp_off[g + u + 1] + hi * kGenRowFloats + pt;
+            const float* bp = lds + op.grp_off[g0 + g + u + 1] + hi * kGenRowFloats + pt;
             bn0 = bp[0]; bn1 = bp[2 * kGenRowFloats]; bn2 = bp[4 * kGenRowFloats]; bn3 = bp[6 * kGenRowFloats];
             // group g + u has landed when at most the loads of the three younger groups are outstanding
             if constexpr (TWO) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r0[u]), "+v"(r1[u]) : : "memory");
@@ -223,14 +242,43 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         auto v_feat = [&](int f) { return erow ? (f < G.v_dim ? erow[G.x_dim + f] : 0.0f) : gen_feature(dv, f, G.v_dim, G.v_freqs); };
         if (erow)      // (every part of a point scans the whole row: each writes some of the point's output channels)
             for (int f = 0; f < G.x_dim + G.v_dim; ++f) poison += erow[f] - erow[f];
-        for (int f = part; f < G.x_rows; f += NP) lds[G.x_off + f * kGenRowFloats + p] = x_feat(f);
-        for (int f = part; f < G.v_rows; f += NP) lds[G.v_off + f * kGenRowFloats + p] = v_feat(f);
-        if constexpr (SAVE) {
-            if (valid) {       // (evaluated again rather than read back from LDS: no barrier in between; blocks are padded to 32 columns with zeros)
-                float* arow = P.acts + gp * G.act_ld;
-                if ((P.save_mask >> 62) & 1) for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = x_feat(f);
-                if ((P.save_mask >> 63) & 1) for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = v_feat(f);
+        // One sincos per (octave, coordinate) and point: it yields TWO rows (sin: 3 + 6 k + c, cos: + 3), written to LDS and -- SAVE -- to the
+        // point's saved row in the same pass.  (Until round 5 every ROW was evaluated on its own, both functions computed and one dropped, and
+        // the SAVE variant evaluated everything a second time: the encode phase was 6.6 % of an 8 x 256 tile, profiles/r05.)
+        auto encode = [&](const float (&xv)[3], int dim, int rows, int freqs, int off, bool save, int col) {
+            float* arow = (SAVE && save && valid) ? P.acts + gp * G.act_ld + col : nullptr;
+            const int n_units = freqs < 0 ? 3 : 3 + 3 * freqs;
+            for (int u = part; u < n_units; u += NP) {
+                if (u < 3) {
+                    const float v = u == 0 ? xv[0] : (u == 1 ? xv[1] : xv[2]);
+                    lds[off + u * kGenRowFloats + p] = v;
+                    if (SAVE && arow) arow[u] = v;
+                } else {
+                    const int m = u - 3, k = m / 3, c = m - 3 * k, r = 3 + 6 * k + c;
+                    const float a = (c == 0 ? xv[0] : (c == 1 ? xv[1] : xv[2])) * __builtin_bit_cast(float, (unsigned)(127 + k) << 23);   // 2^k, exact
+                    float sn, cs;
+                    sincos_pe(a, sn, cs);
+                    lds[off + r * kGenRowFloats + p] = sn;
+                    lds[off + (r + 3) * kGenRowFloats + p] = cs;
+                    if (SAVE && arow) { arow[r] = sn; arow[r + 3] = cs; }
+                }
             }
+            for (int f = dim + part; f < rows; f += NP) lds[off + f * kGenRowFloats + p] = 0.0f;                 // the buffer's pad rows
+            if (SAVE && arow) for (int f = dim + part; f < ((dim + 31) & ~31); f += NP) arow[f] = 0.0f;        // the block's pad columns
+        };
+        if (erow) {
+            for (int f = part; f < G.x_rows; f += NP) lds[G.x_off + f * kGenRowFloats + p] = x_feat(f);
+            for (int f = part; f < G.v_rows; f += NP) lds[G.v_off + f * kGenRowFloats + p] = v_feat(f);
+            if constexpr (SAVE) {
+                if (valid) {       // (blocks are padded to 32 columns with zeros)
+                    float* arow = P.acts + gp * G.act_ld;
+                    if ((P.save_mask >> 62) & 1) for (int f = part; f < ((G.x_dim + 31) & ~31); f += NP) arow[G.x_col + f] = x_feat(f);
+                    if ((P.save_mask >> 63) & 1) for (int f = part; f < ((G.v_dim + 31) & ~31); f += NP) arow[G.v_col + f] = v_feat(f);
+                }
+            }
+        } else {
+            encode(x, G.x_dim, G.x_rows, G.x_freqs, G.x_off, (P.save_mask >> 62) & 1, G.x_col);
+            if (G.v_dim) encode(dv, G.v_dim, G.v_rows, G.v_freqs, G.v_off, (P.save_mask >> 63) & 1, G.v_col);
         }
         for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = 0.0f;
         GEN_PROF_WORK(1);
@@ -250,21 +298,65 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
             int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu, o_act = op.act_col, o_boff = op.b_off;
             asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags), "+s"(o_act), "+s"(o_boff));
             const bool relu = o_flags & 1, padw = o_flags & 2;
+            int o_ks = op.ksplit_off;
+            asm volatile("" : "+s"(o_ks));
+            if (o_ks) {
+                // ONE output tile with a few real rows (alpha 1, rgb 3, output_linear 4 ..): as a plain op wave 0 ran its whole K range while three
+                // waves waited at the barrier -- 6.4 % + 4.3 % of an 8 x 256 tile's time (profiles/r05).  Split over K instead: wave w
+                // contracts groups w ng/4 .. (w+1) ng/4 - 1 (wave 0 starts from the bias), waves 1..3 park rows 0..7 of their partial tiles in
+                // dead LDS rows, wave 0 adds them in a fixed order ((own + w1) + w2) + w3 and finishes the op as before.
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+                const int gq = op.n_groups >> 2;
+                if (wave == 0) dense_tiles<false, RF, true>(op, P.wts, lds, 0, lane, pt, hi, acc0, acc1, o_boff, 0, gq);
+                else dense_tiles<false, RF, false>(op, P.wts, lds, 0, lane, pt, hi, acc0, acc1, 0, wave * gq, gq);
+                float* slab = lds + o_ks + (4 * hi) * kGenRowFloats + pt;       // accumulator register r < 4 of lane (j, hi) = row r + 4 hi
+                if (wave != 0 && (RF == 32 || own)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[((wave - 1) * 8 + r) * kGenRowFloats] = acc0[r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    if (RF == 32 || own) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc0[r] = ((acc0[r] + slab[r * kGenRowFloats]) + slab[(8 + r) * kGenRowFloats]) + slab[(16 + r) * kGenRowFloats];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc0[r] = fmaxf(acc0[r], 0.0f);
+                    }
+                    if (RF == 32 || own) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r + 4 * hi < o_dim) lds[o_off + (r + 4 * hi) * kGenRowFloats + pt] = acc0[r];
+                    }
+                    if constexpr (SAVE) {
+                        const long long gpl = (long long)tile * RF + pt;
+                        if (own && gpl < P.n_pts && ((P.save_mask >> oi) & 1)) {
+                            float* dst = P.acts + gpl * G.act_ld + o_act + 4 * hi;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f32x4 v0;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v0[j] = acc0[4 * q + j];       // (rows >= 8: zero weights and zero bias, exact zeros)
+                                *reinterpret_cast<f32x4*>(dst + 8 * q) = v0;
+                            }
+                        }
+                    }
+                }
+                GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
+                __syncthreads();
+                GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
+                continue;
+            }
             for (int t0 = wave; t0 < out_tiles; t0 += 8) {
                 f32x16 acc0, acc1;
                 const bool two = t0 + 4 < out_tiles;          // wave-uniform
-                {   // acc = bias: register r of lane (j, hi) is output feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi -- 16 floats per (tile, hi)
-                    const f32x4* b0 = reinterpret_cast<const f32x4*>(P.wts + o_boff + (t0 * 2 + hi) * 16);
-                    const f32x4* b1 = reinterpret_cast<const f32x4*>(P.wts + o_boff + ((two ? t0 + 4 : t0) * 2 + hi) * 16);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v0 = b0[q], v1 = b1[q];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { acc0[4 * q + j] = v0[j]; acc1[4 * q + j] = v1[j]; }
-                    }
-                }
-                if (two) dense_tiles<true, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
-                else dense_tiles<false, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;       // (one-tile items: acc1 is stored nowhere, but read by the ReLU pass)
+                if (two) dense_tiles<true, RF, true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1, o_boff);
+                else dense_tiles<false, RF, true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1, o_boff);
                 if (relu) {     // (asm: fmaxf is two instructions -- a canonicalising v_max x, x in front of the v_max 0, x; same values, a NaN -> 0 either way)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -376,14 +468,24 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
         const int row = tid / RF, col = tid % RF;
         if (row < 8) lds[G.ones_off + row * kGenRowFloats + col] = row == 0 ? 1.0f : 0.0f;     // (pad groups carry zero weights: any finite rows do)
     }
+#ifdef NSOS_GEN_PROF
+    unsigned long long pw[64], pb[64];
+    for (int k = 0; k < 64; ++k) pw[k] = pb[k] = 0;
+#endif
     for (int tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+#ifdef NSOS_GEN_PROF
+        unsigned long long tp = GEN_PROF_T(), tq;
+        pw[0] += 1;
+#endif
         const int p = tid % RF, part = tid / RF;
         const long long gp = (long long)tile * RF + p;
         const bool valid = gp < P.n_pts;
         const long long gc = valid ? gp : P.n_pts - 1;
         // d loss / d raw into the OUT rows (points past the end: zero gradient, so nothing of theirs reaches gbuf or a neighbour)
         for (int r = part; r < G.out_rows; r += NP) lds[out_off + r * kGenRowFloats + p] = (r < n_out && valid) ? P.g_raw[gp * n_out + r] : 0.0f;
+        GEN_PROF_WORK(1);
         __syncthreads();
+        GEN_PROF_BAR(1);
         for (int oi = 0; oi < n_ops; ++oi) {
             const __attribute__((address_space(4))) GenOp& op = G.ops[oi];
             if (op.kind == kGenBwdMul) {
@@ -393,7 +495,9 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                     lds[op.out_off + r * kGenRowFloats + p] = g * mv;
                     lds[op.src_off + r * kGenRowFloats + p] = g * sv;
                 }
+                GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
                 __syncthreads();
+                GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
                 continue;
             }
             if (op.kind == kGenBwdHead) {
@@ -436,7 +540,9 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                         if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
                     }
                 }
+                GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
                 __syncthreads();
+                GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
                 continue;
             }
             int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu;      // pinned: see the forward kernel
@@ -475,7 +581,9 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                     if (two) put(d0 + 128 * kGenRowFloats, acc1, rb + 128, padw || 32 * t0 + 160 <= o_dim);
                 }
             }
+            GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
             __syncthreads();
+            GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
         }
         // ---- d loss / d point and / d view direction through the positional encodings (models/embedder.py:34-48):
         //      d/dx [x, sin(2^k x), cos(2^k x)] = [1, 2^k cos(2^k x), -2^k sin(2^k x)]; thread (point, part): part 0..2 = xyz, 3..5 = direction
@@ -506,7 +614,12 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 if (valid) (isdir ? P.g_dirs : P.g_pts)[gp * 3 + c] = (float)g;
             }
         }
+        GEN_PROF_WORK(62);
     }
+#ifdef NSOS_GEN_PROF
+    if (blockIdx.x == 1 && lane == 0)
+        for (int k = 0; k < 64; ++k) { nsos_gen_prof[wave][0][k] = pw[k]; nsos_gen_prof[wave][1][k] = pb[k]; }
+#endif
 }
 
 // Per ray: the gradients of its points folded back onto the ray (autograd of pts = o + d z, models/sampler.py:70,166; of
@@ -659,7 +772,8 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     produced[n_produced++] = {G.x_off, G.x_col};
     if (v_dim) produced[n_produced++] = {G.v_off, G.v_col};
     auto col_of = [&](int buf_off) { for (int k = n_produced - 1; k >= 0; --k) if (produced[k].off == buf_off) return produced[k].col; return -1; };
-    auto dense = [&](const nsos_generic_linear& L, int out_buf, int out_row0, bool relu, int n_seg, const HostSeg* segs) {
+    // ks_scratch >= 0: a buffer that is dead while the op runs (>= 24 rows) -- the op's K range is split over the waves if it qualifies
+    auto dense = [&](const nsos_generic_linear& L, int out_buf, int out_row0, bool relu, int n_seg, const HostSeg* segs, int ks_scratch = -1) {
         if (n >= kGenMaxOps || !L.weight || !L.bias) { H.err = H.err ? H.err : (n >= kGenMaxOps ? NSOS_ERR_UNSUPPORTED : NSOS_ERR_NULL_POINTER); return; }
         HostOp& ho = H.hops[n];
         GenOp& op = ho.op;
@@ -678,7 +792,9 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
             }
         }
         if (in_dim != L.in_dim) { H.err = NSOS_ERR_BAD_SHAPE; return; }
-        while (g % 4) {                                   // the kernel's loop is unrolled by four groups: pad with zero-weight groups
+        const bool ksplit = ks_scratch > 0 && out_buf == G.out_off && L.out_dim <= 8 && g >= 8 && pad_to(g, 16) <= kGenMaxGroups && Wp >= 24;
+        op.ksplit_off = ksplit ? ks_scratch : 0;
+        while (g % (ksplit ? 16 : 4)) {                   // the kernel's loop is unrolled by four groups (per wave, for a K-split op): pad with zero-weight groups
             if (g >= kGenMaxGroups) { H.err = NSOS_ERR_UNSUPPORTED; return; }
             op.grp_off[g++] = G.ones_off;
         }
@@ -709,9 +825,9 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     const int other = cur == HA ? HB : HA;
     const HostSeg hs = {cur, W, 0, 0};
     if (!M.use_viewdirs) {
-        dense(M.output, G.out_off, 0, false, 1, &hs);                                          // output_linear (:97-98)
+        dense(M.output, G.out_off, 0, false, 1, &hs, other);                                   // output_linear (:97-98); `other` is dead (it held h[D-2])
     } else {
-        dense(M.alpha, G.out_off, 3, false, 1, &hs);                                           // alpha = alpha_linear(h) (:77)
+        dense(M.alpha, G.out_off, 3, false, 1, &hs, other);                                    // alpha = alpha_linear(h) (:77); `other` is dead until the heads write it
         if (sem) {
             int src = -1, src_rows = 0;
             for (int k = 0; k < M.sem_layers; ++k) {                                           // semantic_linear (:58-64, :79-80)
@@ -744,7 +860,7 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
         const HostSeg fv[2] = {{other, W, 0, 0}, Vs};
         dense(M.views, cur, 0, true, 2, fv);                                                   // relu(views_linears.0(cat([feature, input_views]))) (:87-90)
         const HostSeg vh = {cur, M.views.out_dim, 0, 0};
-        dense(M.rgb, G.out_off, 0, false, 1, &vh);                                             // rgb_linear (:92)
+        dense(M.rgb, G.out_off, 0, false, 1, &vh, other);                                      // rgb_linear (:92); `other` held feature: consumed by the view branch
     }
     G.n_ops = n;
     G.w_floats = w_off;

@@ -388,6 +388,24 @@ extern "C" int32_t nsos_wgrad_xh(const float* G, int32_t ldg, const void* X_f16,
     return wgrad_entry<_Float16>(G, ldg, static_cast<const _Float16*>(X_f16), ldx, n_pts, M, N, dW, ldw, db, workspace, workspace_bytes, stream);
 }
 
+// A whole list of reductions over column blocks of ONE (G, X) pair of row-major buffers -- the weight gradients of a generic-architecture
+// net (backward.py: generic_mlp_backward): one call, and no host work per item, instead of one Python-level nsos_wgrad call with three
+// tensor slicings per (Linear, segment, 256 / 128 / 64 / 32 tile).  Items run in list order on the stream; they share the workspace, so
+// each item is its kernel + its reduction exactly as nsos_wgrad issues them (same numbers).
+extern "C" int32_t nsos_wgrad_batch(const nsos_wgrad_item* items, int32_t n_items, const float* G, int32_t ldg, const float* X, int32_t ldx,
+                                    int64_t n_pts, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    NSOS_REQUIRE(n_items >= 0 && (n_items == 0 || items), NSOS_ERR_NULL_POINTER);
+    NSOS_REQUIRE(n_items == 0 || out, NSOS_ERR_NULL_POINTER);
+    for (int i = 0; i < n_items; ++i) {
+        const nsos_wgrad_item& it = items[i];
+        NSOS_REQUIRE(it.g_col >= 0 && it.x_col >= 0 && it.w_off >= 0 && it.g_col + it.M <= ldg && it.x_col + it.N <= ldx, NSOS_ERR_BAD_SHAPE);
+        const int32_t rc = wgrad_entry<float>(G + it.g_col, ldg, X + it.x_col, ldx, n_pts, it.M, it.N, out + it.w_off, it.ldw,
+                                              it.b_off >= 0 ? out + it.b_off : nullptr, workspace, workspace_bytes, stream);
+        if (rc != NSOS_OK) return rc;
+    }
+    return NSOS_OK;
+}
+
 extern "C" int32_t nsos_relu_mask(float* g, int32_t ldg, const float* h, int32_t ldh, int64_t n_pts, int32_t n_cols, void* stream) {
     if (n_pts == 0) return NSOS_OK;
     NSOS_REQUIRE(g && h, NSOS_ERR_NULL_POINTER);

@@ -993,6 +993,20 @@ def wgrad(G: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch
     _lib.check(fn(G.data_ptr(), ldg, X.data_ptr(), ldx, P_, M, N, dW.data_ptr(), ldw, _p(db), _p(ws), ws.numel() * 4, _stream()), "nsos_wgrad")
 
 
+def wgrad_batch(items, n_items: int, G: torch.Tensor, X: torch.Tensor, out: torch.Tensor) -> None:
+    """A prepared list of nsos_wgrad reductions over column blocks of G [P, ldg] and X [P, ldx] into the flat fp32 buffer `out`
+    (nsos_wgrad_batch; backward.generic_weight_grads builds the list)."""
+    G, X, out = _dev(G, "G"), _dev(X, "X"), _dev(out, "out")
+    if G.dim() != 2 or X.dim() != 2 or G.shape[0] != X.shape[0] or G.dtype != torch.float32 or X.dtype != torch.float32 or out.dtype != torch.float32:
+        raise ValueError("wgrad_batch: G [P, ldg] and X [P, ldx] must be fp32 matrices over the same points")
+    dev = G.device
+    if dev not in _WG_WS:
+        _WG_WS[dev] = torch.empty(_lib.lib().nsos_wgrad_workspace_bytes() // 4, device=dev, dtype=torch.float32)
+    ws = _WG_WS[dev]
+    _lib.check(_lib.lib().nsos_wgrad_batch(items, int(n_items), G.data_ptr(), G.shape[1], X.data_ptr(), X.shape[1], G.shape[0],
+                                          out.data_ptr(), _p(ws), ws.numel() * 4, _stream()), "nsos_wgrad_batch")
+
+
 def relu_mask_(g: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
     """In place g *= (h > 0) for row-major matrices / column slices with the same shape."""
     g, ldg = _rows(g, "g")
