@@ -135,11 +135,14 @@ int32_t nsos_mlp_generic_forward_points(const nsos_generic_mlp* mlp, const void*
 /* ---- K7-G: training a generic-architecture net (every parameter; autograd of models/nerf_mlp.py:67-100 over the points of a ray
  * batch, the model the reference trains in engines/trainer.py:201-203 when its constructor arguments are not the shipped ones).
  *   forward_rays_save  = forward_rays + `acts` [n_rays * n_samples, ld]: per point the two encodings and every Linear's
- *                        post-activation output, each in a column block padded to 32 with zeros (ld and the blocks: save_layout).
+ *                        post-activation output, each in a column block padded to 32 with zeros (ld and the blocks: save_layout),
+ *                        and behind the blocks (ABI 7) the ReLU patterns as BITS: one 32-bit word per output tile of every ReLU
+ *                        Linear, in program order (bit r + 16 h = [feature 32 t + (r & 3) + 8 (r >> 2) + 4 h of tile t > 0]); the row
+ *                        is padded to a multiple of 4 floats.  The chain reads its masks from these words, never from the blocks.
  *   pack_bwd           the transposed weight streams + the reversed program, into nsos_mlp_generic_bwd_packed_bytes(mlp) bytes
  *                        (re-pack whenever a weight changed, like nsos_mlp_generic_pack).
  *   input_grads        one kernel: g_raw [n_pts, out_channels] (d loss / d raw, e.g. from nsos_composite_backward) -> `gbuf`
- *                        [n_pts, ld]: every Linear's pre-activation gradient in its column block (ReLU masks from `acts`).
+ *                        [n_pts, ld]: every Linear's pre-activation gradient in its column block (ReLU masks from `acts`' bit words).
  *   save_layout        table[0] = ld, table[1] = number of Linear ops, then NSOS_GENERIC_LAYOUT_STRIDE ints per op in forward order:
  *                        position of the Linear in nsos_generic_mlp (pts 0..15, alpha 16, feature 17, views 18, rgb 19, output 20,
  *                        sem 21..28, geo 29..30), its column block, out_dim, number of input segments, then per segment (3 slots)
@@ -158,8 +161,9 @@ int32_t nsos_mlp_generic_save_layout(const nsos_generic_mlp* mlp, int32_t* table
 int32_t nsos_mlp_generic_forward_rays_save(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
                                            const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                            float* raw, float* acts, void* stream);
-/* forward_rays_save for a trainable subset (the mask of nsos_mlp_generic_pack_bwd_subset): only the blocks that subset's backward reads
- * are stored (inputs of the trainable Linears, outputs of the ReLU layers downstream of one); the other columns of `acts` stay unwritten. */
+/* forward_rays_save for a trainable subset (the mask of nsos_mlp_generic_pack_bwd_subset, bit 31 included): only the blocks that subset's
+ * backward reads are stored (the inputs of the trainable Linears, the factors of semantics * mapping) + the bit words, always; the other
+ * columns of `acts` stay unwritten.  trainable = 1u << 31 (pose refinement against a frozen net): the bit words alone. */
 int32_t nsos_mlp_generic_forward_rays_save_subset(const nsos_generic_mlp* mlp, const void* packed, const float* rays_o, const float* rays_d,
                                                   const float* viewdirs, const float* z_vals, int64_t n_rays, int32_t n_samples,
                                                   float* raw, float* acts, uint32_t trainable, void* stream);
@@ -168,7 +172,10 @@ int32_t nsos_mlp_generic_pack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd,
 /* The chain for a SUBSET of trainable Linears (bit p of `trainable` = position p of the Linear in nsos_generic_mlp, as in save_layout):
  * only the pre-activation gradients of those Linears and of everything downstream of them are formed -- with a frozen backbone (the
  * shipped recipe, run_nerf.py:307-318) the chain stops at the semantic head.  gbuf blocks of the other Linears are left unwritten.
- * with_header = 0: weights only, as nsos_mlp_generic_repack (same subset as the pack that wrote the header).  No input gradients. */
+ * with_header = 0: weights only, as nsos_mlp_generic_repack (same subset as the pack that wrote the header).
+ * Bit 31 of `trainable` (ABI 7): the program ALSO carries the gradient into the encodings (as input_grads != 0 of nsos_mlp_generic_pack_bwd;
+ * packed_bytes of nsos_mlp_generic_bwd_packed_bytes(mlp, 1)): every gradient of the chain is formed, and only the trainable Linears'
+ * are written to gbuf -- a frozen net's chain (trainable = 1u << 31) touches neither the activation blocks nor gbuf. */
 int32_t nsos_mlp_generic_pack_bwd_subset(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, uint32_t trainable,
                                          int32_t with_header, void* stream);
 int32_t nsos_mlp_generic_repack_bwd(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, int32_t input_grads, void* stream);  /* as nsos_mlp_generic_repack */

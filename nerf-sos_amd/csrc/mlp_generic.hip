@@ -49,6 +49,9 @@ struct GenOp {
     int src_off;     // mul: LDS float offset of the factor rows
     int act_col;     // first column of the op's block (pad32(out_dim) columns) in the saved-activation / gradient rows (training)
     int aux_col;     // kGenBwdMul: the column block of geo_map_sem's output
+    int mask_col;    // ReLU ops (forward dense op / its backward head step), -1 = none: the column of the point's saved row that holds the op's
+                     // ReLU pattern as BITS -- one 32-bit word per output tile: bit r + 16 hi = [accumulator register r of lane (point, hi) > 0]
+                     // (round 5: the chain read 4 bytes of saved activation per mask bit, and the backward of a frozen net stored them for nothing else)
     int ksplit_off;  // forward dense op, 0 = none: a ONE-tile op with <= 8 outputs (alpha, rgb, output_linear) whose K range is split over the
                      // four waves -- LDS float offset of 24 dead rows (3 slabs x 8) for the partial sums of waves 1..3; n_groups is then a multiple of 16
     int b_off;       // forward dense op: float offset of the bias table [out_tiles][2 (hi)][16] in the packed weights -- the accumulators'
@@ -295,8 +298,8 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
             // the op's scalars, read ONCE from the program and pinned in SGPRs: as plain constant-address-space reads hipcc re-issued the
             // s_load of op.out_off (and waited for it with lgkmcnt(0)) in front of EVERY accumulator store of the epilogue -- 32 exposed
             // scalar-cache round trips per op and wave, about a quarter of a 256 x 256 layer's time (round 5, found in the ISA)
-            int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu, o_act = op.act_col, o_boff = op.b_off;
-            asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags), "+s"(o_act), "+s"(o_boff));
+            int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu, o_act = op.act_col, o_boff = op.b_off, o_mcol = op.mask_col;
+            asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags), "+s"(o_act), "+s"(o_boff), "+s"(o_mcol));
             const bool relu = o_flags & 1, padw = o_flags & 2;
             int o_ks = op.ksplit_off;
             asm volatile("" : "+s"(o_ks));
@@ -395,6 +398,14 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 }
                 if constexpr (SAVE) {
                     const long long gpl = (long long)tile * RF + pt;
+                    if (o_mcol >= 0 && own && gpl < P.n_pts) {      // the ReLU pattern as bits: 2 bytes per lane and tile (always stored: the chain's masks)
+                        unsigned m0 = 0, m1 = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { m0 |= (acc0[r] > 0.0f ? 1u : 0u) << r; m1 |= (acc1[r] > 0.0f ? 1u : 0u) << r; }
+                        unsigned short* mrow = reinterpret_cast<unsigned short*>(P.acts + gpl * G.act_ld + o_mcol);
+                        mrow[2 * t0 + hi] = (unsigned short)m0;
+                        if (two) mrow[2 * (t0 + 4) + hi] = (unsigned short)m1;
+                    }
                     if (own && gpl < P.n_pts && ((P.save_mask >> oi) & 1)) {
                         float* dst = P.acts + gpl * G.act_ld + o_act + 32 * t0 + 4 * hi;
 #pragma unroll
@@ -501,43 +512,45 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 continue;
             }
             if (op.kind == kGenBwdHead) {
-                int h_tiles = op.out_tiles, h_off = op.out_off, h_dim = op.out_dim, h_flags = op.relu, h_act = op.act_col;     // pinned: see the forward kernel
-                asm volatile("" : "+s"(h_tiles), "+s"(h_off), "+s"(h_dim), "+s"(h_flags), "+s"(h_act));
+                int h_tiles = op.out_tiles, h_off = op.out_off, h_dim = op.out_dim, h_flags = op.relu, h_act = op.act_col, h_mcol = op.mask_col;     // pinned: see the forward kernel
+                asm volatile("" : "+s"(h_tiles), "+s"(h_off), "+s"(h_dim), "+s"(h_flags), "+s"(h_act), "+s"(h_mcol));
                 const long long gpl = (long long)tile * RF + pt;
                 const bool vpt = own && gpl < P.n_pts;
-                const float* arow = P.acts + (vpt ? gpl : P.n_pts - 1) * ld + h_act;
+                // the ReLU pattern comes from the forward's bit words (2 bytes per lane and tile; bit r of half hi = accumulator register r =
+                // feature 32 t + (r & 3) + 8 (r >> 2) + 4 hi: exactly the four-feature runs 8 q + 4 hi + j, r = 4 q + j, this step walks);
+                // bit 3 of the flags: no weight-gradient reduction reads this op's gradient (a frozen Linear) -- nothing goes to gbuf
+                const unsigned short* mrow = reinterpret_cast<const unsigned short*>(P.acts + (vpt ? gpl : P.n_pts - 1) * ld + (h_mcol >= 0 ? h_mcol : 0));
                 float* grow = P.gbuf + gpl * ld + h_act;
-                const bool relu = h_flags & 1;
+                const bool relu = (h_flags & 1) && h_mcol >= 0, store = !(h_flags & 8);
                 for (int t = wave; t < h_tiles; t += 4) {
                     float* lrow = lds + h_off + (32 * t + 4 * hi) * kGenRowFloats + pt;
+                    const unsigned mw = relu ? (unsigned)mrow[2 * t + hi] : 0xffffu;
                     if (32 * t + 32 <= h_dim && (RF == 32 || own)) {       // a tile wholly inside the op's rows: no per-element tests
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int f0 = 32 * t + 8 * q + 4 * hi;
-                            f32x4 g, a = {1.0f, 1.0f, 1.0f, 1.0f};
-                            if (relu) a = *reinterpret_cast<const f32x4*>(arow + f0);
+                            f32x4 g;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const float v = lrow[(8 * q + j) * kGenRowFloats];
-                                g[j] = a[j] > 0.0f ? v : 0.0f;                        // relu'(x) = [x > 0] (ATen threshold_backward)
+                                g[j] = ((mw >> (4 * q + j)) & 1u) ? v : 0.0f;          // relu'(x) = [x > 0] (ATen threshold_backward)
                                 if (relu) lrow[(8 * q + j) * kGenRowFloats] = g[j];   // (ReLU outputs own whole pad32 buffers)
                             }
-                            if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
+                            if (vpt && store) *reinterpret_cast<f32x4*>(grow + f0) = g;
                         }
                         continue;
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int f0 = 32 * t + 8 * q + 4 * hi;
-                        f32x4 g, a = {1.0f, 1.0f, 1.0f, 1.0f};
-                        if (relu) a = *reinterpret_cast<const f32x4*>(arow + f0);
+                        f32x4 g;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float v = (own && f0 + j < h_dim) ? lds[h_off + (f0 + j) * kGenRowFloats + pt] : 0.0f;
-                            g[j] = a[j] > 0.0f ? v : 0.0f;
+                            g[j] = ((mw >> (4 * q + j)) & 1u) ? v : 0.0f;
                             if (relu && own) lds[h_off + (f0 + j) * kGenRowFloats + pt] = g[j];
                         }
-                        if (vpt) *reinterpret_cast<f32x4*>(grow + f0) = g;
+                        if (vpt && store) *reinterpret_cast<f32x4*>(grow + f0) = g;
                     }
                 }
                 GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
@@ -862,6 +875,13 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
         const HostSeg vh = {cur, M.views.out_dim, 0, 0};
         dense(M.rgb, G.out_off, 0, false, 1, &vh, other);                                      // rgb_linear (:92); `other` held feature: consumed by the view branch
     }
+    // the ReLU patterns as bits, behind the blocks: one 32-bit word per output tile of every ReLU op (two 16-bit halves: hi = 0, 1)
+    for (int i = 0; i < n; ++i) {
+        GenOp& op = H.hops[i].op;
+        op.mask_col = -1;
+        if (op.kind == kGenDense && (op.relu & 1)) { op.mask_col = next_col; next_col += op.out_tiles; }
+    }
+    next_col = pad_to(next_col, 4);                         // rows stay 16-byte aligned
     G.n_ops = n;
     G.w_floats = w_off;
     G.act_ld = next_col;
@@ -902,17 +922,20 @@ void compute_need(const nsos_generic_mlp& M, const HostProgram& H, bool input_gr
 }
 // Which blocks of the saved-activation row a backward for this trainable subset reads: the inputs of a trainable Linear (the X operand of
 // its weight-gradient reduction), the outputs of ReLU ops whose gradient is formed (their masks), the two factors of semantics * mapping.
+// (round 5: the ReLU patterns travel as bit words that every SAVE launch writes, so a block is stored only for the reductions and the
+//  product's factors.)  Bit 31 of `trainable` (kGenInputGrads): the chain also reaches the inputs -- every op's gradient is formed.
+constexpr unsigned kGenInputGrads = 1u << 31;
 unsigned long long save_mask_for(const nsos_generic_mlp& M, const HostProgram& H, unsigned trainable) {
     if (trainable == ~0u) return ~0ull;
     const GenProgram& F = H.prog;
     bool need[kGenMaxOps];
     int sem_last_op, geo1_op;
-    compute_need(M, H, false, trainable, need, sem_last_op, geo1_op);
+    compute_need(M, H, (trainable & kGenInputGrads) != 0, trainable & ~kGenInputGrads, need, sem_last_op, geo1_op);
+    trainable &= ~kGenInputGrads;
     unsigned long long m = 0;
     for (int oi = 0; oi < F.n_ops; ++oi) {
         const HostOp& ho = H.hops[oi];
         if (ho.op.kind != kGenDense) continue;
-        if (need[oi] && (ho.op.relu & 1)) m |= 1ull << oi;
         if (!((trainable >> ho.lin_id) & 1u)) continue;
         for (int s = 0; s < ho.n_seg; ++s) {
             if (ho.seg[s].buf_off == F.x_off) m |= 1ull << 62;
@@ -977,7 +1000,8 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
             GenOp& op = G.ops[n++];
             op = GenOp{};
             op.kind = kGenBwdHead; op.out_off = ho.op.out_off; op.out_dim = ho.op.out_dim; op.out_tiles = ho.op.out_tiles;
-            op.relu = ho.op.relu & 1; op.act_col = ho.op.act_col;
+            op.relu = (ho.op.relu & 1) | (((trainable >> ho.lin_id) & 1u) ? 0 : 8);      // bit 3: a frozen Linear -- its gradient feeds no reduction, nothing goes to gbuf
+            op.act_col = ho.op.act_col; op.mask_col = ho.op.mask_col;
         }
         for (int s = 0; s < ho.n_seg && need[oi]; ++s) {
             const HostSeg& sg = ho.seg[s];
@@ -1222,7 +1246,9 @@ extern "C" int32_t nsos_mlp_generic_repack_bwd(const nsos_generic_mlp* mlp, void
 }
 extern "C" int32_t nsos_mlp_generic_pack_bwd_subset(const nsos_generic_mlp* mlp, void* packed_bwd, size_t packed_bytes, uint32_t trainable,
                                                     int32_t with_header, void* stream) {
-    return generic_pack_bwd(mlp, packed_bwd, packed_bytes, 0, stream, with_header != 0, trainable);
+    // bit 31 of `trainable`: the program also reaches the encodings (ray / point gradients) -- e.g. pose refinement against a frozen net:
+    // trainable = 1u << 31 forms every gradient of the chain and stores none of them
+    return generic_pack_bwd(mlp, packed_bwd, packed_bytes, (trainable & kGenInputGrads) ? 1 : 0, stream, with_header != 0, trainable & ~kGenInputGrads);
 }
 
 static int32_t generic_bwd_launch(const nsos_generic_mlp* mlp, const void* packed_bwd, GenBwdParams p, int64_t n_pts, hipStream_t st) {

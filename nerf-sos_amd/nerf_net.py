@@ -117,8 +117,8 @@ class MLP(nn.Module):
 
     def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
         plan = self._generic_plan()
-        mask = None if input_grads else plan.trainable_mask(self)
-        key = "generic_bwd_in" if input_grads else ("generic_bwd" if mask is None else "generic_bwd_sub")
+        mask = plan.trainable_mask(self)
+        key = ("generic_bwd_in" if mask is None else "generic_bwd_in_sub") if input_grads else ("generic_bwd" if mask is None else "generic_bwd_sub")
         self._enc_packed[key] = plan.run_bwd(self._enc_packed.get(key), input_grads=input_grads, trainable=mask)
         return self._enc_packed[key]
 
@@ -239,14 +239,17 @@ class NeRFMLP(nn.Module):
         self._frozen_key.clear()
         self._plan = self._gplan = None
 
-    def query_rays(self, rays_o, rays_d, viewdirs, z_vals, save: bool = False, subset: bool = False):
+    def query_rays(self, rays_o, rays_d, viewdirs, z_vals, save: bool = False, subset: bool = False, input_grads: bool = False):
         """raw [R,S,C] of a generic-architecture net for the points o + d z (NeRFNet's ray path); save=True: the training variant,
         (raw, acts) with every Linear's output saved per point (raw bit-identical)."""
         packed = self.packed_weights("generic")
         dirs = viewdirs if self.use_viewdirs else None
-        if save:   # subset: store only what the backward of the parameters that require grad reads (no input gradients then)
-            return ops.mlp_generic_forward_rays_save(self._gplan, packed, rays_o, rays_d, dirs, z_vals,
-                                                     trainable=self._gplan.trainable_mask(self.mlp) if subset else None)
+        if save:   # subset: store only what the backward of the parameters that require grad reads; input_grads: ... of a backward that
+            # also reaches the rays (the ReLU patterns always travel as bits: a frozen net then stores no activation block at all)
+            mask = self._gplan.trainable_mask(self.mlp) if (subset or input_grads) else None
+            if mask is not None and input_grads:
+                mask |= ops.INPUT_GRADS_BIT
+            return ops.mlp_generic_forward_rays_save(self._gplan, packed, rays_o, rays_d, dirs, z_vals, trainable=mask)
         return ops.mlp_generic_forward_rays(self._gplan, packed, rays_o, rays_d, dirs, z_vals)
 
     def packed_bwd_generic(self, input_grads: bool = False) -> torch.Tensor:
@@ -255,8 +258,8 @@ class NeRFMLP(nn.Module):
         Without input gradients the chain is cut to what the parameters that require grad need (frozen backbone: the head alone)."""
         if self._gplan is None:
             self.packed_weights("generic")
-        mask = None if input_grads else self._gplan.trainable_mask(self.mlp)
-        key = "generic_bwd_in" if input_grads else ("generic_bwd" if mask is None else "generic_bwd_sub")
+        mask = self._gplan.trainable_mask(self.mlp)
+        key = ("generic_bwd_in" if mask is None else "generic_bwd_in_sub") if input_grads else ("generic_bwd" if mask is None else "generic_bwd_sub")
         self._packed[key] = self._gplan.run_bwd(self._packed.get(key), input_grads=input_grads, trainable=mask)
         return self._packed[key]
 
@@ -693,7 +696,7 @@ class NeRFNet(nn.Module):
         def query(net, z, tag):
             if not net.fast or force_generic:     # any other architecture (or ray gradients): the generic fp32 kernels
                 if save:         # (training a generic net always takes the full backward: _FullRender)
-                    raw, acts = net.query_rays(rays_o, rays_d, viewdirs, z, save=True, subset=not force_generic)
+                    raw, acts = net.query_rays(rays_o, rays_d, viewdirs, z, save=True, subset=not force_generic, input_grads=force_generic)
                     saved[tag] = dict(acts=acts, raw=raw, z=z, generic=True)
                     return raw
                 return net.query_rays(rays_o, rays_d, viewdirs, z)

@@ -291,9 +291,12 @@ class GenericPlan:
     def run_bwd(self, out: Optional[torch.Tensor] = None, input_grads: bool = False, trainable: Optional[int] = None) -> torch.Tensor:
         """The transposed weight streams + the reversed program of the input-gradient chain (nsos_mlp_generic_pack_bwd);
         input_grads: the chain also reaches the positional encodings (gradients w.r.t. the rays); trainable (a trainable_mask()):
-        the chain only as far as a trainable Linear needs it (nsos_mlp_generic_pack_bwd_subset; not with input_grads)."""
+        the chain only as far as a trainable Linear needs it, and only trainable Linears' gradients are written to gbuf
+        (nsos_mlp_generic_pack_bwd_subset; with input_grads every gradient is formed and a frozen net's chain stores nothing)."""
         nbytes = int(_lib.lib().nsos_mlp_generic_bwd_packed_bytes(C.byref(self.desc), int(input_grads)))
-        if trainable is not None and not input_grads:
+        if trainable is not None:
+            if input_grads:      # bit 31: the subset's chain continued to the encodings (pose refinement against a partly / wholly frozen net)
+                trainable = int(trainable) | INPUT_GRADS_BIT
             if nbytes == 0:
                 raise NotImplementedError("nerf_sos_amd: this architecture is outside the generic backward kernel's limits")
             if out is None or out.numel() * 4 < nbytes or out.device != self.device:
@@ -338,6 +341,9 @@ class GenericPlan:
                 ops_.append((self.lin_names[int(e[0])], int(e[1]), int(e[2]), segs))
             self._layout = (ld, ops_)
         return self._layout
+
+
+INPUT_GRADS_BIT = 1 << 31      # OR-ed into a trainable mask: "the backward also reaches the inputs" (nsos_mlp_generic_*_subset)
 
 
 def mlp_generic_forward_rays(plan: GenericPlan, packed: torch.Tensor, rays_o: torch.Tensor, rays_d: torch.Tensor,

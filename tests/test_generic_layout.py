@@ -53,7 +53,13 @@ def test_saved_row_layout_is_a_partition(name, monkeypatch):
         assert covered == w.shape[1], (name_, covered, w.shape)
         blocks[col] = pad(out_dim)
         end = col + pad(out_dim)
-    assert end == ld
+    # ... followed by the ReLU patterns as bit words (round 5): one 32-bit word per output tile of every ReLU Linear, the row padded to 16 bytes
+    sem = [n for n in linears if n.startswith("semantic_linear.")]
+    relu = [n for n in linears if n.startswith("pts_linears.") or n == "views_linears.0" or n == "geo_map_sem.0" or (n in sem and n != sem[-1])]
+    if not (m.mlp.use_viewdirs and sem):
+        relu = [n for n in relu if not n.startswith(("semantic_linear.", "geo_map_sem."))]    # the head never runs without view directions
+    words = sum(pad(params[n + ".weight"].shape[0]) // 32 for n in relu)
+    assert ld == (end + words + 3) // 4 * 4, (ld, end, words)
     lib = _lib.lib()
     fwd = lib.nsos_mlp_generic_packed_bytes(C.byref(plan.desc))
     bwd = lib.nsos_mlp_generic_bwd_packed_bytes(C.byref(plan.desc), 0)
