@@ -62,6 +62,7 @@ struct GenProgram {              // at the head of the packed buffer (device mem
     int n_ops, lds_floats, n_out, out_off;
     int x_off, x_rows, x_dim, x_freqs;      // encoded xyz: buffer, padded rows, real rows, octaves (-1: raw coordinates)
     int v_off, v_rows, v_dim, v_freqs;      // encoded view direction (v_dim = 0 without view directions)
+    int n_waves;     // waves per workgroup the program is laid out for (4 or 8: see mlp_generic_kernel)
     int ones_off, w_floats, act_ld, input_grads;   // input_grads (backward program): the chain also fills the encodings' gradient rows   // act_ld: floats per point of the saved activations = columns of X | V | every dense op
     int x_col, v_col, row_floats, out_rows;
     GenOp ops[kGenMaxOps];
@@ -116,7 +117,7 @@ __device__ __forceinline__ unsigned long long gen_uniform64(const void* p) {   /
 // BIAS: the accumulators start from the op's bias table (forward; b_off = its float offset): the table's loads are issued BEHIND the
 // ring's first eight and everything is awaited once -- one L2 round trip in front of an op's first MFMA instead of two (the table
 // first, waited for, then the ring: what hipcc made of loads written in front of the call).
-template <bool TWO, int RF, bool BIAS = false>
+template <bool TWO, int RF, bool BIAS = false, int NW = 4>
 __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const float* lds, int t0, int lane, int pt, int hi,
                                             f32x16& acc0, f32x16& acc1, int b_off = 0, int g0 = 0, int ng_part = 0) {
     constexpr int kGenRowFloats = RF;
@@ -124,7 +125,7 @@ __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const
     const int ng_all = op.n_groups;
     const int ng = ng_part ? ng_part : ng_all;          // (K-split ops: this wave's groups g0 .. g0 + ng_part - 1 of the tile's stream)
     const unsigned long long base0 = gen_uniform64(wts + op.w_off + (size_t)t0 * ng_all * 256 + (size_t)g0 * 256);
-    const unsigned long long base1 = gen_uniform64(wts + op.w_off + (size_t)(t0 + (TWO ? 4 : 0)) * ng_all * 256);
+    const unsigned long long base1 = gen_uniform64(wts + op.w_off + (size_t)(t0 + (TWO ? NW : 0)) * ng_all * 256);
     unsigned voff = (unsigned)lane * 16u;
     f32x4 r0[4], r1[4];
     gen_ld_off<0>(r0[0], voff, base0);
@@ -141,7 +142,7 @@ __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const
         const unsigned boff = (unsigned)hi * 64u;
         f32x4 v0[4], v1[4];
         gen_ld_off<0>(v0[0], boff, bb); gen_ld_off<16>(v0[1], boff, bb); gen_ld_off<32>(v0[2], boff, bb); gen_ld_off<48>(v0[3], boff, bb);
-        if constexpr (TWO) { gen_ld_off<512>(v1[0], boff, bb); gen_ld_off<528>(v1[1], boff, bb); gen_ld_off<544>(v1[2], boff, bb); gen_ld_off<560>(v1[3], boff, bb); }
+        if constexpr (TWO) { gen_ld_off<128 * NW>(v1[0], boff, bb); gen_ld_off<128 * NW + 16>(v1[1], boff, bb); gen_ld_off<128 * NW + 32>(v1[2], boff, bb); gen_ld_off<128 * NW + 48>(v1[3], boff, bb); }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]), "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]) : : "memory");
         if constexpr (TWO) asm volatile("" : "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]));
 #pragma unroll
@@ -184,10 +185,14 @@ __device__ __forceinline__ void dense_tiles(GenOpRef op, const float* wts, const
 // SAVE: the training variant -- every dense op's post-activation output tile and both encodings also go to P.acts (point-major
 // rows of act_ld floats, one 32-aligned column block per op: the layout nsos_wgrad reads its X operand in), straight from the
 // accumulators: lane (point, hi) holds features 8 q + 4 hi + (0..3) of its point = one 16-byte store per q.
-template <bool SAVE, int RF>
-__global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
+// NW: waves per workgroup.  4: one per SIMD -- nets whose buffers leave room for TWO workgroups per CU (one's barriers, epilogues and
+// load latencies run under the other's MFMAs).  8: two per SIMD inside ONE workgroup -- nets whose buffers (three 256-row buffers:
+// deep semantic heads, sem_with_geo; wide nets) let only one workgroup live on a CU: with four waves every exposed cycle was the CU's.
+// A wave then owns tiles t and t + NW of an op (a 256-wide layer: one tile per wave).
+template <bool SAVE, int RF, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(const GenParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int kGenRowFloats = RF, NP = 256 / RF;      // points per tile; thread (point p, part): NP parts share a point's rows
+    constexpr int kGenRowFloats = RF, NP = 64 * NW / RF;      // points per tile; thread (point p, part): NP parts share a point's rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = lane & 31, hi = lane >> 5;
     const bool own = pt < RF;              // (16-point tiles: lanes 16..31 of a half-wave hold duplicates)
@@ -311,9 +316,9 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 f32x16 acc0, acc1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-                const int gq = op.n_groups >> 2;
-                if (wave == 0) dense_tiles<false, RF, true>(op, P.wts, lds, 0, lane, pt, hi, acc0, acc1, o_boff, 0, gq);
-                else dense_tiles<false, RF, false>(op, P.wts, lds, 0, lane, pt, hi, acc0, acc1, 0, wave * gq, gq);
+                const int gq = op.n_groups / NW;              // (a multiple of 4: the builder pads a K-split op's groups to 4 NW)
+                if (wave == 0) dense_tiles<false, RF, true, NW>(op, P.wts, lds, 0, lane, pt, hi, acc0, acc1, o_boff, 0, gq);
+                else dense_tiles<false, RF, false, NW>(op, P.wts, lds, 0, lane, pt, hi, acc0, acc1, 0, wave * gq, gq);
                 float* slab = lds + o_ks + (4 * hi) * kGenRowFloats + pt;       // accumulator register r < 4 of lane (j, hi) = row r + 4 hi
                 if (wave != 0 && (RF == 32 || own)) {
 #pragma unroll
@@ -323,7 +328,12 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 if (wave == 0) {
                     if (RF == 32 || own) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc0[r] = ((acc0[r] + slab[r * kGenRowFloats]) + slab[(8 + r) * kGenRowFloats]) + slab[(16 + r) * kGenRowFloats];
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc0[r];
+#pragma unroll
+                            for (int w = 0; w < NW - 1; ++w) v += slab[(8 * w + r) * kGenRowFloats];      // fixed order: ((own + w1) + w2) + ...
+                            acc0[r] = v;
+                        }
                     }
                     if (relu) {
 #pragma unroll
@@ -353,13 +363,13 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                 GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
                 continue;
             }
-            for (int t0 = wave; t0 < out_tiles; t0 += 8) {
+            for (int t0 = wave; t0 < out_tiles; t0 += 2 * NW) {
                 f32x16 acc0, acc1;
-                const bool two = t0 + 4 < out_tiles;          // wave-uniform
+                const bool two = t0 + NW < out_tiles;         // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;       // (one-tile items: acc1 is stored nowhere, but read by the ReLU pass)
-                if (two) dense_tiles<true, RF, true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1, o_boff);
-                else dense_tiles<false, RF, true>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1, o_boff);
+                if (two) dense_tiles<true, RF, true, NW>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1, o_boff);
+                else dense_tiles<false, RF, true, NW>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1, o_boff);
                 if (relu) {     // (asm: fmaxf is two instructions -- a canonicalising v_max x, x in front of the v_max 0, x; same values, a NaN -> 0 either way)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -385,14 +395,14 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                             if (rb + (r & 3) + 8 * (r >> 2) < o_dim) d0[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc0[r];
                     }
                     if (two) {
-                        float* d1 = d0 + 128 * kGenRowFloats;
-                        if (padw || 32 * t0 + 160 <= o_dim) {
+                        float* d1 = d0 + 32 * NW * kGenRowFloats;
+                        if (padw || 32 * (t0 + NW) + 32 <= o_dim) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) d1[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc1[r];
                         } else {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                if (rb + 128 + (r & 3) + 8 * (r >> 2) < o_dim) d1[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc1[r];
+                                if (rb + 32 * NW + (r & 3) + 8 * (r >> 2) < o_dim) d1[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc1[r];
                         }
                     }
                 }
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
                         for (int r = 0; r < 16; ++r) { m0 |= (acc0[r] > 0.0f ? 1u : 0u) << r; m1 |= (acc1[r] > 0.0f ? 1u : 0u) << r; }
                         unsigned short* mrow = reinterpret_cast<unsigned short*>(P.acts + gpl * G.act_ld + o_mcol);
                         mrow[2 * t0 + hi] = (unsigned short)m0;
-                        if (two) mrow[2 * (t0 + 4) + hi] = (unsigned short)m1;
+                        if (two) mrow[2 * (t0 + NW) + hi] = (unsigned short)m1;
                     }
                     if (own && gpl < P.n_pts && ((P.save_mask >> oi) & 1)) {
                         float* dst = P.acts + gpl * G.act_ld + o_act + 32 * t0 + 4 * hi;
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { v0[j] = acc0[4 * q + j]; v1[j] = acc1[4 * q + j]; }
                             *reinterpret_cast<f32x4*>(dst + 8 * q) = v0;           // (rows past out_dim: exact zeros, the block's padding)
-                            if (two) *reinterpret_cast<f32x4*>(dst + 128 + 8 * q) = v1;
+                            if (two) *reinterpret_cast<f32x4*>(dst + 32 * NW + 8 * q) = v1;
                         }
                     }
                 }
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(256) void mlp_generic_kernel(const GenParams P) {
         GEN_PROF_BAR(62);
     }
 #ifdef NSOS_GEN_PROF
-    if (blockIdx.x == 1 && lane == 0)
+    if (blockIdx.x == 1 && lane == 0 && wave < 4)
         for (int k = 0; k < 64; ++k) { nsos_gen_prof[wave][0][k] = pw[k]; nsos_gen_prof[wave][1][k] = pb[k]; }
 #endif
 }
@@ -466,10 +476,10 @@ struct GenBwdParams {
     int n_tiles;
 };
 
-template <int RF>
-__global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams P) {
+template <int RF, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int kGenRowFloats = RF, NP = 256 / RF;
+    constexpr int kGenRowFloats = RF, NP = 64 * NW / RF;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = lane & 31, hi = lane >> 5;
     const bool own = pt < RF;
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                 const unsigned short* mrow = reinterpret_cast<const unsigned short*>(P.acts + (vpt ? gpl : P.n_pts - 1) * ld + (h_mcol >= 0 ? h_mcol : 0));
                 float* grow = P.gbuf + gpl * ld + h_act;
                 const bool relu = (h_flags & 1) && h_mcol >= 0, store = !(h_flags & 8);
-                for (int t = wave; t < h_tiles; t += 4) {
+                for (int t = wave; t < h_tiles; t += NW) {
                     float* lrow = lds + h_off + (32 * t + 4 * hi) * kGenRowFloats + pt;
                     const unsigned mw = relu ? (unsigned)mrow[2 * t + hi] : 0xffffu;
                     if (32 * t + 32 <= h_dim && (RF == 32 || own)) {       // a tile wholly inside the op's rows: no per-element tests
@@ -561,13 +571,13 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
             int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu;      // pinned: see the forward kernel
             asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags));
             const bool padw = o_flags & 2, add = o_flags & 4;
-            for (int t0 = wave; t0 < out_tiles; t0 += 8) {
+            for (int t0 = wave; t0 < out_tiles; t0 += 2 * NW) {
                 f32x16 acc0, acc1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-                const bool two = t0 + 4 < out_tiles;
-                if (two) dense_tiles<true, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
-                else dense_tiles<false, RF>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                const bool two = t0 + NW < out_tiles;
+                if (two) dense_tiles<true, RF, false, NW>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
+                else dense_tiles<false, RF, false, NW>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 if (RF == 32 || own) {
                     float* d0 = lds + o_off + (32 * t0 + 4 * hi) * kGenRowFloats + pt;
                     const int rb = 32 * t0 + 4 * hi;
@@ -591,7 +601,7 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
                         }
                     };
                     put(d0, acc0, rb, padw || 32 * t0 + 32 <= o_dim);
-                    if (two) put(d0 + 128 * kGenRowFloats, acc1, rb + 128, padw || 32 * t0 + 160 <= o_dim);
+                    if (two) put(d0 + 32 * NW * kGenRowFloats, acc1, rb + 32 * NW, padw || 32 * (t0 + NW) + 32 <= o_dim);
                 }
             }
             GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(256) void mlp_generic_bwd_kernel(const GenBwdParams
         GEN_PROF_WORK(62);
     }
 #ifdef NSOS_GEN_PROF
-    if (blockIdx.x == 1 && lane == 0)
+    if (blockIdx.x == 1 && lane == 0 && wave < 4)
         for (int k = 0; k < 64; ++k) { nsos_gen_prof[wave][0][k] = pw[k]; nsos_gen_prof[wave][1][k] = pb[k]; }
 #endif
 }
@@ -775,6 +785,9 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
     G.out_rows = (sem && M.sem_with_geo) ? 32 : 16;      // rows 0..2 rgb, 3 sigma, 4.. logits (<= 8), then geo_map_sem's (<= 8); the widest read is 8 rows from row 4
     G.out_off = alloc(G.out_rows);
     G.lds_floats = off;
+    // one workgroup per CU only (its buffers take more than half of the 160 KiB): two waves per SIMD inside it instead
+    G.n_waves = (2 * G.lds_floats * 4 > 160 * 1024 && Wp >= 64) ? 8 : 4;
+    const int NWp = G.n_waves;
     G.n_out = M.use_viewdirs ? 4 + sem_dim : 4;
     int n = 0, w_off = 0;
     // the saved-activation row of a point (training): [X pad32 | V pad32 | one pad32(out_dim) block per dense op, in program order]
@@ -805,9 +818,9 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
             }
         }
         if (in_dim != L.in_dim) { H.err = NSOS_ERR_BAD_SHAPE; return; }
-        const bool ksplit = ks_scratch > 0 && out_buf == G.out_off && L.out_dim <= 8 && g >= 8 && pad_to(g, 16) <= kGenMaxGroups && Wp >= 24;
+        const bool ksplit = ks_scratch > 0 && out_buf == G.out_off && L.out_dim <= 8 && g >= 8 && pad_to(g, 4 * NWp) <= kGenMaxGroups && Wp >= 8 * (NWp - 1);
         op.ksplit_off = ksplit ? ks_scratch : 0;
-        while (g % (ksplit ? 16 : 4)) {                   // the kernel's loop is unrolled by four groups (per wave, for a K-split op): pad with zero-weight groups
+        while (g % (ksplit ? 4 * NWp : 4)) {                   // the kernel's loop is unrolled by four groups (per wave, for a K-split op): pad with zero-weight groups
             if (g >= kGenMaxGroups) { H.err = NSOS_ERR_UNSUPPORTED; return; }
             op.grp_off[g++] = G.ones_off;
         }
@@ -1105,20 +1118,26 @@ static int32_t generic_launch(const nsos_generic_mlp* mlp, const void* packed, G
     p.n_tiles = (int)((n_pts + rf - 1) / rf);
     const int lds_bytes = H.prog.lds_floats * 4;
     // (per call: the attribute is a property of the kernel on this device, the size a property of the architecture rendered)
-    const void* fn = rf == 32 ? (p.acts ? reinterpret_cast<const void*>(&mlp_generic_kernel<true, 32>) : reinterpret_cast<const void*>(&mlp_generic_kernel<false, 32>))
-                              : (p.acts ? reinterpret_cast<const void*>(&mlp_generic_kernel<true, 16>) : reinterpret_cast<const void*>(&mlp_generic_kernel<false, 16>));
+    const int nw = H.prog.n_waves;
+    const bool sv = p.acts != nullptr;
+#define NSOS_GEN_FN(S, R, W) reinterpret_cast<const void*>(&mlp_generic_kernel<S, R, W>)
+    const void* fn = rf == 32 ? (nw == 8 ? (sv ? NSOS_GEN_FN(true, 32, 8) : NSOS_GEN_FN(false, 32, 8)) : (sv ? NSOS_GEN_FN(true, 32, 4) : NSOS_GEN_FN(false, 32, 4)))
+                              : (nw == 8 ? (sv ? NSOS_GEN_FN(true, 16, 8) : NSOS_GEN_FN(false, 16, 8)) : (sv ? NSOS_GEN_FN(true, 16, 4) : NSOS_GEN_FN(false, 16, 4)));
+#undef NSOS_GEN_FN
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int32_t)e;
     const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
     const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
+#define NSOS_GEN_GO(S, R, W) hipLaunchKernelGGL((mlp_generic_kernel<S, R, W>), dim3(grid), dim3(64 * W), lds_bytes, st, p)
     if (rf == 32) {
-        if (p.acts) hipLaunchKernelGGL((mlp_generic_kernel<true, 32>), dim3(grid), dim3(256), lds_bytes, st, p);
-        else hipLaunchKernelGGL((mlp_generic_kernel<false, 32>), dim3(grid), dim3(256), lds_bytes, st, p);
+        if (nw == 8) { if (sv) NSOS_GEN_GO(true, 32, 8); else NSOS_GEN_GO(false, 32, 8); }
+        else { if (sv) NSOS_GEN_GO(true, 32, 4); else NSOS_GEN_GO(false, 32, 4); }
     } else {
-        if (p.acts) hipLaunchKernelGGL((mlp_generic_kernel<true, 16>), dim3(grid), dim3(256), lds_bytes, st, p);
-        else hipLaunchKernelGGL((mlp_generic_kernel<false, 16>), dim3(grid), dim3(256), lds_bytes, st, p);
+        if (nw == 8) { if (sv) NSOS_GEN_GO(true, 16, 8); else NSOS_GEN_GO(false, 16, 8); }
+        else { if (sv) NSOS_GEN_GO(true, 16, 4); else NSOS_GEN_GO(false, 16, 4); }
     }
+#undef NSOS_GEN_GO
     return nsos_launch_status();
 }
 
@@ -1260,14 +1279,19 @@ static int32_t generic_bwd_launch(const nsos_generic_mlp* mlp, const void* packe
     const int rf = H.prog.row_floats;
     p.n_pts = n_pts; p.n_tiles = (int)((n_pts + rf - 1) / rf);
     const int lds_bytes = H.prog.lds_floats * 4;
-    hipError_t e = hipFuncSetAttribute(rf == 32 ? reinterpret_cast<const void*>(&mlp_generic_bwd_kernel<32>) : reinterpret_cast<const void*>(&mlp_generic_bwd_kernel<16>),
+    const int nw = H.prog.n_waves;
+#define NSOS_GENB_FN(R, W) reinterpret_cast<const void*>(&mlp_generic_bwd_kernel<R, W>)
+    hipError_t e = hipFuncSetAttribute(rf == 32 ? (nw == 8 ? NSOS_GENB_FN(32, 8) : NSOS_GENB_FN(32, 4)) : (nw == 8 ? NSOS_GENB_FN(16, 8) : NSOS_GENB_FN(16, 4)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#undef NSOS_GENB_FN
     if (e != hipSuccess) return (int32_t)e;
     const int per_cu = lds_bytes > 0 ? (160 * 1024) / lds_bytes : 1;
     const int wgs = nsos_device_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const int grid = p.n_tiles < wgs ? p.n_tiles : wgs;
-    if (rf == 32) hipLaunchKernelGGL(mlp_generic_bwd_kernel<32>, dim3(grid), dim3(256), lds_bytes, st, p);
-    else hipLaunchKernelGGL(mlp_generic_bwd_kernel<16>, dim3(grid), dim3(256), lds_bytes, st, p);
+#define NSOS_GENB_GO(R, W) hipLaunchKernelGGL((mlp_generic_bwd_kernel<R, W>), dim3(grid), dim3(64 * W), lds_bytes, st, p)
+    if (rf == 32) { if (nw == 8) NSOS_GENB_GO(32, 8); else NSOS_GENB_GO(32, 4); }
+    else { if (nw == 8) NSOS_GENB_GO(16, 8); else NSOS_GENB_GO(16, 4); }
+#undef NSOS_GENB_GO
     return nsos_launch_status();
 }
 
