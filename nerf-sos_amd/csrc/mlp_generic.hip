@@ -568,29 +568,51 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                 GEN_PROF_BAR(2 + (oi < 58 ? oi : 58));
                 continue;
             }
-            int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu;      // pinned: see the forward kernel
-            asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags));
+            int out_tiles = op.out_tiles, o_off = op.out_off, o_dim = op.out_dim, o_flags = op.relu, o_fuse = op.aux_col, o_mcol = op.mask_col, o_act = op.act_col;   // pinned: see the forward kernel
+            asm volatile("" : "+s"(out_tiles), "+s"(o_off), "+s"(o_dim), "+s"(o_flags), "+s"(o_fuse), "+s"(o_mcol), "+s"(o_act));
             const bool padw = o_flags & 2, add = o_flags & 4;
+            // o_fuse != 0 (build_bwd_program): this op is the LAST contribution to the gradient of a forward op's output, and that op's head
+            // step (ReLU mask from the bit words, the gradient's copy to gbuf) happens HERE, on the values in registers, instead of in a step of
+            // its own behind one more barrier and one more pass over the buffer.  bit 0: mask; bit 3: nothing goes to gbuf (a frozen Linear)
+            const bool f_relu = (o_fuse & 1) && o_mcol >= 0, f_store = o_fuse && !(o_fuse & 8);
+            const long long gpl = (long long)tile * RF + pt;
+            const bool vpt = own && gpl < P.n_pts;
             for (int t0 = wave; t0 < out_tiles; t0 += 2 * NW) {
                 f32x16 acc0, acc1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
                 const bool two = t0 + NW < out_tiles;
+                unsigned mw0 = 0xffffu, mw1 = 0xffffu;
+                if (f_relu) {       // requested ahead of the contraction (older than every load of the ring: its counted waits still hold)
+                    const unsigned short* mrow = reinterpret_cast<const unsigned short*>(P.acts + (vpt ? gpl : P.n_pts - 1) * ld + o_mcol);
+                    mw0 = mrow[2 * t0 + hi];
+                    if (two) mw1 = mrow[2 * (t0 + NW) + hi];
+                }
                 if (two) dense_tiles<true, RF, false, NW>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 else dense_tiles<false, RF, false, NW>(op, P.wts, lds, t0, lane, pt, hi, acc0, acc1);
                 if (RF == 32 || own) {
                     float* d0 = lds + o_off + (32 * t0 + 4 * hi) * kGenRowFloats + pt;
                     const int rb = 32 * t0 + 4 * hi;
-                    auto put = [&](float* d, const f32x16& acc, int rbase, bool full) {
-                        if (full && add) {
-                            float old[16];
+                    auto put = [&](float* d, f32x16& acc, int rbase, bool full, unsigned mw, int t) {
+                        if (full) {
+                            if (add) {
+                                float old[16];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) old[r] = d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats];
+                                for (int r = 0; r < 16; ++r) old[r] = d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = old[r] + acc[r];
-                        } else if (full) {
+                                for (int r = 0; r < 16; ++r) acc[r] = old[r] + acc[r];
+                            }
+                            if (f_relu) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[r] = ((mw >> r) & 1u) ? acc[r] : 0.0f;      // relu'(x) = [x > 0] (ATen threshold_backward)
+                            }
 #pragma unroll
                             for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2)) * kGenRowFloats] = acc[r];
+                            if (f_store && vpt) {       // the head step's store: register r = 4 q + j is feature 32 t + 8 q + 4 hi + j
+                                float* grow = P.gbuf + gpl * ld + o_act + 32 * t + 4 * hi;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(grow + 8 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                            }
                         } else {
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
@@ -600,8 +622,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                                 }
                         }
                     };
-                    put(d0, acc0, rb, padw || 32 * t0 + 32 <= o_dim);
-                    if (two) put(d0 + 32 * NW * kGenRowFloats, acc1, rb + 32 * NW, padw || 32 * (t0 + NW) + 32 <= o_dim);
+                    put(d0, acc0, rb, padw || 32 * t0 + 32 <= o_dim, mw0, t0);
+                    if (two) put(d0 + 32 * NW * kGenRowFloats, acc1, rb + 32 * NW, padw || 32 * (t0 + NW) + 32 <= o_dim, mw1, t0 + NW);
                 }
             }
             GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
@@ -1044,6 +1066,26 @@ void build_bwd_program(const nsos_generic_mlp& M, const HostProgram& H, HostBwd&
         }
         if (!in_out(ho.op.out_off)) has_grad(ho.out_buf) = false;     // consumed: the buffer's next tenant starts afresh
     }
+    // Fuse a head step into the transposed product right in front of it when that product is the last contribution to the head's buffer
+    // and writes the whole of it (every hidden layer of a trunk or a head chain: its one consumer's product; the trunk's last layer: the
+    // alpha head's): the mask and the copy to gbuf then happen in that product's epilogue (mlp_generic_bwd_kernel), one barrier and one
+    // pass over the buffer less per layer.  aux_col of a dense op (unused there otherwise) carries the head's flags + 16.
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        GenOp& op = G.ops[i];
+        if (i + 1 < n && op.kind == kGenDense && (op.relu & 2) && G.ops[i + 1].kind == kGenBwdHead && G.ops[i + 1].out_off == op.out_off &&
+            G.ops[i + 1].out_tiles == op.out_tiles && G.ops[i + 1].out_dim == op.out_dim) {
+            const GenOp& h = G.ops[i + 1];
+            op.aux_col = 16 | (h.relu & 1) | (h.relu & 8);
+            op.mask_col = h.mask_col; op.act_col = h.act_col;
+            G.ops[m++] = op;
+            ++i;                     // the head step is gone
+            continue;
+        }
+        if (op.kind == kGenDense) op.aux_col = 0;
+        G.ops[m++] = op;
+    }
+    n = m;
     G.n_ops = n;
     G.w_floats = w_off;
     G.input_grads = input_grads ? 1 : 0;

@@ -52,7 +52,7 @@ else
     cp $(find $O/c3trace -name "*kernel_stats.csv" | head -1) $O/h_c3_step_kernel_stats.csv
     cp $(find $O/c5trace -name "*kernel_stats.csv" | head -1) $O/h_c5_image_kernel_stats.csv
     cp $(find $O/posetrace -name "*kernel_stats.csv" | head -1) $O/p_pose_step_kernel_stats.csv
-    tail -2 $O/deftrace.log > $O/f_default_bench_line_under_rocprof.json
+    grep '^{"metric"' $O/deftrace.log | tail -1 > $O/f_default_bench_line_under_rocprof.json
     rm -rf $O/deftrace $O/c3trace $O/c4trace $O/c5trace $O/posetrace
     tail -c 600 $O/i_bench_default.out
 fi
