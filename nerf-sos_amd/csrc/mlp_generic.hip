@@ -98,6 +98,11 @@ __device__ __forceinline__ float gen_feature(const float (&x)[3], int f, int dim
 
 typedef const __attribute__((address_space(4))) GenOp& GenOpRef;
 
+// Saved activations and gbuf are written once and read by a LATER kernel: non-temporal stores keep their 7-50 GB per step from evicting the
+// weight stream (0.3-3 MB, re-read by every workgroup for every tile) from the XCD L2s (what the tuned 16-bit kernel's training variant
+// measured in round 4: 66 -> 7.6 MB of fetches per launch).
+__device__ __forceinline__ void gen_store_nt(float* p, const f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+
 template <int OFF>
 __device__ __forceinline__ void gen_ld_off(f32x4& v, unsigned voff, unsigned long long base) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "i"(OFF) : "memory");
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(const GenParams P)
                                 f32x4 v0;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v0[j] = acc0[4 * q + j];       // (rows >= 8: zero weights and zero bias, exact zeros)
-                                *reinterpret_cast<f32x4*>(dst + 8 * q) = v0;
+                                gen_store_nt(dst + 8 * q, v0);
                             }
                         }
                     }
@@ -423,8 +428,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(const GenParams P)
                             f32x4 v0, v1;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { v0[j] = acc0[4 * q + j]; v1[j] = acc1[4 * q + j]; }
-                            *reinterpret_cast<f32x4*>(dst + 8 * q) = v0;           // (rows past out_dim: exact zeros, the block's padding)
-                            if (two) *reinterpret_cast<f32x4*>(dst + 32 * NW + 8 * q) = v1;
+                            gen_store_nt(dst + 8 * q, v0);                          // (rows past out_dim: exact zeros, the block's padding)
+                            if (two) gen_store_nt(dst + 32 * NW + 8 * q, v1);
                         }
                     }
                 }
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                                 g[j] = ((mw >> (4 * q + j)) & 1u) ? v : 0.0f;          // relu'(x) = [x > 0] (ATen threshold_backward)
                                 if (relu) lrow[(8 * q + j) * kGenRowFloats] = g[j];   // (ReLU outputs own whole pad32 buffers)
                             }
-                            if (vpt && store) *reinterpret_cast<f32x4*>(grow + f0) = g;
+                            if (vpt && store) gen_store_nt(grow + f0, g);
                         }
                         continue;
                     }
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                             g[j] = ((mw >> (4 * q + j)) & 1u) ? v : 0.0f;
                             if (relu && own) lds[h_off + (f0 + j) * kGenRowFloats + pt] = g[j];
                         }
-                        if (vpt && store) *reinterpret_cast<f32x4*>(grow + f0) = g;
+                        if (vpt && store) gen_store_nt(grow + f0, g);
                     }
                 }
                 GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                             if (f_store && vpt) {       // the head step's store: register r = 4 q + j is feature 32 t + 8 q + 4 hi + j
                                 float* grow = P.gbuf + gpl * ld + o_act + 32 * t + 4 * hi;
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(grow + 8 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                                for (int q = 0; q < 4; ++q) gen_store_nt(grow + 8 * q, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
                             }
                         } else {
 #pragma unroll
