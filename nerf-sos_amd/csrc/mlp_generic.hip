@@ -98,10 +98,10 @@ __device__ __forceinline__ float gen_feature(const float (&x)[3], int f, int dim
 
 typedef const __attribute__((address_space(4))) GenOp& GenOpRef;
 
-// Saved activations and gbuf are written once and read by a LATER kernel: non-temporal stores keep their 7-50 GB per step from evicting the
-// weight stream (0.3-3 MB, re-read by every workgroup for every tile) from the XCD L2s (what the tuned 16-bit kernel's training variant
-// measured in round 4: 66 -> 7.6 MB of fetches per launch).
-__device__ __forceinline__ void gen_store_nt(float* p, const f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+// The stores of saved activations and gbuf.  (Round 5 tried non-temporal stores here, as the tuned 16-bit kernel's training variant uses
+// for its 700 MB per launch: no gain on these kernels -- training steps 26.7 -> 28.3 / 46.0 -> 45.4 / 113.8 -> 115.1 ms across two boxes --
+// so they stay plain.)
+__device__ __forceinline__ void gen_store_nt(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 template <int OFF>
 __device__ __forceinline__ void gen_ld_off(f32x4& v, unsigned voff, unsigned long long base) {
