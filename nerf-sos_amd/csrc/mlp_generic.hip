@@ -101,7 +101,7 @@ typedef const __attribute__((address_space(4))) GenOp& GenOpRef;
 // The stores of saved activations and gbuf.  (Round 5 tried non-temporal stores here, as the tuned 16-bit kernel's training variant uses
 // for its 700 MB per launch: no gain on these kernels -- training steps 26.7 -> 28.3 / 46.0 -> 45.4 / 113.8 -> 115.1 ms across two boxes --
 // so they stay plain.)
-__device__ __forceinline__ void gen_store_nt(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void gen_store4(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 template <int OFF>
 __device__ __forceinline__ void gen_ld_off(f32x4& v, unsigned voff, unsigned long long base) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(const GenParams P)
                                 f32x4 v0;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v0[j] = acc0[4 * q + j];       // (rows >= 8: zero weights and zero bias, exact zeros)
-                                gen_store_nt(dst + 8 * q, v0);
+                                gen_store4(dst + 8 * q, v0);
                             }
                         }
                     }
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_kernel(const GenParams P)
                             f32x4 v0, v1;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { v0[j] = acc0[4 * q + j]; v1[j] = acc1[4 * q + j]; }
-                            gen_store_nt(dst + 8 * q, v0);                          // (rows past out_dim: exact zeros, the block's padding)
-                            if (two) gen_store_nt(dst + 32 * NW + 8 * q, v1);
+                            gen_store4(dst + 8 * q, v0);                          // (rows past out_dim: exact zeros, the block's padding)
+                            if (two) gen_store4(dst + 32 * NW + 8 * q, v1);
                         }
                     }
                 }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                                 g[j] = ((mw >> (4 * q + j)) & 1u) ? v : 0.0f;          // relu'(x) = [x > 0] (ATen threshold_backward)
                                 if (relu) lrow[(8 * q + j) * kGenRowFloats] = g[j];   // (ReLU outputs own whole pad32 buffers)
                             }
-                            if (vpt && store) gen_store_nt(grow + f0, g);
+                            if (vpt && store) gen_store4(grow + f0, g);
                         }
                         continue;
                     }
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                             g[j] = ((mw >> (4 * q + j)) & 1u) ? v : 0.0f;
                             if (relu && own) lds[h_off + (f0 + j) * kGenRowFloats + pt] = g[j];
                         }
-                        if (vpt && store) gen_store_nt(grow + f0, g);
+                        if (vpt && store) gen_store4(grow + f0, g);
                     }
                 }
                 GEN_PROF_WORK(2 + (oi < 58 ? oi : 58));
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_generic_bwd_kernel(const GenBwdPa
                             if (f_store && vpt) {       // the head step's store: register r = 4 q + j is feature 32 t + 8 q + 4 hi + j
                                 float* grow = P.gbuf + gpl * ld + o_act + 32 * t + 4 * hi;
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) gen_store_nt(grow + 8 * q, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+                                for (int q = 0; q < 4; ++q) gen_store4(grow + 8 * q, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
                             }
                         } else {
 #pragma unroll
