@@ -369,7 +369,7 @@ KERNEL_SOURCES = {   # traffic.json key -> the files whose content decides the d
     "c2_fp16x3": ("mlp_x3.hip", "x3_common.h", "mlp_common.h"),
     "lp16": ("mlp_lp16.hip", "lp_common.h", "mlp_common.h"),
 }
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05", "traffic.json")
 
 
 def kernel_source_hash(key: str = "c2_fp32") -> str:
@@ -380,7 +380,7 @@ def kernel_source_hash(key: str = "c2_fp32") -> str:
 
 
 def add_traffic(roof, key: str):
-    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r04/traffic.json: FETCH_SIZE
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r05/traffic.json: FETCH_SIZE
     and WRITE_SIZE collected in separate rocprofv3 --pmc runs and corrected as MI355X_MICROARCH.md prescribes), reported only
     while the kernel's sources still hash to the build the passes were measured on."""
     if roof is None or not os.path.exists(TRAFFIC_JSON):
@@ -393,10 +393,10 @@ def add_traffic(roof, key: str):
         roof["traffic_detail"] = {"fetch_size_kb": t["fetch_size_kb"], "write_size_kb": t["write_size_kb"],
                                   "algorithmic_bytes_per_launch_without_weights": t["algorithmic_bytes_per_launch_without_weights"],
                                   "ratio_to_algorithmic": t["ratio"], "scratch_bytes": t.get("scratch_bytes"),
-                                  "source": "profiles/r04/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                  "source": "profiles/r05/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                             "2 x FETCH_SIZE + WRITE_SIZE)"}
     else:
-        roof["traffic_note"] = "profiles/r04/traffic.json was measured on a different build of this kernel: not reported"
+        roof["traffic_note"] = "profiles/r05/traffic.json was measured on a different build of this kernel: not reported"
     return roof
 
 
