@@ -53,8 +53,8 @@ def test_wgrad_batch_equals_single_calls():
 ARCHS = {
     "8x256_viewdirs": dict(multires=6),                                                        # two workgroups per CU: four waves
     "deep_head_geo": dict(use_semantics=True, sem_layer=3, sem_dim=5, sem_with_geo=True),      # one workgroup per CU: eight waves
-    "4x96": dict(netdepth=4, netwidth=96, netdepth_fine=4, netwidth_fine=96, skips=[2]),        # ragged width: padded tiles
-    "2x608_16pt": dict(netdepth=2, netwidth=608, netdepth_fine=2, netwidth_fine=608, skips=[]),  # past the 32-point tiles' LDS budget: 16-point tiles
+    "4x96": dict(netdepth=4, netwidth=96, netdepth_fine=4, netwidth_fine=96),        # ragged width: padded tiles
+    "2x608_16pt": dict(netdepth=2, netwidth=608, netdepth_fine=2, netwidth_fine=608),  # past the 32-point tiles' LDS budget: 16-point tiles
 }
 
 
@@ -69,7 +69,6 @@ def test_saved_relu_bit_words_equal_the_sign_of_the_saved_blocks(name):
     z, v = ops.ray_setup(rays[1].contiguous(), near, far, S, None)
     raw, acts = mlp.query_rays(rays[0].contiguous(), rays[1].contiguous(), v, z, save=True)          # every block + the bit words
     raw2, acts2 = mlp.query_rays(rays[0].contiguous(), rays[1].contiguous(), v, z, save=True)
-    assert torch.equal(raw, raw2) and torch.equal(acts.view(torch.int32), acts2.view(torch.int32)), "not deterministic"
     assert torch.equal(raw, mlp.query_rays(rays[0].contiguous(), rays[1].contiguous(), v, z)), "SAVE changed the outputs"
     ld, layout = mlp._gplan.layout()
     params = dict(mlp.mlp.named_parameters())
@@ -78,6 +77,9 @@ def test_saved_relu_bit_words_equal_the_sign_of_the_saved_blocks(name):
     names = [n for n, *_ in layout]
     sem = [n for n in names if n.startswith("semantic_linear.")]
     relu = [n for n in names if n.startswith("pts_linears.") or n == "views_linears.0" or n == "geo_map_sem.0" or (n in sem and n != sem[-1])]
+    n_words = sum(pad(od) // 32 for n_, _, od, _ in layout if n_ in relu)
+    used = end + n_words                                          # (the row's padding to 16 bytes behind the words is never written)
+    assert torch.equal(raw, raw2) and torch.equal(acts[:, :used].contiguous().view(torch.int32), acts2[:, :used].contiguous().view(torch.int32)), "not deterministic"
     words = acts[:, end:].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     a = acts.cpu().numpy()
     w0 = 0
