@@ -5,20 +5,25 @@
 // family); everything else renders through this one, on the same exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32:
 // bitwise an fmaf chain); the backward of the same program (training, ray gradients) is further down.
 //
-// Mapping.  A workgroup = 4 waves = one per SIMD = one tile of 32 points.  The network is a PROGRAM of dense ops
+// Mapping.  A workgroup = one tile of 32 points = 4 waves (one per SIMD) where the net's buffers leave room for TWO workgroups per CU,
+// 8 waves (two per SIMD) where only one fits (template parameter NW, GenProgram::n_waves).  The network is a PROGRAM of dense ops
 // (nsos_generic_mlp -> build_program below, mirroring MLP.forward line by line); every op reads its inputs from and writes
 // its output to per-tile activation buffers in LDS, [feature][32 points] fp32 (a feature row = 128 B).  An op's output tiles
-// (32 features each) are dealt to the waves round-robin, two at a time per wave (tiles t and t + 4: one B operand feeds both
+// (32 features each) are dealt to the waves round-robin, two at a time per wave (tiles t and t + NW: one B operand feeds both
 // accumulators); the contraction runs over the op's input SEGMENTS (the concatenations of the reference: [input_pts, h] of
 // the skip layer, [h, input_pts] of the semantic head, [feature, input_views]) in groups of 4 k-steps = 8 input rows:
 //   B operand  lane (point j, hi): row 2 ks + hi of the segment, one ds_read_b32 per k-step (conflict-free: 64 consecutive words)
 //   A operand  one global_load_dwordx4 per group and tile from the packed stream [tile][group][lane][4] (L2-resident: the
-//              whole net is 0.3-3 MB), prefetched four groups ahead -- no LDS staging, no barrier inside an op
+//              whole net is 0.3-3 MB; every wave reads only ITS tiles' stream), prefetched four groups ahead -- no LDS staging, no
+//              barrier inside an op
 //   bias       the accumulators' initial value, from a per-tile table in the packed stream (round 5).  Until then the bias was a leading
 //              GROUP on a constant buffer [1, 0, ...]: 4 k-steps for one useful row, and it pushed a 256-wide layer from 32 groups to 33,
 //              padded to 36 -- 11 % of every trunk layer's matrix time (20 % of a 128-wide head's) spent on zeros
-// One __syncthreads per op.  Small heads (alpha, rgb, logits: one tile) occupy one wave; at 8 x 256 that is ~10 % of a tile's
-// time -- this kernel buys generality, the fast paths keep the shipped configs.
+// One __syncthreads per op; ops with ONE output tile of a few rows (alpha, rgb, output_linear) are split over K across the waves
+// (ksplit_off) and cost a second one.  The op descriptor lives in the constant address space: every scalar of it that an epilogue uses is
+// read once and pinned in an SGPR (left to itself hipcc re-issued the s_load in front of every store, see the kernel).
+// Measured (round 5, profiles/r05): 0.79-0.86 of the fp32-MFMA peak at widths >= 256, a 256 x 256 op 33-34 k cycles against 32.8 k of
+// MFMA issue with two workgroups sharing the pipe.
 // Ceiling: 2 x 64-cycle MFMAs per k-step and wave against 16 B/lane of A operand per 4 k-steps: ~8 B/clk/CU from L2.
 #include "mlp_common.h"
 
