@@ -117,6 +117,27 @@ def _chunks(n: int):
     return out
 
 
+def _cover(n: int, room: int):
+    """Tiles of nsos_wgrad's sizes covering columns 0 .. n-1 of a block (n a 32-multiple) that has `room` readable columns from its
+    start: whole 256s first, then ONE tile for the rest -- the smallest size that holds it, reading past the block where the row has
+    room (what lies there is another block or the bit words: the products it feeds land in output rows / columns that are sliced
+    away; every output element is a sum over its own pair of columns only).  96 = one 128-tile instead of 64 + 32: for a 96 x 96
+    layer one reduction over 128 + 128 columns per point instead of four over 384 in all -- the reductions are HBM-bound.  Falls back
+    to exact tiles where the row ends.  [(offset, size)]"""
+    out, o = [], 0
+    while n - o > 256:
+        out.append((o, 256))
+        o += 256
+    r = n - o
+    if r > 0:
+        c = next(c for c in reversed(_CHUNKS) if c >= r)
+        if o + c <= room:
+            out.append((o, c))
+        else:
+            out += [(o + oo, cc) for oo, cc in _chunks(r)]
+    return out
+
+
 def _wgrad_plan(plan, wanted: tuple):
     """The reductions of one generic net as ONE nsos_wgrad_batch list (cached per plan and set of Linears): per wanted Linear a block
     [pad32(out_dim), sum of pad32(segment rows)] + a bias row in one flat output buffer, every (row tile, column tile) of every segment
@@ -130,24 +151,27 @@ def _wgrad_plan(plan, wanted: tuple):
     if hit is not None and hit[0] is plan:
         return hit[1]
     pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
-    _, layout = plan.layout()
+    ld, layout = plan.layout()
     items, blocks, off = [], [], 0
     for name, col, out_dim, segs in layout:
         if name not in wanted:
             continue
-        Mp, Kp = pad(out_dim), sum(pad(rows) for _, rows, _ in segs)
+        m_tiles = _cover(pad(out_dim), ld - col)
+        n_tiles = [_cover(pad(rows), ld - src_col) for src_col, rows, _ in segs]
+        Mp = m_tiles[-1][0] + m_tiles[-1][1]                           # rows / columns of the output block: what the tiles cover
+        Nps = [t[-1][0] + t[-1][1] for t in n_tiles]
+        Kp = sum(Nps)
         w_off, b_off = off, off + Mp * Kp
         off = b_off + Mp
         kc, placed, first = 0, [], True
-        for src_col, rows, wcol in segs:
-            Np = pad(rows)
-            for mo, mc in _chunks(Mp):
-                for no, nc in _chunks(Np):
+        for (src_col, rows, wcol), tiles, Np in zip(segs, n_tiles, Nps):
+            for mo, mc in m_tiles:
+                for no, nc in tiles:
                     items.append((w_off + mo * Kp + kc + no, (b_off + mo) if (first and no == 0) else -1, col + mo, src_col + no, mc, nc, Kp))
             placed.append((rows, wcol, kc))
             kc += Np
             first = False
-        aligned = Mp == out_dim and all(pad(r) == r for r, _, _ in placed) and all(w == k for _, w, k in placed)
+        aligned = Mp == out_dim and all(np_ == r for (r, _, _), np_ in zip(placed, Nps)) and all(w == k for _, w, k in placed)
         blocks.append((name, out_dim, w_off, Mp, Kp, b_off, placed, aligned))
     arr = (_lib.WgradItem * max(len(items), 1))()
     for i, (w, b, g, x, m, n, ldw) in enumerate(items):
