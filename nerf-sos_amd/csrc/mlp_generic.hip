@@ -850,7 +850,8 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
             }
         }
         if (in_dim != L.in_dim) { H.err = NSOS_ERR_BAD_SHAPE; return; }
-        const bool ksplit = ks_scratch > 0 && out_buf == G.out_off && L.out_dim <= 8 && g >= 8 && pad_to(g, 4 * NWp) <= kGenMaxGroups && Wp >= 8 * (NWp - 1);
+        const int ks_rows = ks_scratch == G.x_off ? G.x_rows : Wp;          // rows of the scratch buffer (a trunk buffer, or the encoded-xyz one)
+        const bool ksplit = ks_scratch > 0 && out_buf == G.out_off && L.out_dim <= 8 && g >= 8 && pad_to(g, 4 * NWp) <= kGenMaxGroups && ks_rows >= 8 * (NWp - 1);
         op.ksplit_off = ksplit ? ks_scratch : 0;
         while (g % (ksplit ? 4 * NWp : 4)) {                   // the kernel's loop is unrolled by four groups (per wave, for a K-split op): pad with zero-weight groups
             if (g >= kGenMaxGroups) { H.err = NSOS_ERR_UNSUPPORTED; return; }
@@ -891,12 +892,14 @@ void build_program_rf(const nsos_generic_mlp& M, HostProgram& H, const int kGenR
             for (int k = 0; k < M.sem_layers; ++k) {                                           // semantic_linear (:58-64, :79-80)
                 const bool last = k == M.sem_layers - 1;
                 const int out = last ? G.out_off : ((k & 1) ? SA : other);
+                // (the chain's last Linear -- one tile of logits -- is split over K like alpha and rgb: the encoded-xyz buffer is dead by then,
+                //  every reader of it (layer 0, the skip layers, semantic_linear.0 with sem_with_coord) lies in front; not when it IS that reader)
                 if (k == 0) {
                     if (M.sem_with_coord) { const HostSeg two[2] = {hs, Xs}; dense(M.sem[0], out, last ? 4 : 0, !last, 2, two); }   // cat([h, input_pts])
-                    else dense(M.sem[0], out, last ? 4 : 0, !last, 1, &hs);
+                    else dense(M.sem[0], out, last ? 4 : 0, !last, 1, &hs, last ? G.x_off : -1);
                 } else {
                     const HostSeg ss = {src, src_rows, 0, 0};
-                    dense(M.sem[k], out, last ? 4 : 0, !last, 1, &ss);
+                    dense(M.sem[k], out, last ? 4 : 0, !last, 1, &ss, last ? G.x_off : -1);
                 }
                 src = out; src_rows = M.sem[k].out_dim;
             }
