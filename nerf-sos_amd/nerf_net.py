@@ -435,6 +435,11 @@ class _FullRender(torch.autograd.Function):
                 continue
             sfx = "0" if (tag == "coarse" and has_fine) else ""
             get = lambda k: g.get(k + sfx)  # noqa: E731
+            if not any(get(k) is not None for k in ("rgb", "semantics", "depth", "acc", "disp", "weights", "raw", "pts")):
+                # no output of this network reached the loss (e.g. a loss on the fine maps only: the fine samples are detached from the
+                # coarse weights, models/sampler.py:159): autograd would not visit its branch either -- no compositing backward, no chain
+                grads += [None] * len(names)
+                continue
             g_raw = ops.composite_backward(sv["raw"], sv["z"], saved["rays_d"], sv["noise"], saved["noise_std"],
                                            net.white_bkgd, g_rgb=get("rgb"), g_sem=get("semantics"), g_depth=get("depth"),
                                            g_acc=get("acc"), g_disp=get("disp"), g_weights=get("weights"))

@@ -17,17 +17,21 @@ gt = torch.rand(R, 3, device=dev)
 
 
 def step(grad):
-    r = rays.clone().requires_grad_(grad)
+    r = rays.clone().requires_grad_(bool(grad))
     ret = net(r, (syn.NEAR, syn.FAR), retraw=False)
     if grad:
-        ((ret["rgb"] - gt) ** 2).mean().backward()
+        loss = ((ret["rgb"] - gt) ** 2).mean()
+        if grad == 2:           # the trainer's loss (engines/trainer.py:113-121): both maps -> both networks are differentiated
+            loss = loss + ((ret["rgb0"] - gt) ** 2).mean()
+        loss.backward()
         return r.grad
     return ret["rgb"]
 
 
 out = {"rays": R}
-for grad in (False, True):
-    with torch.set_grad_enabled(grad):
+# grad 1: a loss on the fine map only -- the coarse net gets no gradient (its samples are detached) and is not differentiated
+for grad, key in ((0, "render_ms_tuned_kernel"), (2, "pose_step_ms_generic_kernels"), (1, "pose_step_ms_loss_on_the_fine_map_only")):
+    with torch.set_grad_enabled(bool(grad)):
         for _ in range(3):
             step(grad)
         torch.cuda.synchronize()
@@ -35,6 +39,6 @@ for grad in (False, True):
         for _ in range(8):
             g = step(grad)
         torch.cuda.synchronize()
-    out["pose_step_ms_generic_kernels" if grad else "render_ms_tuned_kernel"] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
+    out[key] = round((time.perf_counter() - t0) / 8 * 1e3, 2)
 out["g_rays_finite"] = bool(torch.isfinite(g).all())
 print(json.dumps(out))

@@ -121,3 +121,26 @@ def test_ray_gradients_of_a_frozen_net_equal_the_all_trainable_backward(name):
             assert all(p.grad is None for p in net.parameters())
     assert torch.isfinite(grads[True]).all() and float(grads[True].abs().max()) > 0
     assert torch.equal(grads[True], grads[False])
+
+
+def test_a_net_whose_outputs_get_no_gradient_is_not_differentiated():
+    """A loss on the fine maps only: the fine samples are detached from the coarse weights (models/sampler.py:159), so the coarse net gets
+    no gradient at all (None, as autograd leaves an unvisited branch) and the fine net's gradients equal those of the same loss with a
+    zero-weighted coarse term added -- bit for bit (the skipped branch contributed exact zeros)."""
+    rays = syn.synthetic_rays(48, seed=6, device=DEV)
+    gt = torch.rand(48, 3, device=DEV)
+    out = {}
+    for with_coarse in (False, True):
+        torch.manual_seed(2)
+        net = nerf_sos_amd.NeRFNet(N_samples=16, N_importance=16, perturb=0.0, raw_noise_std=0.0, netwidth=128, netwidth_fine=128).to(DEV).train()
+        ret = net(rays, (syn.NEAR, syn.FAR), retraw=False)
+        loss = ((ret["rgb"] - gt) ** 2).mean()
+        if with_coarse:
+            loss = loss + 0.0 * ((ret["rgb0"] - gt) ** 2).mean()
+        loss.backward()
+        out[with_coarse] = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    assert all(v is None for n, v in out[False].items() if n.startswith("nerf.")), "the coarse net was differentiated"
+    assert all(v is not None for n, v in out[False].items() if n.startswith("nerf_fine."))
+    for n, v in out[False].items():
+        if n.startswith("nerf_fine."):
+            assert torch.equal(v, out[True][n]), n
