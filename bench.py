@@ -1198,15 +1198,22 @@ def run_generic_paths(ctx, rays_n: int = 4096, steps: int = 10):
     for p_ in net.parameters():
         p_.requires_grad_(False)
 
-    def pose_step():
+    def pose_step(both=False):
         r = rays.clone().requires_grad_(True)
         ret = net(r, (syn.NEAR, syn.FAR), retraw=False)
-        ((ret["rgb"] - gt) ** 2).mean().backward()
+        loss = ((ret["rgb"] - gt) ** 2).mean()
+        if both:
+            loss = loss + ((ret["rgb0"] - gt) ** 2).mean()
+        loss.backward()
         return r.grad
 
+    # the loss on the fine map (this entry's definition since round 4): the coarse net gets no gradient -- its samples are detached,
+    # models/sampler.py:159 -- and since round 5 is not differentiated; `ms_per_step_loss_on_both_maps`: both networks' chains run
     ms = clock(pose_step)
+    ms2 = clock(lambda: pose_step(True))
     g = pose_step()
-    out["pose_step_shipped_architecture"] = {"ms_per_step": round(ms, 3), "rays_per_s": round(rays_n / ms * 1e3), "g_rays_finite": bool(torch.isfinite(g).all())}
+    out["pose_step_shipped_architecture"] = {"ms_per_step": round(ms, 3), "rays_per_s": round(rays_n / ms * 1e3), "ms_per_step_loss_on_both_maps": round(ms2, 3),
+                                             "g_rays_finite": bool(torch.isfinite(g).all())}
     del net
     torch.cuda.empty_cache()
     return out
