@@ -1125,7 +1125,7 @@ def compact_line(line: dict) -> dict:
         cv = {}
         for name, v in line["variants"].items():
             if "value" not in v:                       # generic_paths_fp32: two sub-records
-                cv[name] = {k: pick(x, ("ms_per_step", "rays_per_s", "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point")) for k, x in v.items() if isinstance(x, dict)}
+                cv[name] = {k: pick(x, ("ms_per_step", "rays_per_s", "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point", "ms_per_step_loss_on_both_maps")) for k, x in v.items() if isinstance(x, dict)}
                 continue
             e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_by_rank", "finite", "loss", "max_abs_rgb0_vs_exact_fp32"))
             e["roofline"] = pick(roof(v.get("roofline")) or {}, ("frac", "kernel_ms", "kernel", "traffic", "whole_path_frac", "whole_step_frac_forward_flops_only"))
