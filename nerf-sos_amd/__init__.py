@@ -10,7 +10,8 @@ from . import sharding  # noqa: F401
 from . import losses  # noqa: F401
 from . import io  # noqa: F401
 from . import synthetic  # noqa: F401
+from . import quality  # noqa: F401
 from .graphs import GraphedPatchStep, GraphedRender  # noqa: F401
 from .losses import CorrelationLoss, GeoCorrelationLoss, NeRFContrastive  # noqa: F401
 
-__all__ = ["NeRFNet", "NeRFMLP", "MLP", "export_density", "ops", "sharding", "losses", "io", "synthetic", "CorrelationLoss", "GeoCorrelationLoss", "NeRFContrastive", "GraphedRender", "GraphedPatchStep"]
+__all__ = ["NeRFNet", "NeRFMLP", "MLP", "export_density", "ops", "sharding", "losses", "io", "synthetic", "quality", "CorrelationLoss", "GeoCorrelationLoss", "NeRFContrastive", "GraphedRender", "GraphedPatchStep"]

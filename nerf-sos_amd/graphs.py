@@ -82,21 +82,27 @@ class GraphedPatchStep:
     b mod N) and `n_patches` the batch's size; the step's four collectives (sharding.sharded_patch_step) are captured with the
     kernels when the group runs on RCCL ("nccl": its work is enqueued on a stream and joins the capture like any kernel) -- the
     eager step spends 1.25 of its 2.8 ms on host enqueue (profiles/r04/d_graph_step_time.txt), which is what an 8-GPU step would
-    otherwise be bound by.  A group whose collectives are host-driven (gloo) cannot be captured, and a capture that RCCL refuses
-    raises inside torch: both fall back to the eager step AUTOMATICALLY (`self.graph is None`, the reason in
-    `self.capture_fallback`), so the caller's loop is the same either way.  Every rank must construct the object (the warm-up
-    steps and the capture issue collectives).
+    otherwise be bound by.  Every rank must construct the object (the warm-up steps and the capture issue collectives).
+    What happens when the graph cannot be had (round 6):
+      * a group whose collectives are host-driven (gloo) cannot be captured -- a property of the backend, the same on every rank:
+        the step runs eagerly (`self.graph is None`, the reason in `self.capture_fallback`), the caller's loop is the same;
+      * a capture that RAISES (RCCL or torch refusing mid-capture) is LOUD by default: the exception propagates with the reason.
+        `allow_eager_fallback=True` opts into continuing eagerly -- then the ranks AGREE on it first (an all-reduce MIN of a
+        "captured" flag: no rank replays a graph while another steps eagerly, which would desynchronise their collective
+        sequences), the loss generator is rebuilt from its pre-capture state and the gradients are reset.
+    The path is executed on one GPU by tests/test_gpu_sharded.py::test_graphed_step_rccl_world_1_captures_its_collectives (a
+    `backend="nccl"`, world-size-1 group with sharding.FORCE_COLLECTIVES: real RCCL launches inside the capture).
     """
 
     def __init__(self, net, optimizer, rays: torch.Tensor, bounds: Tuple[float, float], feat: torch.Tensor, cls_tokens: torch.Tensor,
                  corr_loss=None, geo_loss=None, contrast_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01,
                  contrast_w: float = 0.0, seed: int = 0, overlap_losses: bool = True, warmup: int = 3, capture: bool = True,
-                 group=None, n_patches: int = None):
+                 group=None, n_patches: int = None, allow_eager_fallback: bool = False):
         import torch.distributed as dist
         from . import sharding
         self.group, self.capture_fallback = group, None
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1:
+        multi = sharding.multi_process(group)            # collectives in the step: N > 1, or one rank under FORCE_COLLECTIVES
+        if multi:
             if n_patches is None:
                 raise ValueError("GraphedPatchStep under a process group: pass n_patches (the size of the whole patch batch)")
             if capture and dist.get_backend(group) != "nccl":
@@ -136,23 +142,40 @@ class GraphedPatchStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             self.opt.zero_grad(set_to_none=True)          # the captured backward allocates the gradients in the graph's pool
             graph = torch.cuda.CUDAGraph()
+            gen_state = self.generator.get_state()        # (to rebuild the generator if the capture is abandoned)
             graph.register_generator_state(self.generator)
-            if world == 1:
+            if not multi:
                 with torch.cuda.graph(graph):
                     self._step()
                 self.graph = graph
             else:
-                # RCCL work inside a capture: supported by ProcessGroupNCCL (the collective is enqueued on its stream, which the
-                # capture follows through the wait).  If this build refuses, every rank refuses alike (same library, same calls):
-                # fall back to eager on all of them instead of leaving the job half captured.
+                # RCCL work inside a capture: ProcessGroupNCCL enqueues the collective on its own stream, which the capture follows
+                # through the wait (executed on one GPU by the world-size-1 test named above).
                 try:
                     with torch.cuda.graph(graph):
                         self._step()
                     self.graph = graph
                 except Exception as e:   # noqa: BLE001  (torch raises RuntimeError / DistBackendError depending on where it fails)
                     self.graph = None
-                    self.capture_fallback = f"capture of the sharded step failed ({type(e).__name__}: {str(e)[:200]}); stepping eagerly"
+                    self.capture_fallback = f"capture of the sharded step failed ({type(e).__name__}: {str(e)[:300]})"
+                    if not allow_eager_fallback:
+                        raise RuntimeError("nerf_sos_amd.GraphedPatchStep: " + self.capture_fallback + " -- pass allow_eager_fallback=True to "
+                                           "step eagerly instead (every rank then agrees on it first), or capture=False") from e
+                if allow_eager_fallback:
+                    # one agreement collective: every rank learns whether EVERY rank holds a graph; a rank-dependent failure
+                    # (allocator, stream state) must not leave one rank replaying while another enqueues eagerly
+                    flag = torch.tensor([1 if self.graph is not None else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                    if int(flag.item()) == 0:
+                        if self.graph is not None:
+                            self.capture_fallback = "another rank's capture of the sharded step failed; stepping eagerly on every rank"
+                        else:
+                            self.capture_fallback += "; stepping eagerly on every rank"
+                        self.graph = None
+                if self.graph is None:
                     torch.cuda.synchronize(dev)
+                    self.generator = torch.Generator(device=dev)      # the abandoned capture left the old one registered with a dead graph
+                    self.generator.set_state(gen_state)
                     self.opt.zero_grad(set_to_none=True)
 
     def _step(self):

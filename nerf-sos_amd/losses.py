@@ -34,10 +34,10 @@ def _run_phases(run, ws: torch.Tensor, batch: int, n_points: int, group) -> None
     owns no patch contributes zeros): the sequence of collectives does not depend on the data."""
     import ctypes as C_
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    from .sharding import collective, multi_process
+    if not multi_process(group):
         run(3)
         return
-    from .sharding import collective
     so, go, gn = C_.c_int64(), C_.c_int64(), C_.c_int64()
     _lib.check(_lib.lib().nsos_corr_workspace_slots(batch, n_points, C_.byref(so), C_.byref(go), C_.byref(gn)), "nsos_corr_workspace_slots")
     means = ws[so.value // 8: so.value // 8 + 4]

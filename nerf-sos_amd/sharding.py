@@ -110,6 +110,22 @@ def _world(group) -> Tuple[int, int]:
     return 0, 1
 
 
+# The N > 1 code path on ONE process (round 6): with FORCE_COLLECTIVES (env NSOS_FORCE_COLLECTIVES=1, or
+# `sharding.FORCE_COLLECTIVES = True`) and an initialised process group of world size 1, the sharded step takes every branch an
+# N-rank job takes -- the flat all-gather with its re-ordering, the row-partitioned loss phases with their two reductions, the flat
+# gradient all-reduce -- and issues its four collectives on the group.  A `backend="nccl"`, `world_size=1` group makes them real RCCL
+# launches on a single GPU: the only way to execute RCCL work inside a HIP-graph capture (graphs.GraphedPatchStep) on a one-GPU box.
+FORCE_COLLECTIVES: bool = os.environ.get("NSOS_FORCE_COLLECTIVES", "") not in ("", "0")
+
+
+def multi_process(group=None) -> bool:
+    """Whether the sharded paths issue their collectives: a process group of more than one rank -- or any initialised group under
+    FORCE_COLLECTIVES."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
 def render_image_sharded(render: Callable[..., Dict[str, torch.Tensor]], rays_o: torch.Tensor,
                          rays_d: torch.Tensor, bounds, group=None, gather: bool = False,
                          keys: Optional[Iterable[str]] = None, **kwargs) -> Dict[str, torch.Tensor]:
@@ -126,7 +142,7 @@ def render_image_sharded(render: Callable[..., Dict[str, torch.Tensor]], rays_o:
     out = render((flat_o[s:e], flat_d[s:e]), (near, far), **kwargs)
     if keys is not None:
         out = {k: out[k] for k in keys}
-    if not gather or world == 1:
+    if not gather or not multi_process(group):
         return out
     sizes = [shard_bounds(R, r, world) for r in range(world)]
     return {k: all_gather_rows(v, [b - a for a, b in sizes], group) for k, v in out.items()}
@@ -135,7 +151,7 @@ def render_image_sharded(render: Callable[..., Dict[str, torch.Tensor]], rays_o:
 def all_gather_rows(t: torch.Tensor, rows_per_rank: Sequence[int], group=None) -> torch.Tensor:
     """All-gather along dim 0 with (possibly) unequal row counts: pad to the max, one collective, trim."""
     rank, world = _world(group)
-    if world == 1:
+    if not multi_process(group):
         return t
     m = max(rows_per_rank)
     pad = t
@@ -159,7 +175,7 @@ def all_gather_patches(local: Dict[str, torch.Tensor], n_patches: int, group=Non
     `stats`, if given, receives ``bytes_per_patch`` and ``collectives``."""
     rank, world = _world(group)
     present = [k for k in keys if k in local]
-    if world == 1:
+    if not multi_process(group):
         return {k: local[k].detach() for k in present}
     counts = [len(local_patches(n_patches, r, world)) for r in range(world)]
     order = [b for r in range(world) for b in local_patches(n_patches, r, world)]  # rank-major -> global id
@@ -202,7 +218,7 @@ def splice_local_patches(gathered: Dict[str, torch.Tensor], local: Dict[str, tor
     for k, g in gathered.items():
         if k in local and local[k].requires_grad and len(own):
             # one process: the "gathered" batch IS the local one (no copy, no index kernel)
-            out[k] = local[k] if world == 1 else g.index_put((device_index(own, torch.long, g.device),), local[k])
+            out[k] = local[k] if not multi_process(group) else g.index_put((device_index(own, torch.long, g.device),), local[k])
     return out
 
 
@@ -224,7 +240,7 @@ def device_index(values, dtype, device) -> torch.Tensor:
 def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
     """ONE flat all-reduce (sum, or mean with average=True) of the gradients of `params`, in place.  82 436 floats for
     the frozen-backbone recipe, 1.27 M for the full model: latency-bound, so a single bucket."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not multi_process(group):
         return
     ps = [p for p in params if p.requires_grad]
     if not ps:
@@ -325,8 +341,7 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
         # the three evaluations write their loss into slots of ONE buffer: the step's total is one reduction launch (straight into
         # `loss_out` when the caller has a place for it) instead of a stack (cat), a sum and a copy
         lbuf = torch.empty(3, device=dev, dtype=torch.float32)
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if multi_process(group):
             # N > 1: all three evaluations row-partitioned (each rank the pair sets of its own patches), their phases interleaved
             # so that the step issues ONE all-reduce per phase for all of them: the means (3 x 8 doubles) and the sums (the
             # gradients' role sums + the split loss sums, fp32)
@@ -363,7 +378,7 @@ def _losses_direct(full, sim, s0, s1, own, gen, corr_loss, geo_loss, correlation
         else:
             la0, ga0 = corr_loss.value_and_grad(f, s0, sim, correlation_w, neg, coords=xy[0], loss_out=lbuf[0])
             la1, ga1 = corr_loss.value_and_grad(f, s1, sim, correlation_w, neg, coords=xy[1], loss_out=lbuf[1])
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        if not multi_process(group):
             lg, gg0, gg1 = geo_loss.pair_value_and_grads(full["depth"], full["semantics0"], full["semantics"], full["ray_o"], full["ray_d"],
                                                           sim, rows=own, group=group, weight=geo_w, neg=neg2, grad_mode=True, loss_out=lbuf[2])
         if side is not None:

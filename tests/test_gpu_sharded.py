@@ -300,7 +300,10 @@ def _graph_worker(rank, world, port, backend, q):
                 ok = False
                 why.append(f"a gloo group must fall back to eager: graph={graphed.graph}, reason={graphed.capture_fallback!r}")
         elif graphed.graph is None:
-            why.append(f"RCCL capture fell back: {graphed.capture_fallback}")      # allowed (reported), the numbers below must still agree
+            ok = False
+            why.append(f"RCCL capture fell back: {graphed.capture_fallback}")      # (the world-size-1 test shows this build captures RCCL work)
+        else:
+            eager.eager_step(); eager.eager_step()                                 # the captured twin's two warm-up steps
         for k in range(3):
             la, lb = float(graphed()), float(eager())
             if abs(la - lb) > 1e-6 * (1 + abs(lb)):
@@ -350,3 +353,121 @@ def test_graphed_step_two_ranks_over_rccl():
     """The first multi-GPU box answers whether this build's RCCL accepts the capture: either way the replayed and the eager step
     must agree; the outcome (captured / fell back, with the reason) is printed."""
     print(_run_graph("nccl"))
+
+
+# ---------------------------------------------------------- RCCL inside a HIP-graph capture on ONE GPU (round 6, VERDICT r05 #2)
+def _rccl_world1_worker(port, q):
+    """One process, `backend="nccl"`, world size 1, sharding.FORCE_COLLECTIVES: the sharded step takes its N > 1 branches and issues
+    its four collectives as real RCCL launches -- inside the capture of GraphedPatchStep.  Asserted: the capture happened (no
+    fall-back), the per-step collective table is the four-collective one, five replays equal five eager steps of a twin bit for
+    bit, and the forced-collective step equals the plain single-process step (the N > 1 branches compute the same numbers)."""
+    import nerf_sos_amd
+    from nerf_sos_amd import sharding, synthetic as syn
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ok, why = True, []
+        B, P = 4, 16
+        rays, feat, cls_ = _batch(B, P, dev)
+
+        def make(capture, force):
+            sharding.FORCE_COLLECTIVES = force
+            net = _build(dev)
+            net.perturb, net.raw_noise_std = 1.0, 1.0
+            net.render_kwargs_train.update(perturb=1.0, raw_noise_std=1.0)
+            net.rng, net.rng_seed = "philox", 3
+            opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=5e-3, fused=True, capturable=True)
+            corr, geo = nerf_sos_amd.CorrelationLoss(_loss_args()), nerf_sos_amd.GeoCorrelationLoss(_loss_args())
+            g = nerf_sos_amd.GraphedPatchStep(net, opt, rays, (syn.NEAR, syn.FAR), feat, cls_, corr, geo, seed=21, warmup=2,
+                                              capture=capture, n_patches=B)
+            return net, g
+
+        net_g, graphed = make(True, True)
+        if graphed.graph is None or graphed.capture_fallback is not None:
+            ok = False
+            why.append(f"the RCCL step was not captured: graph={graphed.graph}, reason={graphed.capture_fallback!r}")
+        net_e, eager = make(False, True)
+        net_p, plain = make(False, False)                   # the ordinary single-process step: no collectives at all
+        sharding.FORCE_COLLECTIVES = True
+        eager.eager_step(); eager.eager_step()              # the captured instance's two warm-up steps
+        sharding.reset_collective_counts()
+        eager()
+        table = sharding.reset_collective_counts()
+        want = {"all_gather": 1, "loss_means_all_reduce": 1, "loss_sums_all_reduce": 1, "grad_all_reduce": 1}
+        if table != want:
+            ok = False
+            why.append(f"collectives per eager step {table} != {want}")
+        graphed()
+        for k in range(1, 5):
+            la, lb = float(graphed()), float(eager())
+            if la != lb:
+                ok = False
+                why.append(f"step {k}: loss {la!r} (replayed) vs {lb!r} (eager)")
+        if sharding.reset_collective_counts():
+            pass                                            # (replays issue no Python-level collectives; eager ones were counted)
+        for (n_, a), (_, b) in zip(net_g.named_parameters(), net_e.named_parameters()):
+            if a.requires_grad and not torch.equal(a, b):
+                ok = False
+                why.append(f"{n_}: replayed and eager parameters differ by {float((a.detach() - b.detach()).abs().max()):.2e} after five steps")
+        sharding.FORCE_COLLECTIVES = False
+        for k in range(7):
+            plain()
+        for (n_, a), (_, b) in zip(net_p.named_parameters(), net_e.named_parameters()):
+            if a.requires_grad:
+                err = float((a.detach() - b.detach()).abs().max()) / (1e-12 + float(b.detach().abs().max()))
+                if err > 2e-5:
+                    ok = False
+                    why.append(f"{n_}: forced-collective and plain single-process steps differ by {err:.2e} of scale after five steps")
+        # a capture that raises is LOUD by default, and with allow_eager_fallback the step runs eagerly after the agreement collective
+        sharding.FORCE_COLLECTIVES = True
+        net_f = _build(dev)
+        net_f.rng = "philox"
+        opt_f = torch.optim.Adam([p for p in net_f.parameters() if p.requires_grad], lr=5e-3, fused=True, capturable=True)
+
+        class Boom(nerf_sos_amd.CorrelationLoss):
+            def rows_phased(self, *a, **k):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("injected failure inside the capture")
+                return super().rows_phased(*a, **k)
+        kw = dict(seed=21, warmup=1, capture=True, n_patches=B)
+        try:
+            nerf_sos_amd.GraphedPatchStep(net_f, opt_f, rays, (syn.NEAR, syn.FAR), feat, cls_, Boom(_loss_args()),
+                                          nerf_sos_amd.GeoCorrelationLoss(_loss_args()), **kw)
+            ok = False
+            why.append("a failing capture did not raise")
+        except RuntimeError as e:
+            if "injected failure" not in str(e) or "allow_eager_fallback" not in str(e):
+                ok = False
+                why.append(f"unexpected message: {e}")
+        torch.cuda.synchronize()
+        fb = nerf_sos_amd.GraphedPatchStep(net_f, opt_f, rays, (syn.NEAR, syn.FAR), feat, cls_, Boom(_loss_args()),
+                                           nerf_sos_amd.GeoCorrelationLoss(_loss_args()), allow_eager_fallback=True, **kw)
+        if fb.graph is not None or "stepping eagerly on every rank" not in (fb.capture_fallback or ""):
+            ok = False
+            why.append(f"fall-back state: graph={fb.graph}, reason={fb.capture_fallback!r}")
+        l0 = float(fb())
+        l1 = float(fb())
+        if not (l0 == l0 and l1 == l1):
+            ok = False
+            why.append("the eager fall-back step returned NaN")
+        q.put((0, ok, "; ".join(why)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_graphed_step_rccl_world_1_captures_its_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 331
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
+    p.start()
+    try:
+        res = q.get(timeout=400)
+        p.join(60)
+    finally:
+        if p.is_alive():                                   # a hung collective must not outlive the test (exact PID: our own child)
+            p.kill()
+    assert res[:2] == (0, True), res

@@ -151,6 +151,94 @@ def test_trained_field_16_bit_quality_vs_reference(golden, precision):
     assert abs(rec["psnr_vs_analytic_gt_db"] - rec["reference_psnr_vs_analytic_gt_db"]) < 1.0, rec
 
 
+# ------------------------------------------------------------------------------ the 16-bit TAIL (round 6)
+# 256 rays cannot show a one-in-a-thousand ray.  trained_4k.npz: the REAL reference's eval render of the 4096 rays bench.py's
+# `parity.trained_field` uses; trained_img64k.npz: of 65 536 pixels of the full 1008x756 image of held-out pose 0 (C5's workload).
+# What the tail is (scripts/diag/lp_outliers.py, profiles/r06/a_lp_outliers.json): silhouette rays whose 128 importance samples land
+# elsewhere when the COARSE weights carry 16-bit error; the fine network's own 16-bit error on given positions is 9 rays of 762 048
+# over 0.01.  `coarse_precision = "fp16x3"` removes it.  Bars: measured values (profiles/r06/b_trained_field_report.json) with headroom;
+# they are COUNTS and percentiles, not only a PSNR.
+TAIL_BARS = {
+    # (precision, coarse_precision): (4096 rays, 65 536 pixels): PSNR floor, max count of rays with |d rgb| > 0.01 / > 0.05, p99.9 ceiling.
+    # measured (profiles/r06/b_trained_field_report.json): fp16 64.35 / 57.34 dB, 3 / 60 rays over 0.01, 0 / 11 over 0.05, max 0.039 / 0.24;
+    # bf16 56.71 / 54.74 dB, 7 / 116, 1 / 17, max 0.10 / 0.24; fp16 with a split-fp16 coarse pass 85.58 / 84.00 dB, 0 / 0 rays, max 0.0022 /
+    # 0.0077; bf16 with it 69.66 / 68.96 dB, 1 / 17 rays over 0.01, none over 0.05, max 0.010 / 0.029
+    ("fp16", None): dict(psnr=(61.0, 54.0), n01=(10, 110), n05=(3, 25), p999=(0.02, 0.02)),
+    ("bf16", None): dict(psnr=(53.5, 52.0), n01=(20, 200), n05=(5, 40), p999=(0.035, 0.03)),
+    ("fp16", "fp16x3"): dict(psnr=(80.0, 80.0), n01=(0, 2), n05=(0, 0), p999=(0.002, 0.002)),
+    ("bf16", "fp16x3"): dict(psnr=(66.0, 66.0), n01=(5, 40), n05=(1, 3), p999=(0.01, 0.01)),
+}
+
+
+def _tail_case(g, rays, precision, coarse, which):
+    from nerf_sos_amd import quality
+    net = _net(precision)
+    net.coarse_precision = coarse
+    net.chunk = 65536
+    near, far = (float(v) for v in g["near_far"])
+    with torch.no_grad():
+        out = net(rays, (near, far), radii=None, retraw=False)
+    assert torch.isfinite(out["rgb"]).all() and torch.isfinite(out["depth"]).all()
+    st = quality.tail_stats(out["rgb"], T(g["eval_rgb"]), out["depth"], T(g["eval_depth"]),
+                            out["semantics"].argmax(-1), T(g["eval_semantics"]).argmax(-1))
+    st["psnr_vs_analytic_gt_db"] = float(-10 * np.log10(np.mean((N(out["rgb"]) - g["gt_rgb"]) ** 2)))
+    st["reference_psnr_vs_analytic_gt_db"] = float(-10 * np.log10(np.mean((g["eval_rgb"] - g["gt_rgb"]) ** 2)))
+    _report(f"tail_{which}_{precision}_coarse_{coarse or 'same'}", st)
+    bar, i = TAIL_BARS[(precision, coarse)], 0 if which == "4k" else 1
+    a = st["abs_rgb"]
+    assert st["psnr_db"] >= bar["psnr"][i], st
+    assert a["n_gt_0.01"] <= bar["n01"][i] and a["n_gt_0.05"] <= bar["n05"][i] and a["p99.9"] <= bar["p999"][i], st
+    assert st["label_agreement"] >= 0.998, st
+    assert abs(st["psnr_vs_analytic_gt_db"] - st["reference_psnr_vs_analytic_gt_db"]) < 0.5, st
+    if coarse == "fp16x3" and precision == "fp16":
+        # the fix's acceptance bar: max |d rgb| <= 0.02 on >= 99.99 % of the rays
+        assert st["share_of_rays_within_0.02"] >= 0.9999, st
+    return st
+
+
+@pytest.mark.parametrize("precision,coarse", list(TAIL_BARS))
+def test_trained_field_16_bit_tail_vs_reference_4096_rays(golden, precision, coarse):
+    g = golden("trained_4k")
+    _tail_case(g, T(g["rays"]), precision, coarse, "4k")
+
+
+@pytest.mark.parametrize("precision,coarse", list(TAIL_BARS))
+def test_trained_field_16_bit_tail_vs_reference_image_65536_pixels(golden, precision, coarse):
+    """65 536 pixels of the full-size image (C5's workload on the trained field) against the REAL reference's render of them.  The rays
+    come from K0 on the device and are asserted bit-identical (sha256) to the reference's get_persp_rays (utils/ray.py:12-22)."""
+    import hashlib
+    from nerf_sos_amd import ops, synthetic as syn
+    g = golden("trained_img64k")
+    scene = syn.ProceduralScene()
+    H, W, focal = int(g["image_hwf"][0]), int(g["image_hwf"][1]), float(g["image_hwf"][2])
+    full = ops.generate_rays(H, W, syn.intrinsics(H, W, focal), scene.poses[int(g["pose_index"][0]), :3, :4], DEV).reshape(2, -1, 3)
+    rays = full[:, T(g["pixel_index"]).long()].contiguous()
+    assert hashlib.sha256(N(rays).tobytes()).digest() == bytes(g["rays_sha256"]), "K0's rays differ from the reference's get_persp_rays"
+    _tail_case(g, rays, precision, coarse, "img64k")
+
+
+def test_trained_field_fp32_paths_vs_reference_4096_rays(golden):
+    """The exact and the split-fp16 paths on the same 4096 rays, free-running, against the reference: image maps inside 1e-4 up to the
+    reference's own sensitivity (n_self = 0 rays on this set), z_std counted against ITS yardstick (n_self_z_std: the reference moves
+    that many rays against its own fp64-coarse variant) -- VERDICT r05 weak-3."""
+    g = golden("trained_4k")
+    near, far = (float(v) for v in g["near_far"])
+    R = g["rays"].shape[1]
+    n_self, n_self_z = int(g["n_self"][0]), int(g["n_self_z_std"][0])
+    for precision in ("fp32", "fp16x3"):
+        net = _net(precision)
+        with torch.no_grad():
+            out = net(T(g["rays"]), (near, far), radii=None, retraw=False)
+        per_key = {}
+        for k in ("rgb", "depth", "acc", "disp", "semantics", "z_std", "rgb0", "depth0", "acc0", "disp0", "semantics0"):
+            want = g[f"eval_{k}"].reshape(R, -1)
+            per_key[k] = int((np.abs(N(out[k]).reshape(R, -1).astype(np.float64) - want) > 1e-4 * (1 + np.abs(want))).any(-1).sum())
+        _report(f"free_running_4k_{precision}", {"per_key": per_key, "n_self_maps": n_self, "n_self_z_std": n_self_z, "rays": R})
+        assert all(per_key[k] == 0 for k in ("rgb0", "depth0", "acc0", "disp0", "semantics0")), per_key
+        assert max(per_key[k] for k in ("rgb", "depth", "acc", "disp", "semantics")) <= 2 * n_self + 2, (per_key, n_self)
+        assert per_key["z_std"] <= 2 * n_self_z + 3 * (2 * n_self_z) ** 0.5 + 1, (per_key, n_self_z)
+
+
 def _rescaled(sd, s, layer=3):
     """W_k, b_k *= s; the h-columns of W_{k+1} /= s: the same function, layer k's activations s times larger."""
     sd = {k: v.clone() for k, v in sd.items()}
