@@ -324,7 +324,9 @@ def parity_yardstick(tp, sd, cfg, rays, ref, got, inds_hip=None, tol: float = 1e
         z_fine, _ = torch.sort(torch.cat([z, zs], -1), -1)
         pts = tp.ray_points(rays[0], rays[1], z_fine)
         raw = tp.point_query(sd, "nerf_fine", pts, viewdirs[..., None, :].expand(pts.shape), cfg)
-        return inds, tp.composite(raw, z_fine, rays[1], None, cfg)
+        maps = tp.composite(raw, z_fine, rays[1], None, cfg)
+        maps["z_std"] = torch.std(zs, dim=-1, unbiased=False)                      # models/nerf_net.py:124
+        return inds, maps
 
     def outside(maps):
         o = torch.zeros(n, dtype=torch.bool)
@@ -341,7 +343,12 @@ def parity_yardstick(tp, sd, cfg, rays, ref, got, inds_hip=None, tol: float = 1e
         pts = tp.ray_points(rays[0], rays[1], z)
         sd64 = {k: v.double() for k, v in sd.items()}
         raw64 = tp.point_query(sd64, "nerf", pts.double(), viewdirs.double()[..., None, :].expand(pts.shape), cfg).float()
-        n_self = outside(fine_pass(tp.composite(raw64, z, rays[1], None, cfg)["weights"])[1])
+        self_maps = fine_pass(tp.composite(raw64, z, rays[1], None, cfg)["weights"])[1]
+        n_self = outside(self_maps)
+
+    def z_std_outside(t):
+        a, b = t.detach().double().cpu().reshape(-1), ref["z_std"].double().reshape(-1)
+        return int((~((a - b).abs() <= tol + tol * b.abs())).sum())
     n_gpu = outside(got)
     res = {"keys": keys, "band": "|a - ref| <= 1e-4 + 1e-4 * |ref|", "rays": n,
            "gpu_rays_outside": n_gpu, "reference_self_sensitivity_rays_outside": n_self,
@@ -349,6 +356,10 @@ def parity_yardstick(tp, sd, cfg, rays, ref, got, inds_hip=None, tol: float = 1e
            "max_abs_raw0_minus_fp64": {"reference_fp32": float((ref["raw0"] - raw64).abs().max()),
                                        "gpu": float((got["raw0"].detach().float().cpu().reshape(raw64.shape) - raw64).abs().max())},
            "staged_port_reproduces_port": staged_ok}
+    if "z_std" in ref and "z_std" in got:
+        # z_std (std of the 128 importance samples) sits on the sampler's discontinuities and is in none of the image maps: its own
+        # yardstick -- the reference against its fp64-coarse self, and the GPU against the reference
+        res["z_std_rays_outside"] = {"gpu": z_std_outside(got["z_std"]), "reference_self": z_std_outside(self_maps["z_std"])}
     if inds_hip is not None:
         res["index_flip_rays"] = int((inds_hip.cpu().reshape(inds_ref.shape) != inds_ref)[:, :-1].any(-1).sum())
     return res
@@ -431,10 +442,14 @@ def trained_field_parity(torch, dev, n_rays: int = 4096):
     rays = torch.cat(rays, 1).contiguous()
     bounds = (scene.NEAR, scene.FAR)
     outs = {}
+    net.validate_precision = False
+    modes = {"fp32": ("fp32", None), "fp16x3": ("fp16x3", None), "bf16": ("bf16", None), "fp16": ("fp16", None),
+             "fp16_coarse_fp16x3": ("fp16", "fp16x3"), "bf16_coarse_fp16x3": ("bf16", "fp16x3")}
     with torch.no_grad():
-        for prec in ("fp32", "fp16x3", "bf16", "fp16"):
-            net.mlp_precision = prec
-            outs[prec] = {k: v.detach().clone() for k, v in net(rays, bounds).items()}
+        for name, (prec, coarse) in modes.items():
+            net.mlp_precision, net.coarse_precision = prec, coarse
+            outs[name] = {k: v.detach().clone() for k, v in net(rays, bounds, retraw=name == "fp32").items() if name == "fp32" or k in ("rgb", "depth", "semantics")}
+    net.mlp_precision, net.coarse_precision = "fp32", None
     inds = gpu_bisect_indices(torch, outs["fp32"], rays, N_COARSE, N_IMPORTANCE, *bounds)
     torch.cuda.synchronize()
     cfg = tp.PortConfig(n_samples=N_COARSE, n_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True, pts_chunk=1024 * 256)
@@ -453,16 +468,19 @@ def trained_field_parity(torch, dev, n_rays: int = 4096):
                             f"{per_view} random pixels of each of the {len(scene.i_test)} held-out views",
                     "reference_psnr_vs_analytic_gt_db": psnr_gt(ref["rgb"]), "gpu_fp32_psnr_vs_analytic_gt_db": psnr_gt(outs["fp32"]["rgb"]),
                     "mean_acc": round(float(ref["acc"].mean()), 4)}
+    from nerf_sos_amd import quality
     lab_ref = ref["semantics"].argmax(-1)
     q = {}
-    for prec in ("fp16x3", "bf16", "fp16"):
-        o = outs[prec]
-        d = o["rgb"].cpu().double() - ref["rgb"].double()
-        q[prec] = {"psnr_db_rgb_vs_reference": round(float(-10 * torch.log10((d ** 2).mean() + 1e-30)), 2),
-                   "max_abs_rgb": float(d.abs().max()), "label_agreement": round(float((o["semantics"].cpu().argmax(-1) == lab_ref).float().mean()), 5),
-                   "max_rel_depth": float(((o["depth"].cpu() - ref["depth"]).abs() / ref["depth"].abs()).max()),
-                   "psnr_vs_analytic_gt_db": psnr_gt(o["rgb"])}
+    for name in modes:
+        if name == "fp32":
+            continue
+        o = outs[name]
+        st = quality.tail_stats(o["rgb"].cpu(), ref["rgb"], o["depth"].cpu(), ref["depth"], o["semantics"].cpu().argmax(-1), lab_ref)
+        st["psnr_vs_analytic_gt_db"] = psnr_gt(o["rgb"])
+        q[name] = st
     res["other_precisions_vs_reference"] = q
+    res["tail_note"] = ("16-bit tail = silhouette rays whose importance samples move with the COARSE pass's 16-bit error (scripts/diag/lp_outliers.py, "
+                        "profiles/r06/a_lp_outliers.json); `coarse_precision='fp16x3'` removes it (the *_coarse_fp16x3 rows)")
     return res
 
 
@@ -502,14 +520,14 @@ def hbm_kernel_rooflines(torch, dev, n_rays: int = 65536):
     return out
 
 
-def c5_trained_quality(torch, dev, precision: str, chunk: int = 65536):
+def c5_trained_quality(torch, dev, precision: str, chunk: int = 65536, coarse=None):
     """C5's `quality` on the TRAINED field: the full 1008x756 image of held-out pose 0 (the scene's field of view) in `precision`
-    and through the exact fp32 kernels (= the reference within 1e-4 on this field, parity.trained_field), PSNR / max-abs / labels,
-    and both against the analytic image.  Outside the timed region."""
+    (coarse pass in `coarse`, if given: NeRFNet.coarse_precision) and through the exact fp32 kernels (= the reference within 1e-4 on
+    this field, parity.trained_field): PSNR AND the tail -- percentiles, counts of rays over 0.01 / 0.05 in rgb, share within 0.02,
+    relative depth, labels (nerf_sos_amd.quality.tail_stats) -- and both against the analytic image.  Outside the timed region."""
     import math
-    import numpy as np
     import nerf_sos_amd
-    from nerf_sos_amd import io as nio, ops, synthetic as syn
+    from nerf_sos_amd import io as nio, ops, quality, synthetic as syn
     scene = syn.ProceduralScene()
     net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True, ray_chunk=chunk).to(dev).eval()
     nio.load_checkpoint(TRAINED_CKPT, net)
@@ -521,21 +539,20 @@ def c5_trained_quality(torch, dev, precision: str, chunk: int = 65536):
     rays = ops.generate_rays(H, W, syn.intrinsics(H, W, focal), scene.poses[i, :3, :4], dev).reshape(2, -1, 3)
     res = {}
     with torch.no_grad():
-        for prec in (precision, "fp32"):
-            net.mlp_precision = prec
+        for prec, cp in ((precision, coarse), ("fp32", None)):
+            net.mlp_precision, net.coarse_precision = prec, cp
             ret = net(rays, (scene.NEAR, scene.FAR), retraw=False)
             res[prec] = (ret["rgb"].clone(), ops.eval_postprocess(semantics=ret["semantics"])["sem"].clone(), ret["depth"].clone())
     gt_rgb, gt_lab, _ = scene.view(i, H, W)
     gt = torch.from_numpy(gt_rgb.reshape(-1, 3)).to(dev)
     lo, hi = res[precision], res["fp32"]
-    mse = float(((lo[0] - hi[0]) ** 2).mean())
     psnr = lambda a: round(-10.0 * math.log10(max(float(((a - gt) ** 2).mean()), 1e-30)), 2)   # noqa: E731
-    return {"psnr_db_rgb_vs_exact_fp32": round(-10.0 * math.log10(max(mse, 1e-30)), 2), "max_abs_rgb": float((lo[0] - hi[0]).abs().max()),
-            "label_agreement": round(float((lo[1] == hi[1]).float().mean()), 6),
-            "max_rel_depth": float(((lo[2] - hi[2]).abs() / hi[2].abs()).max()),
-            "psnr_vs_analytic_image_db": {precision: psnr(lo[0]), "fp32": psnr(hi[0])},
-            "what": f"full {W}x{H} image of held-out pose {i} of the TRAINED procedural scene (tests/golden/trained_scene.ckpt), {precision} vs the exact-fp32 kernels"}
-
+    st = quality.tail_stats(lo[0], hi[0], lo[2], hi[2], lo[1], hi[1])
+    st.update({"psnr_db_rgb_vs_exact_fp32": st["psnr_db"], "max_abs_rgb": st["abs_rgb"]["max"], "max_rel_depth": st["rel_depth"]["max"],
+               "psnr_vs_analytic_image_db": {precision: psnr(lo[0]), "fp32": psnr(hi[0])}, "coarse_precision": coarse,
+               "what": f"full {W}x{H} image of held-out pose {i} of the TRAINED procedural scene (tests/golden/trained_scene.ckpt), {precision}"
+                       + (f" with the coarse pass in {coarse}" if coarse else "") + " vs the exact-fp32 kernels"})
+    return st
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1000,7 +1017,7 @@ def run_patch_training(ctx, args, patches_per_gpu: int, precision: str, steps: i
 
 
 # ------------------------------------------------------------------------------------------------------------------ c5
-def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1):
+def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1, coarse=None):
     """Full-image eval: every rank renders its contiguous block of the 762 048 rays in 65 536-ray chunks (rays generated
     on device from the pose, `raw` never materialised) and post-processes its rows on device."""
     import nerf_sos_amd
@@ -1010,7 +1027,8 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1):
     torch.manual_seed(0)
     net = nerf_sos_amd.NeRFNet(N_samples=N_COARSE, N_importance=N_IMPORTANCE, use_semantics=True, sem_with_coord=True,
                                perturb=1.0, raw_noise_std=1.0, ray_chunk=chunk).to(ctx.dev).eval()
-    net.mlp_precision = precision
+    net.mlp_precision, net.coarse_precision = precision, coarse
+    net.validate_precision = False                         # (random-init weights, far inside fp16's range; no extra render in the timed loop)
     s, e = sharding.shard_bounds(syn.H * syn.W, ctx.rank, ctx.world)
     state = {}
 
@@ -1044,9 +1062,9 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1):
         field = make_dense_field(net, rays, (syn.NEAR, syn.FAR))
         with torch.no_grad():
             lo = net(rays, (syn.NEAR, syn.FAR), retraw=False)
-            net.mlp_precision = "fp32"
+            net.mlp_precision, net.coarse_precision = "fp32", None
             hi = net(rays, (syn.NEAR, syn.FAR), retraw=False)
-            net.mlp_precision = precision
+            net.mlp_precision, net.coarse_precision = precision, coarse
             mse = float(((lo["rgb"] - hi["rgb"]) ** 2).mean())
             agree = float((ops.eval_postprocess(semantics=lo["semantics"])["sem"] == ops.eval_postprocess(semantics=hi["semantics"])["sem"]).float().mean())
             import math
@@ -1054,14 +1072,15 @@ def run_c5(ctx, args, precision: str, steps: int, warmup: int, blocks: int = 1):
                        "max_abs_rgb": float((lo["rgb"] - hi["rgb"]).abs().max()), "label_agreement": round(agree, 5),
                        "mean_acc": round(float(hi["acc"].mean()), 4), "field": field,
                        "what": f"{rays.shape[1]} rays of the image through a dense field, {precision} vs the exact-fp32 kernels"}
-    res.update(roofline=roof, rays_per_gpu=n_rays, precision=precision, image=f"{syn.W}x{syn.H}", chunk=chunk,
+    res.update(roofline=roof, rays_per_gpu=n_rays, precision=precision, coarse_precision=coarse, image=f"{syn.W}x{syn.H}", chunk=chunk,
                finite=bool(torch.isfinite(state["rgb"]).all().item()), quality_dense_random_field=quality)
     if ctx.rank == 0:
         del net
         torch.cuda.empty_cache()
         if precision != "fp32":
-            res["quality"] = c5_trained_quality(torch, ctx.dev, precision, chunk)
-        res["hbm_kernels"] = hbm_kernel_rooflines(torch, ctx.dev, chunk)
+            res["quality"] = c5_trained_quality(torch, ctx.dev, precision, chunk, coarse)
+        if coarse is None:
+            res["hbm_kernels"] = hbm_kernel_rooflines(torch, ctx.dev, chunk)
     return res
 
 
@@ -1114,10 +1133,11 @@ def compact_line(line: dict) -> dict:
                  "frac_rays_outside_1e-4_any_fine_map": f["frac_rays_outside_1e-4_any_fine_map"],
                  "frac_rays_outside_1e-4_image_maps": f.get("frac_rays_outside_1e-4_image_maps"),
                  "gpu_rays_outside": y.get("gpu_rays_outside"), "reference_self_rays_outside": y.get("reference_self_sensitivity_rays_outside"),
-                 "index_flip_rays": y.get("index_flip_rays"), "rays": y.get("rays"),
+                 "index_flip_rays": y.get("index_flip_rays"), "rays": y.get("rays"), "z_std_rays_outside": y.get("z_std_rays_outside"),
                  "max_abs_raw0_minus_fp64": y.get("max_abs_raw0_minus_fp64")}
             if "other_precisions_vs_reference" in f:
-                e["vs_reference"] = {k: pick(v, ("psnr_db_rgb_vs_reference", "max_abs_rgb", "label_agreement")) for k, v in f["other_precisions_vs_reference"].items()}
+                from nerf_sos_amd import quality
+                e["vs_reference"] = {k: quality.compact(v) for k, v in f["other_precisions_vs_reference"].items()}
                 e["reference_psnr_vs_analytic_gt_db"] = f["field"].get("reference_psnr_vs_analytic_gt_db")
             cp[name] = e
         out["parity"] = cp
@@ -1135,14 +1155,19 @@ def compact_line(line: dict) -> dict:
             if isinstance(g, dict):
                 e["replayed"] = pick(g, ("ms_per_step", "rays_per_s", "host_enqueue_ms_per_step"))
             if isinstance(v.get("quality"), dict):
-                e["quality_trained_field"] = pick(v["quality"], ("psnr_db_rgb_vs_exact_fp32", "max_abs_rgb", "label_agreement", "psnr_vs_analytic_image_db"))
+                from nerf_sos_amd import quality
+                e["quality_trained_field"] = dict(quality.compact(v["quality"]), psnr_vs_analytic_image_db=v["quality"].get("psnr_vs_analytic_image_db"))
             if isinstance(v.get("hbm_kernels"), dict):
                 e["hbm_kernels"] = {k: pick(x, ("achieved", "frac", "kernel_us")) for k, x in v["hbm_kernels"].items()}
             cv[name] = e
         out["variants"] = cv
     for k in ("quality", "hbm_kernels", "collectives", "whole_step_graph", "replayed_as_hip_graph"):
         if k in line and line[k] is not None:
-            out[k] = line[k] if k != "quality" else pick(line[k], ("psnr_db_rgb_vs_exact_fp32", "max_abs_rgb", "label_agreement", "psnr_vs_analytic_image_db"))
+            if k == "quality":
+                from nerf_sos_amd import quality
+                out[k] = dict(quality.compact(line[k]), psnr_vs_analytic_image_db=line[k].get("psnr_vs_analytic_image_db"))
+            else:
+                out[k] = line[k]
     d = line.get("distributed", {})
     out["distributed"] = pick(d, ("backend", "ranks_seen_by_collective", "calls_per_step_by_kind", "step_breakdown_ms", "host_enqueue_ms_per_step_by_rank"))
     out["detail"] = "full tables: the stdout line before this one ({\"bench_detail\": ...}) and ./bench_detail.json"
@@ -1228,6 +1253,8 @@ def main():
                     help="BASELINE.json configs[0..4]; c2 is the headline the metric is quoted on")
     ap.add_argument("--precision", choices=("fp32", "fp16x3", "bf16", "fp16"), default=None,
                     help="MLP arithmetic; default: fp32 for c2 (the reference's), bf16 for c3/c4, fp16 for c5 (BASELINE's dtypes)")
+    ap.add_argument("--coarse-precision", choices=("fp32", "fp16x3", "bf16", "fp16"), default=None,
+                    help="c5 only: NeRFNet.coarse_precision (the coarse pass's arithmetic; default: the same as --precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
@@ -1292,6 +1319,11 @@ def main():
                          "softmax/argmax; row blocks sharded over the GPUs (strong scaling, no collective); a step = one image")
             add_traffic(v.get("roofline"), "c5_fp16")
             variants["c5_fp16"] = v
+            if ctx.world == 1:
+                v = _strip(run_c5(ctx, args, "fp16", 2, 1, blocks=3, coarse="fp16x3"))
+                v["what"] = ("c5 with NeRFNet.coarse_precision = 'fp16x3': the coarse pass (1/4 of the points) on the split-fp16 kernel (fp32-grade), the fine "
+                             "pass on the fp16 kernel -- removes the 16-bit tail on a trained field (quality_trained_field) at this cost")
+                variants["c5_fp16_coarse_fp16x3"] = v
             v = _strip(run_patch_training(ctx, args, 2, "bf16", vsteps, 6, blocks=5))
             v["what"] = ("BASELINE configs[3]: 8192 rays/GPU (2 patches of 64x64 per GPU), the c3 step sharded over the GPUs: one flat "
                          "all-gather of semantics0/semantics/depth/feat/cls_/ray_o/ray_d, one flat gradient all-reduce")
@@ -1319,12 +1351,12 @@ def main():
         line["whole_step_graph"] = res.get("whole_step_graph")
         line["contrastive_loss"] = res.get("contrastive_loss")
     else:
-        res = _strip(run_c5(ctx, args, prec, args.steps, args.warmup))
+        res = _strip(run_c5(ctx, args, prec, args.steps, args.warmup, coarse=args.coarse_precision))
         line.update({k: res[k] for k in ("value", "ms_per_step", "host_enqueue_ms_per_step", "per_rank_rays_per_s")})
         line["scaling"] = "strong"
         line["dtype"] = {"fp32": "f32", "fp16x3": "f16x3"}.get(prec, prec)
         line["config"] = {"workload": f"BASELINE configs[4]: full-image render {res['image']} = 762048 rays in {res['chunk']}-ray chunks, "
-                                      f"eval mode, sem+coord head, {prec} MLP, rays generated on device, on-device post-processing; step = one image",
+                                      f"eval mode, sem+coord head, {prec} MLP" + (f" (coarse pass {args.coarse_precision})" if args.coarse_precision else "") + f", rays generated on device, on-device post-processing; step = one image",
                           "rays_per_gpu": res["rays_per_gpu"], "parallelism": f"row blocks sharded x{ctx.world}, no collective",
                           "flop_per_ray": 2 * MAC_SEMCOORD * EVALS_PER_RAY}
         line["roofline"] = add_traffic(res["roofline"], "c5_fp16") if prec == "fp16" else res["roofline"]

@@ -97,7 +97,14 @@ int32_t nsos_mlp_pack(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* p
  * embedding: the raw 3-vector), use_viewdirs (0: output_linear only, :97-98), the semantic head as its Linear modules in order
  * (sem_layers of them: 2 for sem_layer <= 2, sem_layer otherwise, :58-63; ReLU between them), sem_with_coord (cat([h,
  * input_pts]), :79), sem_with_geo (geo[0..1] = geo_map_sem's two Linears on alpha; semantics *= mapping, :60,:81-83).
- * Exact-fp32 MFMA arithmetic (fmaf chains, bias first); training: the K7-G entries below.  raw: [n, 4 + sem_dim] (4 without view directions).
+ * Exact-fp32 MFMA arithmetic: every Linear is an fmaf chain over its inputs in k order starting from the bias (the accumulators'
+ * initial value) -- EXCEPT single-tile output ops (alpha 1 row, rgb 3, output_linear 4, the last Linear of the semantic chain), whose
+ * K range is split into n_waves (4 or 8, chosen from the architecture's LDS footprint: two workgroups per CU -> 4, one -> 8) partial
+ * chains that wave 0 adds in a fixed order: the same Linear therefore rounds differently under different architectures (always
+ * deterministic; every case is held to the reference goldens at 1e-4, tests/test_generic_arch.py, re-validated after the change of
+ * the reduction order in round 5).  Wave-wide sums / scans of the compositing, loss and eval kernels are DPP / permlane trees in a
+ * fixed association (csrc/common.h nsos_wave_sum, nsos_wave_excl_scan).  Training: the K7-G entries below.
+ * raw: [n, 4 + sem_dim] (4 without view directions).
  * The shipped architecture (8 x 256, skips {4}, 10 / 4 octaves, view directions, two-Linear head) should use nsos_mlp_forward_*:
  * this path is ~2x slower there.  Limits: depth <= 16, sem_layers <= 8, sem_dim <= 8, and the per-tile
  * activation buffers (ceil(W / 32) * 32 rows each) within 160 KiB of LDS: 32-point tiles up to W = 576 (384 with a deep semantic

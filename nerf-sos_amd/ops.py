@@ -188,18 +188,29 @@ class PackPlan:
             _lib.check(L.nsos_mlp_bwd_pack_x3(T, self.sem_mode, _p(out), nbytes, _stream()), "nsos_mlp_bwd_pack_x3")
         elif heads_only and self.sem_mode != SEM_NONE:
             _lib.check(L.nsos_mlp_pack_lp_heads(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp_heads")
-            out._nsos_partial = lp_selected_kernel()       # only this kernel's stream holds the new heads (check_lp_stream)
+            _LP_PARTIAL[_storage_key(out)] = lp_selected_kernel()       # only this kernel's stream holds the new heads (check_lp_stream)
         else:
             _lib.check(L.nsos_mlp_pack_lp(T, self.sem_mode, DTYPES[precision], _p(out), nbytes, _stream()), "nsos_mlp_pack_lp")
-            out._nsos_partial = None
+            _LP_PARTIAL.pop(_storage_key(out), None)
         return out
+
+
+# Which of a 16-bit weight buffer's three streams holds current semantic-head weights after a heads-only re-pack, keyed by the
+# buffer's STORAGE (device, address): every view, reshape or slice of the buffer shares it, so the tag survives them (a
+# Python attribute on the tensor object did not).  A clone is a new storage with no entry -- a clone of a partially re-packed buffer
+# must be re-packed in full by its owner; the C ABI's own callers hold the same obligation (include/nerf_sos_hip.h, nsos_mlp_pack_lp_heads).
+_LP_PARTIAL: Dict[tuple, int] = {}
+
+
+def _storage_key(t: torch.Tensor) -> tuple:
+    return (str(t.device), t.untyped_storage().data_ptr())
 
 
 def check_lp_stream(packed: torch.Tensor, kernel: int) -> None:
     """A 16-bit weight buffer that had a heads-only re-pack (PackPlan.run(heads_only=True)) holds current semantic-head weights in
     ONE of its three streams.  Called with the kernel a launch is about to run on (1 = mlp_lp_kernel, the fall-back for fp32 sem_in
     saves and >= 2^31 points; 2 = lp8; 3 = lp16): raises instead of rendering with stale heads."""
-    cur = getattr(packed, "_nsos_partial", None)
+    cur = _LP_PARTIAL.get(_storage_key(packed))
     if cur is not None and cur != kernel:
         raise RuntimeError(f"nerf_sos_amd: this packed 16-bit weight buffer was last updated by a heads-only re-pack for kernel {cur}; the "
                            f"launch needs kernel {kernel}'s stream, whose semantic-head weights are stale -- do a full pack first "
