@@ -508,14 +508,17 @@ def hbm_kernel_rooflines(torch, dev, n_rays: int = 65536):
     for name, (fn, nbytes) in cases.items():
         for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        out[name] = {"bound": "hbm", "achieved": round(nbytes / us / 1e6, 3), "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+        us = float("inf")
+        for _ in range(3):        # best of three blocks: inside the default run the first block has read 2.7 x slow (allocator / clock state
+            torch.cuda.synchronize()   # left by the image renders before it; stand-alone all three agree: scripts/diag/hbm_check.py)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = min(us, e0.elapsed_time(e1) / 20 * 1e3)
+        out[name] = {"bound": "hbm (VALU-issue-bound in fact: profiles/r06/d_hbm_kernels_pmc_summary.txt)", "achieved": round(nbytes / us / 1e6, 3), "peak": PEAK_HBM_TBPS, "unit": "TB/s",
                      "frac": round(nbytes / us / 1e6 / PEAK_HBM_TBPS, 4), "kernel_us": round(us, 1), "algorithmic_mb": round(nbytes / 1e6, 1)}
     return out
 

@@ -31,7 +31,7 @@ extern "C" {
  * sem_hid16 of the default 16-bit kernel, nsos_mlp_save16_layout's NSOS_SEM_HID_TILED bit; 6: `scale` of nsos_mlp_input_grads_x3[_a16]
  * is three floats -- trunk scale, colour-branch factor, semantic-branch factor; 7: the generic kernels' packed program gained a field
  * (GenOp::ksplit_off: an older binding's buffer sizes still agree, but the two sides must match) + nsos_wgrad_batch) */
-#define NSOS_ABI_VERSION 7
+#define NSOS_ABI_VERSION 8
 
 enum {
     NSOS_OK = 0,
@@ -397,8 +397,16 @@ int32_t nsos_mlp_forward_rays_save16_lp(const void* packed, int32_t sem_mode, in
  * numbers): max / rms error against an fp64 evaluation equal to plain fp32 arithmetic's (~1e-7 .. 2e-6 max), i.e.
  * three orders of magnitude inside the 1e-4 parity tolerance, at ~2.8x the exact-fp32 kernel's speed.
  * Limits: |activation| must stay below 65504 (fp16 range).  Opt-in; inference and frozen-backbone training.
- * Weights are packed by nsos_mlp_pack_x3 into their own stream layout (nsos_mlp_packed_bytes_x3 bytes). */
+ * Weights are packed by nsos_mlp_pack_x3 into their own stream layout (nsos_mlp_packed_bytes_x3 bytes).
+ * ABI 8 (round 6): the buffer holds TWO streams -- [aux | the 32x32x16 kernel's (csrc/mlp_x3.hip: training variants, backward
+ * chain) | the 16x16x32 kernel's (csrc/mlp_x316.hip: inference; mlp_lp16's workgroup and chunk schedule, three MFMAs per product)];
+ * nsos_mlp_pack_x3 writes both, nsos_mlp_forward_rays_x3 runs the selected one (default: 16x16x32).  The two kernels agree to the
+ * split format's accuracy (other contraction order inside the MFMAs), not bit for bit. */
 size_t nsos_mlp_packed_bytes_x3(int32_t sem_mode);
+/* Diagnostics / A-B: 1 = mlp_x3_kernel (32x32x16, one wave per SIMD), 2 = mlp_x316_kernel (16x16x32, two waves per SIMD; default;
+ * NSOS_X3_KERNEL=1|2 in the environment chooses at first use).  Applies to nsos_mlp_forward_rays_x3 / nsos_mlp_profile_rays_x3. */
+int32_t nsos_mlp_x3_select_kernel(int32_t kernel);
+int32_t nsos_mlp_x3_selected_kernel(void);
 int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* tensors, int32_t sem_mode, void* packed, size_t packed_bytes,
                          void* stream);
 int32_t nsos_mlp_forward_rays_x3(const void* packed, int32_t sem_mode, const float* rays_o, const float* rays_d,

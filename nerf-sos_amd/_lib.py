@@ -112,6 +112,8 @@ SIGNATURES = {
     "nsos_mlp_profile_rays_x3": (_i32, [_fp, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_lp_select_kernel": (_i32, [_i32]),
     "nsos_mlp_lp_selected_kernel": (_i32, []),
+    "nsos_mlp_x3_select_kernel": (_i32, [_i32]),
+    "nsos_mlp_x3_selected_kernel": (_i32, []),
     "nsos_mlp_lp_set_stamp_buffer": (_i32, [_fp]),
     "nsos_mlp_profile_rays_lp": (_i32, [_fp, _i32, _i32, _fp, _fp, _fp, _fp, _i64, _i32, _fp, _fp, _fp]),
     "nsos_mlp_forward_points": (_i32, [_fp, _i32, _fp, _fp, _i64, _fp, _fp]),
@@ -141,7 +143,7 @@ SIGNATURES = {
     "nsos_importance_sample": (_i32, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
 }
 
-ABI_VERSION = 7          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
+ABI_VERSION = 8          # = NSOS_ABI_VERSION of include/nerf_sos_hip.h (an older .so is refused at load)
 _lib = None
 
 

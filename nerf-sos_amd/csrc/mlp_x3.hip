@@ -28,6 +28,9 @@
 //     output heads: fp32 VALU on the summed fp32 accumulators.
 // Compiled with -ffp-contract=off (x = o + d*z stays a separately rounded multiply and add).
 #include "x3_common.h"
+#include "x316.h"
+#include <cstdlib>
+#include <cstring>
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 namespace {
@@ -595,10 +598,31 @@ int32_t launch_x3(const X3Params& p, hipStream_t stream) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
+// One packed buffer, two forward kernels (round 6): [aux | mlp_x3_kernel's chunks | mlp_x316_kernel's stream (csrc/mlp_x316.hip)].
+// The training variants (SAVE) and the backward chain read the first stream only; inference runs the selected kernel.
+namespace {
+size_t x3_first_stream_bytes(int sem_mode) { return (size_t)kAuxWords * 4 + (size_t)x3_chunks(sem_mode) * kSlotBytes; }
+int g_x3_kernel = 0;      // 0: not chosen yet -> NSOS_X3_KERNEL (1 = mlp_x3_kernel, 32x32x16; 2 = mlp_x316_kernel, 16x16x32: the default)
+int x3_kernel() {
+    if (g_x3_kernel == 0) {
+        const char* e = getenv("NSOS_X3_KERNEL");
+        g_x3_kernel = (e && (e[0] == '1' || !strcmp(e, "x3"))) ? 1 : 2;
+    }
+    return g_x3_kernel;
+}
+}  // namespace
+
 extern "C" size_t nsos_mlp_packed_bytes_x3(int32_t sem_mode) {
     if (sem_mode < 0 || sem_mode > 2) return 0;
-    return (size_t)kAuxWords * 4 + (size_t)x3_chunks(sem_mode) * kSlotBytes;
+    return x3_first_stream_bytes(sem_mode) + nsos::x316::stream_bytes(sem_mode);
 }
+
+extern "C" int32_t nsos_mlp_x3_select_kernel(int32_t kernel) {
+    NSOS_REQUIRE(kernel == 1 || kernel == 2, NSOS_ERR_UNSUPPORTED);
+    g_x3_kernel = kernel;
+    return NSOS_OK;
+}
+extern "C" int32_t nsos_mlp_x3_selected_kernel(void) { return x3_kernel(); }
 
 extern "C" int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_mode, void* packed, size_t packed_bytes, void* stream) {
     NSOS_REQUIRE(T_ && packed, NSOS_ERR_NULL_POINTER);
@@ -649,7 +673,9 @@ extern "C" int32_t nsos_mlp_pack_x3(const nsos_mlp_tensors* T_, int32_t sem_mode
     P.chunks = reinterpret_cast<unsigned short*>(P.aux + kAuxWords);
     const long long total = (long long)n * (kSlotBytes / 2);
     hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
-    return nsos_launch_status();
+    const int32_t rc = nsos_launch_status();
+    if (rc != NSOS_OK) return rc;
+    return nsos::x316::pack(T_, sem_mode, static_cast<unsigned char*>(packed) + x3_first_stream_bytes(sem_mode), (hipStream_t)stream);
 }
 
 namespace {
@@ -673,6 +699,9 @@ int32_t forward_x3(const void* packed, int32_t sem_mode, const float* rays_o, co
     }
     const long long n_pts = (long long)n_rays * n_samples;
     NSOS_REQUIRE((n_pts + kTilePts - 1) / kTilePts < (1ll << 31), NSOS_ERR_UNSUPPORTED);
+    if (save == 0 && x3_kernel() == 2)          // inference: the 16x16x32 kernel on its own stream behind the first one
+        return nsos::x316::launch(static_cast<const unsigned char*>(packed) + x3_first_stream_bytes(sem_mode), sem_mode, rays_o, rays_d, viewdirs,
+                                  z_vals, n_pts, n_samples, raw, prof, (hipStream_t)stream);
     X3Params p = {};
     p.aux = static_cast<const unsigned*>(packed);
     p.chunks = reinterpret_cast<const unsigned char*>(p.aux + kAuxWords);

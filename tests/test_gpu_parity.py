@@ -591,7 +591,8 @@ def test_render_x3_end_to_end(manifest):
 
 @pytest.mark.parametrize("name", ["semcoord", "sem"])
 def test_x3_frozen_backbone_training(manifest, name):
-    """--fix_backbone training on the split-fp16 kernel: its SAVE variant returns bit-identical outputs, and the
+    """--fix_backbone training on the split-fp16 kernel: its SAVE variant returns the inference outputs (bit-identical within a kernel
+    family; to fp32 rounding across the two forward kernels), and the
     semantic-head gradients equal the exact-fp32 path's to fp32-rounding accuracy (coarse-only net: no resampling
     between the two arithmetics, so the comparison is not blurred by index flips)."""
     cfg = CFGS[name]
@@ -607,9 +608,25 @@ def test_x3_frozen_backbone_training(manifest, name):
             a = net(rays, (tp.NEAR, tp.FAR))
         b = net(rays, (tp.NEAR, tp.FAR))
         for k in a:
-            assert torch.equal(a[k], b[k].detach()), (prec, k)
+            if prec == "fp32":
+                assert torch.equal(a[k], b[k].detach()), (prec, k)
+            else:
+                # round 6: inference runs mlp_x316_kernel (16x16x32), the SAVE variant stays on mlp_x3_kernel (32x32x16): the same split
+                # arithmetic in another contraction order -- equal to fp32 rounding (measured 3e-7 on raw), no longer bit for bit
+                close(N(b[k].detach()), N(a[k]), atol=2e-5, rtol=1e-5, what=f"{prec} {k}: SAVE forward vs inference forward")   # (measured <= 7.5e-6 on depth ~ 2)
         (b["semantics"].square().mean() + 0.3 * b["semantics"][:, 0].mean()).backward()
         grads[prec] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # ... and with the 32x32x16 kernel selected for inference the two are the same kernel family again: bit-identical
+    from nerf_sos_amd import _lib
+    _lib.check(_lib.lib().nsos_mlp_x3_select_kernel(1), "select")
+    try:
+        with torch.no_grad():
+            a = net(rays, (tp.NEAR, tp.FAR))
+        b = net(rays, (tp.NEAR, tp.FAR))
+        for k in a:
+            assert torch.equal(a[k], b[k].detach()), ("fp16x3 on mlp_x3_kernel", k)
+    finally:
+        _lib.check(_lib.lib().nsos_mlp_x3_select_kernel(2), "select")
     assert set(grads["fp32"]) == set(grads["fp16x3"]) and len(grads["fp32"]) == 4
     for n, g in grads["fp32"].items():
         close(N(grads["fp16x3"][n]), N(g), atol=1e-6 + 1e-5 * float(g.abs().max()), rtol=1e-4, what=n)
