@@ -377,10 +377,10 @@ def gpu_bisect_indices(torch, out, rays, n_coarse, n_importance, near, far):
 
 KERNEL_SOURCES = {   # traffic.json key -> the files whose content decides the dominant kernel's memory traffic
     "c2_fp32": ("mlp_fused.hip", "mlp_common.h"),
-    "c2_fp16x3": ("mlp_x3.hip", "x3_common.h", "mlp_common.h"),
-    "lp16": ("mlp_lp16.hip", "lp_common.h", "mlp_common.h"),
+    "c2_fp16x3": ("mlp_x316.hip", "lp16_sched.h", "x316.h", "lp_common.h", "mlp_common.h"),
+    "lp16": ("mlp_lp16.hip", "lp16_sched.h", "lp_common.h", "mlp_common.h"),
 }
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06", "traffic.json")
 
 
 def kernel_source_hash(key: str = "c2_fp32") -> str:
@@ -391,7 +391,7 @@ def kernel_source_hash(key: str = "c2_fp32") -> str:
 
 
 def add_traffic(roof, key: str):
-    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r05/traffic.json: FETCH_SIZE
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r06/traffic.json: FETCH_SIZE
     and WRITE_SIZE collected in separate rocprofv3 --pmc runs and corrected as MI355X_MICROARCH.md prescribes), reported only
     while the kernel's sources still hash to the build the passes were measured on."""
     if roof is None or not os.path.exists(TRAFFIC_JSON):
@@ -404,10 +404,10 @@ def add_traffic(roof, key: str):
         roof["traffic_detail"] = {"fetch_size_kb": t["fetch_size_kb"], "write_size_kb": t["write_size_kb"],
                                   "algorithmic_bytes_per_launch_without_weights": t["algorithmic_bytes_per_launch_without_weights"],
                                   "ratio_to_algorithmic": t["ratio"], "scratch_bytes": t.get("scratch_bytes"),
-                                  "source": "profiles/r05/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                  "source": "profiles/r06/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                             "2 x FETCH_SIZE + WRITE_SIZE)"}
     else:
-        roof["traffic_note"] = "profiles/r05/traffic.json was measured on a different build of this kernel: not reported"
+        roof["traffic_note"] = "profiles/r06/traffic.json was measured on a different build of this kernel: not reported"
     return roof
 
 
@@ -703,6 +703,12 @@ def lp_kernel_clock_ghz(torch, dev, precision: str, R: int):
     return _LP_CLOCK[(precision, R)]
 
 
+def x3_kernel_selected() -> int:
+    """2 = mlp_x316_kernel (16x16x32, the default split-fp16 forward since round 6), 1 = mlp_x3_kernel (NSOS_X3_KERNEL=1)."""
+    from nerf_sos_amd import _lib
+    return int(_lib.lib().nsos_mlp_x3_selected_kernel())
+
+
 def lp_kernel_name() -> str:
     """The 16-bit MLP kernel the library dispatches to (NSOS_LP_KERNEL / nsos_mlp_lp_select_kernel; default: mlp_lp16_kernel)."""
     k = os.environ.get("NSOS_LP_KERNEL", "")
@@ -787,7 +793,7 @@ def run_c2(ctx, args, precision="fp32", steps=None, warmup=None, blocks=1):
         peak = PEAK_FP32_MFMA_TFLOPS
     else:
         roof = kernel_roofline(events, n_rays * N_FINE, MAC_NOSEM, PEAK_16BIT_MFMA_TFLOPS,
-                               "mlp_x3_kernel<0> (fine pass, 786432 points)")
+                               ("mlp_x316_kernel<0>" if x3_kernel_selected() == 2 else "mlp_x3_kernel<0>") + " (fine pass, 786432 points)")
         roof["issued_frac"] = round(3 * roof["frac"], 4)   # three 16-bit MFMAs per product
         peak = PEAK_16BIT_MFMA_TFLOPS
     roof["whole_path_frac"] = round(res["value"] / ctx.world * flop_per_ray / 1e12 / peak, 4)
@@ -1101,7 +1107,7 @@ def compact_line(line: dict) -> dict:
         c["kernel"] = str(r.get("kernel", ""))[:72]
         if "traffic_detail" in r:
             c["traffic_ratio_to_algorithmic"] = r["traffic_detail"].get("ratio_to_algorithmic")
-        for k in ("whole_path_frac", "whole_step_frac_forward_flops_only"):
+        for k in ("whole_path_frac", "whole_step_frac_forward_flops_only", "issued_frac"):
             if k in r:
                 c[k] = r[k]
         c.setdefault("traffic", None)
@@ -1151,7 +1157,7 @@ def compact_line(line: dict) -> dict:
                 cv[name] = {k: pick(x, ("ms_per_step", "rays_per_s", "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point", "ms_per_step_loss_on_both_maps")) for k, x in v.items() if isinstance(x, dict)}
                 continue
             e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_by_rank", "finite", "loss", "max_abs_rgb0_vs_exact_fp32"))
-            e["roofline"] = pick(roof(v.get("roofline")) or {}, ("frac", "kernel_ms", "kernel", "traffic", "whole_path_frac", "whole_step_frac_forward_flops_only"))
+            e["roofline"] = pick(roof(v.get("roofline")) or {}, ("frac", "issued_frac", "kernel_ms", "kernel", "traffic", "whole_path_frac", "whole_step_frac_forward_flops_only"))
             if "timing_blocks" in v:
                 e["ms_per_step_min_max"] = [v["timing_blocks"]["ms_per_step_min"], v["timing_blocks"]["ms_per_step_max"]]
             g = v.get("whole_step_graph")

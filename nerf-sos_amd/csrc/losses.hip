@@ -129,7 +129,7 @@ __device__ __forceinline__ float geo_code_pair(const float (&c1)[C], const float
 
 // ------------------------------------------------------------------------------------------ geometric loss: prep
 __global__ __launch_bounds__(256) void depth_max_kernel(const float* __restrict__ depth, long long n, float max_depth,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, double* __restrict__ scal) {
     __shared__ double sm[4];
     double m = -1.0e300;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -143,13 +143,44 @@ __global__ __launch_bounds__(256) void depth_max_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = sm[i] > m ? sm[i] : m;
         partial[blockIdx.x] = m;
+        if (blockIdx.x == 0) {
+            scal[7] = 0.0;  // set by geo_prep_kernel when a point's depth / ray / code holds a NaN: the loss is NaN then, as the reference's is
+            scal[8] = 0.0;  // the last-arriver tickets of the pair passes (nsos_last_block: two 32-bit counters)
+        }
     }
 }
-__global__ void depth_max_finish_kernel(const double* __restrict__ partial, int nb, double* __restrict__ scal) {
-    double m = -1.0e300;
-    for (int i = 0; i < nb; ++i) m = partial[i] > m ? partial[i] : m;
-    scal[6] = m;   // -1e300 if no element was below max_depth (torch raises on the empty max; here the filter yields NaN-free -inf)
-    scal[7] = 0.0; // set by geo_prep_kernel when a point's depth / ray / code holds a NaN: the loss is NaN then, as the reference's is
+// the maximum over depth_max_kernel's block partials (nb <= 256 = the block size of its callers), valid in every thread: what
+// depth_max_finish_kernel computed in a launch of its own until round 6 (-1e300 if no element was below max_depth: torch raises
+// on the empty max; here the filter yields NaN-free -inf)
+__device__ __forceinline__ double depth_max_of(const double* __restrict__ partial, int nb) {
+    __shared__ double dm[4];
+    double m = (int)threadIdx.x < nb ? partial[threadIdx.x] : -1.0e300;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off, NSOS_WAVE); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) dm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = dm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = dm[i] > m ? dm[i] : m;
+    return m;
+}
+
+// Exactly ONE workgroup of a grid of `total` gets true (in all its threads): the one that arrives last -- every other workgroup's
+// global writes made before its call are visible to it (agent-scope release by each arriver, acquire by the last).  The ticket
+// resets itself for the next launch.  Folds a reduction's finishing step into the kernel that produced the partials: a launch of
+// its own costs ~4.8 us on the step's critical path (profiles/r05/h_c3_step_timeline.txt), seven of them per training step.
+__device__ __forceinline__ bool nsos_last_block(unsigned* ticket, unsigned total) {
+    __shared__ int last_s;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        last_s = t == total - 1u;
+        if (last_s) *ticket = 0u;
+    }
+    __syncthreads();
+    const bool last = last_s != 0;
+    if (last) __threadfence();
+    return last;
 }
 
 // How a kernel finds the inputs of patch n of a (possibly stacked) batch.  The training step scores TWO semantic maps (coarse
@@ -175,14 +206,16 @@ template <int C>
 __global__ __launch_bounds__(256) void geo_prep_kernel(float* __restrict__ depth, const GeoInputs in,
                                                        int B, int N, float max_depth, int write_back,
                                                        const double* __restrict__ scal, float* __restrict__ pts,
-                                                       float* __restrict__ cn, float* __restrict__ dinv) {
+                                                       float* __restrict__ cn, float* __restrict__ dinv,
+                                                       const double* __restrict__ dmax_partial, int dmax_blocks) {
+    const double dmax = depth_max_of(dmax_partial, dmax_blocks);      // (before the early return: a block-wide reduction)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)B * N) return;
     const int n = (int)(i / N), p = (int)(i % N);
     const int g = n % in.Bg, which = n / in.Bg;
     float d = depth[(size_t)g * N + p];
     if (d > max_depth) {  // :455
-        d = (float)scal[6];
+        d = (float)dmax;
         if (write_back && which == 0) depth[(size_t)g * N + p] = d;
     }
 #pragma unroll
@@ -231,6 +264,14 @@ struct PairArgs {
     int n_rows;
     float* gcolp;          // geo, fused pass 3: column-gradient partials [2][row slots][row blocks][C][N]
     int Bg;                // geo: geometry patches behind the B code patches (patch n -> geometry n % Bg); 0 = B
+    // single-process calls (round 6): the passes' finishing reductions run in the LAST workgroup of the pass itself (nsos_last_block)
+    // instead of in launches of their own.  tickets = two zeroed 32-bit counters (workspace scal[8]), nb = block partials per set.
+    unsigned* tickets;     // NULL: finish kernels are launched (the row-partitioned multi-GPU phases)
+    int nb;
+    double cnt;            // pass 3: B N N
+    float* loss;           // pass 3: where the loss goes
+    const double* flags;   // pass 3, geo: scal of the workspace ([7] = NaN flag)
+    int geo;
 };
 
 __device__ __forceinline__ int row_patch(const PairArgs& A) { return A.rows ? A.rows[blockIdx.y] : (int)blockIdx.y; }
@@ -327,6 +368,9 @@ __device__ __forceinline__ int col_of_lane(unsigned lane) {
 // (block of 64 rows, column); pair_cols_fold_kernel adds the row blocks in fp64, in order.  That replaces the fourth pass
 // over all N^2 pairs (pair_cols_kernel: 88 of the 220 us the geometric loss took per C3 step) by ~4 VALU per pair here.
 __host__ __device__ inline int pair_padded_columns(int N, int slabs) { return ((N + slabs * 32 - 1) / (slabs * 32)) * 32 * slabs; }
+
+__device__ __forceinline__ void pass1_finish_in_block(const PairArgs& A, double* red);
+__device__ __forceinline__ void pass3_finish_in_block(const PairArgs& A);
 
 template <bool GEO, int C, int PASS, bool NARROW = false, bool FUSE = false>
 __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_kernel(const PairArgs A) {
@@ -478,6 +522,18 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_
         for (int c = 0; c < kMaxC; ++c) A.grow[(((size_t)set * A.B + n) * N + p) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
     const double s = block_sum(owner ? acc : 0.0, red);
     if (threadIdx.x == 0) A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
+    // single-process calls: the pass's finishing reduction in its last workgroup (PASS 1 of a stacked geometric batch finishes in
+    // pair_rowsum_copy_kernel instead, which runs between the two)
+    if (A.tickets != nullptr && (PASS == 3 || !(GEO && A.Bg > 0 && A.Bg < A.B))) {
+        if (nsos_last_block(A.tickets + (PASS == 1 ? 0 : 1), gridDim.x * gridDim.y * gridDim.z)) {
+            if constexpr (PASS == 1) {
+                __shared__ double fin[16];
+                pass1_finish_in_block(A, fin);
+            } else {
+                pass3_finish_in_block(A);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void pair_rowsum_copy_kernel(const PairArgs A, int row_blocks) {
@@ -490,6 +546,23 @@ __global__ __launch_bounds__(256) void pair_rowsum_copy_kernel(const PairArgs A,
     if (blockIdx.x == 0)
         for (int k = threadIdx.x; k < row_blocks; k += blockDim.x)
             A.partial[(size_t)set * kRedBlocks + blockIdx.y * row_blocks + k] = A.partial[(size_t)cset * kRedBlocks + cslot * row_blocks + k];
+}
+// the same with pass 1's finishing reduction in the last workgroup (single-process calls; blocks that copy nothing take part too)
+__global__ __launch_bounds__(256) void pair_rowsum_copy_finish_kernel(const PairArgs A, int row_blocks) {
+    int cset, cslot;
+    const int set = blockIdx.z, N = A.N;
+    if (first_with_same_geometry(A, set, blockIdx.y, &cset, &cslot)) {
+        const int n = row_patch(A), cn = A.rows ? A.rows[cslot] : cslot;
+        const int p = blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < N) A.rowsum[((size_t)set * A.B + n) * N + p] = A.rowsum[((size_t)cset * A.B + cn) * N + p];
+        if (blockIdx.x == 0)
+            for (int k = threadIdx.x; k < row_blocks; k += blockDim.x)
+                A.partial[(size_t)set * kRedBlocks + blockIdx.y * row_blocks + k] = A.partial[(size_t)cset * kRedBlocks + cslot * row_blocks + k];
+    }
+    if (nsos_last_block(A.tickets, gridDim.x * gridDim.y * gridDim.z)) {
+        __shared__ double fin[16];
+        pass1_finish_in_block(A, fin);
+    }
 }
 
 // What used to be PASS 2: scal[2 + set] = sum over the evaluated pairs of (fd - rowmean), the numerator of the mean the
@@ -525,6 +598,50 @@ __global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, d
     const double s = partial_sum(partial, nb, blockIdx.x);
     if (threadIdx.x == 0) scal[slot + blockIdx.x] = s;
 }
+// The same two finishing steps as device functions for the LAST workgroup of a pass (any block size that is a multiple of 64):
+// identical summation orders, so the folded and the launched forms give the same bits.
+__device__ __forceinline__ void pass1_finish_in_block(const PairArgs& A, double* red /* [16] */) {
+    for (int set = 0; set < 2; ++set) {
+        if (threadIdx.x < 64) {
+            const double s = partial_sum(A.partial, A.nb, set);
+            if (threadIdx.x == 0) A.scal[set] = s;
+        }
+        // rowmean_residual_sum strides by blockDim.x: pass1_finish_kernel runs it with 1024 threads -- keep that order
+        double r = 0.0;
+        {
+            const int N = A.N, nr = A.rows ? A.n_rows : A.B;
+            for (int v = threadIdx.x; v < 1024; v += blockDim.x) {          // virtual thread v of the 1024-thread form
+                double sv = 0.0;
+                for (long long k = v; k < (long long)nr * N; k += 1024) {
+                    const int n = A.rows ? A.rows[k / N] : (int)(k / N), p = (int)(k % N);
+                    const double rs = A.rowsum[((size_t)set * A.B + n) * N + p];
+                    const float rm = (float)(rs / (double)N);
+                    sv += rs - (double)N * (double)rm;
+                }
+                // fold the virtual wave (64 consecutive virtual threads = this wave's lanes) exactly as block_sum does
+                sv = nsos_wave_sum(sv);
+                if ((threadIdx.x & 63) == 0) red[v >> 6] = sv;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 16; ++i) r += red[i];
+            A.scal[2 + set] = r;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void pass3_finish_in_block(const PairArgs& A) {
+    if (threadIdx.x >= 64) return;
+    const double s0 = partial_sum(A.partial, A.nb, 0), s1 = partial_sum(A.partial, A.nb, 1);
+    if (threadIdx.x != 0) return;
+    A.scal[4] = s0;
+    A.scal[5] = s1;
+    const float l_neg = (float)(s0 / A.cnt), l_self = (float)(s1 / A.cnt);
+    A.loss[0] = A.prm.neg_weight * l_neg + A.prm.self_weight * l_self;
+    if (A.geo && A.flags[7] != 0.0) A.loss[0] = __builtin_nanf("");
+}
+
 // single-process call: what follows pass 1 in ONE launch (block = set): scal[set] = sum of the pass's block partials (wave 0,
 // the same order as pair_finish_kernel) and scal[2 + set] = the row-mean residual (all 1024 threads)
 __global__ __launch_bounds__(1024) void pass1_finish_kernel(const PairArgs A, int nb) {
@@ -782,8 +899,9 @@ __global__ __launch_bounds__(128) void app_sample_kernel(const float* __restrict
                                                          const float* __restrict__ rnd2, int B, int Cf, int Hf, int Wf, int Hc,
                                                          int Wc, int S, float* __restrict__ fn, float* __restrict__ cn,
                                                          float* __restrict__ cn2, float* __restrict__ dinv, float* __restrict__ dinv2,
-                                                         int channel_last, const int* __restrict__ rows) {
+                                                         int channel_last, const int* __restrict__ rows, double* __restrict__ scal) {
     __shared__ double red[2];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) scal[8] = 0.0;   // the pair passes' last-arriver tickets
     const int p = blockIdx.x, n = rows ? rows[blockIdx.y] : (int)blockIdx.y, side = blockIdx.z, N = S * S;
     const int src = side == 0 ? n : (int)neg[n];
     float gx, gy;
@@ -944,7 +1062,8 @@ __global__ __launch_bounds__(256) void app_scatter_kernel(int B, int N, int S, i
 
 // ------------------------------------------------------------------------------------------ host side
 template <bool GEO, int C, bool NARROW>
-int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hipStream_t st, int phases, const double* flags) {
+int32_t run_pair_passes_shape(const PairArgs& A_in, bool want_grad, float* loss, hipStream_t st, int phases, const double* flags) {
+    PairArgs A = A_in;
     const int N = A.N, B = A.B;
     const int tb = PairShape<GEO, NARROW>::kThreads, rows_per_block = PairShape<GEO, NARROW>::kRows;
     const dim3 grid((N + rows_per_block - 1) / rows_per_block, A.rows ? A.n_rows : B, 2);
@@ -975,11 +1094,27 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
     // phases (bit mask): 1 = pass 1, 2 = pass 2, 4 = passes 3 (+4).  A single-process call runs all of them; the row-partitioned
     // multi-GPU call runs them one at a time and all-reduces scal[0..1], scal[2..3] over the ranks in between (the global
     // means of fd and fd1 couple every patch of the batch, utils/image.py:316-319).
+    // single-process call (all phases, a loss to write): fold the finishing reductions into the passes' last workgroups
+    // MEASURED, NOT KEPT AS THE DEFAULT (round 6, profiles/r06/e_loss_finish_fold_ab.txt): the replayed C3 step takes 1.583 ms folded
+    // against 1.517 ms with the seven finish launches (C4: 2.917 against 2.721) -- every workgroup of a pass pays an agent-scope
+    // release (an L2 write-back + invalidate on a chip whose eight XCD L2s are not coherent with each other) so that ONE workgroup
+    // may read the others' partials; 256-512 of those cost more than the ~4.8 us per launch they save, and the invalidations evict
+    // the next kernel's weight stream.  NSOS_LOSS_FOLD_FINISH=1 selects the folded form (same bits: tests/test_gpu_losses.py).
+    const bool fold = phases == 7 && loss != nullptr && nsos_env_flag("NSOS_LOSS_FOLD_FINISH");
+    A.tickets = fold ? reinterpret_cast<unsigned*>(A.scal + 8) : nullptr;
+    A.nb = nb;
+    A.cnt = (double)B * N * N;
+    A.loss = loss;
+    A.flags = flags ? flags : A.scal;
+    A.geo = GEO ? 1 : 0;
     if (phases & 1) {
         hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 1, NARROW>), grid, dim3(tb), lds_rows12, st, A);
-        if (GEO && A.Bg > 0 && A.Bg < B)
-            hipLaunchKernelGGL(pair_rowsum_copy_kernel, dim3((N + 255) / 256, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
-        if (phases & 2) hipLaunchKernelGGL(pass1_finish_kernel, dim3(2), dim3(1024), 0, st, A, nb);
+        if (GEO && A.Bg > 0 && A.Bg < B) {
+            if (fold) hipLaunchKernelGGL(pair_rowsum_copy_finish_kernel, dim3((N + 255) / 256, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
+            else hipLaunchKernelGGL(pair_rowsum_copy_kernel, dim3((N + 255) / 256, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
+        }
+        if (fold) {}
+        else if (phases & 2) hipLaunchKernelGGL(pass1_finish_kernel, dim3(2), dim3(1024), 0, st, A, nb);
         else hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 0);
     } else if (phases & 2) hipLaunchKernelGGL(rowmean_residual_kernel, dim3(2), dim3(256), 0, st, A);
     if (phases & 4) {
@@ -989,7 +1124,8 @@ int32_t run_pair_passes_shape(const PairArgs& A, bool want_grad, float* loss, hi
             if (fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW, true>), grid, dim3(tb), lds_rows3, st, A);
         }
         if (!fuse) hipLaunchKernelGGL((pair_rows_kernel<GEO, C, 3, NARROW>), grid, dim3(tb), lds_rows3, st, A);
-        if (loss) hipLaunchKernelGGL(pass3_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0, flags ? flags : A.scal);
+        if (fold) {}
+        else if (loss) hipLaunchKernelGGL(pass3_finish_kernel, dim3(1), dim3(64), 0, st, A.partial, nb, A.scal, (double)B * N * N, A.prm, loss, GEO ? 1 : 0, flags ? flags : A.scal);
         else hipLaunchKernelGGL(pair_finish_kernel, dim3(2), dim3(64), 0, st, A.partial, nb, A.scal, 4);
         if constexpr (kCanFuse) {
             if (fuse) hipLaunchKernelGGL((pair_cols_fold_kernel<C>), dim3((N + 63) / 64, grid.y, 2), dim3(256), 0, st, A, (int)grid.x);
@@ -1017,10 +1153,9 @@ int32_t geo_impl(float* depth, const GeoInputs in, const long long* neg, int B, 
     ws_layout(&w, workspace, B, N, 0, false);
     const long long tot = (long long)B * N, tot_geo = (long long)in.Bg * N;      // depth: one map per GEOMETRY patch
     const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
-    hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial);
-    hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
+    hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial, w.scal);
     hipLaunchKernelGGL((geo_prep_kernel<C>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, depth, in, B, N,
-                       max_depth, write_back, w.scal, w.pts, w.cn, w.dinv);
+                       max_depth, write_back, w.scal, w.pts, w.cn, w.dinv, w.partial, rb);
     PairArgs A = {B, N, C, neg, w.pts, w.cn, nullptr, nullptr, w.rowsum, w.partial, w.scal, w.grow, w.gcol, max_depth, prm, nullptr, 0, w.gcolp, in.Bg};
     const int32_t rc = run_pair_passes<true, C>(A, want_grad, loss, st);
     if (rc != NSOS_OK) return rc;
@@ -1101,10 +1236,9 @@ int32_t geo_rows_impl(int phase, float* depth, const GeoInputs in, const long lo
     if (phase == 0 || phase == 3) {
         const long long tot_geo = (long long)in.Bg * N;                            // depth: one map per GEOMETRY patch
         const int rb = (int)((tot_geo + 255) / 256 < 256 ? (tot_geo + 255) / 256 : 256);
-        hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial);
-        hipLaunchKernelGGL(depth_max_finish_kernel, dim3(1), dim3(1), 0, st, w.partial, rb, w.scal);
+        hipLaunchKernelGGL(depth_max_kernel, dim3(rb), dim3(256), 0, st, depth, tot_geo, max_depth, w.partial, w.scal);
         hipLaunchKernelGGL((geo_prep_kernel<C>), dim3(gb), dim3(256), 0, st, depth, in, B, N, max_depth, write_back,
-                           w.scal, w.pts, w.cn, w.dinv);
+                           w.scal, w.pts, w.cn, w.dinv, w.partial, rb);
     }
     if (phase == 3) {   // single process: nothing to reduce between the phases -- every launch of the loss from one call
         if (n_rows == 0) {
@@ -1151,7 +1285,7 @@ int32_t app_impl(const float* feats, const float* code, const long long* neg, co
     Ws w;
     ws_layout(&w, workspace, B, N, Cf, true);
     hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, B, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
-                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last, nullptr);
+                       w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last, nullptr, w.scal);
     hipLaunchKernelGGL(app_fd_kernel, dim3(N, B, 2), dim3(1024), 0, st, w.fn, B, N, Cf, w.fdmat, nullptr);   // 16 waves x 2 column quads each: a short dependent chain
     PairArgs A = {B, N, C, neg, nullptr, w.cn, w.cn2, w.fdmat, w.rowsum, w.partial, w.scal, w.grow, w.gcol, 0.0f, prm, nullptr, 0, nullptr, 0};
     const int32_t rc = run_pair_passes<false, C>(A, grad_code != nullptr, loss, st);
@@ -1190,7 +1324,7 @@ int32_t app_rows_impl(int phase, const float* feats, const float* code, const lo
         if (e != hipSuccess) return (int32_t)e;
         if (n_rows == 0) return nsos_launch_status();
         hipLaunchKernelGGL((app_sample_kernel<C>), dim3(N, n_rows, 2), dim3(128), 0, st, feats, code, neg, rnd1, rnd2, B, Cf, Hf, Wf, Hc, Wc, S,
-                           w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last, rows);
+                           w.fn, w.cn, w.cn2, w.dinv, w.dinv2, channel_last, rows, w.scal);
         hipLaunchKernelGGL(app_fd_kernel, dim3(N, n_rows, 2), dim3(1024), 0, st, w.fn, B, N, Cf, w.fdmat, rows);
         return run_pair_passes<false, C>(A, true, nullptr, st, 3);
     }

@@ -539,7 +539,13 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_lp16_kernel(const LpParams P
                         if constexpr (SAVE && g >= 3 && (g - 3) % 6 == 0 && (g - 3) / 6 < (CH == 2 ? 2 : 3)) store_h7_k(IC(3 * CH + (g - 3) / 6));
                     };
                     slice_chunk(IC(8), IC(4), IC(1), S8, from_Hlo, [&](auto gc_) { ride_sem(gc_, IC(0)); }, SEM == 2 ? 29 : 21);   // (the head's tail chunk)
+#ifdef NSOS_LP16_HEAD_STAMPS      // (A/B builds only, scripts/diag/build_variant.sh: the heads' three chunks stamped one by one)
+                    stamp();
+#endif
                     slice_chunk(IC(8), IC(4), IC(0), S8, from_Hhi, [&](auto gc_) { ride_sem(gc_, IC(1)); }, 33);
+#ifdef NSOS_LP16_HEAD_STAMPS
+                    stamp();
+#endif
                     // the head's hidden activations -> Sp (one exposed pass, inside the tail chunk below, before the logit MFMAs)
                     auto activate_sem = [&]() {
                         asm volatile("s_nop 7" ::: "memory");

@@ -26,7 +26,7 @@ S = 192
 # (key used by bench.py, kernel-name test, launch index range inside that kernel's dispatch order, rays, C, SAVE bytes/pt, sem)
 LAUNCHES = [
     ("c2_fp32", lambda n: "mlp_fused_kernel<0, true, 0>" in n, 0, 4096, 4, 0, 0),
-    ("c2_fp16x3", lambda n: "mlp_x3_kernel<0, 0>" in n, 0, 4096, 4, 0, 0),
+    ("c2_fp16x3", lambda n: "mlp_x316_kernel<0, false>" in n, 0, 4096, 4, 0, 0),
     ("c5_fp16", lambda n: "mlp_lp16_kernel" in n and "F16, 2, false" in n and "BF16" not in n, 0, 65536, 6, 0, 2),
     ("c3_bf16", lambda n: "mlp_lp16_kernel" in n and "BF16, 2, true" in n, 0, 4096, 6, 896, 2),
     ("c4_bf16", lambda n: "mlp_lp16_kernel" in n and "BF16, 2, true" in n, 1, 8192, 6, 896, 2),

@@ -60,8 +60,11 @@ if wps == 3:
         names += [f"L{l} mfma", f"L{l} act"]
         ideal[f"L{l} mfma"] = (320 if l == 5 else 256) * M
         if l == 7:
+            if os.environ.get("NSOS_LP16_HEAD_STAMPS") and sem:      # a -DNSOS_LP16_HEAD_STAMPS build: the heads' chunks one by one
+                names += ["sem0 h chunk 0", "sem0 h chunk 1"]
+                ideal["sem0 h chunk 0"] = ideal["sem0 h chunk 1"] = 64 * M
             names.append("sigma+sem heads")
-            ideal["sigma+sem heads"] = {0: 16, 1: 128 + 16 + 16 + 8, 2: 160 + 16 + 8}[sem] * M
+            ideal["sigma+sem heads"] = {0: 16, 1: 128 + 16 + 16 + 8, 2: 160 + 16 + 8}[sem] * M - (128 * M if os.environ.get("NSOS_LP16_HEAD_STAMPS") and sem else 0)
     names += ["dir enc", "view mfma", "rgb mfma", "stores"]
     ideal["view mfma"] = 144 * M
     ideal["rgb mfma"] = 8 * M      # (operands resident in LDS: no chunk of its own)
