@@ -26,7 +26,7 @@ for _ in range(REPS):
     ops.mlp_forward_rays(net.nerf_fine.packed_weights(), 0, o, d, v, z)                       # mlp_fused_kernel<0,true,0>
 pk = net.nerf_fine.packed_weights("fp16x3")
 for _ in range(REPS):
-    ops.mlp_forward_rays_lp(pk, 0, "fp16x3", o, d, v, z)                                       # mlp_x3_kernel<0,0>
+    ops.mlp_forward_rays_lp(pk, 0, "fp16x3", o, d, v, z)                                       # mlp_x316_kernel<0,false> (the default split-fp16 forward; NSOS_X3_KERNEL=1: mlp_x3_kernel<0,0>)
 net, o, d, v, z = setup(65536, True)
 pk = net.nerf_fine.packed_weights("fp16")
 for _ in range(REPS):

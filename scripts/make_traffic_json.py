@@ -5,7 +5,7 @@ per kernel x launch shape the median counter values, the HBM bytes per launch af
 algorithmic bytes next to them, and the hash of the kernel sources the passes were measured on (bench.py reports
 `roofline.traffic` for a variant only while that hash still holds).
 
-usage: make_traffic_json.py gpurun_out/traffic_<tag> profiles/r04/traffic.json [<summary text file to write>]
+usage: make_traffic_json.py gpurun_out/traffic_<tag> profiles/r06/traffic.json [<summary text file to write>]
 """
 import csv
 import json

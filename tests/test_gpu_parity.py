@@ -649,6 +649,54 @@ def test_render_lp_end_to_end(manifest, precision, min_psnr):
     assert a["acc"].max() > 0.5
 
 
+def test_coarse_precision_in_inference_and_frozen_backbone_training(manifest):
+    """NeRFNet.coarse_precision (round 6): the coarse pass in one arithmetic, the fine pass in another.  (a) coarse 'fp16x3' + fine
+    'bf16': the coarse outputs are the all-fp16x3 render's, the fine pass runs on the bf16 kernel at the coarse pass's sample
+    positions (so it equals neither pure render: checked against a staged render with ops); (b) the frozen-backbone step saves each
+    pass's head operands in that pass's format (fp32 rows for the split kernel, tile-major bf16 for the 16-bit one) and both heads get
+    finite, non-zero gradients that agree with the all-fp16x3 step's to the 16-bit format's accuracy; (c) a wrong value raises."""
+    net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, **CFGS["semcoord"]).to(DEV)
+    net.load_state_dict(ref_state("semcoord", manifest, True, 128))
+    _frozen(net).eval()
+    rays = tp.synthetic_rays(512, seed=11).to(DEV)
+    with pytest.raises(ValueError):
+        net.coarse_precision = "fp8"
+    with torch.no_grad():
+        net.mlp_precision, net.coarse_precision = "fp16x3", None
+        x3 = net(rays, (tp.NEAR, tp.FAR))
+        net.mlp_precision, net.coarse_precision = "bf16", "fp16x3"
+        assert net.pass_precision("coarse") == "fp16x3" and net.pass_precision("fine") == "bf16"
+        mix = net(rays, (tp.NEAR, tp.FAR))
+    assert set(mix) == set(x3)
+    for k in ("rgb0", "depth0", "acc0", "weights0", "semantics0", "raw0", "z_std"):       # the coarse pass and its sampler: the split kernel's
+        assert torch.equal(mix[k], x3[k]), k
+    # the fine pass: the bf16 kernel on the positions the fp16x3 coarse pass produced
+    R = rays.shape[1]
+    near, far = torch.full((R,), tp.NEAR, device=DEV), torch.full((R,), tp.FAR, device=DEV)
+    z, v = ops.ray_setup(rays[1].contiguous(), near, far, 64, None)
+    raw0 = ops.mlp_forward_rays_lp(net.nerf.packed_weights("fp16x3"), net.nerf.sem_mode, "fp16x3", rays[0].contiguous(), rays[1].contiguous(), v, z)
+    _, zf, _, _ = ops.composite_importance(raw0, z, rays[1].contiguous(), 128)
+    raw = ops.mlp_forward_rays_lp(net.nerf_fine.packed_weights("bf16"), net.nerf_fine.sem_mode, "bf16", rays[0].contiguous(), rays[1].contiguous(), v, zf)
+    assert torch.equal(raw.reshape(mix["raw"].shape), mix["raw"])
+    # (b) training: gradients of both heads
+    grads = {}
+    for name, (prec, coarse) in {"x3": ("fp16x3", None), "mixed": ("bf16", "fp16x3")}.items():
+        net.mlp_precision, net.coarse_precision = prec, coarse
+        net.zero_grad()
+        out = net(rays, (tp.NEAR, tp.FAR))
+        (out["semantics"].square().sum() + out["semantics0"].square().sum()).backward()
+        grads[name] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        assert len(grads[name]) == 8 and all(torch.isfinite(g_).all() and g_.abs().max() > 0 for g_ in grads[name].values())
+    for n_, g_ in grads["x3"].items():
+        scale = float(g_.abs().max()) + 1e-12
+        err = float((grads["mixed"][n_] - g_).abs().max()) / scale
+        if n_.startswith("nerf."):          # the coarse head: the same kernels in both steps
+            assert err <= 1e-6, (n_, err)
+        else:                               # the fine head: bf16 operands (8 bits) and a spiky field -- a sanity bound, as in test_lp_training_variant
+            assert err <= 0.5, (n_, err)
+    net.coarse_precision = None
+
+
 @pytest.mark.parametrize("precision,tol", [("fp16", 2e-2), ("bf16", 1.5e-1)])
 def test_lp_training_variant(golden, manifest, precision, tol, lp_kernel):
     """Config C3: frozen-backbone training at reduced precision.  The SAVE variant of the 16-bit kernel (a) renders
