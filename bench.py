@@ -1104,7 +1104,7 @@ def compact_line(line: dict) -> dict:
         if not r:
             return None
         c = pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"))
-        c["kernel"] = str(r.get("kernel", ""))[:72]
+        c["kernel"] = str(r.get("kernel", ""))[:44]
         if "traffic_detail" in r:
             c["traffic_ratio_to_algorithmic"] = r["traffic_detail"].get("ratio_to_algorithmic")
         for k in ("whole_path_frac", "whole_step_frac_forward_flops_only", "issued_frac"):
@@ -1123,7 +1123,7 @@ def compact_line(line: dict) -> dict:
     cb = line.get("cpu_baseline")
     if cb:
         c = pick(cb, ("value", "unit", "cores", "kind", "physical_cores"))
-        c["sample"] = str(cb.get("sample", ""))[:200]
+        c["sample"] = str(cb.get("sample", ""))[:150]
         if "all_physical_cores" in cb:
             c["all_physical_cores_rays_per_s"] = cb["all_physical_cores"].get("value")
         if "frozen_recipe_train_step" in cb:
@@ -1143,10 +1143,13 @@ def compact_line(line: dict) -> dict:
                  "frac_rays_outside_1e-4_image_maps": f.get("frac_rays_outside_1e-4_image_maps"),
                  "gpu_rays_outside": y.get("gpu_rays_outside"), "reference_self_rays_outside": y.get("reference_self_sensitivity_rays_outside"),
                  "index_flip_rays": y.get("index_flip_rays"), "rays": y.get("rays"), "z_std_rays_outside": y.get("z_std_rays_outside"),
-                 "max_abs_raw0_minus_fp64": y.get("max_abs_raw0_minus_fp64")}
+                 "max_abs_raw0_minus_fp64": {k_: float(f"{v_:.3g}") for k_, v_ in (y.get("max_abs_raw0_minus_fp64") or {}).items()}}
             if "other_precisions_vs_reference" in f:
                 from nerf_sos_amd import quality
-                e["vs_reference"] = {k: quality.compact(v) for k, v in f["other_precisions_vs_reference"].items()}
+                e["vs_reference"] = {k: quality.compact(v, brief=True) for k, v in f["other_precisions_vs_reference"].items()}
+                for row in e["vs_reference"].values():
+                    row.pop("within_0.02", None)
+                e["vs_reference"]["rays"] = y.get("rays")
                 e["reference_psnr_vs_analytic_gt_db"] = f["field"].get("reference_psnr_vs_analytic_gt_db")
             cp[name] = e
         out["parity"] = cp
@@ -1156,7 +1159,9 @@ def compact_line(line: dict) -> dict:
             if "value" not in v:                       # generic_paths_fp32: two sub-records
                 cv[name] = {k: pick(x, ("ms_per_step", "rays_per_s", "frac_of_fp32_mfma_peak_over_6_mac_per_weight_and_point", "ms_per_step_loss_on_both_maps")) for k, x in v.items() if isinstance(x, dict)}
                 continue
-            e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_by_rank", "finite", "loss", "max_abs_rgb0_vs_exact_fp32"))
+            e = pick(v, ("value", "ms_per_step", "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_by_rank", "loss", "max_abs_rgb0_vs_exact_fp32"))
+            if v.get("finite") is False:
+                e["finite"] = False
             e["roofline"] = pick(roof(v.get("roofline")) or {}, ("frac", "issued_frac", "kernel_ms", "kernel", "traffic", "whole_path_frac", "whole_step_frac_forward_flops_only"))
             if "timing_blocks" in v:
                 e["ms_per_step_min_max"] = [v["timing_blocks"]["ms_per_step_min"], v["timing_blocks"]["ms_per_step_max"]]
@@ -1166,6 +1171,8 @@ def compact_line(line: dict) -> dict:
             if isinstance(v.get("quality"), dict):
                 from nerf_sos_amd import quality
                 e["quality_trained_field"] = dict(quality.compact(v["quality"]), psnr_vs_analytic_image_db=v["quality"].get("psnr_vs_analytic_image_db"))
+                for drop in ("p99.9", "depth_n_gt_0.01"):
+                    e["quality_trained_field"].pop(drop, None)
             if isinstance(v.get("hbm_kernels"), dict):
                 e["hbm_kernels"] = {k: pick(x, ("achieved", "frac", "kernel_us")) for k, x in v["hbm_kernels"].items()}
             cv[name] = e

@@ -48,11 +48,14 @@ def tail_stats(rgb: torch.Tensor, ref_rgb: torch.Tensor, depth: Optional[torch.T
     return out
 
 
-def compact(stats: Dict[str, object]) -> Dict[str, object]:
-    """The one-row form bench.py's driver line carries."""
+def compact(stats: Dict[str, object], brief: bool = False) -> Dict[str, object]:
+    """The one-row form bench.py's driver line carries (brief: PSNR, max, the two counts and the share within 0.02 only)."""
     a = stats["abs_rgb"]
     row = {"rays": stats["rays"], "psnr_db": stats["psnr_db"], "p99.9": round(a["p99.9"], 5), "max": round(a["max"], 4),
            "n_gt_0.01": a["n_gt_0.01"], "n_gt_0.05": a["n_gt_0.05"], "within_0.02": stats["share_of_rays_within_0.02"]}
+    if brief:
+        del row["rays"], row["p99.9"]
+        return row
     if "rel_depth" in stats:
         row["depth_n_gt_0.01"] = stats["rel_depth"]["n_gt_0.01"]
         row["depth_max_rel"] = round(stats["rel_depth"]["max"], 4)

@@ -160,8 +160,13 @@ def test_split_fp16_entry_points_validate_without_a_gpu():
     """K2-X3 / K7-X3: sizes, empty batches and argument validation are host-side (no launch)."""
     lib = _lib.lib()
     slot = 36 * 1024
-    assert lib.nsos_mlp_packed_bytes_x3(0) == 4096 + 73 * slot and lib.nsos_mlp_packed_bytes_x3(2) == 4096 + 78 * slot
+    # ABI 8: [aux | mlp_x3_kernel's chunks | mlp_x316_kernel's chunks + rgb_linear's eight resident operands] (both kernels: 73 / 77 / 78 chunks)
+    assert lib.nsos_mlp_packed_bytes_x3(0) == 4096 + 73 * slot + 73 * slot + 8192 and lib.nsos_mlp_packed_bytes_x3(2) == 4096 + 78 * slot + 78 * slot + 8192
+    assert lib.nsos_mlp_packed_bytes_x3(1) == 4096 + 77 * slot + 77 * slot + 8192
     assert lib.nsos_mlp_packed_bytes_x3(3) == 0
+    assert lib.nsos_mlp_x3_selected_kernel() in (1, 2) and lib.nsos_mlp_x3_select_kernel(3) == -3
+    prev = lib.nsos_mlp_x3_selected_kernel()
+    assert lib.nsos_mlp_x3_select_kernel(1) == 0 and lib.nsos_mlp_x3_selected_kernel() == 1 and lib.nsos_mlp_x3_select_kernel(prev) == 0
     assert lib.nsos_mlp_bwd_packed_bytes_x3(0) == 4096 + 68 * slot and lib.nsos_mlp_bwd_packed_bytes_x3(1) == 4096 + 72 * slot
     buf = (C.c_double * 8)()
     p = C.cast(buf, C.c_void_p)

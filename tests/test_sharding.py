@@ -123,3 +123,85 @@ def test_geo_loss_both_stacks_codes_geometry_and_negatives():
     neg = torch.min(sim, dim=0)[1]
     assert torch.equal(torch.min(seen["sim"], dim=0)[1], torch.cat([neg, neg + B]))
     assert torch.equal(out, 2.0 * (c0.sum() + c1.sum()))
+
+
+# ---------------------------------------------------------------- round 6: the N > 1 branches on ONE process (FORCE_COLLECTIVES)
+def _forced_worker(port, q):
+    """gloo, world size 1, sharding.FORCE_COLLECTIVES: the gather / splice / gradient all-reduce take their multi-rank branches and
+    issue their collectives (counted), and return what the single-process short cuts return."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ok, why = True, []
+        torch.manual_seed(0)
+        B = 3
+        local = {"semantics": torch.randn(B, 4, 4, 2, requires_grad=True), "semantics0": torch.randn(B, 4, 4, 2), "depth": torch.randn(B, 4, 4, 1),
+                 "feat": torch.randn(B, 6, 2, 2), "cls_": torch.randn(B, 6), "ray_o": torch.randn(B, 4, 4, 3), "ray_d": torch.randn(B, 4, 4, 3)}
+        assert not sharding.multi_process(None)
+        plain = sharding.all_gather_patches(local, B, None)
+        sharding.FORCE_COLLECTIVES = True
+        assert sharding.multi_process(None)
+        sharding.reset_collective_counts()
+        stats = {}
+        forced = sharding.all_gather_patches(local, B, None, stats=stats)
+        full = sharding.splice_local_patches(forced, local, B, None)
+        counts = sharding.reset_collective_counts()
+        if counts != {"all_gather": 1}:
+            ok = False
+            why.append(f"collectives {counts}")
+        for k in plain:
+            if not torch.equal(plain[k], forced[k]):
+                ok = False
+                why.append(f"gathered `{k}` differs from the local batch")
+        if not (full["semantics"].requires_grad and torch.equal(full["semantics"].detach(), local["semantics"].detach())):
+            ok = False
+            why.append("the rank's own gradient-carrying patches were not spliced back")
+        lin = torch.nn.Linear(3, 2)
+        lin(torch.randn(5, 3)).sum().backward()
+        want = [p.grad.clone() for p in lin.parameters()]
+        sharding.all_reduce_grads(lin.parameters(), None)
+        counts = sharding.reset_collective_counts()
+        if counts != {"grad_all_reduce": 1} or any(not torch.equal(p.grad, w) for p, w in zip(lin.parameters(), want)):
+            ok = False
+            why.append(f"gradient all-reduce: {counts}")
+        sharding.FORCE_COLLECTIVES = False
+        q.put((ok, "; ".join(why)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_collectives_runs_the_multi_rank_branches_on_one_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(29500 + (os.getpid() % 2000) + 431, q))
+    p.start()
+    try:
+        res = q.get(timeout=120)
+        p.join(30)
+    finally:
+        if p.is_alive():
+            p.kill()
+    assert res[0], res
+
+
+def test_tail_stats_counts_and_percentiles():
+    """nerf_sos_amd.quality.tail_stats: PSNR, order statistics and counts over fixed thresholds of |d rgb| (max over channels)."""
+    from nerf_sos_amd import quality
+    ref = torch.zeros(10000, 3)
+    got = ref.clone()
+    got[:5, 1] = 0.03          # five rays over 0.02
+    got[5:7, 2] = 0.2          # two over 0.05
+    got[7:107, 0] = 0.005      # a hundred small ones
+    depth, ref_depth = torch.full((10000,), 2.0), torch.full((10000,), 2.0)
+    depth[0] = 3.0
+    lab = torch.zeros(10000, dtype=torch.long)
+    st = quality.tail_stats(got, ref, depth, ref_depth, lab, lab)
+    a = st["abs_rgb"]
+    assert (a["n_gt_0.01"], a["n_gt_0.02"], a["n_gt_0.05"]) == (7, 7, 2) and abs(a["max"] - 0.2) < 1e-7
+    assert a["p50"] == 0.0 and abs(a["p99"] - 0.005) < 1e-7 and abs(a["p99.99"] - 0.2) < 1e-7
+    assert st["share_of_rays_within_0.02"] == round(1 - 7 / 10000, 6) and st["label_agreement"] == 1.0
+    assert st["rel_depth"]["n_gt_0.1"] == 1 and abs(st["rel_depth"]["max"] - 0.5) < 1e-7
+    mse = (5 * 0.03 ** 2 + 2 * 0.2 ** 2 + 100 * 0.005 ** 2) / 30000
+    assert abs(st["psnr_db"] - round(-10 * __import__("math").log10(mse), 2)) < 0.011
+    row = quality.compact(st)
+    assert row["n_gt_0.01"] == 7 and row["rays"] == 10000 and row["depth_n_gt_0.01"] == 1
