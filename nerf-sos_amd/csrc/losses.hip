@@ -168,19 +168,28 @@ __device__ __forceinline__ double depth_max_of(const double* __restrict__ partia
 // global writes made before its call are visible to it (agent-scope release by each arriver, acquire by the last).  The ticket
 // resets itself for the next launch.  Folds a reduction's finishing step into the kernel that produced the partials: a launch of
 // its own costs ~4.8 us on the step's critical path (profiles/r05/h_c3_step_timeline.txt), seven of them per training step.
+// Round 6, second form (the first one released with __threadfence(): buffer_wbl2 + buffer_inv per workgroup, 66-196 us per step
+// slower than the launches it saved, profiles/r06/e_loss_finish_fold_ab.txt): NO cache-wide fence.  What the last workgroup reads --
+// the block partials and the row sums -- is written with agent-scope (sc1, write-through) stores and read with agent-scope loads
+// (dev_store / dev_load below), so only those few kilobytes travel through memory; "s_waitcnt vmcnt(0)" before the ticket makes each
+// wave's own stores complete first, and the ticket itself is a device-scope atomic.
+__device__ __forceinline__ void dev_store(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double dev_load(const double* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 __device__ __forceinline__ bool nsos_last_block(unsigned* ticket, unsigned total) {
     __shared__ int last_s;
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(ticket, 1u);
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = t == total - 1u;
-        if (last_s) *ticket = 0u;
+        if (last_s) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const bool last = last_s != 0;
-    if (last) __threadfence();
-    return last;
+    return last_s != 0;
 }
 
 // How a kernel finds the inputs of patch n of a (possibly stacked) batch.  The training step scores TWO semantic maps (coarse
@@ -516,12 +525,18 @@ __global__ __launch_bounds__((PairShape<GEO, NARROW>::kThreads)) void pair_rows_
             }
     }
     const bool owner = live && sl == 0;
-    if (PASS == 1 && owner) A.rowsum[((size_t)set * A.B + n) * N + p] = acc;
+    if (PASS == 1 && owner) {
+        if (A.tickets) dev_store(&A.rowsum[((size_t)set * A.B + n) * N + p], acc);     // (read by this launch's last workgroup)
+        else A.rowsum[((size_t)set * A.B + n) * N + p] = acc;
+    }
     if (PASS == 3 && owner)
 #pragma unroll
         for (int c = 0; c < kMaxC; ++c) A.grow[(((size_t)set * A.B + n) * N + p) * kMaxC + c] = c < C ? (float)g[c] : 0.0f;
     const double s = block_sum(owner ? acc : 0.0, red);
-    if (threadIdx.x == 0) A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (threadIdx.x == 0) {
+        if (A.tickets) dev_store(&A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x], s);
+        else A.partial[(size_t)set * kRedBlocks + blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
     // single-process calls: the pass's finishing reduction in its last workgroup (PASS 1 of a stacked geometric batch finishes in
     // pair_rowsum_copy_kernel instead, which runs between the two)
     if (A.tickets != nullptr && (PASS == 3 || !(GEO && A.Bg > 0 && A.Bg < A.B))) {
@@ -554,10 +569,10 @@ __global__ __launch_bounds__(256) void pair_rowsum_copy_finish_kernel(const Pair
     if (first_with_same_geometry(A, set, blockIdx.y, &cset, &cslot)) {
         const int n = row_patch(A), cn = A.rows ? A.rows[cslot] : cslot;
         const int p = blockIdx.x * blockDim.x + threadIdx.x;
-        if (p < N) A.rowsum[((size_t)set * A.B + n) * N + p] = A.rowsum[((size_t)cset * A.B + cn) * N + p];
+        if (p < N) dev_store(&A.rowsum[((size_t)set * A.B + n) * N + p], A.rowsum[((size_t)cset * A.B + cn) * N + p]);
         if (blockIdx.x == 0)
             for (int k = threadIdx.x; k < row_blocks; k += blockDim.x)
-                A.partial[(size_t)set * kRedBlocks + blockIdx.y * row_blocks + k] = A.partial[(size_t)cset * kRedBlocks + cslot * row_blocks + k];
+                dev_store(&A.partial[(size_t)set * kRedBlocks + blockIdx.y * row_blocks + k], A.partial[(size_t)cset * kRedBlocks + cslot * row_blocks + k]);
     }
     if (nsos_last_block(A.tickets, gridDim.x * gridDim.y * gridDim.z)) {
         __shared__ double fin[16];
@@ -600,10 +615,16 @@ __global__ void pair_finish_kernel(const double* __restrict__ partial, int nb, d
 }
 // The same two finishing steps as device functions for the LAST workgroup of a pass (any block size that is a multiple of 64):
 // identical summation orders, so the folded and the launched forms give the same bits.
+// partial_sum with agent-scope loads (the partials were written by other workgroups of the SAME launch)
+__device__ __forceinline__ double partial_sum_dev(const double* __restrict__ partial, int nb, int set) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += dev_load(&partial[(size_t)set * kRedBlocks + i]);
+    return nsos_wave_sum(s);
+}
 __device__ __forceinline__ void pass1_finish_in_block(const PairArgs& A, double* red /* [16] */) {
     for (int set = 0; set < 2; ++set) {
         if (threadIdx.x < 64) {
-            const double s = partial_sum(A.partial, A.nb, set);
+            const double s = partial_sum_dev(A.partial, A.nb, set);
             if (threadIdx.x == 0) A.scal[set] = s;
         }
         // rowmean_residual_sum strides by blockDim.x: pass1_finish_kernel runs it with 1024 threads -- keep that order
@@ -614,7 +635,7 @@ __device__ __forceinline__ void pass1_finish_in_block(const PairArgs& A, double*
                 double sv = 0.0;
                 for (long long k = v; k < (long long)nr * N; k += 1024) {
                     const int n = A.rows ? A.rows[k / N] : (int)(k / N), p = (int)(k % N);
-                    const double rs = A.rowsum[((size_t)set * A.B + n) * N + p];
+                    const double rs = dev_load(&A.rowsum[((size_t)set * A.B + n) * N + p]);
                     const float rm = (float)(rs / (double)N);
                     sv += rs - (double)N * (double)rm;
                 }
@@ -633,7 +654,7 @@ __device__ __forceinline__ void pass1_finish_in_block(const PairArgs& A, double*
 }
 __device__ __forceinline__ void pass3_finish_in_block(const PairArgs& A) {
     if (threadIdx.x >= 64) return;
-    const double s0 = partial_sum(A.partial, A.nb, 0), s1 = partial_sum(A.partial, A.nb, 1);
+    const double s0 = partial_sum_dev(A.partial, A.nb, 0), s1 = partial_sum_dev(A.partial, A.nb, 1);
     if (threadIdx.x != 0) return;
     A.scal[4] = s0;
     A.scal[5] = s1;
@@ -1095,11 +1116,13 @@ int32_t run_pair_passes_shape(const PairArgs& A_in, bool want_grad, float* loss,
     // multi-GPU call runs them one at a time and all-reduces scal[0..1], scal[2..3] over the ranks in between (the global
     // means of fd and fd1 couple every patch of the batch, utils/image.py:316-319).
     // single-process call (all phases, a loss to write): fold the finishing reductions into the passes' last workgroups
-    // MEASURED, NOT KEPT AS THE DEFAULT (round 6, profiles/r06/e_loss_finish_fold_ab.txt): the replayed C3 step takes 1.583 ms folded
-    // against 1.517 ms with the seven finish launches (C4: 2.917 against 2.721) -- every workgroup of a pass pays an agent-scope
-    // release (an L2 write-back + invalidate on a chip whose eight XCD L2s are not coherent with each other) so that ONE workgroup
-    // may read the others' partials; 256-512 of those cost more than the ~4.8 us per launch they save, and the invalidations evict
-    // the next kernel's weight stream.  NSOS_LOSS_FOLD_FINISH=1 selects the folded form (same bits: tests/test_gpu_losses.py).
+    // MEASURED, NOT KEPT AS THE DEFAULT (round 6, profiles/r06/e_loss_finish_fold_ab.txt).  First form (__threadfence() per
+    // workgroup): the replayed C3 step 1.583 ms folded against 1.517 ms with the finish launches (C4: 2.917 against 2.721) -- an
+    // agent-scope release is an L2 write-back + invalidate on a chip whose eight XCD L2s are not coherent with each other, 256-1024 of
+    // them per pass.  Second form (no fence: sc1 stores / loads of exactly the values the last workgroup reads, nsos_last_block):
+    // 1.586 against 1.581 ms, C4 2.889 against 2.866 -- no slower any more and no faster either: the appearance loss's finish
+    // launches run on the side stream under the geometric loss, and ONE workgroup summing 8 k row sums through memory takes what the
+    // two 1024-thread finish blocks took.  NSOS_LOSS_FOLD_FINISH=1 selects the folded form (same bits: tests/test_gpu_losses.py).
     const bool fold = phases == 7 && loss != nullptr && nsos_env_flag("NSOS_LOSS_FOLD_FINISH");
     A.tickets = fold ? reinterpret_cast<unsigned*>(A.scal + 8) : nullptr;
     A.nb = nb;
