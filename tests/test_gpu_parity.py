@@ -571,6 +571,34 @@ def test_mlp_x3_ragged_tiles(manifest, S):
     assert (guard == 777.0).all()
 
 
+@pytest.mark.parametrize("sem", [0, 1, 2])
+def test_both_split_fp16_forward_kernels_agree(manifest, sem):
+    """nsos_mlp_x3_select_kernel: 2 = mlp_x316_kernel (16x16x32, the default since round 6), 1 = mlp_x3_kernel (32x32x16, rounds 2-5; still
+    the training variants' kernel).  Same packed buffer (two streams), same inputs, every semantic mode, a ragged point count: both
+    within 1e-5 of the exact kernel and within 2e-6 of each other (other contraction order inside the MFMAs; measured 3e-7)."""
+    from nerf_sos_amd import _lib
+    name = {0: "nosem", 1: "sem", 2: "semcoord"}[sem]
+    sd = ref_state(name, manifest, peaky=True)
+    R, S = 93, 37                                   # 3441 points: a ragged last tile for both kernels (128-point tiles)
+    rays = tp.synthetic_rays(R, seed=8)
+    o, d = T(rays[0]), T(rays[1])
+    near, far = torch.full((R,), tp.NEAR, device=DEV), torch.full((R,), tp.FAR, device=DEV)
+    z, v = ops.ray_setup(d, near, far, S, torch.rand(R, S, device=DEV))
+    params = {k[len("nerf_fine") + 5:]: t.to(DEV) for k, t in sd.items() if k.startswith("nerf_fine.mlp.")}
+    packed = ops.pack_mlp(params, sem, precision="fp16x3")
+    exact = ops.mlp_forward_rays(ops.pack_mlp(params, sem), sem, o, d, v, z)
+    outs = {}
+    assert _lib.lib().nsos_mlp_x3_selected_kernel() == 2
+    try:
+        for k in (1, 2):
+            _lib.check(_lib.lib().nsos_mlp_x3_select_kernel(k), "select")
+            outs[k] = ops.mlp_forward_rays_lp(packed, sem, "fp16x3", o, d, v, z).clone()
+            close(N(outs[k]), N(exact), atol=1e-5, rtol=1e-5, what=f"split-fp16 kernel {k}, sem_mode {sem}, vs the exact kernel")
+    finally:
+        _lib.check(_lib.lib().nsos_mlp_x3_select_kernel(2), "select")
+    close(N(outs[2]), N(outs[1]), atol=2e-6, rtol=2e-6, what=f"mlp_x316_kernel vs mlp_x3_kernel, sem_mode {sem}")
+
+
 def test_render_x3_end_to_end(manifest):
     """whole pipeline with mlp_precision = "fp16x3": same keys, and everything that is not an index-flip casualty
      within the fp32 parity tolerance of the exact path"""
