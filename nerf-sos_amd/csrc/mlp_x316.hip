@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
         };
         // slice-major chunk over NT tiles and NSL slices: group g = (slice g / (2 NT), tile (g % (2 NT)) / 2, part g & 1).  ZF: 0 accumulate;
         // 1: slice 0 starts both accumulators from zero; 2: slice 0 starts the lo accumulator only (the main one holds the bias)
-        auto slice_chunk = [&](auto nt_c, auto nsl_c, auto zf_c, auto& acc, auto&& bh, auto&& bl, const int nfill) {
+        auto slice_chunk_r = [&](auto nt_c, auto nsl_c, auto zf_c, auto& acc, auto&& bh, auto&& bl, auto&& ride, const int nfill) {
             constexpr int NT = decltype(nt_c)::value, NSL = decltype(nsl_c)::value, ZF = decltype(zf_c)::value;
             pipeline16<2 * NT * NSL, 2 * NT * NSL, 0ull>(ring, ctx(), [&](auto ic, const f32x4& a32, const f32x4&) {
                 constexpr int g = decltype(ic)::value, sl = g / (2 * NT), t = (g % (2 * NT)) >> 1, p = g & 1;
@@ -280,9 +280,13 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                 if constexpr (sl == 0 && ZF == 1) part_work(IC(p), IC(1), aop, acc[t][0], acc[t][1], bh(IC(sl)), bl(IC(sl)));
                 else if constexpr (sl == 0 && ZF == 2 && p == 1) part_work(IC(1), IC(1), aop, acc[t][0], acc[t][1], bh(IC(sl)), bl(IC(sl)));
                 else part_work(IC(p), IC(0), aop, acc[t][0], acc[t][1], bh(IC(sl)), bl(IC(sl)));
+                ride(ic);
             }, mid, tail, side, nfill);
 #pragma unroll
             for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]));   // (keeps LLVM from sinking the chunk: see mlp_lp8.hip)
+        };
+        auto slice_chunk = [&](auto nt_c, auto nsl_c, auto zf_c, auto& acc, auto&& bh, auto&& bl, const int nfill) {
+            slice_chunk_r(nt_c, nsl_c, zf_c, acc, bh, bl, [](auto) {}, nfill);
         };
         // tile-pair chunk of a hidden layer: 32 A operands, group g = (slice g >> 2, tile (g >> 1) & 1, part g & 1); zq[t][0] holds the
         // tile's bias when the chunk starts (read from LDS by the PREVIOUS chunk, or by bias_now).  EXTRA / extra: this chunk's own
@@ -352,10 +356,18 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
             activate_all(Z);
             stamp();  // 3: L0 activation
         }
-        auto pair_layer = [&](const int l, const bool bias_now) {
+        // pair 7 of a layer (in Zq[1] when its last chunk ends) -> H[7]: rides in whatever chunk comes next -- the next pair layer's
+        // first chunk, the heads' first chunk, the view branch's first chunk -- since none of them reads slice 7 before its last groups
+        // and none touches Zq[1] before group 24; only layer 4 (layer 5's slice chunks need the registers) converts it exposed
+        auto ride_tail = [&](auto gc_, auto first_c, auto step_c, float floor) {
+            constexpr int g = decltype(gc_)::value, FIRST = decltype(first_c)::value, STEP = decltype(step_c)::value;
+            if constexpr (g >= FIRST && g < FIRST + 4 * STEP && (g - FIRST) % STEP == 0) pair_word(Zq[1], IC((g - FIRST) / STEP), floor, Hh[7], Hl[7]);
+        };
+        auto pair_layer = [&](const int l, const bool bias_now, const bool tail_pending, const bool leave_tail) {
             // chunk c accumulates output tiles 2c, 2c+1 over all 8 input slices into Zq[c & 1]; the activation of the PREVIOUS pair rides
             // behind this chunk's MFMAs into Ho[c - 1].  The layer's input H stays live until its last chunk; there the finished slices
-            // move into H, each right after the last use of the slice it replaces.  The last pair is one exposed pass.
+            // move into H, each right after the last use of the slice it replaces.  The last pair stays in Zq[1] for the next chunk
+            // to convert (`leave_tail`; ride_tail), and this layer's first chunk converts its predecessor's (`tail_pending`).
             // Biases: chunk c reads the NEXT chunk's two bias vectors into Zq[(c + 1) & 1][t][0] at groups 24, 25 -- the riding activation
             // has consumed those registers by group 16 -- from c1 (tail() rotates the names at group 29).  The last chunk's reads fetch
             // the next layer's first block; where no pair layer follows they read another chunk's operand bytes, and nobody uses them.
@@ -373,6 +385,8 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                     constexpr int g = decltype(gc_)::value;
                     if constexpr (c >= 1 && g >= 4 && g <= 16 && (g & 3) == 0)       // the previous pair -> slice c - 1 of the next layer's input
                         pair_word(Zq[prv], IC((g - 4) >> 2), floor, Hoh[c - 1], Hol[c - 1]);
+                    if constexpr (c == 0)
+                        if (tail_pending) ride_tail(gc_, IC(4), IC(4), 0.0f);          // (a pair layer's predecessor is always a ReLU layer)
                     if constexpr (c == 7 && g >= 4) {
                         // input slice s was last used by group 4 s + 3: Ho[s] -> H[s] (hi in the first two groups after it, lo in the next two)
                         constexpr int k = g - 4, s = k >> 2, j = k & 3;
@@ -384,14 +398,16 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                 }, [&](auto gc_) { read_bias(IC(decltype(gc_)::value - 24), Zq[prv][decltype(gc_)::value - 24][0], c1); }, c >= 6 ? (l == 8 ? 36 : 33) : 33);
             });
             stamp();  // 2 + 2l: MFMAs of layer l (with the riding activation of pairs 0..6)
-            // slice 6 was last used by group 27 of the last chunk: its replacement moved at groups 28, 29.  The last pair: exposed.
-            asm volatile("s_nop 7" ::: "memory");
-            static_for<0, 4>([&](auto wc) { pair_word(Zq[1], wc, floor, Hh[7], Hl[7]); });
-            stamp();  // 3 + 2l: the exposed rest of the activation (pair 7)
+            // slice 6 was last used by group 27 of the last chunk: its replacement moved at groups 28, 29
+            if (!leave_tail) {
+                asm volatile("s_nop 7" ::: "memory");
+                static_for<0, 4>([&](auto wc) { pair_word(Zq[1], wc, floor, Hh[7], Hl[7]); });
+            }
+            stamp();  // 3 + 2l: the exposed rest of the activation (pair 7), unless it rides in the next chunk
         };
         dead();
 #pragma unroll 1
-        for (int l = 1; l <= 4; ++l) pair_layer(l, l == 1);
+        for (int l = 1; l <= 4; ++l) pair_layer(l, l == 1, l != 1, l != 4);
         dead();
         {   // ---- layer 5 (skip): h part slice-major over all 16 tiles (8 chunks of one slice), then the x63 part (bias in its pad column)
             f32x4 Z[16][2];
@@ -415,9 +431,8 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
         dead();
 #pragma unroll 1
         for (int l = 6; l <= 8; ++l) {
-            pair_layer(l, l != 7);
+            pair_layer(l, l != 7, l == 7, true);      // (layer 7's last pair rides in the heads' first chunk, layer 8's in the view branch's)
             if (l == 7) {
-                dead();
                 // ---- H = relu(h7): sigma head (models/nerf_mlp.py:77) and the semantic head (:79-80), all split MFMAs
                 if constexpr (SEM == 0) {
                     // [bias of the raw tile][8 slices x (hi, lo): row 3 = alpha_linear]
@@ -433,6 +448,7 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                                 R[1] = mfma_x(aop, Hh[s], s == 0 ? zero4 : R[1]);
                             }
                         }
+                        ride_tail(ic, IC(2), IC(2), 0.0f);          // layer 7's last pair -> H[7], read at groups 15, 16
                     }, mid, tail, side, 33);
                     asm volatile("" : "+v"(R[0]), "+v"(R[1]));
                 } else {
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                         constexpr int j = decltype(jc)::value;
                         auto bh = [&](auto sc) { return Hh[2 * j + decltype(sc)::value]; };
                         auto bl = [&](auto sc) { return Hl[2 * j + decltype(sc)::value]; };
-                        if constexpr (j == 0) slice_chunk(IC(8), IC(2), IC(2), S8, bh, bl, 32);
+                        if constexpr (j == 0) slice_chunk_r(IC(8), IC(2), IC(2), S8, bh, bl, [&](auto gc_) { ride_tail(gc_, IC(4), IC(4), 0.0f); }, 32);   // (+ layer 7's last pair -> H[7], read by the fourth chunk)
                         else slice_chunk(IC(8), IC(2), IC(0), S8, bh, bl, j == 2 ? (SEM == 2 ? 32 : 25) : (j == 3 ? (SEM == 2 ? 25 : 33) : 32));
                     });
                     if constexpr (SEM == 2) slice_chunk(IC(8), IC(2), IC(0), S8, ex_h, ex_l, 33);     // the x63 part (sem_with_coord)
@@ -491,7 +507,6 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                 stamp();  // 18 (l == 7 only; the later slots shift by one): sigma + semantic heads
             }
         }
-        dead();
         // ---- view branch (models/nerf_mlp.py:87-92): cat([feature, dir27]) -> 128 -> rgb.  H = feature (no activation).
         // Pair-major over the 8 hidden tiles: chunk j = tiles 2j, 2j+1 x (8 feature slices + the direction slice, whose pad column
         // carries the bias) x (hi, lo): 36 A operands; the previous pair's activation rides.
@@ -527,6 +542,7 @@ __global__ __launch_bounds__(64 * kW16, 1) void mlp_x316_kernel(const X316Params
                 }
                 if constexpr (j >= 1 && g >= 8 && g <= 20 && (g & 3) == 0)
                     pair_word(Zq[prv], IC((g - 8) >> 2), 0.0f, Vph[j - 1], Vpl[j - 1]);
+                if constexpr (j == 0) ride_tail(ic, IC(4), IC(4), -__builtin_inff());   // feature_linear's last pair -> H[7] (no activation), read at groups 28..31
             }, mid, tail, side, j < 2 ? 36 : (j == 2 ? 32 : 32));      // (the last two fetch the next tile's layer 0)
 #pragma unroll
             for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(Zq[cur][t][0]), "+v"(Zq[cur][t][1]));
