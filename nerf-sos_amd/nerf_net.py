@@ -568,7 +568,7 @@ class NeRFNet(nn.Module):
     def check_numerics(self, ray_batch=None, bound_batch=None, max_rays: int = 1024) -> Dict[str, float]:
         """Render up to `max_rays` of `ray_batch` (a constant stride over the batch; default: the sample of the last validated render)
         in eval mode with the exact fp32 kernels and with `mlp_precision` / `coarse_precision`; raise FloatingPointError when the
-        reduced-precision image is non-finite or more than 5 % of the rays (and at least two) differ by more than 0.05 in rgb -- the
+        reduced-precision image (fine or coarse: `rgb`, `rgb0`) is non-finite or more than 5 % of the rays (and at least two) differ by more than 0.05 -- the
         signature of activations or weights outside fp16's range.  Returns the measured figures.  Costs two renders of the sample and
         host synchronisations; `NeRFNet.validate_precision` runs it once per weight version."""
         prec, cprec = self.mlp_precision, self.coarse_precision
@@ -593,24 +593,30 @@ class NeRFNet(nn.Module):
             self.mlp_precision, self.coarse_precision = prec, cprec
             self.train(was_training)
             self.validate_precision = was_validating
-        finite = bool(torch.isfinite(got["rgb"]).all()) and bool(torch.isfinite(got["depth"]).all())
+        # both images: an overflowing COARSE pass alone leaves the fine image plausible (its 64 stratified samples are still there) while
+        # the importance samples -- and `rgb0` -- are garbage
+        maps = [k for k in ("rgb", "rgb0") if k in got and k in want]
+        finite = all(bool(torch.isfinite(got[k]).all()) for k in maps) and bool(torch.isfinite(got["depth"]).all())
         n = int(o.shape[0])
         if finite:
             err = (got["rgb"].double() - want["rgb"].double()).reshape(n, -1)
             mse = float((err ** 2).mean())
-            n_off = int((err.abs().amax(-1) > self._GUARD_RGB).sum())
+            off = torch.zeros(n, dtype=torch.bool, device=err.device)
+            for k in maps:
+                off |= (got[k].double() - want[k].double()).reshape(n, -1).abs().amax(-1) > self._GUARD_RGB
+            n_off = int(off.sum())
         else:
             mse, n_off = float("inf"), n
         psnr = -10.0 * math.log10(max(mse, 1e-30)) if finite else float("-inf")
         res = {"precision": prec, "coarse_precision": cprec, "rays": n, "finite": finite, "psnr_vs_fp32_db": psnr,
-               "rays_off_by_more_than_0.05": n_off}
+               "rays_off_by_more_than_0.05": n_off}          # (in `rgb` or `rgb0`)
         if not bool(torch.isfinite(want["rgb"]).all()):
             return res                      # the exact render itself is non-finite (inf / nan inputs propagate, as in the reference): no verdict
         guarded = prec in self._GUARDED or cprec in self._GUARDED
         if guarded and (not finite or (n_off >= 2 and n_off > self._GUARD_SHARE * n)):
             raise FloatingPointError(
                 f"nerf_sos_amd: mlp_precision={prec!r}" + (f" / coarse_precision={cprec!r}" if cprec else "") + " does not reproduce this field: "
-                + ("non-finite outputs" if not finite else f"{n_off} of {n} rays differ by more than {self._GUARD_RGB} in rgb ({psnr:.1f} dB)")
+                + ("non-finite outputs" if not finite else f"{n_off} of {n} rays differ by more than {self._GUARD_RGB} in rgb / rgb0 (fine image {psnr:.1f} dB)")
                 + " against the exact fp32 render of the same rays.  An activation beyond fp16's 65 504 or weights below its 6e-5 are the "
                 "usual cause; use mlp_precision='bf16' (fp32's exponent range) or 'fp32' for this checkpoint.")
         return res

@@ -706,6 +706,12 @@ def test_coarse_precision_in_inference_and_frozen_backbone_training(manifest):
     _, zf, _, _ = ops.composite_importance(raw0, z, rays[1].contiguous(), 128)
     raw = ops.mlp_forward_rays_lp(net.nerf_fine.packed_weights("bf16"), net.nerf_fine.sem_mode, "bf16", rays[0].contiguous(), rays[1].contiguous(), v, zf)
     assert torch.equal(raw.reshape(mix["raw"].shape), mix["raw"])
+    # ... independent of the ray chunking, like every other mode
+    net.chunk = 100
+    with torch.no_grad():
+        again = net(rays, (tp.NEAR, tp.FAR))
+    net.chunk = 1024 * 32
+    assert all(torch.equal(again[k], mix[k]) for k in mix)
     # (b) training: gradients of both heads
     grads = {}
     for name, (prec, coarse) in {"x3": ("fp16x3", None), "mixed": ("bf16", "fp16x3")}.items():

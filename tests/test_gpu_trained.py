@@ -296,6 +296,13 @@ def test_fp16_overflow_is_reported_not_returned_silently(golden, precision):
         assert bad > 0.2, "the rescaled field was expected to break this precision"
         with pytest.raises(FloatingPointError):                            # ... and the explicit check still says so
             net.check_numerics((T(g["rays"][0]), T(g["rays"][1])), (near, far))
+        # round 6: the guard also covers a guarded precision on the COARSE pass alone (bf16 fine pass: fp32's exponent range)
+        mixed = _net("bf16", big)
+        mixed.coarse_precision = precision
+        with pytest.raises(FloatingPointError, match="coarse_precision"):
+            mixed(T(g["rays"]), (near, far), radii=None)
+        mixed.coarse_precision = None                                      # bf16 everywhere: nothing to guard, renders
+        assert torch.isfinite(mixed(T(g["rays"]), (near, far), radii=None)["rgb"]).all()
 
 
 # ---------------------------------------------------------------------------------- gradients on the trained field (training side)
