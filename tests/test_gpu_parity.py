@@ -825,12 +825,17 @@ def test_lp_training_variant(golden, manifest, precision, tol, lp_kernel):
     assert (logits - raw[..., 4:6].reshape(-1, 2)).abs().max() < 1e-4 * (1 + logits.abs().max())
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "fp16x3", "fp16+coarse_fp16x3"])
 def test_graphed_render_equals_eager(manifest, precision):
-    """hipGraph capture of the eval-mode step: replay is bit-identical to the eager launches, for new inputs too."""
+    """hipGraph capture of the eval-mode step: replay is bit-identical to the eager launches, for new inputs too (round 6: also on the
+    16x16x32 split kernel and with the coarse pass in another precision than the fine one)."""
     net = nerf_sos_amd.NeRFNet(N_samples=64, N_importance=128, use_semantics=True, sem_with_coord=True).to(DEV).eval()
     net.load_state_dict(ref_state("semcoord", manifest, peaky=True))
-    net.mlp_precision = precision
+    net.validate_precision = False              # (the range guard renders twice outside any capture; not what is tested here)
+    if "+" in precision:
+        net.mlp_precision, net.coarse_precision = "fp16", "fp16x3"
+    else:
+        net.mlp_precision = precision
     g = nerf_sos_amd.GraphedRender(net, 300, (tp.NEAR, tp.FAR), retraw=False)
     for seed in (1, 2):
         rays = tp.synthetic_rays(300, seed=seed).to(DEV)
