@@ -8,6 +8,7 @@ next call).  The C ABI only enqueues on the current stream and never synchronise
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -90,6 +91,8 @@ class GraphedPatchStep:
         `allow_eager_fallback=True` opts into continuing eagerly -- then the ranks AGREE on it first (an all-reduce MIN of a
         "captured" flag: no rank replays a graph while another steps eagerly, which would desynchronise their collective
         sequences), the loss generator is rebuilt from its pre-capture state and the gradients are reset.
+      * `capture_collectives=False` (or NSOS_GRAPH_COLLECTIVES=0 in the environment) keeps a multi-rank step eager on purpose: more
+        than one RCCL rank has never run under capture on the builder's hardware.
     The path is executed on one GPU by tests/test_gpu_sharded.py::test_graphed_step_rccl_world_1_captures_its_collectives (a
     `backend="nccl"`, world-size-1 group with sharding.FORCE_COLLECTIVES: real RCCL launches inside the capture).
     """
@@ -97,7 +100,7 @@ class GraphedPatchStep:
     def __init__(self, net, optimizer, rays: torch.Tensor, bounds: Tuple[float, float], feat: torch.Tensor, cls_tokens: torch.Tensor,
                  corr_loss=None, geo_loss=None, contrast_loss=None, correlation_w: float = 1.0, geo_w: float = 0.01,
                  contrast_w: float = 0.0, seed: int = 0, overlap_losses: bool = True, warmup: int = 3, capture: bool = True,
-                 group=None, n_patches: int = None, allow_eager_fallback: bool = False):
+                 group=None, n_patches: int = None, allow_eager_fallback: bool = False, capture_collectives: bool = True):
         import torch.distributed as dist
         from . import sharding
         self.group, self.capture_fallback = group, None
@@ -109,6 +112,12 @@ class GraphedPatchStep:
                 capture = False
                 self.capture_fallback = (f"process group backend {dist.get_backend(group)!r}: its collectives are driven by the host "
                                          "and cannot be captured in a HIP graph; stepping eagerly")
+            elif capture and not (capture_collectives and os.environ.get("NSOS_GRAPH_COLLECTIVES", "1") != "0"):
+                # the escape hatch for a first run on a new multi-GPU system: RCCL-under-capture has executed with ONE
+                # rank only (tests/test_gpu_sharded.py); `capture_collectives=False` / NSOS_GRAPH_COLLECTIVES=0 keeps the sharded
+                # step eager on every rank alike (an argument / the environment: the same everywhere by construction)
+                capture = False
+                self.capture_fallback = "capture_collectives=False / NSOS_GRAPH_COLLECTIVES=0: the sharded step is not captured; stepping eagerly"
         if not net.training:
             raise ValueError("GraphedPatchStep captures the train-mode step: call net.train() first")
         if net.rng != "philox":

@@ -449,6 +449,16 @@ def _rccl_world1_worker(port, q):
             why.append(f"fall-back state: graph={fb.graph}, reason={fb.capture_fallback!r}")
         l0 = float(fb())
         l1 = float(fb())
+        # the escape hatch: capture_collectives=False keeps the multi-rank step eager without attempting a capture
+        net_h = _build(dev)
+        net_h.rng = "philox"
+        opt_h = torch.optim.Adam([p for p in net_h.parameters() if p.requires_grad], lr=5e-3, fused=True, capturable=True)
+        hatch = nerf_sos_amd.GraphedPatchStep(net_h, opt_h, rays, (syn.NEAR, syn.FAR), feat, cls_, nerf_sos_amd.CorrelationLoss(_loss_args()),
+                                              nerf_sos_amd.GeoCorrelationLoss(_loss_args()), capture_collectives=False, **kw)
+        if hatch.graph is not None or "capture_collectives" not in (hatch.capture_fallback or ""):
+            ok = False
+            why.append(f"capture_collectives=False: graph={hatch.graph}, reason={hatch.capture_fallback!r}")
+        float(hatch())
         if not (l0 == l0 and l1 == l1):
             ok = False
             why.append("the eager fall-back step returned NaN")
