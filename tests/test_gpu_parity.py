@@ -1230,7 +1230,7 @@ def test_fuzz_shapes_module_vs_port(case):
             a, b = N(out[k]).reshape(R, -1), ref[k].numpy().reshape(R, -1)
             n_bad = int((np.abs(a - b) > 1e-4 * (1 + np.abs(b))).any(-1).sum())
             # measured (round 4): no ray of any of the 16 cases outside 1e-4; one index flip may move one ray
-            assert n_bad <= 1, (case, k, bad, dict(R=R, S=S, N=N_, name=name, white=white, peaky=peaky))
+            assert n_bad <= 1, (case, k, n_bad, dict(R=R, S=S, N=N_, name=name, white=white, peaky=peaky))
 
 
 @pytest.mark.parametrize("case", range(12))
